@@ -23,4 +23,29 @@ enum { ZKO_OK = 0, ZKO_ERR_WEIGHT = 1,        /* census.circom:72  checkWeight.o
 void zko_poseidon(uint64_t out[4], const uint64_t *in /* n x 4 */, int n);   /* n = 2,3,4 ; standard form in/out */
 int  zko_witness(int nLevels, const uint64_t *inputs, uint64_t *wires);      /* wires: zko_n_wires x 4 u64, standard form */
 
+
+/* ---- Groth16 (binary interfaces: every field element is 32 bytes little-endian, STANDARD form;
+ *      G1 affine = x||y (64 B), G2 affine = x.c0||x.c1||y.c0||y.c1 (128 B); all-zero = infinity) ---- */
+/* vk layout: alpha1(64) beta2(128) gamma2(128) delta2(128) IC[nPub+1](64 each) */
+int  zko_groth16_verify(const uint8_t *vk, int nPub, const uint8_t *pub /* nPub x 32 */, const uint8_t *proof /* A64 B128 C64 */);
+void zko_ntt(uint64_t *data /* n x 4, standard form, in place */, int logn, int inverse);
+void zko_root_of_unity(uint64_t out[4], int logn);          /* 5^((r-1)/2^logn), ffjavascript's Fr.w[logn] */
+void zko_msm_g1(uint8_t out[64], const uint8_t *bases /* n x 64 */, const uint8_t *scalars /* n x 32 */, size_t n);
+void zko_msm_g2(uint8_t out[128], const uint8_t *bases /* n x 128 */, const uint8_t *scalars, size_t n);
+void zko_g1_mul(uint8_t out[64], const uint8_t base[64], const uint8_t k[32]);
+/* .zkey (snarkjs groth16 format) */
+typedef struct {
+    uint32_t nVars, nPublic, domainSize, nCoeffs;
+    const uint8_t *alpha1, *beta1, *beta2, *gamma2, *delta1, *delta2;   /* Montgomery, as stored */
+    const uint8_t *ic, *coeffs, *pointsA, *pointsB1, *pointsB2, *pointsC, *pointsH;
+} zko_zkey_t;
+int  zko_zkey_parse(const uint8_t *buf, size_t len, zko_zkey_t *z);       /* 0 ok */
+/* stage outputs for parity tests */
+int  zko_build_abc(const zko_zkey_t *z, const uint64_t *wtns, uint64_t *A, uint64_t *B, uint64_t *C); /* each domainSize x 4, standard form */
+int  zko_h_evals(const zko_zkey_t *z, const uint64_t *wtns, uint64_t *P);  /* domainSize x 4: (A'B'-C') on the odd coset, standard form */
+/* full prove: proof = A(64) B(128) C(64) standard-form affine; pub = nPublic x 32 */
+int  zko_groth16_prove(const uint8_t *zkey, size_t len, const uint64_t *wtns, uint32_t nWtns, const uint8_t r[32], const uint8_t s[32],
+                       uint8_t proof[256], uint8_t *pub);
+int  zko_zkey_vk(const uint8_t *zkey, size_t len, uint8_t *vk_out /* 448 + 64*(nPub+1) */);
+
 #endif
