@@ -1,0 +1,69 @@
+"""GPU parity: the HIP witness kernels (through the C ABI) vs the CPU oracle and the reference-wasm golden vectors."""
+import hashlib, random
+import pytest
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+VEC = ol.load_json('witness_vectors.json')
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    import zkcensus_amd
+    c = zkcensus_amd.Context(0)
+    yield c
+    c.close()
+
+
+def test_shape(ctx):
+    assert ctx.n_wires(160) == 82754 and ctx.n_inputs(160) == 334
+    assert ctx.n_wires(160) == ol.lib().zko_n_wires(160)
+    for nl in (10, 32, 100, 252):
+        assert ctx.n_wires(nl) == ol.lib().zko_n_wires(nl)
+
+
+def test_golden_vectors_batch(ctx):
+    vecs = VEC['vectors']
+    ws, st = ctx.witness([v['inputs'] for v in vecs])
+    assert st == [0] * len(vecs)
+    for v, w in zip(vecs, ws):
+        assert hashlib.sha256(w).hexdigest() == v['sha256'], v['name']
+        assert [str(int.from_bytes(w[32 * i:32 * i + 32], 'little')) for i in range(1, 9)] == v['public']
+
+
+def test_negative_vectors(ctx):
+    expect = {'weight_exceeds': 1, 'bad_sik_root': 2, 'bad_census_root': 3, 'bad_nullifier': 4, 'last_sibling_nonzero': 5}
+    negs = VEC['negative']
+    good = VEC['vectors'][0]['inputs']
+    ws, st = ctx.witness([good] + [v['inputs'] for v in negs] + [good])
+    assert st[0] == 0 and st[-1] == 0                # failures do not poison the batch
+    assert st[1:-1] == [expect[v['name']] for v in negs]
+    assert hashlib.sha256(ws[0]).hexdigest() == VEC['vectors'][0]['sha256'] == hashlib.sha256(ws[-1]).hexdigest()
+
+
+def test_random_voters_vs_oracle(ctx):
+    import sys, os
+    sys.path.insert(0, os.path.join(ol.ROOT, 'tools'))
+    from census_gen import random_voter
+    rng = random.Random(20261003)
+    voters = [random_voter(rng, ol.poseidon, depth_c=rng.randrange(0, 40), depth_s=rng.randrange(0, 40)) for _ in range(96)]
+    voters += [random_voter(rng, ol.poseidon, depth_c=160, depth_s=160, zero_frac=0.0)]
+    ws, st = ctx.witness(voters)
+    assert st == [0] * len(voters)
+    for v, w in zip(voters, ws):
+        rc, wo = ol.witness(v)
+        assert rc == 0 and w == wo
+
+
+def test_other_depths_vs_oracle(ctx):
+    import sys, os
+    sys.path.insert(0, os.path.join(ol.ROOT, 'tools'))
+    from census_gen import random_voter
+    rng = random.Random(7)
+    for nl in (10, 31):
+        voters = [random_voter(rng, ol.poseidon, nLevels=nl, depth_c=rng.randrange(0, nl + 1), depth_s=rng.randrange(0, nl + 1)) for _ in range(8)]
+        ws, st = ctx.witness(voters, nLevels=nl)
+        assert st == [0] * len(voters)
+        for v, w in zip(voters, ws):
+            rc, wo = ol.witness(v, nLevels=nl)
+            assert rc == 0 and w == wo

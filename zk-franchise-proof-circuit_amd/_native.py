@@ -1,0 +1,42 @@
+"""ctypes loader for libzkcensus.so (the C ABI declared in include/zkcensus.h).
+
+The product has no CPU path: if the HIP library is missing or no GPU is visible, everything here raises."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libzkcensus.so')
+_lib = None
+
+
+class ZkcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('libzkcensus error %d: %s' % (code, msg))
+        self.code = code
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError('libzkcensus.so is not built (run `python -c "import __graft_entry__ as g; g.build()"`); '
+                          'there is no CPU fallback for the product path')
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)
+    L.zkc_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    L.zkc_ctx_destroy.argtypes = [vp]
+    L.zkc_last_error.argtypes = [vp]; L.zkc_last_error.restype = ctypes.c_char_p
+    L.zkc_ctx_stream.argtypes = [vp]; L.zkc_ctx_stream.restype = vp
+    L.zkc_witness.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, i32p]
+    L.zkc_witness_dev.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, vp]
+    _lib = L
+    return L
+
+
+def declared_symbols():
+    """Every `zkc_*` / `groth16_*` function name declared in include/zkcensus.h (used by the CPU export test)."""
+    import re
+    hdr = open(os.path.join(_HERE, '..', 'include', 'zkcensus.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    return sorted(set(re.findall(r'\b((?:zkc|groth16)_[a-z0-9_]+)\s*\(', hdr)))

@@ -1,0 +1,153 @@
+// zkc_api.hip -- context + witness entry points of the C ABI (include/zkcensus.h).  Product code: there is no
+// CPU fallback here -- without a working HIP device every call fails with ZKC_ERR_HIP.
+#include "zkc_internal.h"
+#include <cstring>
+#include "../../include/zkc_poseidon_constants.inc"
+
+using namespace zkc;
+
+extern "C" __global__ void zkc_witness_chains(WitnessLayout L, PoseidonTable tab, const uint32_t* inputs, uint32_t* wtns, int32_t* status, int B, int tmpl_mode);
+extern "C" __global__ void zkc_witness_fill(const uint4* tmpl, uint4* wtns, int nWires, int B);
+
+static thread_local std::string g_create_err;
+
+int zkc_fail(zkc_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg; else g_create_err = msg;
+    return code;
+}
+int zkc_ensure(zkc_ctx* ctx, void** p, size_t* cur, size_t need) {
+    if (*cur >= need) return ZKC_OK;
+    if (*p) { ZKC_HIP_CHECK(ctx, hipFree(*p)); *p = nullptr; *cur = 0; }
+    ZKC_HIP_CHECK(ctx, hipMalloc(p, need));
+    *cur = need;
+    return ZKC_OK;
+}
+
+__global__ void zkc_status_combine(const int32_t* __restrict__ s3, int32_t* __restrict__ s, int B) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    // report in the order the circuit states its asserts: weight (misc), sik tree, census tree, nullifier (misc)
+    int m = s3[3 * b + 2], c = s3[3 * b + 0], k = s3[3 * b + 1], r = 0;
+    if (m == ZKC_W_ERR_INPUT_RANGE) r = m;
+    else if (m == ZKC_W_ERR_WEIGHT) r = m;
+    else if (k) r = k; else if (c) r = c; else r = m;
+    s[b] = r;
+}
+
+template <size_t N>
+static void conv_consts(std::vector<Fr>& out, const unsigned long long (&src)[N][4]) {
+    for (size_t i = 0; i < N; i++) {
+        uint32_t s[8];
+        for (int k = 0; k < 4; k++) { s[2 * k] = (uint32_t)src[i][k]; s[2 * k + 1] = (uint32_t)(src[i][k] >> 32); }
+        out.push_back(fp_from_std<FrParams>(s));
+    }
+}
+
+extern "C" int zkc_ctx_create(int device, zkc_ctx** out) {
+    if (!out) return zkc_fail(nullptr, ZKC_ERR_BAD_ARG, "out == NULL");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return zkc_fail(nullptr, ZKC_ERR_HIP, "no HIP device: libzkcensus has no CPU path (the CPU restatement lives in oracle/ and is test-only)");
+    if (device < 0 || device >= ndev) return zkc_fail(nullptr, ZKC_ERR_BAD_ARG, "bad device ordinal");
+    zkc_ctx* ctx = new zkc_ctx();
+    ctx->device = device;
+    auto fail = [&](hipError_t e, const char* what) { g_create_err = std::string(what) + ": " + hipGetErrorString(e); delete ctx; return (int)ZKC_ERR_HIP; };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+    // Poseidon parameter tables -> Montgomery form -> HBM (about 1.6k Fr = 51 KB; L2/scalar-cache resident)
+    std::vector<Fr> all; size_t off[12]; int k = 0;
+    off[k++] = all.size(); conv_consts(all, ZKC_POSEIDON_C3); off[k++] = all.size(); conv_consts(all, ZKC_POSEIDON_S3);
+    off[k++] = all.size(); conv_consts(all, ZKC_POSEIDON_M3); off[k++] = all.size(); conv_consts(all, ZKC_POSEIDON_P3);
+    off[k++] = all.size(); conv_consts(all, ZKC_POSEIDON_C4); off[k++] = all.size(); conv_consts(all, ZKC_POSEIDON_S4);
+    off[k++] = all.size(); conv_consts(all, ZKC_POSEIDON_M4); off[k++] = all.size(); conv_consts(all, ZKC_POSEIDON_P4);
+    off[k++] = all.size(); conv_consts(all, ZKC_POSEIDON_C5); off[k++] = all.size(); conv_consts(all, ZKC_POSEIDON_S5);
+    off[k++] = all.size(); conv_consts(all, ZKC_POSEIDON_M5); off[k++] = all.size(); conv_consts(all, ZKC_POSEIDON_P5);
+    if ((e = hipMalloc(&ctx->d_ptab_mem, all.size() * sizeof(Fr))) != hipSuccess) return fail(e, "hipMalloc(poseidon)");
+    if ((e = hipMemcpy(ctx->d_ptab_mem, all.data(), all.size() * sizeof(Fr), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(poseidon)");
+    const Fr* base = (const Fr*)ctx->d_ptab_mem;
+    for (int t = 3; t <= 5; t++) {
+        ctx->ptab.C[t] = base + off[(t - 3) * 4 + 0]; ctx->ptab.S[t] = base + off[(t - 3) * 4 + 1];
+        ctx->ptab.M[t] = base + off[(t - 3) * 4 + 2]; ctx->ptab.P[t] = base + off[(t - 3) * 4 + 3];
+    }
+    *out = ctx;
+    return ZKC_OK;
+}
+extern "C" void zkc_ctx_destroy(zkc_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->tmpl) (void)hipFree(kv.second);
+    if (ctx->d_ptab_mem) (void)hipFree(ctx->d_ptab_mem);
+    if (ctx->d_scratch_in) (void)hipFree(ctx->d_scratch_in);
+    if (ctx->d_scratch_out) (void)hipFree(ctx->d_scratch_out);
+    if (ctx->d_status3) (void)hipFree(ctx->d_status3);
+    if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+extern "C" const char* zkc_last_error(const zkc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+extern "C" void* zkc_ctx_stream(zkc_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+extern "C" int zkc_circuit_n_inputs(int nLevels) { return nLevels < 3 ? 0 : WitnessLayout::make(nLevels).nInputs; }
+extern "C" int zkc_circuit_n_wires(int nLevels) { return nLevels < 3 ? 0 : WitnessLayout::make(nLevels).nWires; }
+
+// The voter-independent part of the witness (empty-level Poseidon(0,0) traces, oldKey = 0 decomposition) is computed
+// once per (ctx, nLevels) ON THE DEVICE by running the chain kernel in template mode over an all-zero voter.
+static int get_template(zkc_ctx* ctx, const WitnessLayout& L, uint32_t** out) {
+    auto it = ctx->tmpl.find(L.nL);
+    if (it != ctx->tmpl.end()) { *out = it->second; return ZKC_OK; }
+    uint32_t *d_t = nullptr, *d_in = nullptr; int32_t* d_st = nullptr;
+    ZKC_HIP_CHECK(ctx, hipMalloc(&d_t, (size_t)L.nWires * 32));
+    ZKC_HIP_CHECK(ctx, hipMalloc(&d_in, (size_t)L.nInputs * 32));
+    ZKC_HIP_CHECK(ctx, hipMalloc(&d_st, 3 * sizeof(int32_t)));
+    ZKC_HIP_CHECK(ctx, hipMemsetAsync(d_t, 0, (size_t)L.nWires * 32, ctx->stream));
+    ZKC_HIP_CHECK(ctx, hipMemsetAsync(d_in, 0, (size_t)L.nInputs * 32, ctx->stream));
+    hipLaunchKernelGGL(zkc_witness_chains, dim3(1), dim3(64), 0, ctx->stream, L, ctx->ptab, d_in, d_t, d_st, 1, 1);
+    ZKC_HIP_CHECK(ctx, hipGetLastError());
+    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ZKC_HIP_CHECK(ctx, hipFree(d_in)); ZKC_HIP_CHECK(ctx, hipFree(d_st));
+    ctx->tmpl[L.nL] = d_t; *out = d_t;
+    return ZKC_OK;
+}
+
+static int witness_dev3(zkc_ctx* ctx, const WitnessLayout& L, const void* d_inputs, int B, void* d_wtns, int32_t* d_status3) {
+    uint32_t* tmpl; int rc = get_template(ctx, L, &tmpl); if (rc) return rc;
+    const size_t total = (size_t)L.nWires * 2 * (size_t)B;
+    int fill_blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(zkc_witness_fill, dim3(fill_blocks), dim3(256), 0, ctx->stream, (const uint4*)tmpl, (uint4*)d_wtns, L.nWires, B);
+    ZKC_HIP_CHECK(ctx, hipGetLastError());
+    // lanes of a wave share the chain kind; ceil so that kinds start on wave boundaries only when B % 64 == 0 (harmless otherwise)
+    hipLaunchKernelGGL(zkc_witness_chains, dim3((3 * B + 63) / 64), dim3(64), 0, ctx->stream, L, ctx->ptab, (const uint32_t*)d_inputs,
+                       (uint32_t*)d_wtns, d_status3, B, 0);
+    ZKC_HIP_CHECK(ctx, hipGetLastError());
+    return ZKC_OK;
+}
+
+extern "C" int zkc_witness_dev(zkc_ctx* ctx, int nLevels, const void* d_inputs, int B, void* d_wtns, int32_t* d_status) {
+    if (!ctx || !d_inputs || !d_wtns || !d_status || B <= 0 || nLevels < 3 || nLevels > 252) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_witness_dev: bad argument");
+    ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    WitnessLayout L = WitnessLayout::make(nLevels);
+    int rc = zkc_ensure(ctx, (void**)&ctx->d_status3, &ctx->status3_n, (size_t)B * 3 * sizeof(int32_t)); if (rc) return rc;
+    rc = witness_dev3(ctx, L, d_inputs, B, d_wtns, ctx->d_status3); if (rc) return rc;
+    hipLaunchKernelGGL(zkc_status_combine, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_status3, d_status, B);
+    ZKC_HIP_CHECK(ctx, hipGetLastError());
+    return ZKC_OK;
+}
+
+extern "C" int zkc_witness(zkc_ctx* ctx, int nLevels, const void* inputs, int B, void* wtns, int32_t* status) {
+    if (!ctx || !inputs || !wtns || !status || B <= 0 || nLevels < 3 || nLevels > 252) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_witness: bad argument");
+    ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    WitnessLayout L = WitnessLayout::make(nLevels);
+    const size_t in_sz = (size_t)B * L.nInputs * 32, out_sz = (size_t)B * L.nWires * 32;
+    int rc;
+    if ((rc = zkc_ensure(ctx, &ctx->d_scratch_in, &ctx->scratch_in_sz, in_sz))) return rc;
+    if ((rc = zkc_ensure(ctx, &ctx->d_scratch_out, &ctx->scratch_out_sz, out_sz))) return rc;
+    if ((rc = zkc_ensure(ctx, (void**)&ctx->d_status, &ctx->status_n, (size_t)B * sizeof(int32_t)))) return rc;
+    ZKC_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_scratch_in, inputs, in_sz, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = zkc_witness_dev(ctx, nLevels, ctx->d_scratch_in, B, ctx->d_scratch_out, ctx->d_status))) return rc;
+    ZKC_HIP_CHECK(ctx, hipMemcpyAsync(wtns, ctx->d_scratch_out, out_sz, hipMemcpyDeviceToHost, ctx->stream));
+    ZKC_HIP_CHECK(ctx, hipMemcpyAsync(status, ctx->d_status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < B; b++) if (status[b] != ZKC_W_OK) return zkc_fail(ctx, ZKC_ERR_WITNESS, "witness: voter " + std::to_string(b) + " failed circuit assert " + std::to_string(status[b]));
+    return ZKC_OK;
+}

@@ -1,0 +1,157 @@
+// zkc_field.h -- BN254 prime-field arithmetic for the MI355X prover (product code, host + device).
+//
+// 8 x 32-bit little-endian limbs, Montgomery form with R = 2^256.  32-bit limbs are the native shape for
+// CDNA4: the integer multiplier is 32x32 and `v_mad_u64_u32` folds the accumulate, so every inner step below is
+// one mad plus a 64-bit carry add.  Fq is the curve base field, Fr the scalar field (witness, NTT, Poseidon).
+// Replaces what the reference reaches inside ffjavascript/wasmcurves (ts_inputs/src/example.ts:358) and
+// rapidsnark's Fr/Fq asm (zk_census_test.go:89).
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+#define ZKC_HD __host__ __device__ __forceinline__
+
+namespace zkc {
+
+struct FqParams {
+    static constexpr uint32_t p[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    static constexpr uint32_t r1[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u, 0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+    static constexpr uint32_t r2[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u, 0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+    static constexpr uint32_t inv = 0xe4866389u;   // -p^-1 mod 2^32
+};
+struct FrParams {
+    static constexpr uint32_t p[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    static constexpr uint32_t r1[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+    static constexpr uint32_t r2[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+    static constexpr uint32_t inv = 0xefffffffu;
+};
+
+template <class P>
+struct Fp {
+    uint32_t v[8];
+
+    ZKC_HD static Fp zero() { Fp r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.v[i] = 0; return r; }
+    ZKC_HD static Fp one() { Fp r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.v[i] = P::r1[i]; return r; }
+    ZKC_HD bool is_zero() const { uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o |= v[i]; return o == 0; }
+    ZKC_HD bool operator==(const Fp& b) const { uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o |= v[i] ^ b.v[i]; return o == 0; }
+    ZKC_HD bool operator!=(const Fp& b) const { return !(*this == b); }
+};
+
+// r = a - p if a >= p (a < 2p)
+template <class P>
+ZKC_HD void fp_reduce_once(uint32_t a[8]) {
+    uint32_t t[8]; uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { uint64_t d = (uint64_t)a[i] - P::p[i] - br; t[i] = (uint32_t)d; br = (d >> 63) & 1; }
+    if (!br) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) a[i] = t[i];
+    }
+}
+template <class P>
+ZKC_HD Fp<P> operator+(const Fp<P>& a, const Fp<P>& b) {
+    Fp<P> r; uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { c += (uint64_t)a.v[i] + b.v[i]; r.v[i] = (uint32_t)c; c >>= 32; }
+    fp_reduce_once<P>(r.v);      // p < 2^254 so a+b < 2^255: no carry out of limb 7
+    return r;
+}
+template <class P>
+ZKC_HD Fp<P> operator-(const Fp<P>& a, const Fp<P>& b) {
+    Fp<P> r; uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { uint64_t d = (uint64_t)a.v[i] - b.v[i] - br; r.v[i] = (uint32_t)d; br = (d >> 63) & 1; }
+    if (br) { uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { c += (uint64_t)r.v[i] + P::p[i]; r.v[i] = (uint32_t)c; c >>= 32; }
+    }
+    return r;
+}
+template <class P>
+ZKC_HD Fp<P> fp_neg(const Fp<P>& a) { return a.is_zero() ? a : Fp<P>::zero() - a; }
+template <class P>
+ZKC_HD Fp<P> fp_dbl(const Fp<P>& a) { return a + a; }
+
+// Montgomery product a*b/R mod p (CIOS over 32-bit limbs; p < 2^254 keeps every partial sum below 2^(256+32))
+template <class P>
+ZKC_HD Fp<P> operator*(const Fp<P>& a, const Fp<P>& b) {
+    uint32_t t[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t c = 0;
+        const uint32_t bi = b.v[i];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { c += (uint64_t)a.v[j] * bi + t[j]; t[j] = (uint32_t)c; c >>= 32; }
+        c += t[8];                       // < 2^33
+        const uint32_t m = t[0] * P::inv;
+        uint64_t d = (uint64_t)m * P::p[0] + t[0]; d >>= 32;
+#pragma unroll
+        for (int j = 1; j < 8; j++) { d += (uint64_t)m * P::p[j] + t[j]; t[j - 1] = (uint32_t)d; d >>= 32; }
+        d += c; t[7] = (uint32_t)d; t[8] = (uint32_t)(d >> 32);
+    }
+    Fp<P> r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = t[i];
+    fp_reduce_once<P>(r.v);              // result < 2p and t[8] == 0 because 4p < R
+    return r;
+}
+template <class P>
+ZKC_HD Fp<P> fp_sqr(const Fp<P>& a) { return a * a; }
+
+template <class P>
+ZKC_HD Fp<P> fp_from_std(const uint32_t s[8]) {        // standard -> Montgomery
+    Fp<P> a, r2;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { a.v[i] = s[i]; r2.v[i] = P::r2[i]; }
+    return a * r2;
+}
+template <class P>
+ZKC_HD void fp_to_std(uint32_t s[8], const Fp<P>& a) { // Montgomery -> standard
+    Fp<P> one;
+#pragma unroll
+    for (int i = 0; i < 8; i++) one.v[i] = (i == 0);
+    Fp<P> r = a * one;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s[i] = r.v[i];
+}
+template <class P>
+ZKC_HD Fp<P> fp_from_u32(uint32_t x) { uint32_t s[8] = {x, 0, 0, 0, 0, 0, 0, 0}; return fp_from_std<P>(s); }
+
+// a^(p-2) by square-and-multiply (0 -> 0)
+template <class P>
+ZKC_HD Fp<P> fp_inv(const Fp<P>& a) {
+    uint32_t e[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) e[i] = P::p[i] - (i == 0 ? 2u : 0u);   // p[0] >= 2 for both moduli
+    Fp<P> r = Fp<P>::one();
+    for (int k = 255; k >= 0; k--) {
+        r = r * r;
+        uint32_t w = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) w = (i == (k >> 5)) ? e[i] : w;
+        if ((w >> (k & 31)) & 1) r = r * a;
+    }
+    return r;
+}
+template <class P>
+ZKC_HD bool fp_std_lt_p(const uint32_t s[8]) {       // s < p ?
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { uint64_t d = (uint64_t)s[i] - P::p[i] - br; br = (d >> 63) & 1; }
+    return br != 0;
+}
+
+using Fq = Fp<FqParams>;
+using Fr = Fp<FrParams>;
+
+}  // namespace zkc

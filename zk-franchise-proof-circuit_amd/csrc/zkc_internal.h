@@ -1,0 +1,29 @@
+// zkc_internal.h -- host-side internals of libzkcensus (product code).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <map>
+#include "../../include/zkcensus.h"
+#include "zkc_device.h"
+
+#define ZKC_HIP_CHECK(ctx, call)                                                                            \
+    do { hipError_t _e = (call); if (_e != hipSuccess) {                                                     \
+        return zkc_fail((ctx), ZKC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); } } while (0)
+
+struct zkc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    zkc::PoseidonTable ptab{};            // device pointers
+    void* d_ptab_mem = nullptr;
+    std::map<int, uint32_t*> tmpl;        // nLevels -> device template witness (nWires x 8 u32)
+    // scratch reused by the host-buffer entry points
+    void* d_scratch_in = nullptr; size_t scratch_in_sz = 0;
+    void* d_scratch_out = nullptr; size_t scratch_out_sz = 0;
+    int32_t* d_status3 = nullptr; size_t status3_n = 0;
+    int32_t* d_status = nullptr; size_t status_n = 0;
+};
+
+int zkc_fail(zkc_ctx* ctx, int code, const std::string& msg);
+int zkc_ensure(zkc_ctx* ctx, void** p, size_t* cur, size_t need);

@@ -1,0 +1,355 @@
+// zkc_witness.hip -- K2: batched zkCensus witness generation on MI355X (product code).
+//
+// Replaces the reference's witness stage: circom_runtime + circuit.wasm inside snarkjs `groth16.fullProve`
+// (ts_inputs/src/example.ts:358-362) and go-rapidsnark/witness + wasmer (zk_census_test.go:89).  The spec is
+// circuit/census.circom:49-115 with the circomlib 2.0.5 templates; the output is the circom 2.1.5 wire order of
+// artifacts/zkCensus/dev/160/circuit.wasm (see DESIGN.md "witness layout").
+//
+// Two kernels:
+//   zkc_witness_fill     wide, coalesced: every voter's witness := the voter-independent template witness
+//                        (empty-subtree Poseidon(0,0) level traces, oldKey=0 bit decomposition, ...)
+//   zkc_witness_chains   one lane per (voter, chain) with chain in {census tree, sik tree, misc}: walks the
+//                        Merkle path leaf->root (Poseidon is sequential along a path), and stores every surviving
+//                        signal of the non-empty levels straight into its wire slot (standard form).
+// HBM layout: inputs  [B][nInputs][8 x u32]  standard form, census.circom declaration order
+//             witness [B][nWires ][8 x u32]  standard form (what .wtns section 2 holds and what MSM digits read)
+#include "zkc_field.h"
+#include "zkc_device.h"
+
+namespace zkc {
+
+struct Emit {                       // writes Montgomery values as standard-form wires
+    uint32_t* base;                 // witness of this voter
+    __device__ __forceinline__ void put(int wire, const Fr& v) const {
+        uint32_t s[8]; fp_to_std<FrParams>(s, v);
+        uint4* d = reinterpret_cast<uint4*>(base + 8 * (size_t)wire);
+        d[0] = make_uint4(s[0], s[1], s[2], s[3]); d[1] = make_uint4(s[4], s[5], s[6], s[7]);
+    }
+    __device__ __forceinline__ void put_std(int wire, const uint32_t s[8]) const {
+        uint4* d = reinterpret_cast<uint4*>(base + 8 * (size_t)wire);
+        d[0] = make_uint4(s[0], s[1], s[2], s[3]); d[1] = make_uint4(s[4], s[5], s[6], s[7]);
+    }
+    __device__ __forceinline__ void put_small(int wire, uint32_t x) const {
+        uint4* d = reinterpret_cast<uint4*>(base + 8 * (size_t)wire);
+        d[0] = make_uint4(x, 0, 0, 0); d[1] = make_uint4(0, 0, 0, 0);
+    }
+    __device__ __forceinline__ void put_raw(int wire, const Fr& mont) const {      // scratch use of a wire slot
+        uint4* d = reinterpret_cast<uint4*>(base + 8 * (size_t)wire);
+        d[0] = make_uint4(mont.v[0], mont.v[1], mont.v[2], mont.v[3]); d[1] = make_uint4(mont.v[4], mont.v[5], mont.v[6], mont.v[7]);
+    }
+    __device__ __forceinline__ Fr get_raw(int wire) const {
+        const uint4* d = reinterpret_cast<const uint4*>(base + 8 * (size_t)wire);
+        uint4 a = d[0], b = d[1]; Fr r; r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w; return r;
+    }
+};
+
+__device__ __forceinline__ Fr sbox(const Fr& x, Fr& in2, Fr& in4) { in2 = x * x; in4 = in2 * in2; return in4 * x; }
+
+// Optimised Poseidon (circomlib 2.0.5 schedule) over t = T state words, storing the surviving trace signals.
+// LAYOUT 0: the survivor set of every t=3 / t=4 instance; LAYOUT 1: the single t=5 instance (computedNullifier).
+// cmask bit j = state word j is a compile-time constant at round 0 (bit 0 always: initialState = 0).
+// `blk` = wire index of the first internal signal of this Poseidon block; emit.base == nullptr -> hash only.
+template <int T, int LAYOUT>
+__device__ Fr poseidon_trace(const Fr* in, unsigned cmask, const PoseidonTable& tab, const Emit& e, int blk) {
+    constexpr int RP = (T == 3) ? 57 : (T == 4) ? 56 : 60;
+    const Fr* __restrict__ C = tab.C[T]; const Fr* __restrict__ S = tab.S[T];
+    const Fr* __restrict__ M = tab.M[T]; const Fr* __restrict__ Pm = tab.P[T];
+    const bool on = e.base != nullptr;
+    int rank[T]; int nc1 = 0;
+#pragma unroll
+    for (int j = 0; j < T; j++) { rank[j] = nc1; nc1 += !((cmask >> j) & 1); }
+    // block offsets (LAYOUT 0)
+    const int nA = nc1 + 6 * T, oLast = nA, oMS = nA + T - 1, oF = oMS + RP, oP = oF + 2 * (nc1 + 7 * T);
+    auto ark_idx = [&](int r, int j) -> int {
+        if (LAYOUT == 0) return r == 1 ? (((cmask >> j) & 1) ? -1 : rank[j]) : nc1 + (r - 2) * T + j;
+        // t=5: ark[1][1..4], ark[2][*], ark[3][*], ark[4][0], ark[5..7][*]
+        if (r == 1) return j == 0 ? -1 : j - 1;
+        if (r <= 3) return 4 + (r - 2) * 5 + j;
+        if (r == 4) return j == 0 ? 14 : -1;
+        return 15 + (r - 5) * 5 + j;
+    };
+    auto sF_idx = [&](int r, int j) -> int {
+        if (LAYOUT == 0) return oF + 2 * (r == 0 ? (((cmask >> j) & 1) ? -1000 : rank[j]) : nc1 + (r - 1) * T + j);
+        return 98 + 2 * (r == 0 ? (j == 0 ? -1000 : j - 1) : 4 + (r - 1) * 5 + j);
+    };
+    const int oPp = (LAYOUT == 0) ? oP : 176;
+
+    Fr st[T];
+    st[0] = Fr::zero();
+#pragma unroll
+    for (int j = 1; j < T; j++) st[j] = in[j - 1];
+#pragma unroll
+    for (int j = 0; j < T; j++) st[j] = st[j] + C[j];
+    // first half of the full rounds: sigmaF[0..3], ark[1..4], mix[0..2] (M) and mix[3] (P)
+    for (int r = 0; r < 4; r++) {
+        Fr ns[T];
+#pragma unroll
+        for (int j = 0; j < T; j++) {
+            Fr i2, i4; Fr o = sbox(st[j], i2, i4);
+            int fi = sF_idx(r, j);
+            if (on && fi >= 0) { e.put(blk + fi, i2); e.put(blk + fi + 1, i4); }
+            ns[j] = o + C[(r + 1) * T + j];
+            int ai = ark_idx(r + 1, j);
+            if (on && ai >= 0) e.put(blk + ai, ns[j]);
+        }
+        const Fr* __restrict__ MM = (r < 3) ? M : Pm;
+#pragma unroll
+        for (int i = 0; i < T; i++) {
+            Fr acc = MM[i] * ns[0];
+#pragma unroll
+            for (int j = 1; j < T; j++) acc = acc + MM[j * T + i] * ns[j];
+            st[i] = acc;
+        }
+    }
+    if (LAYOUT == 1 && on) e.put(blk + 30, st[4]);                    // mix[3].out[4]
+    // partial rounds
+    for (int r = 0; r < RP; r++) {
+        const Fr* __restrict__ Sr = S + (2 * T - 1) * r;
+        Fr i2, i4; Fr o = sbox(st[0], i2, i4);
+        if (on) { e.put(blk + oPp + 2 * r, i2); e.put(blk + oPp + 2 * r + 1, i4); }
+        Fr in0 = o + C[5 * T + r];
+        if (LAYOUT == 1 && on && r == 59) e.put(blk + 97, in0);      // mixS[59].in[0]
+        Fr n0 = Sr[0] * in0;
+#pragma unroll
+        for (int i = 1; i < T; i++) n0 = n0 + Sr[i] * st[i];
+#pragma unroll
+        for (int i = 1; i < T; i++) st[i] = st[i] + in0 * Sr[T + i - 1];
+        st[0] = n0;
+        if (on) {
+            if (LAYOUT == 0) e.put(blk + oMS + r, st[0]);
+            else {
+                if (r <= 56) e.put(blk + 35 + r, st[4]);
+                else if (r == 57) { e.put(blk + 92, st[1]); e.put(blk + 93, st[2]); e.put(blk + 94, st[3]); e.put(blk + 95, st[4]); }
+                else if (r == 58) e.put(blk + 96, st[4]);
+            }
+        }
+    }
+    // second half of the full rounds: sigmaF[4..6], ark[5..7], mix[4..6]
+    for (int r = 0; r < 3; r++) {
+        Fr ns[T];
+#pragma unroll
+        for (int j = 0; j < T; j++) {
+            Fr i2, i4; Fr o = sbox(st[j], i2, i4);
+            int fi = sF_idx(4 + r, j);
+            if (on) { e.put(blk + fi, i2); e.put(blk + fi + 1, i4); }
+            ns[j] = o + C[5 * T + RP + r * T + j];
+            if (on) e.put(blk + ark_idx(5 + r, j), ns[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < T; i++) {
+            Fr acc = M[i] * ns[0];
+#pragma unroll
+            for (int j = 1; j < T; j++) acc = acc + M[j * T + i] * ns[j];
+            st[i] = acc;
+        }
+    }
+    // sigmaF[7] and mixLast
+    Fr out = Fr::zero();
+    const int oL = (LAYOUT == 0) ? oLast : 31;
+#pragma unroll
+    for (int j = 0; j < T; j++) {
+        Fr i2, i4; Fr o = sbox(st[j], i2, i4);
+        int fi = sF_idx(7, j);
+        if (on) { e.put(blk + fi, i2); e.put(blk + fi + 1, i4); if (j < T - 1) e.put(blk + oL + j, o); }
+        out = out + M[j * T] * o;
+    }
+    return out;
+}
+
+__device__ __forceinline__ Fr load_std(const uint32_t* p) {
+    const uint4* d = reinterpret_cast<const uint4*>(p); uint4 a = d[0], b = d[1];
+    uint32_t s[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return fp_from_std<FrParams>(s);
+}
+__device__ __forceinline__ void load_raw(uint32_t s[8], const uint32_t* p) {
+    const uint4* d = reinterpret_cast<const uint4*>(p); uint4 a = d[0], b = d[1];
+    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+}
+__device__ __forceinline__ bool raw_is_zero(const uint32_t* p) {
+    const uint4* d = reinterpret_cast<const uint4*>(p); uint4 a = d[0], b = d[1];
+    return (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) == 0;
+}
+__device__ __forceinline__ int bit_of(const uint32_t s[8], int i) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) w = (k == (i >> 5)) ? s[k] : w;
+    return (w >> (i & 31)) & 1;
+}
+
+// CompConstant(r-1) over the bits of key `ks` (circomlib compconstant.circom): parts[0..126] and the surviving bits
+// of Num2Bits(135)(sum parts): out[0..126], out[128..133].  Everything is a small integer (< 2^135): plain limbs.
+__device__ void emit_alias_check(const Emit& e, int wire, const uint32_t ks[8]) {
+    uint32_t ct[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) ct[i] = FrParams::p[i];
+    ct[0] -= 1;
+    uint32_t sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 127; i++) {
+        int c = bit_of(ct, 2 * i) | (bit_of(ct, 2 * i + 1) << 1), v = bit_of(ks, 2 * i) | (bit_of(ks, 2 * i + 1) << 1);
+        uint32_t part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (v < c) {                                   // a = 2^i
+#pragma unroll
+            for (int k = 0; k < 8; k++) part[k] = (k == (i >> 5)) ? (1u << (i & 31)) : 0u;
+        } else if (v > c) {                            // b = 2^128 - 2^i : bits i..127 set
+#pragma unroll
+            for (int k = 0; k < 4; k++) part[k] = (k > (i >> 5)) ? 0xffffffffu : (k == (i >> 5)) ? (0xffffffffu << (i & 31)) : 0u;
+        }
+        e.put_std(wire + i, part);
+        uint64_t cy = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { cy += (uint64_t)sum[k] + part[k]; sum[k] = (uint32_t)cy; cy >>= 32; }
+    }
+    int w = wire + 127;
+    for (int i = 0; i < 134; i++) if (i != 127) e.put_small(w++, (uint32_t)bit_of(sum, i));
+}
+
+// SMTVerifier(n) with enabled=1, fnc=0, old*=0 (census.circom:79-103): all non-template wires of one verifier block.
+// Returns the recomputed root; *bad_last = siblings[n-1] != 0.
+__device__ Fr smt_verifier_chain(const WitnessLayout& L, const PoseidonTable& tab, const Emit& e, int blk,
+                                 const uint32_t key_s[8], const Fr& key, const Fr& value, const uint32_t* sib /* n x 8, std */,
+                                 bool* bad_last, bool tmpl_mode) {
+    const int n = L.n;
+    // depth d = 1 + last non-zero sibling among 0..n-2
+    int d = 0;
+    for (int i = 0; i <= n - 2; i++) if (!raw_is_zero(sib + 8 * i)) d = i + 1;
+    *bad_last = !raw_is_zero(sib + 8 * (n - 1));
+    const bool key0 = key.is_zero();
+    e.put_small(blk + 0, key0 ? 1u : 0u);                               // areKeyEquals.out
+    e.put_small(blk + 2, 0u);                                           // checkRoot.isz.inv
+    Fr hin[3] = {key, value, Fr::one()};
+    Fr h1new = poseidon_trace<4, 0>(hin, 1u | 8u, tab, e, blk + 4);
+    e.put(blk + 3, h1new);
+    // levels d-1 .. 0 hold real hashes; levels >= d keep the template's Poseidon(0,0) trace
+    Fr child = h1new;
+    for (int i = d - 1; i >= 0; i--) {
+        const int lb = blk + L.lvl_off(i);
+        int o = 0;
+        if (i == n - 3) e.put_small(lb + o++, 1u);                      // st_top[n-3] = 1 (i < d)
+        if (i > 0 && i < n - 2) e.put_small(lb + o++, 0u);              // st_inew[i] = 0
+        const int bit = bit_of(key_s, i);
+        e.put_small(lb + o++, (uint32_t)bit);                           // lrbit
+        e.put(lb + o++, child);                                         // child = root of level i+1
+        Fr s = load_std(sib + 8 * i);
+        Fr in2[2];
+        if (bit) { in2[0] = s; in2[1] = child; } else { in2[0] = child; in2[1] = s; }   // Switcher
+        Fr h = poseidon_trace<3, 0>(in2, 1u, tab, e, lb + o + 3);
+        e.put(lb + o, h);                                               // aux[0] = h * st_top (st_top = 1)
+        e.put(lb + o + 1, h);                                           // proofHash.out
+        e.put(lb + o + 2, in2[0]);                                      // proofHash.L
+        child = h;
+    }
+    for (int i = d; i <= n - 2; i++) {                                  // empty levels: control wires only
+        const int lb = blk + L.lvl_off(i);
+        int o = 0;
+        if (i == n - 3) e.put_small(lb + o++, 0u);                      // st_top[n-3] = 0 (i >= d)
+        if (i > 0 && i < n - 2) e.put_small(lb + o++, i == d ? 1u : 0u);// st_inew[i]
+        e.put_small(lb + o++, (uint32_t)bit_of(key_s, i));
+        if (tmpl_mode) {                                                // template: the Poseidon(0,0) trace of an empty level
+            Fr z2[2] = {Fr::zero(), Fr::zero()};
+            e.put_small(lb + o, 0u); e.put_small(lb + o + 1, 0u);       // child, aux[0]
+            Fr h = poseidon_trace<3, 0>(z2, 1u, tab, e, lb + o + 4);
+            e.put(lb + o + 2, h); e.put_small(lb + o + 3, 0u);          // proofHash.out, proofHash.L
+        }
+    }
+    {   // level n-1: st_top[n-2] (== st_inew[n-1]) and lrbit
+        const int lb = blk + L.lvl_off(n - 1);
+        e.put_small(lb, (d == n - 1) ? 1u : 0u);
+        e.put_small(lb + 1, (uint32_t)bit_of(key_s, n - 1));
+    }
+    int w = blk + L.off_n2bnew;
+    for (int i = n; i <= 252; i++) e.put_small(w++, (uint32_t)bit_of(key_s, i));
+    emit_alias_check(e, w, key_s);
+    if (tmpl_mode) {                                                    // n2bOld: oldKey = 0 (voter independent)
+        uint32_t z8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 253; i++) e.put_small(blk + L.off_n2bold + i, 0u);
+        emit_alias_check(e, blk + L.off_n2bold + 253, z8);
+    }
+    w = blk + L.off_levins;
+    for (int i = 1; i <= n - 2; i++) e.put_small(w++, i == d ? 1u : 0u);
+    // IsZero(sibling[i]).{out,inv}, i = 0..n-2 (out of i = n-2 is not a wire) and 1/key: one shared inversion.
+    // The inv slots double as scratch for the running prefix products (Montgomery form).
+    const int oz = blk + L.off_iszero;
+    auto inv_slot = [&](int i) { return i < n - 2 ? oz + 2 * i + 1 : oz + 2 * (n - 2); };
+    Fr acc = key0 ? Fr::one() : key;
+    for (int i = 0; i <= n - 2; i++) {
+        const bool z = raw_is_zero(sib + 8 * i);
+        if (i < n - 2) e.put_small(oz + 2 * i, z ? 1u : 0u);
+        if (z) e.put_small(inv_slot(i), 0u);
+        else { e.put_raw(inv_slot(i), acc); acc = acc * load_std(sib + 8 * i); }
+    }
+    Fr ai = fp_inv<FrParams>(acc);
+    for (int i = n - 2; i >= 0; i--) {
+        if (raw_is_zero(sib + 8 * i)) continue;
+        Fr pre = e.get_raw(inv_slot(i));
+        e.put(inv_slot(i), ai * pre);
+        ai = ai * load_std(sib + 8 * i);
+    }
+    if (key0) e.put_small(blk + 1, 0u); else e.put(blk + 1, ai);        // areKeyEquals.isz.inv = 1/key
+    return child;
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+zkc_witness_chains(WitnessLayout L, PoseidonTable tab, const uint32_t* __restrict__ inputs, uint32_t* __restrict__ wtns,
+                   int32_t* __restrict__ status, int B, int tmpl_mode) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= 3 * B) return;
+    const int kind = gid / B, b = gid - kind * B;          // lanes of a wave share `kind`
+    const uint32_t* in = inputs + (size_t)b * L.nInputs * 8;
+    Emit e{wtns + (size_t)b * L.nWires * 8};
+    const int n = L.n;
+    // input slots (census.circom:51-67 declaration order)
+    const uint32_t *eid = in, *nullifier = in + 16, *avail = in + 24, *vh = in + 32, *sikRoot = in + 48, *censusRoot = in + 56,
+                   *address = in + 64, *password = in + 72, *signature = in + 80, *voteW = in + 88, *cs = in + 96, *ss = in + 96 + 8 * n;
+    int32_t st = ZKC_W_OK;
+    uint32_t key_s[8]; load_raw(key_s, address);
+    if (kind == 2) {
+        // ---- misc chain: header copy, range check, checkWeight, computedNullifier, sik ----
+        bool in_range = true;
+        for (int i = 0; i < L.nInputs; i++) { uint32_t s[8]; load_raw(s, in + 8 * i); in_range &= fp_std_lt_p<FrParams>(s); }
+        if (!in_range) st = ZKC_W_ERR_INPUT_RANGE;
+        e.put_small(0, 1u);
+        const uint32_t* hdr[12] = {eid, eid + 8, nullifier, vh, vh + 8, sikRoot, censusRoot, voteW, avail, address, password, signature};
+        for (int i = 0; i < 12; i++) { uint32_t s[8]; load_raw(s, hdr[i]); e.put_std(1 + i, s); }
+        for (int i = 0; i < L.nL; i++) { uint32_t s[8]; load_raw(s, cs + 8 * i); e.put_std(13 + i, s); }
+        for (int i = 0; i < L.nL; i++) { uint32_t s[8]; load_raw(s, ss + 8 * i); e.put_std(13 + L.nL + i, s); }
+        e.put_small(L.off_checknull, 0u);
+        // LessEqThan(252): bits 0..250 of voteWeight + 2^252 - (availableWeight + 1); bit 252 must be clear
+        uint32_t p252[8] = {0, 0, 0, 0, 0, 0, 0, 1u << 28};
+        Fr x = load_std(voteW) + fp_from_std<FrParams>(p252) - load_std(avail) - Fr::one();
+        uint32_t xs[8]; fp_to_std<FrParams>(xs, x);
+        if ((bit_of(xs, 252) | bit_of(xs, 253)) && st == ZKC_W_OK) st = ZKC_W_ERR_WEIGHT;
+        for (int i = 0; i <= 250; i++) e.put_small(L.off_checkweight + i, (uint32_t)bit_of(xs, i));
+        Fr sig = load_std(signature), pw = load_std(password);
+        Fr nin[4] = {sig, pw, load_std(eid), load_std(eid + 8)};
+        Fr nul = poseidon_trace<5, 1>(nin, 1u, tab, e, L.off_nullifier);
+        if (nul != load_std(nullifier) && st == ZKC_W_OK) st = ZKC_W_ERR_NULLIFIER;
+        Fr sin[3] = {load_std(address), pw, sig};
+        Fr sik = poseidon_trace<4, 0>(sin, 1u, tab, e, L.off_sik + 1);
+        e.put(L.off_sik, sik);
+    } else {
+        Fr key = load_std(address), value; const uint32_t *sib, *root; int blk;
+        if (kind == 0) { value = load_std(avail); sib = cs; root = censusRoot; blk = L.off_census; }
+        else {
+            Fr sin[3] = {key, load_std(password), load_std(signature)};
+            Emit none{nullptr};
+            value = poseidon_trace<4, 0>(sin, 1u, tab, none, 0);
+            sib = ss; root = sikRoot; blk = L.off_sikver;
+        }
+        bool bad_last;
+        Fr r = smt_verifier_chain(L, tab, e, blk, key_s, key, value, sib, &bad_last, tmpl_mode != 0);
+        if (bad_last) st = ZKC_W_ERR_LAST_SIBLING;
+        else if (r != load_std(root)) st = kind == 0 ? ZKC_W_ERR_CENSUS_ROOT : ZKC_W_ERR_SIK_ROOT;
+    }
+    status[(size_t)b * 3 + kind] = st;
+}
+
+// coalesced broadcast of the template witness: one uint4 (half a wire) per lane
+extern "C" __global__ void __launch_bounds__(256)
+zkc_witness_fill(const uint4* __restrict__ tmpl, uint4* __restrict__ wtns, int nWires, int B) {
+    const size_t per = (size_t)nWires * 2;
+    const size_t total = per * (size_t)B;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        wtns[i] = tmpl[i % per];
+}
+
+}  // namespace zkc
