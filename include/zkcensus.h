@@ -57,6 +57,12 @@ int zkc_witness(zkc_ctx* ctx, int nLevels, const void* inputs, int B, void* wtns
 /* same with device-resident buffers (hipMalloc'ed or torch tensors), asynchronous on zkc_ctx_stream */
 int zkc_witness_dev(zkc_ctx* ctx, int nLevels, const void* d_inputs, int B, void* d_wtns, int32_t* d_status /* B */);
 
+/* ---- f3: TEST-ONLY trusted setup with known toxic waste (stand-in for circuit/circuit-compiler.sh:99-136, whose
+ * output proving_key.zkey is a missing blob).  Reads an iden3 .r1cs, writes a snarkjs-format Groth16 .zkey and a
+ * verification_key.json.  Host only; never use the result outside tests and benchmarks. */
+int zkc_setup_from_r1cs(const char* r1cs_path, uint64_t seed, const char* zkey_path, const char* vkey_json_path,
+                        char* err, size_t errlen);
+
 #ifdef __cplusplus
 }
 #endif

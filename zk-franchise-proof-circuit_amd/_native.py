@@ -30,6 +30,7 @@ def load():
     L.zkc_ctx_stream.argtypes = [vp]; L.zkc_ctx_stream.restype = vp
     L.zkc_witness.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, i32p]
     L.zkc_witness_dev.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, vp]
+    L.zkc_setup_from_r1cs.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
     _lib = L
     return L
 
