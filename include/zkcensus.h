@@ -57,6 +57,30 @@ int zkc_witness(zkc_ctx* ctx, int nLevels, const void* inputs, int B, void* wtns
 /* same with device-resident buffers (hipMalloc'ed or torch tensors), asynchronous on zkc_ctx_stream */
 int zkc_witness_dev(zkc_ctx* ctx, int nLevels, const void* d_inputs, int B, void* d_wtns, int32_t* d_status /* B */);
 
+/* ---- f2: proving key residency.  Parses a snarkjs-format Groth16 .zkey (the reference's proving_key.zkey format,
+ * circuit/circuit-compiler.sh:112-131), builds the CSR of section 4 and uploads + pre-shifts the MSM bases. ---- */
+int  zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, zkc_zkey** out);
+void zkc_zkey_free(zkc_zkey* zk);
+int  zkc_zkey_info(const zkc_zkey* zk, uint32_t* nVars, uint32_t* nPublic, uint32_t* domainSize);
+
+/* ---- a2-a7: Groth16 prove (replaces snarkjs groth16.prove / rapidsnark groth16_prover internals).
+ * wtns   : nWitness x 32 B standard form (the payload of .wtns section 2), host (zkc_prove) or device (zkc_prove_dev)
+ * r, s   : the two blinding scalars, 32 B LE, < field order.  snarkjs/rapidsnark draw them at random; they are explicit
+ *          here so that identical (zkey, wtns, r, s) gives identical bytes on every backend (SURVEY.md hard part 3).
+ * proof  : A (64) | B (128) | C (64), affine, standard form.   public_out : nPublic x 32 B (may be NULL). */
+int zkc_prove(zkc_zkey* zk, const void* wtns, uint32_t nWitness, const uint8_t r[32], const uint8_t s[32],
+              uint8_t proof[256], uint8_t* public_out);
+int zkc_prove_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, const uint8_t r[32], const uint8_t s[32],
+                  uint8_t proof[256], uint8_t* public_out);
+
+/* ---- test hooks (stage outputs for parity tests against the oracle; not part of the drop-in surface) ----
+ * zkc_debug_stage: stage 0 -> A_w | B_w | C_w after buildABC (3 x domainSize x 32 B, Montgomery form);
+ *                  stage 1 -> joinABC output (A'B' - C') on the odd coset (domainSize x 32 B, standard form).
+ * zkc_msm_debug  : one MSM over zkey section which (0=A 1=B1 2=B2 3=C 4=H) with caller scalars (device, standard form);
+ *                  host_out = affine point in standard form (64 B, or 128 B for B2). */
+int zkc_debug_stage(zkc_zkey* zk, const void* d_wtns, int stage, void* host_out);
+int zkc_msm_debug(zkc_zkey* zk, int which, const void* d_scalars, uint32_t count, void* host_out);
+
 /* ---- f3: TEST-ONLY trusted setup with known toxic waste (stand-in for circuit/circuit-compiler.sh:99-136, whose
  * output proving_key.zkey is a missing blob).  Reads an iden3 .r1cs, writes a snarkjs-format Groth16 .zkey and a
  * verification_key.json.  Host only; never use the result outside tests and benchmarks. */

@@ -1,0 +1,118 @@
+"""GPU parity of the proving stages (through the C ABI) against the CPU oracle: buildABC, NTT/joinABC, every MSM,
+and whole proofs with injected (r, s) -- identical bytes, and accepted by the oracle's pairing verifier."""
+import json, os, random, sys
+import pytest
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(ol.ROOT, 'tools'))
+R = ol.R
+RINV = pow(1 << 256, -1, R)
+
+
+@pytest.fixture(scope='module')
+def env():
+    import torch, zkcensus_amd
+    from zkcensus_amd import setup
+    ctx = zkcensus_amd.Context(0)
+    keys = {}
+
+    def get(nl):
+        if nl not in keys:
+            _, zp, vp = setup.ensure_test_artifacts(nl)
+            zk = open(zp, 'rb').read()
+            keys[nl] = (zk, zkcensus_amd.ProvingKey(ctx, zk), json.load(open(vp)))
+        return keys[nl]
+    yield ctx, get, torch
+    for _, pk, _ in keys.values():
+        pk.close()
+    ctx.close()
+
+
+def dev_bytes(torch, b):
+    import numpy as np
+    return torch.from_numpy(np.frombuffer(bytes(b), dtype=np.uint8).copy()).cuda()
+
+
+def voter_witness(nl, seed):
+    from census_gen import random_voter
+    rng = random.Random(seed)
+    v = random_voter(rng, ol.poseidon, nLevels=nl, depth_c=min(nl, 7), depth_s=min(nl, 5))
+    rc, w = ol.witness(v, nLevels=nl)
+    assert rc == 0
+    return v, w
+
+
+def test_build_abc_and_h_evals_nl10(env):
+    ctx, get, torch = env
+    zk, pk, _ = get(10)
+    _, w = voter_witness(10, 1)
+    dw = dev_bytes(torch, w)
+    n = pk.domain_size
+    got = pk.debug_stage(dw.data_ptr(), 0)
+    A, B, C = ol.build_abc(zk, w)
+    def demont(b):   # Montgomery bytes -> standard ints
+        return [int.from_bytes(b[32 * i:32 * i + 32], 'little') * RINV % R for i in range(len(b) // 32)]
+    ga, gb, gc = demont(got[:32 * n]), demont(got[32 * n:64 * n]), demont(got[64 * n:])
+    std = lambda b: [int.from_bytes(b[32 * i:32 * i + 32], 'little') for i in range(n)]
+    assert ga == std(A) and gb == std(B) and gc == std(C)
+    assert pk.debug_stage(dw.data_ptr(), 1) == ol.h_evals(zk, w)
+
+
+def test_each_msm_nl10(env):
+    ctx, get, torch = env
+    zk, pk, _ = get(10)
+    z = ol.zkey_parse(zk)
+    import ctypes
+    rng = random.Random(3)
+    _, w = voter_witness(10, 2)
+    sections = [(0, z.pointsA, pk.n_vars, 64), (1, z.pointsB1, pk.n_vars, 64), (2, z.pointsB2, pk.n_vars, 128),
+                (3, z.pointsC, pk.n_vars - pk.n_public - 1, 64), (4, z.pointsH, pk.domain_size, 64)]
+    q, qinv = ol.Q, pow(1 << 256, -1, ol.Q)
+    for which, ptr, cnt, psz in sections:
+        raw = ctypes.string_at(ptr, cnt * psz)         # Montgomery coordinates as stored in the zkey
+        std = b''.join((int.from_bytes(raw[32 * i:32 * i + 32], 'little') * qinv % q).to_bytes(32, 'little') for i in range(len(raw) // 32))
+        # scalar mix: random field elements, witness-like small values, zeros, r-1
+        sc = [rng.randrange(R) for _ in range(cnt)]
+        for i in range(0, cnt, 7): sc[i] = rng.choice([0, 1, 2, R - 1, (1 << 128) - 1])
+        for i in range(cnt // 2, cnt // 2 + 600): sc[i % cnt] = 1          # a heavy bucket
+        scb = b''.join(x.to_bytes(32, 'little') for x in sc)
+        got = pk.msm_debug(which, dev_bytes(torch, scb).data_ptr(), cnt)
+        exp = ol.msm_g2(std, scb) if which == 2 else ol.msm_g1(std, scb)
+        assert got == exp, 'MSM section %d' % which
+
+
+@pytest.mark.parametrize('nl', [10, 160])
+def test_prove_matches_oracle_and_verifies(env, nl):
+    ctx, get, torch = env
+    zk, pk, vk = get(nl)
+    rng = random.Random(nl)
+    for seed in (11, 12):
+        _, w = voter_witness(nl, seed)
+        r, s = rng.randrange(R), rng.randrange(R)
+        proof, pub = pk.prove(w, r, s)
+        assert pub == w[32:32 * 9]
+        assert ol.verify(vk, pub, proof)
+        if nl == 10 or seed == 11:
+            rc, oproof, opub = ol.prove(zk, w, r, s)
+            assert rc == 0 and oproof == proof and opub == pub
+        bad = bytearray(proof); bad[70] ^= 4
+        assert not ol.verify(vk, pub, bytes(bad))
+
+
+def test_example_voter_end_to_end(env):
+    ctx, get, torch = env
+    zk, pk, vk = get(160)
+    ex = ol.load_json('ref/inputs_example.json')
+    ws, st = ctx.witness([ex])
+    assert st == [0]
+    proof, pub = pk.prove(ws[0], 0x1234567, 0x7654321)
+    assert [str(int.from_bytes(pub[32 * i:32 * i + 32], 'little')) for i in range(8)] == ol.load_json('ref/signals.json')
+    assert ol.verify(vk, pub, proof)
+    # determinism: same (zkey, wtns, r, s) -> same bytes
+    assert pk.prove(ws[0], 0x1234567, 0x7654321)[0] == proof
+    # invalid witness length is reported like snarkjs / rapidsnark do
+    import zkcensus_amd
+    with pytest.raises(zkcensus_amd.ZkcError) as ei:
+        pk.prove(ws[0][:-32], 1, 2)
+    assert ei.value.code == 3 and 'Invalid witness length' in str(ei.value)

@@ -9,7 +9,7 @@ from . import _native
 from ._native import ZkcError
 from .inputs import INPUT_KEYS, flatten_inputs, R_MOD
 
-__all__ = ['Context', 'ZkcError', 'INPUT_KEYS', 'flatten_inputs', 'R_MOD']
+__all__ = ['Context', 'ProvingKey', 'ZkcError', 'INPUT_KEYS', 'flatten_inputs', 'R_MOD']
 
 
 class Context:
@@ -63,3 +63,53 @@ class Context:
 
     def witness_dev(self, d_inputs_ptr, B, d_wtns_ptr, d_status_ptr, nLevels=160):
         self._check(self._lib.zkc_witness_dev(self._h, nLevels, d_inputs_ptr, B, d_wtns_ptr, d_status_ptr))
+
+
+class ProvingKey:
+    """A .zkey made device-resident (include/zkcensus.h zkc_zkey_load).  One proof in flight per handle."""
+
+    def __init__(self, ctx, zkey_bytes):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        h = ctypes.c_void_p()
+        ctx._check(self._lib.zkc_zkey_load(ctx._h, zkey_bytes, len(zkey_bytes), ctypes.byref(h)))
+        self._h = h
+        a, b, c = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        self._lib.zkc_zkey_info(h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+        self.n_vars, self.n_public, self.domain_size = a.value, b.value, c.value
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.zkc_zkey_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _scalar(x):
+        return x if isinstance(x, (bytes, bytearray)) else int(x).to_bytes(32, 'little')
+
+    def prove(self, wtns, r, s):
+        """wtns: n_vars x 32 B standard-form bytes (host).  Returns (proof 256 B, public n_public x 32 B)."""
+        proof = ctypes.create_string_buffer(256); pub = ctypes.create_string_buffer(32 * self.n_public)
+        self.ctx._check(self._lib.zkc_prove(self._h, wtns, len(wtns) // 32, self._scalar(r), self._scalar(s), proof, pub))
+        return proof.raw, pub.raw
+
+    def prove_dev(self, d_wtns_ptr, r, s):
+        proof = ctypes.create_string_buffer(256); pub = ctypes.create_string_buffer(32 * self.n_public)
+        self.ctx._check(self._lib.zkc_prove_dev(self._h, d_wtns_ptr, self.n_vars, self._scalar(r), self._scalar(s), proof, pub))
+        return proof.raw, pub.raw
+
+    def debug_stage(self, d_wtns_ptr, stage):
+        out = ctypes.create_string_buffer((96 if stage == 0 else 32) * self.domain_size)
+        self.ctx._check(self._lib.zkc_debug_stage(self._h, d_wtns_ptr, stage, out))
+        return out.raw
+
+    def msm_debug(self, which, d_scalars_ptr, count):
+        out = ctypes.create_string_buffer(128 if which == 2 else 64)
+        self.ctx._check(self._lib.zkc_msm_debug(self._h, which, d_scalars_ptr, count, out))
+        return out.raw

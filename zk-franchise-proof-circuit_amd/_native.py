@@ -30,6 +30,14 @@ def load():
     L.zkc_ctx_stream.argtypes = [vp]; L.zkc_ctx_stream.restype = vp
     L.zkc_witness.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, i32p]
     L.zkc_witness_dev.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, vp]
+    u8p, u32p = ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32)
+    L.zkc_zkey_load.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(vp)]
+    L.zkc_zkey_free.argtypes = [vp]; L.zkc_zkey_free.restype = None
+    L.zkc_zkey_info.argtypes = [vp, u32p, u32p, u32p]
+    L.zkc_prove.argtypes = [vp, ctypes.c_char_p, ctypes.c_uint32, u8p, u8p, ctypes.c_char_p, ctypes.c_char_p]
+    L.zkc_prove_dev.argtypes = [vp, vp, ctypes.c_uint32, u8p, u8p, ctypes.c_char_p, ctypes.c_char_p]
+    L.zkc_debug_stage.argtypes = [vp, vp, ctypes.c_int, ctypes.c_char_p]
+    L.zkc_msm_debug.argtypes = [vp, ctypes.c_int, vp, ctypes.c_uint32, ctypes.c_char_p]
     L.zkc_setup_from_r1cs.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
     _lib = L
     return L

@@ -82,16 +82,16 @@ ZKC_HD Fp<P> fp_dbl(const Fp<P>& a) { return a + a; }
 
 // Montgomery product a*b/R mod p (CIOS over 32-bit limbs; p < 2^254 keeps every partial sum below 2^(256+32))
 template <class P>
-ZKC_HD Fp<P> operator*(const Fp<P>& a, const Fp<P>& b) {
+ZKC_HD void fp_mul_limbs(uint32_t r[8], const uint32_t a[8], const uint32_t b[8]) {
     uint32_t t[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) t[i] = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         uint64_t c = 0;
-        const uint32_t bi = b.v[i];
+        const uint32_t bi = b[i];
 #pragma unroll
-        for (int j = 0; j < 8; j++) { c += (uint64_t)a.v[j] * bi + t[j]; t[j] = (uint32_t)c; c >>= 32; }
+        for (int j = 0; j < 8; j++) { c += (uint64_t)a[j] * bi + t[j]; t[j] = (uint32_t)c; c >>= 32; }
         c += t[8];                       // < 2^33
         const uint32_t m = t[0] * P::inv;
         uint64_t d = (uint64_t)m * P::p[0] + t[0]; d >>= 32;
@@ -99,12 +99,40 @@ ZKC_HD Fp<P> operator*(const Fp<P>& a, const Fp<P>& b) {
         for (int j = 1; j < 8; j++) { d += (uint64_t)m * P::p[j] + t[j]; t[j - 1] = (uint32_t)d; d >>= 32; }
         d += c; t[7] = (uint32_t)d; t[8] = (uint32_t)(d >> 32);
     }
+#pragma unroll
+    for (int i = 0; i < 8; i++) r[i] = t[i];
+    fp_reduce_once<P>(r);                // result < 2p and t[8] == 0 because 4p < R
+}
+// On the GPU the product is ONE out-of-line routine per field (about a thousand instructions), called with both operands
+// and the result in VGPRs (native <8 x i32> vectors).  Inlining it into every group operation produced 200-300 KB
+// straight-line kernels: far beyond the instruction cache, minutes of compile time, and on gfx950/ROCm 7.2 an
+// out-of-line G2 addition built that way never terminated (tools/probe/, DESIGN.md "field multiplication").
+typedef uint32_t zkc_u32x8 __attribute__((ext_vector_type(8)));
+template <class P>
+__device__ __noinline__ zkc_u32x8 fp_mul_dev(zkc_u32x8 a, zkc_u32x8 b) {
+    uint32_t x[8], y[8], r[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { x[i] = a[i]; y[i] = b[i]; }
+    fp_mul_limbs<P>(r, x, y);
+    zkc_u32x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o[i] = r[i];
+    return o;
+}
+template <class P>
+__device__ __forceinline__ Fp<P> operator*(const Fp<P>& a, const Fp<P>& b) {
+    zkc_u32x8 x, y;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { x[i] = a.v[i]; y[i] = b.v[i]; }
+    zkc_u32x8 o = fp_mul_dev<P>(x, y);
     Fp<P> r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = t[i];
-    fp_reduce_once<P>(r.v);              // result < 2p and t[8] == 0 because 4p < R
+    for (int i = 0; i < 8; i++) r.v[i] = o[i];
     return r;
 }
+// host overload (setup, finalize, table generation): plain inline code
+template <class P>
+__host__ inline Fp<P> operator*(const Fp<P>& a, const Fp<P>& b) { Fp<P> r; fp_mul_limbs<P>(r.v, a.v, b.v); return r; }
 template <class P>
 ZKC_HD Fp<P> fp_sqr(const Fp<P>& a) { return a * a; }
 

@@ -1,0 +1,120 @@
+// zkc_ntt.hip -- K3/K3a/K7: sparse mat-vec (buildABC), radix-2 NTT over BN254 Fr and the joinABC pointwise pass.
+//
+// Replaces snarkjs groth16_prove.js buildABC1 / Fr.ifft / batchApplyKey / Fr.fft / joinABC (reached from
+// ts_inputs/src/example.ts:358-362) and rapidsnark's equivalents (zk_census_test.go:89).
+//
+// NTT plan: decimation-in-time over bit-reversed input, log2(n) stages processed in passes of at most 9 stages; a
+// pass keeps its tile (2^b "mid" indices x LO_T neighbouring "lo" indices) resident in LDS, so a 2^17 transform
+// makes two HBM round trips (9 + 8 stages) instead of seventeen.  The bit reversal is folded into the first pass'
+// loads and the 1/n * g^i coset scaling of the inverse transform into the last pass' stores.
+// All vectors are Montgomery-form Fr, 32 B per element, natural order in HBM.
+#include "zkc_internal.h"
+#include "zkc_prover.h"
+
+namespace zkc {
+
+__device__ __forceinline__ Fr ld_fr(const Fr* p) {
+    const uint4* d = reinterpret_cast<const uint4*>(p); uint4 a = d[0], b = d[1];
+    Fr r; r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w; return r;
+}
+__device__ __forceinline__ void st_fr(Fr* p, const Fr& r) {
+    uint4* d = reinterpret_cast<uint4*>(p);
+    d[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]); d[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+
+// ---- buildABC1: rows [0,n) = A, [n,2n) = B ; out = sum coef * w[signal].  coef is stored as val*R^2 (the .zkey
+// convention) so one Montgomery product with the standard-form witness lands in Montgomery form. ----
+extern "C" __global__ void __launch_bounds__(256)
+zkc_matvec(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, const Fr* __restrict__ val,
+           const Fr* __restrict__ wtns_std, Fr* __restrict__ out, int nrows) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    Fr acc = Fr::zero();
+    for (uint32_t k = rowptr[r], e = rowptr[r + 1]; k < e; k++) acc = acc + ld_fr(val + k) * ld_fr(wtns_std + col[k]);
+    st_fr(out + r, acc);
+}
+// c = a * b
+extern "C" __global__ void __launch_bounds__(256)
+zkc_pointwise_mul(const Fr* __restrict__ a, const Fr* __restrict__ b, Fr* __restrict__ c, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) st_fr(c + i, ld_fr(a + i) * ld_fr(b + i));
+}
+// joinABC: p = a*b - c, written in STANDARD form (the H-MSM reads scalar digits from it)
+extern "C" __global__ void __launch_bounds__(256)
+zkc_join_abc(const Fr* __restrict__ a, const Fr* __restrict__ b, const Fr* __restrict__ c, uint32_t* __restrict__ p_std, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr r = ld_fr(a + i) * ld_fr(b + i) - ld_fr(c + i);
+    uint32_t s[8]; fp_to_std<FrParams>(s, r);
+    uint4* d = reinterpret_cast<uint4*>(p_std + 8 * (size_t)i);
+    d[0] = make_uint4(s[0], s[1], s[2], s[3]); d[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+
+// ---- one NTT pass: stages s0+1 .. s0+b of a DIT transform of size 2^logn ----
+// index i = (hi | mid | lo), mid = b bits at position s0, lo = s0 bits.  A block owns tile (hi, lo in [lo0, lo0+LO_T)).
+// tw[j] = w_n^j (or w_n^-j), j < n/2.  first pass (s0 == 0): loads src[bitrev(i)]; otherwise loads src[i] (src may == dst).
+// scale != nullptr: multiply element i by scale[i] when storing (used on the last pass of the inverse transform).
+constexpr int NTT_TILE = 1024;        // elements per block tile = 32 KiB of LDS
+extern "C" __global__ void __launch_bounds__(256)
+zkc_ntt_pass(const Fr* __restrict__ src, Fr* __restrict__ dst, const Fr* __restrict__ tw, const Fr* __restrict__ scale,
+             int logn, int s0, int b, int first) {
+    extern __shared__ uint4 lds4[];
+    Fr* tile = reinterpret_cast<Fr*>(lds4);
+    const int mid_n = 1 << b;
+    const int lo_bits = s0;
+    const int lo_t = (NTT_TILE >> b) < (1 << lo_bits) ? (NTT_TILE >> b) : (1 << lo_bits);   // neighbouring lo per tile
+    const int tiles_per_hi = (1 << lo_bits) / lo_t;
+    const int hi = blockIdx.x / tiles_per_hi, lo0 = (blockIdx.x % tiles_per_hi) * lo_t;
+    const int elems = mid_n * lo_t;
+    const size_t base = (size_t)hi << (s0 + b);
+    // load: LDS slot = mid * lo_t + l  <->  global index base + mid * 2^s0 + lo0 + l
+    for (int e = threadIdx.x; e < elems; e += blockDim.x) {
+        const int mid = e / lo_t, l = e - mid * lo_t;
+        size_t gi = base + ((size_t)mid << s0) + lo0 + l;
+        if (first) gi = __brev((unsigned)gi) >> (32 - logn);
+        tile[e] = ld_fr(src + gi);
+    }
+    __syncthreads();
+    for (int t = 1; t <= b; t++) {
+        const int half = 1 << (t - 1);
+        const int s = s0 + t;                                     // global stage, m = 2^s
+        for (int q = threadIdx.x; q < elems / 2; q += blockDim.x) {
+            const int l = q % lo_t, pr = q / lo_t;                // pr indexes the (mid) butterfly pair
+            const int j = pr & (half - 1), blk = pr >> (t - 1);
+            const int m0 = (blk << t) + j, m1 = m0 + half;
+            const unsigned k = ((unsigned)j << s0) + lo0 + l;     // butterfly index within the half-block of size 2^(s-1)
+            const Fr w = ld_fr(tw + ((size_t)k << (logn - s)));
+            Fr u = tile[m0 * lo_t + l], v = tile[m1 * lo_t + l] * w;
+            tile[m0 * lo_t + l] = u + v; tile[m1 * lo_t + l] = u - v;
+        }
+        __syncthreads();
+    }
+    for (int e = threadIdx.x; e < elems; e += blockDim.x) {
+        const int mid = e / lo_t, l = e - mid * lo_t;
+        const size_t gi = base + ((size_t)mid << s0) + lo0 + l;
+        Fr r = tile[e];
+        if (scale) r = r * ld_fr(scale + gi);
+        st_fr(dst + gi, r);
+    }
+}
+
+// Full transform src -> dst (src is preserved unless src == dst is not allowed for the first pass).
+int ntt_run(zkc_ctx* ctx, const Fr* src, Fr* dst, const Fr* tw, const Fr* scale, int logn) {
+    int s0 = 0; bool first = true;
+    while (s0 < logn) {
+        int b = logn - s0 < 9 ? logn - s0 : 9;
+        if (logn - s0 > 9 && logn - s0 < 18) b = (logn - s0 + 1) / 2;       // balance the last two passes (17 -> 9 + 8)
+        if (b > 9) b = 9;
+        const int lo_t = (NTT_TILE >> b) < (1 << s0) ? (NTT_TILE >> b) : (1 << s0);
+        const int nblocks = (1 << logn) / ((1 << b) * lo_t);
+        const bool last = s0 + b == logn;
+        hipLaunchKernelGGL(zkc_ntt_pass, dim3(nblocks), dim3(256), (size_t)(1 << b) * lo_t * sizeof(Fr), ctx->stream,
+                           first ? src : dst, dst, tw, last ? scale : nullptr, logn, s0, b, first ? 1 : 0);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, std::string("zkc_ntt_pass: ") + hipGetErrorString(e));
+        s0 += b; first = false;
+    }
+    return ZKC_OK;
+}
+
+}  // namespace zkc
