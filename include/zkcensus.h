@@ -81,6 +81,17 @@ int zkc_prove_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, const uin
 int zkc_debug_stage(zkc_zkey* zk, const void* d_wtns, int stage, void* host_out);
 int zkc_msm_debug(zkc_zkey* zk, int which, const void* d_scalars, uint32_t count, void* host_out);
 
+/* ---- f1 support: batched Poseidon over BN254 Fr (circomlib parameters), n_inputs in {2,3,4}; host buffers,
+ * inputs B x n_inputs x 32 B, out B x 32 B.  The census builder hashes whole tree levels with it. ---- */
+int zkc_poseidon_batch(zkc_ctx* ctx, int n_inputs, const void* inputs, size_t B, void* out);
+
+/* ---- measurement: HIP-event timing per kernel category on zkc_ctx_stream (bit i of mask enables category i) ----
+ * 0 witness, 1 buildABC mat-vec, 2 NTT+joinABC, 3 MSM digits+sort+offsets, 4 MSM bucket accumulation G1, 5 same G2,
+ * 6 MSM heavy+reduce+final.  zkc_profile_read returns the summed duration, the number of bracketed launches and the
+ * ALGORITHMIC bytes those launches processed. */
+int zkc_profile_enable(zkc_ctx* ctx, uint32_t mask);
+int zkc_profile_read(zkc_ctx* ctx, int category, double* total_ms, uint64_t* launches, uint64_t* alg_bytes);
+
 /* ---- f3: TEST-ONLY trusted setup with known toxic waste (stand-in for circuit/circuit-compiler.sh:99-136, whose
  * output proving_key.zkey is a missing blob).  Reads an iden3 .r1cs, writes a snarkjs-format Groth16 .zkey and a
  * verification_key.json.  Host only; never use the result outside tests and benchmarks. */

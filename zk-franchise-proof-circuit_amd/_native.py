@@ -38,6 +38,9 @@ def load():
     L.zkc_prove_dev.argtypes = [vp, vp, ctypes.c_uint32, u8p, u8p, ctypes.c_char_p, ctypes.c_char_p]
     L.zkc_debug_stage.argtypes = [vp, vp, ctypes.c_int, ctypes.c_char_p]
     L.zkc_msm_debug.argtypes = [vp, ctypes.c_int, vp, ctypes.c_uint32, ctypes.c_char_p]
+    L.zkc_poseidon_batch.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+    L.zkc_profile_enable.argtypes = [vp, ctypes.c_uint32]
+    L.zkc_profile_read.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     L.zkc_setup_from_r1cs.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
     _lib = L
     return L

@@ -1,0 +1,111 @@
+"""Synthetic census / voter generator: arbo-compatible Poseidon sparse Merkle trees with sibling
+extraction, SIK and nullifier derivation.  Mirrors internal/helpers.go:36-85 (GenTree: arbo.NewTree{Poseidon}, Add,
+GenProof, UnpackSiblings, zero padding) and internal/inputs.go:33-98 (MockInputs); encodings per
+ts_inputs/src/inputs.ts:55-88.  All hashing runs on the GPU through zkc_poseidon_batch, one call per tree level.
+
+arbo tree semantics: leaf = H(key, value, 1); node = H(left, right); path bit i = bit i (LSB first) of
+the key; an empty subtree is 0; a subtree holding a single leaf is that leaf's hash (the leaf sits at the first level
+where its path is unique)."""
+import ctypes
+import hashlib
+from .inputs import R_MOD, bytes_to_arbo
+
+ELECTION_ID_HEX = '7faeab7a7d250527d614e952ae8e446825bd1124c6def410844c7c383d1519a6'   # internal/inputs.go:60, example.ts:341
+
+
+def poseidon_batch(ctx, rows):
+    """rows: list of equal-length tuples of ints (2, 3 or 4 inputs) -> list of ints, hashed on the GPU."""
+    if not rows:
+        return []
+    n = len(rows[0])
+    buf = b''.join(int(x).to_bytes(32, 'little') for r in rows for x in r)
+    out = ctypes.create_string_buffer(32 * len(rows))
+    ctx._check(ctx._lib.zkc_poseidon_batch(ctx._h, n, buf, len(rows), out))
+    raw = out.raw
+    return [int.from_bytes(raw[32 * i:32 * i + 32], 'little') for i in range(len(rows))]
+
+
+class SparseMerkleTree:
+    """Static build over a list of (key, value) pairs; records for every leaf its sibling path."""
+
+    def __init__(self, ctx, keys, values, max_levels=160):
+        assert len(set(keys)) == len(keys), 'duplicate keys'
+        self.n = len(keys)
+        leaf_hash = poseidon_batch(ctx, [(k, v, 1) for k, v in zip(keys, values)])
+        # top-down split into the radix trie; node = (depth, members) ; children by key bit `depth`
+        nodes = []            # (depth, left_id, right_id, members)   id -1 = empty, -(2+i) = single leaf i
+        def ref(members, depth):
+            if not members:
+                return -1
+            if len(members) == 1:
+                return -(2 + members[0])
+            if depth >= max_levels:
+                raise ValueError('keys collide on the first %d bits' % max_levels)
+            nid = len(nodes); nodes.append(None)
+            l = [m for m in members if not (keys[m] >> depth) & 1]; r = [m for m in members if (keys[m] >> depth) & 1]
+            nodes[nid] = [depth, None, None, members]
+            pending.append((nid, l, r, depth))
+            return nid
+        pending = []
+        import sys
+        root_ref = ref(list(range(self.n)), 0)
+        while pending:                                   # iterative expansion (no recursion depth issues)
+            nid, l, r, depth = pending.pop()
+            nodes[nid][1] = ref(l, depth + 1); nodes[nid][2] = ref(r, depth + 1)
+        # bottom-up hashing, one GPU batch per depth
+        val = {}
+        def value_of(rid):
+            return 0 if rid == -1 else leaf_hash[-rid - 2] if rid < -1 else val[rid]
+        by_depth = {}
+        for nid, nd in enumerate(nodes):
+            by_depth.setdefault(nd[0], []).append(nid)
+        for depth in sorted(by_depth, reverse=True):
+            ids = by_depth[depth]
+            hs = poseidon_batch(ctx, [(value_of(nodes[i][1]), value_of(nodes[i][2])) for i in ids])
+            for i, h in zip(ids, hs):
+                val[i] = h
+        self.root = value_of(root_ref)
+        # sibling paths
+        self.siblings = [[] for _ in range(self.n)]
+        for nd in nodes:
+            depth, lref, rref, members = nd
+            lv, rv = value_of(lref), value_of(rref)
+            for m in members:
+                sib = lv if (keys[m] >> depth) & 1 else rv
+                path = self.siblings[m]
+                while len(path) < depth:
+                    path.append(0)
+                if len(path) == depth:
+                    path.append(sib)
+                else:
+                    path[depth] = sib
+        for p in self.siblings:                          # drop trailing zeros (GenProof packs only used levels)
+            while p and p[-1] == 0:
+                p.pop()
+
+
+def synthetic_census(ctx, n_voters, nLevels=160, election_id_hex=ELECTION_ID_HEX):
+    """deterministic census of n_voters; returns the list of 12-key circuit input objects
+    (decimal strings, siblings zero-padded to nLevels+1 like internal/inputs.go:52,72)."""
+    eid = bytes_to_arbo(bytes.fromhex(election_id_hex))
+    u32 = lambda i: int(i).to_bytes(4, 'little')
+    address = [int.from_bytes(hashlib.sha256(b'addr' + u32(i)).digest()[:20], 'little') for i in range(n_voters)]
+    password = [int.from_bytes(hashlib.sha256(b'pw' + u32(i)).digest()[:11], 'big') % R_MOD for i in range(n_voters)]
+    signature = [int.from_bytes(hashlib.sha256(b'sigA' + u32(i)).digest() + hashlib.sha256(b'sigB' + u32(i)).digest(), 'big') % R_MOD
+                 for i in range(n_voters)]
+    avail = [1 + (i % 100) for i in range(n_voters)]
+    sik = poseidon_batch(ctx, list(zip(address, password, signature)))                     # census.circom:74-77
+    nullifier = poseidon_batch(ctx, [(s, p, int(eid[0]), int(eid[1])) for s, p in zip(signature, password)])   # :105-109
+    census = SparseMerkleTree(ctx, address, avail, nLevels)
+    siktree = SparseMerkleTree(ctx, address, sik, nLevels)
+    pad = lambda s: [str(x) for x in s] + ['0'] * (nLevels + 1 - len(s))
+    out = []
+    for i in range(n_voters):
+        vh = bytes_to_arbo(avail[i].to_bytes((avail[i].bit_length() + 7) // 8 or 1, 'big'))   # internal/inputs.go:81
+        out.append({
+            'electionId': list(eid), 'nullifier': str(nullifier[i]), 'availableWeight': str(avail[i]), 'voteHash': vh,
+            'sikRoot': str(siktree.root), 'censusRoot': str(census.root),
+            'address': str(address[i]), 'password': str(password[i]), 'signature': str(signature[i]), 'voteWeight': '1',
+            'censusSiblings': pad(census.siblings[i]), 'sikSiblings': pad(siktree.siblings[i]),
+        })
+    return out

@@ -23,6 +23,60 @@ int zkc_ensure(zkc_ctx* ctx, void** p, size_t* cur, size_t need) {
     return ZKC_OK;
 }
 
+extern "C" __global__ void zkc_poseidon_batch_kernel(PoseidonTable tab, const uint32_t* in, uint32_t* out, int nin, size_t B);
+
+static hipEvent_t prof_event(zkc_ctx* ctx) {
+    if (!ctx->prof.free_events.empty()) { hipEvent_t e = ctx->prof.free_events.back(); ctx->prof.free_events.pop_back(); return e; }
+    hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
+}
+zkc_prof_scope::zkc_prof_scope(zkc_ctx* c, int category, uint64_t alg_bytes) : ctx(c), cat(category) {
+    on = c && ((c->prof.mask >> category) & 1u);
+    if (!on) return;
+    a = prof_event(c); b = prof_event(c);
+    c->prof.bytes[cat] += alg_bytes; c->prof.launches[cat] += 1;
+    (void)hipEventRecord(a, c->stream);
+}
+zkc_prof_scope::~zkc_prof_scope() {
+    if (!on) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->prof.pending.push_back({a, b, cat});
+}
+extern "C" int zkc_profile_enable(zkc_ctx* ctx, uint32_t mask) {
+    if (!ctx) return ZKC_ERR_BAD_ARG;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& r : ctx->prof.pending) { ctx->prof.free_events.push_back(r.a); ctx->prof.free_events.push_back(r.b); }
+    ctx->prof.pending.clear();
+    for (int i = 0; i < ZKC_PROF_NCAT; i++) { ctx->prof.ms[i] = 0; ctx->prof.launches[i] = 0; ctx->prof.bytes[i] = 0; }
+    ctx->prof.mask = mask;
+    return ZKC_OK;
+}
+extern "C" int zkc_profile_read(zkc_ctx* ctx, int cat, double* total_ms, uint64_t* launches, uint64_t* alg_bytes) {
+    if (!ctx || cat < 0 || cat >= ZKC_PROF_NCAT) return ZKC_ERR_BAD_ARG;
+    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& r : ctx->prof.pending) {
+        float ms = 0; (void)hipEventElapsedTime(&ms, r.a, r.b); ctx->prof.ms[r.cat] += ms;
+        ctx->prof.free_events.push_back(r.a); ctx->prof.free_events.push_back(r.b);
+    }
+    ctx->prof.pending.clear();
+    if (total_ms) *total_ms = ctx->prof.ms[cat]; if (launches) *launches = ctx->prof.launches[cat]; if (alg_bytes) *alg_bytes = ctx->prof.bytes[cat];
+    return ZKC_OK;
+}
+
+extern "C" int zkc_poseidon_batch(zkc_ctx* ctx, int n_inputs, const void* inputs, size_t B, void* out) {
+    if (!ctx || !inputs || !out || n_inputs < 2 || n_inputs > 4 || B == 0) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_poseidon_batch: bad argument");
+    ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = zkc_ensure(ctx, &ctx->d_scratch_in, &ctx->scratch_in_sz, B * n_inputs * 32))) return rc;
+    if ((rc = zkc_ensure(ctx, &ctx->d_scratch_out, &ctx->scratch_out_sz, B * 32))) return rc;
+    ZKC_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_scratch_in, inputs, B * n_inputs * 32, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(zkc_poseidon_batch_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, ctx->stream, ctx->ptab, (const uint32_t*)ctx->d_scratch_in,
+                       (uint32_t*)ctx->d_scratch_out, n_inputs, B);
+    ZKC_HIP_CHECK(ctx, hipGetLastError());
+    ZKC_HIP_CHECK(ctx, hipMemcpyAsync(out, ctx->d_scratch_out, B * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKC_OK;
+}
+
 __global__ void zkc_status_combine(const int32_t* __restrict__ s3, int32_t* __restrict__ s, int B) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -77,6 +131,8 @@ extern "C" void zkc_ctx_destroy(zkc_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto& r : ctx->prof.pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : ctx->prof.free_events) (void)hipEventDestroy(e);
     for (auto& kv : ctx->tmpl) (void)hipFree(kv.second);
     if (ctx->d_ptab_mem) (void)hipFree(ctx->d_ptab_mem);
     if (ctx->d_scratch_in) (void)hipFree(ctx->d_scratch_in);
@@ -114,6 +170,7 @@ static int witness_dev3(zkc_ctx* ctx, const WitnessLayout& L, const void* d_inpu
     uint32_t* tmpl; int rc = get_template(ctx, L, &tmpl); if (rc) return rc;
     const size_t total = (size_t)L.nWires * 2 * (size_t)B;
     int fill_blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 16);
+    zkc_prof_scope _ps(ctx, ZKC_PROF_WITNESS, (uint64_t)B * ((uint64_t)L.nWires + L.nInputs) * 32);
     hipLaunchKernelGGL(zkc_witness_fill, dim3(fill_blocks), dim3(256), 0, ctx->stream, (const uint4*)tmpl, (uint4*)d_wtns, L.nWires, B);
     ZKC_HIP_CHECK(ctx, hipGetLastError());
     // lanes of a wave share the chain kind; ceil so that kinds start on wave boundaries only when B % 64 == 0 (harmless otherwise)

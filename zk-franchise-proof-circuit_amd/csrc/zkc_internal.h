@@ -11,6 +11,15 @@
     do { hipError_t _e = (call); if (_e != hipSuccess) {                                                     \
         return zkc_fail((ctx), ZKC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); } } while (0)
 
+// Per-kernel-category HIP-event timing on the context's own stream (bench.py's roofline figure reads it).
+enum { ZKC_PROF_WITNESS = 0, ZKC_PROF_MATVEC = 1, ZKC_PROF_NTT = 2, ZKC_PROF_MSM_SORT = 3, ZKC_PROF_MSM_ACC_G1 = 4, ZKC_PROF_MSM_ACC_G2 = 5,
+       ZKC_PROF_MSM_REDUCE = 6, ZKC_PROF_NCAT = 8 };
+struct zkc_prof {
+    uint32_t mask = 0;
+    struct Rec { hipEvent_t a, b; int cat; };
+    std::vector<Rec> pending; std::vector<hipEvent_t> free_events;
+    double ms[ZKC_PROF_NCAT] = {0}; uint64_t launches[ZKC_PROF_NCAT] = {0}; uint64_t bytes[ZKC_PROF_NCAT] = {0};
+};
 struct zkc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -23,7 +32,14 @@ struct zkc_ctx {
     void* d_scratch_out = nullptr; size_t scratch_out_sz = 0;
     int32_t* d_status3 = nullptr; size_t status3_n = 0;
     int32_t* d_status = nullptr; size_t status_n = 0;
+    zkc_prof prof;
 };
 
 int zkc_fail(zkc_ctx* ctx, int code, const std::string& msg);
 int zkc_ensure(zkc_ctx* ctx, void** p, size_t* cur, size_t need);
+// RAII bracket: records two events around the launches made while it is alive when category `cat` is enabled
+struct zkc_prof_scope {
+    zkc_ctx* ctx; int cat; hipEvent_t a = nullptr, b = nullptr; bool on;
+    zkc_prof_scope(zkc_ctx* c, int category, uint64_t alg_bytes);
+    ~zkc_prof_scope();
+};

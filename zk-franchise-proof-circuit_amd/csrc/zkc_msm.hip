@@ -198,6 +198,11 @@ template <class F>
 static int msm_run(zkc_zkey* zk, const Affine<F>* table, const uint32_t* d_scalars, uint32_t count, int slot) {
     zkc_ctx* ctx = zk->ctx; hipStream_t st = ctx->stream;
     const uint32_t total = count * MSM_NW;
+    constexpr bool kG2 = sizeof(F) == sizeof(Fq2);
+    const uint64_t alg_bytes = (uint64_t)count * (sizeof(Affine<F>) + 32);      // bases + scalars of this MSM
+    uint32_t* heavy_count = zk->d_heavy + MSM_MAX_HEAVY;
+    {
+    zkc_prof_scope _ps(ctx, ZKC_PROF_MSM_SORT, 0);
     hipLaunchKernelGGL(zkc_msm_digits, dim3((count + 255) / 256), dim3(256), 0, st, d_scalars, count, zk->d_keys, zk->d_vals);
     ZKC_LAUNCH_CHECK(zk, "zkc_msm_digits");
     int end_bit = 1; while ((1u << end_bit) <= (uint32_t)MSM_NB) end_bit++;
@@ -208,15 +213,19 @@ static int msm_run(zkc_zkey* zk, const Affine<F>* table, const uint32_t* d_scala
     e = rocprim::radix_sort_pairs(zk->d_sort_tmp, need, zk->d_keys, zk->d_keys2, zk->d_vals, zk->d_vals2, total, 0, end_bit, st);
     if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, "radix_sort_pairs");
     ZKC_LAUNCH_CHECK(zk, "radix_sort_pairs");
-    uint32_t* heavy_count = zk->d_heavy + MSM_MAX_HEAVY;
     hipLaunchKernelGGL(zkc_msm_offsets, dim3((MSM_NB + 1 + 255) / 256), dim3(256), 0, st, zk->d_keys2, total, zk->d_off, heavy_count);
     ZKC_LAUNCH_CHECK(zk, "zkc_msm_offsets");
+    }
     XYZZ<F>* buckets = reinterpret_cast<XYZZ<F>*>(zk->d_buckets);
     XYZZ<F>* partial = reinterpret_cast<XYZZ<F>*>(zk->d_partial);
     XYZZ<F>* results = reinterpret_cast<XYZZ<F>*>(reinterpret_cast<uint8_t*>(zk->d_results) + (size_t)slot * sizeof(XYZZ<Fq2>));
+    {
+    zkc_prof_scope _ps(ctx, kG2 ? ZKC_PROF_MSM_ACC_G2 : ZKC_PROF_MSM_ACC_G1, alg_bytes);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate<F>), dim3((MSM_NB + 127) / 128), dim3(128), 0, st, table, zk->d_vals2, zk->d_off,
                        buckets, zk->d_heavy, heavy_count);
     ZKC_LAUNCH_CHECK(zk, "zkc_msm_accumulate");
+    }
+    zkc_prof_scope _pr(ctx, ZKC_PROF_MSM_REDUCE, 0);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_heavy<F>), dim3(256), dim3(256), 256 * sizeof(XYZZ<F>), st, table, zk->d_vals2, zk->d_off, buckets,
                        zk->d_heavy, heavy_count);
     ZKC_LAUNCH_CHECK(zk, "zkc_msm_heavy");

@@ -149,10 +149,14 @@ extern "C" int zkc_zkey_info(const zkc_zkey* zk, uint32_t* nVars, uint32_t* nPub
 // stages a2..a4: leaves (A'B' - C') on the odd coset in zk->d_p (standard form) and the intermediate vectors in d_a/d_b/d_c
 static int h_evals_dev(zkc_zkey* zk, const uint32_t* d_wtns) {
     zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n; hipStream_t st = ctx->stream;
+    {
+    zkc_prof_scope _ps(ctx, ZKC_PROF_MATVEC, (uint64_t)zk->nCoeffs * 68 + 3ull * n * 32);
     hipLaunchKernelGGL(zkc_matvec, dim3((2 * n + 255) / 256), dim3(256), 0, st, zk->d_rowptr, zk->d_col, zk->d_val, (const Fr*)d_wtns, zk->d_a, (int)(2 * n));
     ZKC_HIP_CHECK(ctx, hipGetLastError());
     hipLaunchKernelGGL(zkc_pointwise_mul, dim3((n + 255) / 256), dim3(256), 0, st, zk->d_a, zk->d_b, zk->d_c, (int)n);
     ZKC_HIP_CHECK(ctx, hipGetLastError());
+    }
+    zkc_prof_scope _pn(ctx, ZKC_PROF_NTT, 6ull * 2 * n * 32 + 4ull * n * 32);   // 6 transforms r+w, joinABC
     Fr* v[3] = {zk->d_a, zk->d_b, zk->d_c};
     for (int k = 0; k < 3; k++) {
         int rc = ntt_run(ctx, v[k], zk->d_t, zk->d_tw_inv, zk->d_coset, (int)zk->logn); if (rc) return rc;

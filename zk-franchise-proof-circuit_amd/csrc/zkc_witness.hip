@@ -101,7 +101,7 @@ __device__ Fr poseidon_trace(const Fr* in, unsigned cmask, const PoseidonTable& 
             st[i] = acc;
         }
     }
-    if (LAYOUT == 1 && on) e.put(blk + 30, st[4]);                    // mix[3].out[4]
+    if constexpr (LAYOUT == 1) { if (on) e.put(blk + 30, st[4]); }                    // mix[3].out[4]
     // partial rounds
     for (int r = 0; r < RP; r++) {
         const Fr* __restrict__ Sr = S + (2 * T - 1) * r;
@@ -116,7 +116,7 @@ __device__ Fr poseidon_trace(const Fr* in, unsigned cmask, const PoseidonTable& 
         for (int i = 1; i < T; i++) st[i] = st[i] + in0 * Sr[T + i - 1];
         st[0] = n0;
         if (on) {
-            if (LAYOUT == 0) e.put(blk + oMS + r, st[0]);
+            if constexpr (LAYOUT == 0) e.put(blk + oMS + r, st[0]);
             else {
                 if (r <= 56) e.put(blk + 35 + r, st[4]);
                 else if (r == 57) { e.put(blk + 92, st[1]); e.put(blk + 93, st[2]); e.put(blk + 94, st[3]); e.put(blk + 95, st[4]); }
@@ -341,6 +341,20 @@ zkc_witness_chains(WitnessLayout L, PoseidonTable tab, const uint32_t* __restric
         else if (r != load_std(root)) st = kind == 0 ? ZKC_W_ERR_CENSUS_ROOT : ZKC_W_ERR_SIK_ROOT;
     }
     status[(size_t)b * 3 + kind] = st;
+}
+
+// Batched Poseidon (t = nin+1 in {3,4,5}), one lane per hash; standard-form in/out.  Used by the census builder (f1).
+extern "C" __global__ void __launch_bounds__(64)
+zkc_poseidon_batch_kernel(PoseidonTable tab, const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int nin, size_t B) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    Emit none{nullptr};
+    Fr x[4];
+    for (int k = 0; k < nin; k++) x[k] = load_std(in + 8 * (i * nin + k));
+    Fr h = nin == 2 ? poseidon_trace<3, 0>(x, 1u, tab, none, 0) : nin == 3 ? poseidon_trace<4, 0>(x, 1u, tab, none, 0) : poseidon_trace<5, 1>(x, 1u, tab, none, 0);
+    uint32_t s[8]; fp_to_std<FrParams>(s, h);
+    uint4* d = reinterpret_cast<uint4*>(out + 8 * i);
+    d[0] = make_uint4(s[0], s[1], s[2], s[3]); d[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
 
 // coalesced broadcast of the template witness: one uint4 (half a wire) per lane
