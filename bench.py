@@ -63,10 +63,10 @@ def main():
 
     def step():
         ctx.witness_dev(d_inputs.data_ptr(), B, d_wtns.data_ptr(), d_status.data_ptr(), args.nlevels)
-        for b in range(B):
-            r = int.from_bytes(rs.bytes(31), 'little'); s = int.from_bytes(rs.bytes(31), 'little')
-            p, pub = pk.prove_dev(d_wtns.data_ptr() + b * nW * 32, r, s)
-            proofs[b] = torch.frombuffer(bytearray(p + pub), dtype=torch.uint8)
+        rsb = b''.join(rs.bytes(31) + b'\0' for _ in range(2 * B))       # r, s < 2^248 < field order
+        p, pub = pk.prove_batch_dev(d_wtns.data_ptr(), B, rsb)
+        proofs[:, :256] = torch.frombuffer(bytearray(p), dtype=torch.uint8).view(B, 256)
+        proofs[:, 256:] = torch.frombuffer(bytearray(pub), dtype=torch.uint8).view(B, 256)
         if world > 1:                                                    # RCCL over xGMI: gather finished proofs only
             dist.all_gather(gathered, proofs.cuda(local))
 

@@ -73,6 +73,11 @@ int zkc_prove(zkc_zkey* zk, const void* wtns, uint32_t nWitness, const uint8_t r
 int zkc_prove_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, const uint8_t r[32], const uint8_t s[32],
                   uint8_t proof[256], uint8_t* public_out);
 
+/* batch form: B witnesses resident in HBM (B x nWitness x 32 B), rs = B x 64 B (r || s per proof), outputs on the host:
+ * proofs B x 256 B, publics B x nPublic x 32 B (may be NULL).  Up to ZKC_INFLIGHT (default 8) proofs share one MSM
+ * pipeline pass.  Mirrors what a rapidsnark / snarkjs caller would loop over (zk_census_test.go:89 per voter). */
+int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, int B, const uint8_t* rs, uint8_t* proofs, uint8_t* publics);
+
 /* ---- test hooks (stage outputs for parity tests against the oracle; not part of the drop-in surface) ----
  * zkc_debug_stage: stage 0 -> A_w | B_w | C_w after buildABC (3 x domainSize x 32 B, Montgomery form);
  *                  stage 1 -> joinABC output (A'B' - C') on the odd coset (domainSize x 32 B, standard form).

@@ -116,3 +116,46 @@ def test_example_voter_end_to_end(env):
     with pytest.raises(zkcensus_amd.ZkcError) as ei:
         pk.prove(ws[0][:-32], 1, 2)
     assert ei.value.code == 3 and 'Invalid witness length' in str(ei.value)
+
+
+def test_batch_prove_with_folding_and_without(env):
+    """zkc_prove_batch_dev: voters of different depths share pipeline passes (constant folding on); a witness that does not
+    match the template (random field elements) must take the unfolded path -- both must equal the oracle's bytes."""
+    ctx, get, torch = env
+    from census_gen import random_voter
+    nl = 10
+    zk, pk, vk = get(nl)
+    rng = random.Random(99)
+    voters = [random_voter(rng, ol.poseidon, nLevels=nl, depth_c=d % (nl + 1), depth_s=(3 * d) % (nl + 1)) for d in range(11)]
+    ws, st = ctx.witness(voters, nLevels=nl)
+    assert st == [0] * len(voters)
+    junk = b''.join([(1).to_bytes(32, 'little')] + [rng.randrange(R).to_bytes(32, 'little') for _ in range(pk.n_vars - 1)])
+    ws = ws + [junk]
+    B = len(ws)
+    rs = [(rng.randrange(R), rng.randrange(R)) for _ in range(B)]
+    rsb = b''.join(r.to_bytes(32, 'little') + s.to_bytes(32, 'little') for r, s in rs)
+    dw = dev_bytes(torch, b''.join(ws))
+    proofs, pubs = pk.prove_batch_dev(dw.data_ptr(), B, rsb)
+    for i in range(B):
+        rc, op, opub = ol.prove(zk, ws[i], rs[i][0], rs[i][1])
+        assert rc == 0 and op == proofs[256 * i:256 * i + 256], 'proof %d' % i
+        assert opub == pubs[256 * i:256 * i + 256]
+        if i < B - 1:
+            assert ol.verify(vk, opub, op)
+
+
+def test_batch_prove_nl160_verifies(env):
+    ctx, get, torch = env
+    from zkcensus_amd import census
+    zk, pk, vk = get(160)
+    voters = census.synthetic_census(ctx, 20)
+    ws, st = ctx.witness(voters)
+    assert st == [0] * 20
+    rng = random.Random(160)
+    rsb = b''.join(rng.randrange(R).to_bytes(32, 'little') for _ in range(40))
+    proofs, pubs = pk.prove_batch_dev(dev_bytes(torch, b''.join(ws)).data_ptr(), 20, rsb)
+    for i in range(20):
+        assert ol.verify(vk, pubs[256 * i:256 * i + 256], proofs[256 * i:256 * i + 256]), i
+    # one of them against the oracle prover, byte for byte
+    rc, op, _ = ol.prove(zk, ws[7], int.from_bytes(rsb[64 * 7:64 * 7 + 32], 'little'), int.from_bytes(rsb[64 * 7 + 32:64 * 7 + 64], 'little'))
+    assert rc == 0 and op == proofs[256 * 7:256 * 8]

@@ -104,6 +104,12 @@ class ProvingKey:
         self.ctx._check(self._lib.zkc_prove_dev(self._h, d_wtns_ptr, self.n_vars, self._scalar(r), self._scalar(s), proof, pub))
         return proof.raw, pub.raw
 
+    def prove_batch_dev(self, d_wtns_ptr, B, rs):
+        """rs: B x 64 bytes (r || s).  Returns (proofs B x 256 B, publics B x n_public x 32 B) as bytes."""
+        proofs = ctypes.create_string_buffer(256 * B); pubs = ctypes.create_string_buffer(32 * self.n_public * B)
+        self.ctx._check(self._lib.zkc_prove_batch_dev(self._h, d_wtns_ptr, self.n_vars, B, bytes(rs), proofs, pubs))
+        return proofs.raw, pubs.raw
+
     def debug_stage(self, d_wtns_ptr, stage):
         out = ctypes.create_string_buffer((96 if stage == 0 else 32) * self.domain_size)
         self.ctx._check(self._lib.zkc_debug_stage(self._h, d_wtns_ptr, stage, out))

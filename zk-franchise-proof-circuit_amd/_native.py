@@ -22,6 +22,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError('libzkcensus.so is not built (run `python -c "import __graft_entry__ as g; g.build()"`); '
                           'there is no CPU fallback for the product path')
+    try:
+        # torch ships its own libamdhip64.so.7; both libraries resolve that soname, and torch only finds its GPUs when ITS copy
+        # is the one loaded first.  Outside Python (N-API / cgo hosts) the system ROCm runtime is used.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, i32p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)
     L.zkc_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
@@ -36,6 +42,7 @@ def load():
     L.zkc_zkey_info.argtypes = [vp, u32p, u32p, u32p]
     L.zkc_prove.argtypes = [vp, ctypes.c_char_p, ctypes.c_uint32, u8p, u8p, ctypes.c_char_p, ctypes.c_char_p]
     L.zkc_prove_dev.argtypes = [vp, vp, ctypes.c_uint32, u8p, u8p, ctypes.c_char_p, ctypes.c_char_p]
+    L.zkc_prove_batch_dev.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
     L.zkc_debug_stage.argtypes = [vp, vp, ctypes.c_int, ctypes.c_char_p]
     L.zkc_msm_debug.argtypes = [vp, ctypes.c_int, vp, ctypes.c_uint32, ctypes.c_char_p]
     L.zkc_poseidon_batch.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]

@@ -166,6 +166,11 @@ static int get_template(zkc_ctx* ctx, const WitnessLayout& L, uint32_t** out) {
     return ZKC_OK;
 }
 
+uint32_t* zkc_get_template(zkc_ctx* ctx, int nLevels) {
+    uint32_t* t = nullptr; WitnessLayout L = WitnessLayout::make(nLevels);
+    return get_template(ctx, L, &t) == ZKC_OK ? t : nullptr;
+}
+
 static int witness_dev3(zkc_ctx* ctx, const WitnessLayout& L, const void* d_inputs, int B, void* d_wtns, int32_t* d_status3) {
     uint32_t* tmpl; int rc = get_template(ctx, L, &tmpl); if (rc) return rc;
     const size_t total = (size_t)L.nWires * 2 * (size_t)B;

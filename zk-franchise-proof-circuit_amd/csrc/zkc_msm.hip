@@ -3,19 +3,23 @@
 // Replaces G1.multiExpAffine / G2.multiExpAffine of ffjavascript/wasmcurves (snarkjs groth16_prove.js, reached from
 // ts_inputs/src/example.ts:358-362) and rapidsnark's multiexp (zk_census_test.go:89).
 //
-// The proving key is constant for the life of a context, so zkc_zkey_load pre-shifts every base once:
-// T[w][i] = 2^(c w) P_i.  Per MSM:
-//   K4  zkc_msm_digits   scalar -> 20 signed 13-bit digits; emits (bucket = w*4096 + |d|-1, entry = w*count+i | sign)
-//       rocPRIM radix sort of the (bucket, entry) pairs, zkc_msm_offsets = bucket segment boundaries
-//   K5  zkc_msm_accumulate  one lane per bucket, XYZZ += affine (8M+2S) over its segment, 64-B gathers from T;
-//       zkc_msm_heavy       buckets with more than MSM_HEAVY entries (witness bits -> digit 1) : one block each
-//   K6  zkc_msm_reduce   running sums over groups of 32 buckets, group offset by a small double-and-add, block tree
-//       zkc_msm_final    sums the block partials.  No window doublings are left because the bases are pre-shifted.
-#include "zkc_prover.h"
+// The proving key is constant for the life of a context, so zkc_zkey_load pre-shifts every base once
+// (T[w][i] = 2^(13 w) P_i): all windows of a job then reduce with plain additions, no doublings.  A pipeline PASS
+// runs a list of jobs (sections x proofs in flight) through the same launches:
+//   K4  zkc_msm_digits      scalar -> 20 signed 13-bit digits; emits key = job*NB + w*4096 + |d|-1, val = point | sign
+//       rocPRIM radix sort of (key, val); zkc_msm_offsets = bucket boundaries; scan of ceil(size/16) -> segments
+//   K5  zkc_msm_accumulate  one lane per SEGMENT (<= 16 sorted entries of one bucket): XYZZ += affine (8M + 2S) with
+//       64-byte gathers from T.  Cutting buckets into segments keeps lanes balanced when many scalars repeat
+//       (witness bits; the circuit has only ~4.5k distinct values among 82k wires).
+//   K6  zkc_msm_window      one workgroup per (job, window): bucket = sum of its segments; per-lane running sums over
+//       16 buckets, a suffix scan across the 256 lanes in LDS, x16, tree sum  ->  sum_d d * B_d
+//       zkc_msm_final       sums the 20 window results of each job.
 #include <cstdio>
+#include <ctime>
 #include <cstdlib>
 #include <cstring>
 #include <string.h>
+#include "zkc_prover.h"
 #include <rocprim/rocprim.hpp>
 
 namespace zkc {
@@ -40,11 +44,16 @@ template <> struct PointIO<Fq2> {
 
 // ---- K4 ----
 extern "C" __global__ void __launch_bounds__(256)
-zkc_msm_digits(const uint32_t* __restrict__ scalars, uint32_t count, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+zkc_msm_digits(MsmJobList jl, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const int j = blockIdx.y;
+    const MsmJob& job = jl.job[j];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const uint4* sp = reinterpret_cast<const uint4*>(scalars + 8 * (size_t)i); uint4 a = sp[0], b = sp[1];
+    if (i >= job.count) return;
+    const uint32_t wire = job.vmap ? job.vmap[i] : i;
+    const uint4* sp = reinterpret_cast<const uint4*>(job.scalars + 8 * (size_t)wire); uint4 a = sp[0], b = sp[1];
     const uint32_t s[9] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, 0};
+    const uint32_t pt = job.tbl_off + (uint32_t)((int32_t)wire - job.pt_shift);
+    const size_t base = (size_t)jl.entry_off[j] * MSM_NW;
     uint32_t carry = 0;
 #pragma unroll
     for (int w = 0; w < MSM_NW; w++) {
@@ -53,112 +62,129 @@ zkc_msm_digits(const uint32_t* __restrict__ scalars, uint32_t count, uint32_t* _
         uint32_t d = (uint32_t)((two >> sh) & ((1u << MSM_C) - 1)) + carry;
         uint32_t neg = 0;
         if (d > (uint32_t)MSM_HALF) { d = (1u << MSM_C) - d; neg = 1; carry = 1; } else carry = 0;
-        keys[(size_t)w * count + i] = d ? (uint32_t)(w * MSM_HALF) + d - 1 : (uint32_t)MSM_NB;
-        vals[(size_t)w * count + i] = ((uint32_t)w * count + i) | (neg << 31);
+        const size_t o = base + (size_t)w * job.count + i;
+        keys[o] = d ? (uint32_t)(j * MSM_NB + w * MSM_HALF) + d - 1 : (uint32_t)(jl.njobs * MSM_NB);      // zero digits sort to the end
+        vals[o] = (pt + (uint32_t)w * job.tbl_count) | (neg << 31);
     }
 }
+// off[b] = first sorted position with key >= b
 extern "C" __global__ void __launch_bounds__(256)
-zkc_msm_offsets(const uint32_t* __restrict__ keys_sorted, uint32_t total, uint32_t* __restrict__ off, uint32_t* __restrict__ heavy_count) {
+zkc_msm_offsets(const uint32_t* __restrict__ keys_sorted, uint32_t total, uint32_t nbuckets, uint32_t* __restrict__ off) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b == 0) *heavy_count = 0;
-    if (b > (uint32_t)MSM_NB) return;
-    uint32_t lo = 0, hi = total;                       // first position with key >= b
+    if (b > nbuckets) return;
+    uint32_t lo = 0, hi = total;
     while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (keys_sorted[mid] < b) lo = mid + 1; else hi = mid; }
     off[b] = lo;
 }
-
-// cold-path group operations are kept out of line (one copy per field) to bound code size and compile time
-template <class F> __device__ __noinline__ XYZZ<F> add_ni(const XYZZ<F>& a, const XYZZ<F>& b) { return xyzz_add(a, b); }
-template <class F> __device__ __noinline__ XYZZ<F> dbl_ni(const XYZZ<F>& a) { return xyzz_dbl(a); }
+// segcnt[b] = ceil(size_b / MSM_SEG); buckets cut into more than MSM_MERGE_T segments are listed for the wave-per-bucket merge
+extern "C" __global__ void __launch_bounds__(256)
+zkc_msm_segcount(const uint32_t* __restrict__ off, uint32_t nbuckets, uint32_t* __restrict__ segcnt, uint32_t* __restrict__ heavy,
+                 uint32_t* __restrict__ heavy_count) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nbuckets) return;
+    const uint32_t c = b < nbuckets ? (off[b + 1] - off[b] + MSM_SEG - 1) / MSM_SEG : 0;
+    segcnt[b] = c;
+    if (c > (uint32_t)MSM_MERGE_T) { uint32_t k = atomicAdd(heavy_count, 1u); if (k < (uint32_t)MSM_MAX_HEAVY) heavy[k] = b; }
+}
+extern "C" __global__ void __launch_bounds__(256)
+zkc_msm_seg2bucket(const uint32_t* __restrict__ segoff, uint32_t nbuckets, uint32_t* __restrict__ seg2bucket, uint32_t max_segments) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbuckets) return;
+    for (uint32_t s = segoff[b], e = segoff[b + 1]; s < e && s < max_segments; s++) seg2bucket[s] = b;
+}
 
 // ---- K5 ----
-
 template <class F>
 __global__ void __launch_bounds__(128)
 zkc_msm_accumulate(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ off,
-                   XYZZ<F>* __restrict__ buckets, uint32_t* __restrict__ heavy, uint32_t* __restrict__ heavy_count) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= (uint32_t)MSM_NB) return;
-    const uint32_t s = off[b], e = off[b + 1];
+                   const uint32_t* __restrict__ segoff, const uint32_t* __restrict__ seg2bucket, uint32_t nbuckets,
+                   XYZZ<F>* __restrict__ partial, uint32_t max_segments) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t nseg = segoff[nbuckets]; if (nseg > max_segments) nseg = max_segments;
+    if (s >= nseg) return;
+    const uint32_t b = seg2bucket[s];
+    const uint32_t start = off[b] + (s - segoff[b]) * MSM_SEG;
+    uint32_t end = start + MSM_SEG; const uint32_t bend = off[b + 1]; if (end > bend) end = bend;
     XYZZ<F> acc = XYZZ<F>::inf();
-    if (e - s > (uint32_t)MSM_HEAVY) {
-        uint32_t k = atomicAdd(heavy_count, 1u);
-        if (k < (uint32_t)MSM_MAX_HEAVY) { heavy[k] = b; buckets[b] = acc; return; }
-        // list full: fall through and do it here (slow but correct)
-    }
-    for (uint32_t j = s; j < e; j++) {
+    for (uint32_t j = start; j < end; j++) {
         const uint32_t v = vals[j];
         Affine<F> p = PointIO<F>::load(table + (v & 0x7fffffffu));
         if (v >> 31) p.y = fp_neg(p.y);
         acc = xyzz_add_affine(acc, p);
     }
-    buckets[b] = acc;
+    partial[s] = acc;
+}
+
+// buckets with many segments (the 7-bit top window holds n/97 entries per bucket; repeated witness values) are summed by
+// one wave each: lanes stride over the segments, then a shuffle tree; the result replaces the bucket's first segment.
+template <class F>
+__device__ __forceinline__ XYZZ<F> shfl_down_xyzz(const XYZZ<F>& p, int delta) {
+    XYZZ<F> r; const uint32_t* s = reinterpret_cast<const uint32_t*>(&p); uint32_t* d = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(XYZZ<F>) / 4; i++) d[i] = (uint32_t)__shfl_down((int)s[i], delta, 64);
+    return r;
 }
 template <class F>
-__global__ void __launch_bounds__(256)
-zkc_msm_heavy(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ off,
-              XYZZ<F>* __restrict__ buckets, const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ heavy_count) {
-    extern __shared__ uint4 lds4[];
-    XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds4);
+__global__ void __launch_bounds__(64)
+zkc_msm_merge(XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ segoff, uint32_t* __restrict__ segcnt,
+              const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ heavy_count, uint32_t max_segments) {
     uint32_t nh = *heavy_count; if (nh > (uint32_t)MSM_MAX_HEAVY) nh = MSM_MAX_HEAVY;
     for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
-        const uint32_t b = heavy[h], s = off[b], e = off[b + 1];
+        const uint32_t b = heavy[h], s0 = segoff[b];
+        uint32_t s1 = s0 + segcnt[b]; if (s1 > max_segments) s1 = max_segments;
         XYZZ<F> acc = XYZZ<F>::inf();
-        for (uint32_t j = s + threadIdx.x; j < e; j += blockDim.x) {
-            const uint32_t v = vals[j];
-            Affine<F> p = PointIO<F>::load(table + (v & 0x7fffffffu));
-            if (v >> 31) p.y = fp_neg(p.y);
-            acc = xyzz_add_affine(acc, p);
-        }
-        sh[threadIdx.x] = acc; __syncthreads();
-        for (int st = blockDim.x / 2; st > 0; st >>= 1) {
-            if ((int)threadIdx.x < st) sh[threadIdx.x] = add_ni(sh[threadIdx.x], sh[threadIdx.x + st]);
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) buckets[b] = sh[0];
-        __syncthreads();
+        for (uint32_t s = s0 + threadIdx.x; s < s1; s += 64) acc = xyzz_add(acc, partial[s]);
+        for (int d = 32; d > 0; d >>= 1) acc = xyzz_add(acc, shfl_down_xyzz(acc, d));
+        if (threadIdx.x == 0) { partial[s0] = acc; segcnt[b] = 1; }
     }
 }
 
-// ---- K6 ----  sum over all windows of sum_d d * B[w][d]; thread = group of MSM_GROUP consecutive buckets of one window
+// ---- K6 ---- one workgroup per (job, window); lane t owns buckets 16t .. 16t+15 (digits 16t+1 .. 16t+16)
 template <class F>
-__global__ void __launch_bounds__(64)
-zkc_msm_reduce(const XYZZ<F>* __restrict__ buckets, XYZZ<F>* __restrict__ partial) {
+__global__ void __launch_bounds__(256)
+zkc_msm_window(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ segoff, const uint32_t* __restrict__ segcnt,
+               XYZZ<F>* __restrict__ wres, uint32_t max_segments) {
     extern __shared__ uint4 lds4[];
     XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds4);
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;           // group id
-    const uint32_t ngroups = MSM_NB / MSM_GROUP;
-    XYZZ<F> contrib = XYZZ<F>::inf();
-    if (g < ngroups) {
-        const uint32_t first = g * MSM_GROUP;                            // bucket index; digit value = (first % HALF) + k + 1
-        const uint32_t base = first % MSM_HALF;                          // digits base+1 .. base+GROUP
-        XYZZ<F> run = XYZZ<F>::inf(), loc = XYZZ<F>::inf();
-        for (int k = MSM_GROUP - 1; k >= 0; k--) { run = add_ni(run, buckets[first + k]); loc = add_ni(loc, run); }
-        // contribution = loc + base * run   (base < 2^12)
-        XYZZ<F> sc = XYZZ<F>::inf();
-        for (int bit = MSM_C - 2; bit >= 0; bit--) { sc = dbl_ni(sc); if ((base >> bit) & 1) sc = add_ni(sc, run); }
-        contrib = add_ni(loc, sc);
+    constexpr int PER = MSM_HALF / 256;                                   // 16
+    const uint32_t first = blockIdx.x * MSM_HALF + threadIdx.x * PER;     // blockIdx.x = job * NW + window
+    // run = sum of the lane's buckets from the top; loc = sum_k k * B_k (k = 1..PER)
+    XYZZ<F> run = XYZZ<F>::inf(), loc = XYZZ<F>::inf();
+    for (int k = PER - 1; k >= 0; k--) {
+        uint32_t s0 = segoff[first + k], s1 = s0 + segcnt[first + k];
+        if (s1 > max_segments) s1 = max_segments;
+        for (uint32_t s = s0; s < s1; s++) run = xyzz_add(run, partial[s]);
+        loc = xyzz_add(loc, run);
     }
-    sh[threadIdx.x] = contrib; __syncthreads();
-    for (int st = blockDim.x / 2; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) sh[threadIdx.x] = add_ni(sh[threadIdx.x], sh[threadIdx.x + st]);
+    // suffix sums R_t = sum_{t' >= t} S_t' across lanes (Hillis-Steele in LDS)
+    sh[threadIdx.x] = run; __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        XYZZ<F> v = XYZZ<F>::inf();
+        if ((int)threadIdx.x + o < 256) v = sh[threadIdx.x + o];
+        __syncthreads();
+        if ((int)threadIdx.x + o < 256) sh[threadIdx.x] = xyzz_add(sh[threadIdx.x], v);
         __syncthreads();
     }
-    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+    // sum_d d B_d = sum_t loc_t + PER * sum_{t>=1} R_t
+    XYZZ<F> y = XYZZ<F>::inf();
+    if (threadIdx.x >= 1) { y = sh[threadIdx.x]; for (int k = 0; k < 4; k++) y = xyzz_dbl(y); }   // x16
+    y = xyzz_add(y, loc);
+    __syncthreads();
+    sh[threadIdx.x] = y; __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] = xyzz_add(sh[threadIdx.x], sh[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) wres[blockIdx.x] = sh[0];
 }
 template <class F>
 __global__ void __launch_bounds__(64)
-zkc_msm_final(const XYZZ<F>* __restrict__ partial, int nparts, XYZZ<F>* __restrict__ result) {
-    extern __shared__ uint4 lds4[];
-    XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds4);
+zkc_msm_final(const XYZZ<F>* __restrict__ wres, int njobs, XYZZ<F>* __restrict__ results) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= njobs) return;
     XYZZ<F> acc = XYZZ<F>::inf();
-    for (int i = threadIdx.x; i < nparts; i += blockDim.x) acc = add_ni(acc, partial[i]);
-    sh[threadIdx.x] = acc; __syncthreads();
-    for (int st = blockDim.x / 2; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) sh[threadIdx.x] = add_ni(sh[threadIdx.x], sh[threadIdx.x + st]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *result = sh[0];
+    for (int w = 0; w < MSM_NW; w++) acc = xyzz_add(acc, wres[j * MSM_NW + w]);
+    results[j] = acc;
 }
 
 // ---- one-time base table: table[w][i] = 2^c * table[w-1][i] ----
@@ -169,10 +195,9 @@ zkc_msm_shift_bases(const Affine<F>* __restrict__ prev, Affine<F>* __restrict__ 
     if (i >= count) return;
     Affine<F> a = PointIO<F>::load(prev + i);
     XYZZ<F> p = xyzz_dbl_affine(a);
-    for (int k = 1; k < MSM_C; k++) p = dbl_ni(p);
+    for (int k = 1; k < MSM_C; k++) p = xyzz_dbl(p);
     next[i] = xyzz_to_affine(p);
 }
-
 template <class F>
 static int precompute(zkc_ctx* ctx, uint32_t count, Affine<F>* d_table) {
     for (int w = 1; w < MSM_NW; w++) {
@@ -183,60 +208,158 @@ static int precompute(zkc_ctx* ctx, uint32_t count, Affine<F>* d_table) {
     }
     return ZKC_OK;
 }
-int msm_precompute_g1(zkc_ctx* ctx, const G1Affine*, uint32_t count, G1Affine* d_table) { return precompute<Fq>(ctx, count, d_table); }
-int msm_precompute_g2(zkc_ctx* ctx, const G2Affine*, uint32_t count, G2Affine* d_table) { return precompute<Fq2>(ctx, count, d_table); }
+int msm_precompute_g1(zkc_ctx* ctx, uint32_t count, G1Affine* d_table) { return precompute<Fq>(ctx, count, d_table); }
+int msm_precompute_g2(zkc_ctx* ctx, uint32_t count, G2Affine* d_table) { return precompute<Fq2>(ctx, count, d_table); }
 
-static const bool g_debug_sync = getenv("ZKC_DEBUG_SYNC") != nullptr;   // serialise + log every launch (diagnostics only)
-#define ZKC_LAUNCH_CHECK(zk, name)                                                                         \
-    do { hipError_t _e = hipGetLastError(); if (_e != hipSuccess)                                          \
-        return zkc_fail((zk)->ctx, ZKC_ERR_HIP, std::string(name ": ") + hipGetErrorString(_e));           \
-        if (g_debug_sync) { fprintf(stderr, "[zkc] %s launched\n", name); fflush(stderr);                  \
-            _e = hipStreamSynchronize((zk)->ctx->stream);                                                  \
-            fprintf(stderr, "[zkc] %s done: %s\n", name, hipGetErrorString(_e)); fflush(stderr); } } while (0)
-
+// ---- constant folding support: out[i] = scalar[wire_i] * P[wire_i - shift] by double-and-add, then per-group sums ----
+__device__ __forceinline__ uint32_t limb_of(const uint32_t k[8], int i) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) w = (q == i) ? k[q] : w;
+    return w;
+}
 template <class F>
-static int msm_run(zkc_zkey* zk, const Affine<F>* table, const uint32_t* d_scalars, uint32_t count, int slot) {
-    zkc_ctx* ctx = zk->ctx; hipStream_t st = ctx->stream;
-    const uint32_t total = count * MSM_NW;
-    constexpr bool kG2 = sizeof(F) == sizeof(Fq2);
-    const uint64_t alg_bytes = (uint64_t)count * (sizeof(Affine<F>) + 32);      // bases + scalars of this MSM
-    uint32_t* heavy_count = zk->d_heavy + MSM_MAX_HEAVY;
-    {
-    zkc_prof_scope _ps(ctx, ZKC_PROF_MSM_SORT, 0);
-    hipLaunchKernelGGL(zkc_msm_digits, dim3((count + 255) / 256), dim3(256), 0, st, d_scalars, count, zk->d_keys, zk->d_vals);
-    ZKC_LAUNCH_CHECK(zk, "zkc_msm_digits");
-    int end_bit = 1; while ((1u << end_bit) <= (uint32_t)MSM_NB) end_bit++;
-    size_t need = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, need, zk->d_keys, zk->d_keys2, zk->d_vals, zk->d_vals2, total, 0, end_bit, st);
-    if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, "radix_sort_pairs(size)");
-    int rc = zkc_ensure(ctx, &zk->d_sort_tmp, &zk->sort_tmp_sz, need); if (rc) return rc;
-    e = rocprim::radix_sort_pairs(zk->d_sort_tmp, need, zk->d_keys, zk->d_keys2, zk->d_vals, zk->d_vals2, total, 0, end_bit, st);
-    if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, "radix_sort_pairs");
-    ZKC_LAUNCH_CHECK(zk, "radix_sort_pairs");
-    hipLaunchKernelGGL(zkc_msm_offsets, dim3((MSM_NB + 1 + 255) / 256), dim3(256), 0, st, zk->d_keys2, total, zk->d_off, heavy_count);
-    ZKC_LAUNCH_CHECK(zk, "zkc_msm_offsets");
+__global__ void __launch_bounds__(64)
+zkc_fold_mul(const Affine<F>* __restrict__ tbl, const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ wires, uint32_t nw,
+             int32_t pt_shift, XYZZ<F>* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nw) return;
+    const uint32_t wire = wires[i];
+    const uint4* sp = reinterpret_cast<const uint4*>(scalars + 8 * (size_t)wire); uint4 a = sp[0], b = sp[1];
+    const uint32_t k[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    Affine<F> p = PointIO<F>::load(tbl + (uint32_t)((int32_t)wire - pt_shift));
+    XYZZ<F> r = XYZZ<F>::inf();
+    for (int bit = 255; bit >= 0; bit--) {
+        r = xyzz_dbl(r);
+        if ((limb_of(k, bit >> 5) >> (bit & 31)) & 1) r = xyzz_add_affine(r, p);
     }
-    XYZZ<F>* buckets = reinterpret_cast<XYZZ<F>*>(zk->d_buckets);
-    XYZZ<F>* partial = reinterpret_cast<XYZZ<F>*>(zk->d_partial);
-    XYZZ<F>* results = reinterpret_cast<XYZZ<F>*>(reinterpret_cast<uint8_t*>(zk->d_results) + (size_t)slot * sizeof(XYZZ<Fq2>));
-    {
-    zkc_prof_scope _ps(ctx, kG2 ? ZKC_PROF_MSM_ACC_G2 : ZKC_PROF_MSM_ACC_G1, alg_bytes);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate<F>), dim3((MSM_NB + 127) / 128), dim3(128), 0, st, table, zk->d_vals2, zk->d_off,
-                       buckets, zk->d_heavy, heavy_count);
-    ZKC_LAUNCH_CHECK(zk, "zkc_msm_accumulate");
-    }
-    zkc_prof_scope _pr(ctx, ZKC_PROF_MSM_REDUCE, 0);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_heavy<F>), dim3(256), dim3(256), 256 * sizeof(XYZZ<F>), st, table, zk->d_vals2, zk->d_off, buckets,
-                       zk->d_heavy, heavy_count);
-    ZKC_LAUNCH_CHECK(zk, "zkc_msm_heavy");
-    const int ngroups = MSM_NB / MSM_GROUP, nblocks = (ngroups + 63) / 64;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_reduce<F>), dim3(nblocks), dim3(64), 64 * sizeof(XYZZ<F>), st, buckets, partial);
-    ZKC_LAUNCH_CHECK(zk, "zkc_msm_reduce");
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_final<F>), dim3(1), dim3(64), 64 * sizeof(XYZZ<F>), st, partial, nblocks, results);
-    ZKC_LAUNCH_CHECK(zk, "zkc_msm_final");
+    out[i] = r;
+}
+template <class F>
+__global__ void __launch_bounds__(64)
+zkc_fold_gsum(const XYZZ<F>* __restrict__ in, const uint32_t* __restrict__ gstart, uint32_t ngroups, XYZZ<F>* __restrict__ out) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups) return;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t i = gstart[g], e = gstart[g + 1]; i < e; i++) acc = xyzz_add(acc, in[i]);
+    out[g] = acc;
+}
+template <class F>
+static int fold_group_sums(zkc_ctx* ctx, const Affine<F>* tbl, const uint32_t* d_scalars, const uint32_t* d_wires, uint32_t nw, int32_t pt_shift,
+                           const uint32_t* d_gstart, uint32_t ngroups, XYZZ<F>* h_out) {
+    XYZZ<F>*d_tmp = nullptr, *d_out = nullptr;
+    ZKC_HIP_CHECK(ctx, hipMalloc(&d_tmp, (size_t)nw * sizeof(XYZZ<F>)));
+    ZKC_HIP_CHECK(ctx, hipMalloc(&d_out, (size_t)ngroups * sizeof(XYZZ<F>)));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_fold_mul<F>), dim3((nw + 63) / 64), dim3(64), 0, ctx->stream, tbl, d_scalars, d_wires, nw, pt_shift, d_tmp);
+    ZKC_HIP_CHECK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_fold_gsum<F>), dim3((ngroups + 63) / 64), dim3(64), 0, ctx->stream, d_tmp, d_gstart, ngroups, d_out);
+    ZKC_HIP_CHECK(ctx, hipGetLastError());
+    ZKC_HIP_CHECK(ctx, hipMemcpyAsync(h_out, d_out, (size_t)ngroups * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, ctx->stream));
+    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ZKC_HIP_CHECK(ctx, hipFree(d_tmp)); ZKC_HIP_CHECK(ctx, hipFree(d_out));
     return ZKC_OK;
 }
-int msm_g1_run(zkc_zkey* zk, const G1Affine* table, const uint32_t* d_scalars, uint32_t count, int slot) { return msm_run<Fq>(zk, table, d_scalars, count, slot); }
-int msm_g2_run(zkc_zkey* zk, const G2Affine* table, const uint32_t* d_scalars, uint32_t count, int slot) { return msm_run<Fq2>(zk, table, d_scalars, count, slot); }
+int fold_group_sums_g1(zkc_ctx* ctx, const G1Affine* tbl, const uint32_t* s, const uint32_t* w, uint32_t nw, int32_t sh, const uint32_t* gs, uint32_t ng, G1XYZZ* o) {
+    return fold_group_sums<Fq>(ctx, tbl, s, w, nw, sh, gs, ng, o);
+}
+int fold_group_sums_g2(zkc_ctx* ctx, const G2Affine* tbl, const uint32_t* s, const uint32_t* w, uint32_t nw, int32_t sh, const uint32_t* gs, uint32_t ng, G2XYZZ* o) {
+    return fold_group_sums<Fq2>(ctx, tbl, s, w, nw, sh, gs, ng, o);
+}
+
+// ---- work space ----
+int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, int max_jobs, bool g2) {
+    w.max_entries = max_entries; w.max_jobs = max_jobs; w.xyzz_size = g2 ? sizeof(G2XYZZ) : sizeof(G1XYZZ);
+    const size_t nb = (size_t)max_jobs * MSM_NB;
+    w.max_segments = max_entries / MSM_SEG + nb;        // every non-empty bucket has at most one short segment
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.keys, max_entries * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.vals, max_entries * 4));
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.keys2, max_entries * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.vals2, max_entries * 4));
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.off, (nb + 2) * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.segcnt, (nb + 2) * 4));
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.segoff, (nb + 2) * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.seg2bucket, w.max_segments * 4));
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.heavy, (MSM_MAX_HEAVY + 1) * 4));
+    ZKC_HIP_CHECK(ctx, hipMalloc(&w.partial, w.max_segments * w.xyzz_size));
+    ZKC_HIP_CHECK(ctx, hipMalloc(&w.wres, (size_t)max_jobs * MSM_NW * w.xyzz_size));
+    ZKC_HIP_CHECK(ctx, hipMalloc(&w.results, (size_t)max_jobs * w.xyzz_size));
+    ZKC_HIP_CHECK(ctx, hipHostMalloc(&w.h_results, (size_t)max_jobs * w.xyzz_size));
+    return ZKC_OK;
+}
+void msm_work_free(MsmWork& w) {
+    void* p[] = {w.keys, w.vals, w.keys2, w.vals2, w.off, w.segcnt, w.segoff, w.seg2bucket, w.heavy, w.partial, w.wres, w.results, w.sort_tmp, w.scan_tmp};
+    for (void* q : p) if (q) (void)hipFree(q);
+    if (w.h_results) (void)hipHostFree(w.h_results);
+    w = MsmWork();
+}
+
+static const bool g_debug_sync = getenv("ZKC_DEBUG_SYNC") != nullptr;   // serialise + log every launch (diagnostics only)
+#define ZKC_LAUNCH_CHECK(ctx, name)                                                                        \
+    do { hipError_t _e = hipGetLastError(); if (_e != hipSuccess)                                          \
+        return zkc_fail((ctx), ZKC_ERR_HIP, std::string(name ": ") + hipGetErrorString(_e));               \
+        if (g_debug_sync) { timespec _t0, _t1; clock_gettime(CLOCK_MONOTONIC, &_t0);                        \
+            _e = hipStreamSynchronize((ctx)->stream); clock_gettime(CLOCK_MONOTONIC, &_t1);                \
+            fprintf(stderr, "[zkc] %-22s %8.3f ms  %s\n", name, (_t1.tv_sec - _t0.tv_sec) * 1e3 + (_t1.tv_nsec - _t0.tv_nsec) * 1e-6, \
+                    hipGetErrorString(_e)); fflush(stderr); } } while (0)
+
+template <class F>
+static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJobList& jl) {
+    zkc_ctx* ctx = zk->ctx; hipStream_t st = ctx->stream;
+    const int nj = jl.njobs;
+    if (nj <= 0 || nj > w.max_jobs) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: job count");
+    const size_t total = (size_t)jl.entry_off[nj] * MSM_NW;
+    if (total > w.max_entries) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: too many entries for the work space");
+    const uint32_t nb = (uint32_t)nj * MSM_NB;
+    constexpr bool kG2 = sizeof(F) == sizeof(Fq2);
+    uint64_t alg_bytes = 0; uint32_t maxcount = 0;
+    for (int j = 0; j < nj; j++) { alg_bytes += (uint64_t)jl.job[j].count * (sizeof(Affine<F>) + 32); maxcount = std::max(maxcount, jl.job[j].count); }
+    {
+        zkc_prof_scope _ps(ctx, ZKC_PROF_MSM_SORT, 0);
+        hipLaunchKernelGGL(zkc_msm_digits, dim3((maxcount + 255) / 256, nj), dim3(256), 0, st, jl, w.keys, w.vals);
+        ZKC_LAUNCH_CHECK(ctx, "zkc_msm_digits");
+        int end_bit = 1; while ((1ull << end_bit) <= (uint64_t)nb) end_bit++;
+        size_t need = 0;
+        hipError_t e = rocprim::radix_sort_pairs(nullptr, need, w.keys, w.keys2, w.vals, w.vals2, total, 0, end_bit, st);
+        if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, "radix_sort_pairs(size)");
+        int rc = zkc_ensure(ctx, &w.sort_tmp, &w.sort_tmp_sz, need); if (rc) return rc;
+        e = rocprim::radix_sort_pairs(w.sort_tmp, need, w.keys, w.keys2, w.vals, w.vals2, total, 0, end_bit, st);
+        if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, "radix_sort_pairs");
+        ZKC_LAUNCH_CHECK(ctx, "radix_sort_pairs");
+        hipLaunchKernelGGL(zkc_msm_offsets, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, w.keys2, (uint32_t)total, nb, w.off);
+        ZKC_LAUNCH_CHECK(ctx, "zkc_msm_offsets");
+        ZKC_HIP_CHECK(ctx, hipMemsetAsync(w.heavy + MSM_MAX_HEAVY, 0, 4, st));
+        hipLaunchKernelGGL(zkc_msm_segcount, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, w.off, nb, w.segcnt, w.heavy, w.heavy + MSM_MAX_HEAVY);
+        ZKC_LAUNCH_CHECK(ctx, "zkc_msm_segcount");
+        need = 0;
+        e = rocprim::exclusive_scan(nullptr, need, w.segcnt, w.segoff, 0u, (size_t)nb + 1, rocprim::plus<uint32_t>(), st);
+        if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, "exclusive_scan(size)");
+        rc = zkc_ensure(ctx, &w.scan_tmp, &w.scan_tmp_sz, need); if (rc) return rc;
+        e = rocprim::exclusive_scan(w.scan_tmp, need, w.segcnt, w.segoff, 0u, (size_t)nb + 1, rocprim::plus<uint32_t>(), st);
+        if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, "exclusive_scan");
+        hipLaunchKernelGGL(zkc_msm_seg2bucket, dim3((nb + 255) / 256), dim3(256), 0, st, w.segoff, nb, w.seg2bucket, (uint32_t)w.max_segments);
+        ZKC_LAUNCH_CHECK(ctx, "zkc_msm_seg2bucket");
+    }
+    XYZZ<F>* partial = reinterpret_cast<XYZZ<F>*>(w.partial);
+    XYZZ<F>* wres = reinterpret_cast<XYZZ<F>*>(w.wres);
+    XYZZ<F>* results = reinterpret_cast<XYZZ<F>*>(w.results);
+    const size_t seg_bound = std::min<size_t>(w.max_segments, total / MSM_SEG + nb);     // launch bound on the number of segments
+    {
+        zkc_prof_scope _ps(ctx, kG2 ? ZKC_PROF_MSM_ACC_G2 : ZKC_PROF_MSM_ACC_G1, alg_bytes);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate<F>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st, table, w.vals2, w.off,
+                           w.segoff, w.seg2bucket, nb, partial, (uint32_t)w.max_segments);
+        ZKC_LAUNCH_CHECK(ctx, "zkc_msm_accumulate");
+    }
+    {
+        zkc_prof_scope _pr(ctx, ZKC_PROF_MSM_REDUCE, 0);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_merge<F>), dim3(1024), dim3(64), 0, st, partial, w.segoff, w.segcnt, w.heavy, w.heavy + MSM_MAX_HEAVY,
+                           (uint32_t)w.max_segments);
+        ZKC_LAUNCH_CHECK(ctx, "zkc_msm_merge");
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_window<F>), dim3(nj * MSM_NW), dim3(256), 256 * sizeof(XYZZ<F>), st, partial, w.segoff, w.segcnt, wres,
+                           (uint32_t)w.max_segments);
+        ZKC_LAUNCH_CHECK(ctx, "zkc_msm_window");
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_final<F>), dim3((nj + 63) / 64), dim3(64), 0, st, wres, nj, results);
+        ZKC_LAUNCH_CHECK(ctx, "zkc_msm_final");
+    }
+    ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.h_results, w.results, (size_t)nj * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+    return ZKC_OK;
+}
+int msm_pass_g1(zkc_zkey* zk, const MsmJobList& jl) { return msm_pass<Fq>(zk, zk->w1, zk->d_g1, jl); }
+int msm_pass_g2(zkc_zkey* zk, const MsmJobList& jl) { return msm_pass<Fq2>(zk, zk->w2, zk->d_g2, jl); }
 
 }  // namespace zkc

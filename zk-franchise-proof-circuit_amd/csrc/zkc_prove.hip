@@ -37,15 +37,36 @@ void g2_to_std(uint8_t* out, const G2Affine& a) {
 }
 }  // namespace
 
+uint32_t* zkc_get_template(zkc_ctx* ctx, int nLevels);     // zkc_api.hip: device template witness (nullptr on error)
+
+// ---- fold check: for every proof and every foldable group, does the witness equal the template there? ----
+// group g of a tree block = level g's non-control wires (g < n-1) ; group n-1 = the n2bOld block
+extern "C" __global__ void __launch_bounds__(64)
+zkc_fold_check(WitnessLayout L, const uint32_t* __restrict__ wtns, const uint32_t* __restrict__ tmpl, uint32_t* __restrict__ flags, int B) {
+    const int n = L.n, g = blockIdx.x, tree = blockIdx.y, b = blockIdx.z;
+    const int blk = tree == 0 ? L.off_census : L.off_sikver;
+    int start, end;
+    if (g < n - 1) {
+        const int nctrl = (g == n - 3) + (g > 0 && g < n - 2) + 1;
+        start = blk + L.lvl_off(g) + nctrl; end = blk + (g + 1 < n - 1 ? L.lvl_off(g + 1) : L.lvl_off(n - 1));
+    } else { start = blk + L.off_n2bold; end = start + 253 + 127 + 133; }
+    const uint4* w = reinterpret_cast<const uint4*>(wtns + (size_t)b * L.nWires * 8) + 2 * (size_t)start;
+    const uint4* t = reinterpret_cast<const uint4*>(tmpl) + 2 * (size_t)start;
+    uint32_t diff = 0;
+    for (int i = threadIdx.x; i < 2 * (end - start); i += 64) { uint4 x = w[i], y = t[i]; diff |= (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w); }
+    const unsigned long long any = __ballot(diff != 0);
+    if (threadIdx.x == 0) flags[((size_t)b * 2 + tree) * n + g] = any ? 1u : 0u;
+}
+
 extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     if (!zk) return;
     (void)hipSetDevice(zk->ctx->device);
     (void)hipStreamSynchronize(zk->ctx->stream);
-    void* ptrs[] = {zk->d_rowptr, zk->d_col, zk->d_val, zk->d_tw_fwd, zk->d_tw_inv, zk->d_coset, zk->d_A, zk->d_B1, zk->d_C, zk->d_H, zk->d_B2,
-                    zk->d_a, zk->d_c, zk->d_t, zk->d_p, zk->d_keys, zk->d_vals, zk->d_keys2, zk->d_vals2, zk->d_off, zk->d_heavy, zk->d_sort_tmp,
-                    zk->d_buckets, zk->d_partial, zk->d_results};
+    void* ptrs[] = {zk->d_rowptr, zk->d_col, zk->d_val, zk->d_tw_fwd, zk->d_tw_inv, zk->d_coset, zk->d_g1, zk->d_g2, zk->d_abc, zk->d_t, zk->d_p, zk->d_flags};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    if (zk->h_results) (void)hipHostFree(zk->h_results);
+    for (auto& kv : zk->fold.vmaps) if (kv.second.first) (void)hipFree(kv.second.first);
+    if (zk->h_flags) (void)hipHostFree(zk->h_flags);
+    msm_work_free(zk->w1); msm_work_free(zk->w2);
     delete zk;
 }
 
@@ -79,6 +100,8 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
     for (uint32_t i = 0; i <= np; i++) zk->ic.push_back(rd_g1(sec[3] + 64ull * i));
     zk->nCoeffs = rd32(sec[4]);
     if (ssz[4] != 4 + 44ull * zk->nCoeffs) { delete zk; return zkc_fail(ctx, ZKC_ERR_FORMAT, "zkey: coefficient section size"); }
+    // a key whose shape is ZkFranchiseProofCircuit(nLevels) can use the voter-independent witness template
+    if (np == 8 && !getenv("ZKC_NO_FOLD")) for (int nl = 3; nl <= 252; nl++) if ((uint32_t)WitnessLayout::make(nl).nWires == nv) { zk->nLevels = nl; break; }
     int rc = ZKC_OK;
     auto bail = [&](int code) { zkc_zkey_free(zk); return code; };
 #define ZKC_UP(dst, src, bytes)                                                                          \
@@ -117,24 +140,31 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
         ZKC_UP(zk->d_tw_inv, b.data(), b.size() * sizeof(Fr));
         ZKC_UP(zk->d_coset, cs.data(), cs.size() * sizeof(Fr));
     }
-    // ---- bases: window 0 = the zkey points as stored (affine, Montgomery), windows 1.. pre-shifted on the device ----
-    if ((rc = dmalloc(ctx, &zk->d_A, (size_t)MSM_NW * nv)) || (rc = dmalloc(ctx, &zk->d_B1, (size_t)MSM_NW * nv)) || (rc = dmalloc(ctx, &zk->d_B2, (size_t)MSM_NW * nv)) ||
-        (rc = dmalloc(ctx, &zk->d_C, (size_t)MSM_NW * nc)) || (rc = dmalloc(ctx, &zk->d_H, (size_t)MSM_NW * n))) return bail(rc);
-    ZKC_UP(zk->d_A, sec[5], 64ull * nv); ZKC_UP(zk->d_B1, sec[6], 64ull * nv);
-    ZKC_UP(zk->d_B2, sec[7], 128ull * nv); ZKC_UP(zk->d_C, sec[8], 64ull * nc);
-    ZKC_UP(zk->d_H, sec[9], 64ull * n);
-    if ((rc = msm_precompute_g1(ctx, nullptr, nv, zk->d_A)) || (rc = msm_precompute_g1(ctx, nullptr, nv, zk->d_B1)) || (rc = msm_precompute_g2(ctx, nullptr, nv, zk->d_B2)) ||
-        (rc = msm_precompute_g1(ctx, nullptr, nc, zk->d_C)) || (rc = msm_precompute_g1(ctx, nullptr, n, zk->d_H))) return bail(rc);
-    // ---- work buffers ----
-    const size_t maxpts = std::max<size_t>(nv, n), total = maxpts * MSM_NW;
-    if ((rc = dmalloc(ctx, &zk->d_a, 2 * (size_t)n)) || (rc = dmalloc(ctx, &zk->d_c, n)) || (rc = dmalloc(ctx, &zk->d_t, n)) || (rc = dmalloc(ctx, &zk->d_p, 8 * (size_t)n)) ||
-        (rc = dmalloc(ctx, &zk->d_keys, total)) || (rc = dmalloc(ctx, &zk->d_vals, total)) || (rc = dmalloc(ctx, &zk->d_keys2, total)) || (rc = dmalloc(ctx, &zk->d_vals2, total)) ||
-        (rc = dmalloc(ctx, &zk->d_off, MSM_NB + 2)) || (rc = dmalloc(ctx, &zk->d_heavy, MSM_MAX_HEAVY + 1))) return bail(rc);
-    zk->d_b = zk->d_a + n;
-    ZKC_HIP_CHECK(ctx, hipMalloc(&zk->d_buckets, (size_t)MSM_NB * sizeof(G2XYZZ)));
-    ZKC_HIP_CHECK(ctx, hipMalloc(&zk->d_partial, (size_t)(MSM_NB / MSM_GROUP / 64 + 1) * sizeof(G2XYZZ)));
-    ZKC_HIP_CHECK(ctx, hipMalloc(&zk->d_results, 8 * sizeof(G2XYZZ)));
-    ZKC_HIP_CHECK(ctx, hipHostMalloc(&zk->h_results, 8 * sizeof(G2XYZZ)));
+    // ---- bases: one G1 array [A | B1 | C | H] and one G2 array [B2]; window 0 = the zkey points as stored (affine,
+    //      Montgomery), windows 1..19 pre-shifted on the device ----
+    zk->offA = 0; zk->offB1 = MSM_NW * nv; zk->offC = 2 * MSM_NW * nv; zk->offH = 2 * MSM_NW * nv + MSM_NW * nc;
+    const size_t g1_points = (size_t)MSM_NW * (2 * (size_t)nv + nc + n);
+    if (g1_points >= (1ull << 31)) return bail(zkc_fail(ctx, ZKC_ERR_FORMAT, "zkey too large for 31-bit point indices"));
+    if ((rc = dmalloc(ctx, &zk->d_g1, g1_points)) || (rc = dmalloc(ctx, &zk->d_g2, (size_t)MSM_NW * nv))) return bail(rc);
+    ZKC_UP(zk->d_g1 + zk->offA, sec[5], 64ull * nv); ZKC_UP(zk->d_g1 + zk->offB1, sec[6], 64ull * nv);
+    ZKC_UP(zk->d_g1 + zk->offC, sec[8], 64ull * nc); ZKC_UP(zk->d_g1 + zk->offH, sec[9], 64ull * n);
+    ZKC_UP(zk->d_g2, sec[7], 128ull * nv);
+    if ((rc = msm_precompute_g1(ctx, nv, zk->d_g1 + zk->offA)) || (rc = msm_precompute_g1(ctx, nv, zk->d_g1 + zk->offB1)) ||
+        (rc = msm_precompute_g1(ctx, nc, zk->d_g1 + zk->offC)) || (rc = msm_precompute_g1(ctx, n, zk->d_g1 + zk->offH)) ||
+        (rc = msm_precompute_g2(ctx, nv, zk->d_g2))) return bail(rc);
+    // ---- work buffers: `inflight` proofs share one MSM pipeline pass ----
+    const char* e_inf = getenv("ZKC_INFLIGHT");
+    zk->max_inflight = e_inf ? std::max(1, std::min(atoi(e_inf), MSM_MAX_JOBS / 4)) : 8;
+    const size_t per_proof_entries = (size_t)MSM_NW * (3 * (size_t)nv + n);
+    if ((rc = dmalloc(ctx, &zk->d_abc, 3 * (size_t)n * zk->max_inflight)) || (rc = dmalloc(ctx, &zk->d_t, n)) ||
+        (rc = dmalloc(ctx, &zk->d_p, 8 * (size_t)n * zk->max_inflight))) return bail(rc);
+    if ((rc = msm_work_alloc(ctx, zk->w1, per_proof_entries * zk->max_inflight, 4 * zk->max_inflight, false))) return bail(rc);
+    if ((rc = msm_work_alloc(ctx, zk->w2, (size_t)MSM_NW * nv * zk->max_inflight, zk->max_inflight, true))) return bail(rc);
+    if (zk->nLevels >= 0) {
+        const size_t nflags = (size_t)zk->max_inflight * 2 * (zk->nLevels + 1);
+        if ((rc = dmalloc(ctx, &zk->d_flags, nflags))) return bail(rc);
+        ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&zk->h_flags, nflags * 4));
+    }
     ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     *out = zk;
     return ZKC_OK;
@@ -146,40 +176,103 @@ extern "C" int zkc_zkey_info(const zkc_zkey* zk, uint32_t* nVars, uint32_t* nPub
     return ZKC_OK;
 }
 
-// stages a2..a4: leaves (A'B' - C') on the odd coset in zk->d_p (standard form) and the intermediate vectors in d_a/d_b/d_c
-static int h_evals_dev(zkc_zkey* zk, const uint32_t* d_wtns) {
+// ---- constant folding tables: per-level sums of template_value * base for every section, then suffix sums ----
+static std::vector<std::pair<int, int>> fold_group_ranges(const WitnessLayout& L, int tree) {   // [start, end) wire ranges, groups 0..n-1
+    std::vector<std::pair<int, int>> r; const int n = L.n, blk = tree == 0 ? L.off_census : L.off_sikver;
+    for (int g = 0; g < n - 1; g++) {
+        const int nctrl = (g == n - 3) + (g > 0 && g < n - 2) + 1;
+        r.push_back({blk + L.lvl_off(g) + nctrl, blk + (g + 1 < n - 1 ? L.lvl_off(g + 1) : L.lvl_off(n - 1))});
+    }
+    r.push_back({blk + L.off_n2bold, blk + L.off_n2bold + 253 + 127 + 133});
+    return r;
+}
+template <class X> static void suffix_sums(std::vector<X>& suf, const X* g, int n) {   // suf[D] = sum_{k >= D} g[k], k < n-1 ; suf[n-1] = inf
+    suf.assign(n, X::inf());
+    for (int D = n - 2; D >= 0; D--) suf[D] = xyzz_add(suf[D + 1], g[D]);
+}
+static int fold_prepare(zkc_zkey* zk) {
+    if (zk->fold.ready) return ZKC_OK;
+    zkc_ctx* ctx = zk->ctx; const WitnessLayout L = WitnessLayout::make(zk->nLevels); const int n = L.n;
+    uint32_t* tmpl = zkc_get_template(ctx, zk->nLevels); if (!tmpl) return ZKC_ERR_HIP;
+    std::vector<uint32_t> wires, gstart;
+    for (int tree = 0; tree < 2; tree++) for (auto& rg : fold_group_ranges(L, tree)) { gstart.push_back((uint32_t)wires.size()); for (int w = rg.first; w < rg.second; w++) wires.push_back((uint32_t)w); }
+    gstart.push_back((uint32_t)wires.size());
+    const uint32_t ng = 2 * n;
+    uint32_t *d_w = nullptr, *d_g = nullptr;
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&d_w, wires.size() * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&d_g, gstart.size() * 4));
+    ZKC_HIP_CHECK(ctx, hipMemcpy(d_w, wires.data(), wires.size() * 4, hipMemcpyHostToDevice));
+    ZKC_HIP_CHECK(ctx, hipMemcpy(d_g, gstart.data(), gstart.size() * 4, hipMemcpyHostToDevice));
+    std::vector<G1XYZZ> gA(ng), gB1(ng), gC(ng); std::vector<G2XYZZ> gB2(ng);
+    int rc;
+    if ((rc = fold_group_sums_g1(ctx, zk->d_g1 + zk->offA, tmpl, d_w, (uint32_t)wires.size(), 0, d_g, ng, gA.data())) ||
+        (rc = fold_group_sums_g1(ctx, zk->d_g1 + zk->offB1, tmpl, d_w, (uint32_t)wires.size(), 0, d_g, ng, gB1.data())) ||
+        (rc = fold_group_sums_g1(ctx, zk->d_g1 + zk->offC, tmpl, d_w, (uint32_t)wires.size(), (int32_t)zk->nPub + 1, d_g, ng, gC.data())) ||
+        (rc = fold_group_sums_g2(ctx, zk->d_g2, tmpl, d_w, (uint32_t)wires.size(), 0, d_g, ng, gB2.data()))) return rc;
+    ZKC_HIP_CHECK(ctx, hipFree(d_w)); ZKC_HIP_CHECK(ctx, hipFree(d_g));
+    auto& f = zk->fold;
+    for (int t = 0; t < 2; t++) {
+        suffix_sums(f.sufA[t], gA.data() + t * n, n); suffix_sums(f.sufB1[t], gB1.data() + t * n, n);
+        suffix_sums(f.sufC[t], gC.data() + t * n, n); suffix_sums(f.sufB2[t], gB2.data() + t * n, n);
+    }
+    f.baseA = {xyzz_add(gA[n - 1], gA[2 * n - 1])}; f.baseB1 = {xyzz_add(gB1[n - 1], gB1[2 * n - 1])};
+    f.baseC = {xyzz_add(gC[n - 1], gC[2 * n - 1])}; f.baseB2 = {xyzz_add(gB2[n - 1], gB2[2 * n - 1])};
+    f.ready = true;
+    return ZKC_OK;
+}
+// device list of the wires that stay in the MSMs when levels >= Dc (census) / >= Ds (sik) and the n2bOld blocks are folded
+static int fold_vmap(zkc_zkey* zk, int Dc, int Ds, uint32_t** d_map, uint32_t* count) {
+    auto it = zk->fold.vmaps.find({Dc, Ds});
+    if (it != zk->fold.vmaps.end()) { *d_map = it->second.first; *count = it->second.second; return ZKC_OK; }
+    zkc_ctx* ctx = zk->ctx; const WitnessLayout L = WitnessLayout::make(zk->nLevels); const int n = L.n;
+    std::vector<uint8_t> folded(L.nWires, 0);
+    for (int tree = 0; tree < 2; tree++) {
+        auto rg = fold_group_ranges(L, tree); const int D = tree == 0 ? Dc : Ds;
+        for (int g = D; g < n - 1; g++) for (int w = rg[g].first; w < rg[g].second; w++) folded[w] = 1;
+        for (int w = rg[n - 1].first; w < rg[n - 1].second; w++) folded[w] = 1;
+    }
+    std::vector<uint32_t> v; for (int w = 0; w < L.nWires; w++) if (!folded[w]) v.push_back((uint32_t)w);
+    uint32_t* d = nullptr;
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&d, v.size() * 4));
+    ZKC_HIP_CHECK(ctx, hipMemcpyAsync(d, v.data(), v.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    zk->fold.vmaps[{Dc, Ds}] = {d, (uint32_t)v.size()};
+    *d_map = d; *count = (uint32_t)v.size();
+    return ZKC_OK;
+}
+
+// stages a2..a4 for proof slot q: leaves (A'B' - C') on the odd coset in d_p[q] (standard form)
+static int h_evals_dev(zkc_zkey* zk, const uint32_t* d_wtns, int q) {
     zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n; hipStream_t st = ctx->stream;
+    Fr *a = zk->d_abc + 3 * (size_t)n * q, *b = a + n, *c = a + 2 * (size_t)n;
     {
-    zkc_prof_scope _ps(ctx, ZKC_PROF_MATVEC, (uint64_t)zk->nCoeffs * 68 + 3ull * n * 32);
-    hipLaunchKernelGGL(zkc_matvec, dim3((2 * n + 255) / 256), dim3(256), 0, st, zk->d_rowptr, zk->d_col, zk->d_val, (const Fr*)d_wtns, zk->d_a, (int)(2 * n));
-    ZKC_HIP_CHECK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(zkc_pointwise_mul, dim3((n + 255) / 256), dim3(256), 0, st, zk->d_a, zk->d_b, zk->d_c, (int)n);
-    ZKC_HIP_CHECK(ctx, hipGetLastError());
+        zkc_prof_scope _ps(ctx, ZKC_PROF_MATVEC, (uint64_t)zk->nCoeffs * 68 + 3ull * n * 32);
+        hipLaunchKernelGGL(zkc_matvec, dim3((2 * n + 255) / 256), dim3(256), 0, st, zk->d_rowptr, zk->d_col, zk->d_val, (const Fr*)d_wtns, a, (int)(2 * n));
+        ZKC_HIP_CHECK(ctx, hipGetLastError());
+        hipLaunchKernelGGL(zkc_pointwise_mul, dim3((n + 255) / 256), dim3(256), 0, st, a, b, c, (int)n);
+        ZKC_HIP_CHECK(ctx, hipGetLastError());
     }
     zkc_prof_scope _pn(ctx, ZKC_PROF_NTT, 6ull * 2 * n * 32 + 4ull * n * 32);   // 6 transforms r+w, joinABC
-    Fr* v[3] = {zk->d_a, zk->d_b, zk->d_c};
+    Fr* v[3] = {a, b, c};
     for (int k = 0; k < 3; k++) {
         int rc = ntt_run(ctx, v[k], zk->d_t, zk->d_tw_inv, zk->d_coset, (int)zk->logn); if (rc) return rc;
         rc = ntt_run(ctx, zk->d_t, v[k], zk->d_tw_fwd, nullptr, (int)zk->logn); if (rc) return rc;
     }
-    hipLaunchKernelGGL(zkc_join_abc, dim3((n + 255) / 256), dim3(256), 0, st, zk->d_a, zk->d_b, zk->d_c, zk->d_p, (int)n);
+    hipLaunchKernelGGL(zkc_join_abc, dim3((n + 255) / 256), dim3(256), 0, st, a, b, c, zk->d_p + 8 * (size_t)n * q, (int)n);
     ZKC_HIP_CHECK(ctx, hipGetLastError());
     return ZKC_OK;
 }
 
 extern "C" int zkc_debug_stage(zkc_zkey* zk, const void* d_wtns, int stage, void* host_out) {
-    // test hook: stage 0 -> A_w | B_w | C_w (3n Fr, Montgomery) after buildABC; stage 1 -> joinABC output (n x 32 B standard)
     if (!zk || !d_wtns || !host_out) return ZKC_ERR_BAD_ARG;
     zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n;
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (stage == 0) {
-        hipLaunchKernelGGL(zkc_matvec, dim3((2 * n + 255) / 256), dim3(256), 0, ctx->stream, zk->d_rowptr, zk->d_col, zk->d_val, (const Fr*)d_wtns, zk->d_a, (int)(2 * n));
-        hipLaunchKernelGGL(zkc_pointwise_mul, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, zk->d_a, zk->d_b, zk->d_c, (int)n);
+        hipLaunchKernelGGL(zkc_matvec, dim3((2 * n + 255) / 256), dim3(256), 0, ctx->stream, zk->d_rowptr, zk->d_col, zk->d_val, (const Fr*)d_wtns, zk->d_abc, (int)(2 * n));
+        hipLaunchKernelGGL(zkc_pointwise_mul, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, zk->d_abc, zk->d_abc + n, zk->d_abc + 2 * (size_t)n, (int)n);
         ZKC_HIP_CHECK(ctx, hipGetLastError());
-        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(host_out, zk->d_a, 64ull * n, hipMemcpyDeviceToHost, ctx->stream));
-        ZKC_HIP_CHECK(ctx, hipMemcpyAsync((uint8_t*)host_out + 64ull * n, zk->d_c, 32ull * n, hipMemcpyDeviceToHost, ctx->stream));
+        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(host_out, zk->d_abc, 96ull * n, hipMemcpyDeviceToHost, ctx->stream));
     } else {
-        int rc = h_evals_dev(zk, (const uint32_t*)d_wtns); if (rc) return rc;
+        int rc = h_evals_dev(zk, (const uint32_t*)d_wtns, 0); if (rc) return rc;
         ZKC_HIP_CHECK(ctx, hipMemcpyAsync(host_out, zk->d_p, 32ull * n, hipMemcpyDeviceToHost, ctx->stream));
     }
     ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -187,28 +280,25 @@ extern "C" int zkc_debug_stage(zkc_zkey* zk, const void* d_wtns, int stage, void
 }
 
 extern "C" int zkc_msm_debug(zkc_zkey* zk, int which, const void* d_scalars, uint32_t count, void* host_out) {
-    // test hook: one MSM over a zkey section (0=A 1=B1 2=B2 3=C 4=H) with caller scalars; host_out = affine standard form
     if (!zk || !d_scalars || !host_out || which < 0 || which > 4) return ZKC_ERR_BAD_ARG;
     zkc_ctx* ctx = zk->ctx;
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const uint32_t full = which == 3 ? zk->nVars - zk->nPub - 1 : which == 4 ? zk->n : zk->nVars;
     if (count != full) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_msm_debug: count must equal the section size");
-    int rc;
-    if (which == 2) rc = msm_g2_run(zk, zk->d_B2, (const uint32_t*)d_scalars, count, 0);
-    else rc = msm_g1_run(zk, which == 0 ? zk->d_A : which == 1 ? zk->d_B1 : which == 3 ? zk->d_C : zk->d_H, (const uint32_t*)d_scalars, count, 0);
-    if (rc) return rc;
-    ZKC_HIP_CHECK(ctx, hipMemcpyAsync(zk->h_results, zk->d_results, sizeof(G2XYZZ), hipMemcpyDeviceToHost, ctx->stream));
+    MsmJobList jl{}; jl.njobs = 1; jl.entry_off[0] = 0; jl.entry_off[1] = count;
+    const uint32_t offs[5] = {zk->offA, zk->offB1, 0, zk->offC, zk->offH};
+    jl.job[0] = MsmJob{(const uint32_t*)d_scalars, nullptr, count, offs[which], full, 0};
+    int rc = which == 2 ? msm_pass_g2(zk, jl) : msm_pass_g1(zk, jl); if (rc) return rc;
     ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (which == 2) g2_to_std((uint8_t*)host_out, xyzz_to_affine(*(G2XYZZ*)zk->h_results));
-    else g1_to_std((uint8_t*)host_out, xyzz_to_affine(*(G1XYZZ*)zk->h_results));
+    if (which == 2) g2_to_std((uint8_t*)host_out, xyzz_to_affine(*(G2XYZZ*)zk->w2.h_results));
+    else g1_to_std((uint8_t*)host_out, xyzz_to_affine(*(G1XYZZ*)zk->w1.h_results));
     return ZKC_OK;
 }
 
 // a7: piA = alpha + A + r delta ; piB = beta + B + s delta ; piC = C + H + s piA + r piB1 - r s delta   (host, constant work)
-static void finalize_proof(const zkc_zkey* zk, const G2XYZZ* res, const uint8_t r32[32], const uint8_t s32[32], uint8_t proof[256]) {
+static void finalize_proof(const zkc_zkey* zk, const G1XYZZ& A, const G1XYZZ& B1, const G2XYZZ& B2, const G1XYZZ& C, const G1XYZZ& H,
+                           const uint8_t r32[32], const uint8_t s32[32], uint8_t proof[256]) {
     uint32_t rk[8], sk[8]; memcpy(rk, r32, 32); memcpy(sk, s32, 32);
-    const G1XYZZ A = *(const G1XYZZ*)&res[0], B1 = *(const G1XYZZ*)&res[1], C = *(const G1XYZZ*)&res[3], H = *(const G1XYZZ*)&res[4];
-    const G2XYZZ B2 = res[2];
     const G1XYZZ d1 = G1XYZZ::from_affine(zk->delta1); const G2XYZZ d2 = G2XYZZ::from_affine(zk->delta2);
     G1XYZZ piA = xyzz_add(xyzz_add_affine(A, zk->alpha1), xyzz_mul(d1, rk));
     G2XYZZ piB = xyzz_add(xyzz_add_affine(B2, zk->beta2), xyzz_mul(d2, sk));
@@ -219,26 +309,74 @@ static void finalize_proof(const zkc_zkey* zk, const G2XYZZ* res, const uint8_t 
     g1_to_std(proof, xyzz_to_affine(piA)); g2_to_std(proof + 64, xyzz_to_affine(piB)); g1_to_std(proof + 192, xyzz_to_affine(piC));
 }
 
-extern "C" int zkc_prove_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, const uint8_t r32[32], const uint8_t s32[32],
-                             uint8_t proof[256], uint8_t* public_out) {
-    if (!zk || !d_wtns || !r32 || !s32 || !proof) return zkc_fail(zk ? zk->ctx : nullptr, ZKC_ERR_BAD_ARG, "zkc_prove_dev: bad argument");
+// B witnesses resident in HBM -> B proofs.  rs: B x 64 B (r || s).  proofs: B x 256 B, publics: B x nPublic x 32 B (host).
+extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, int B, const uint8_t* rs, uint8_t* proofs, uint8_t* publics) {
+    if (!zk || !d_wtns || !rs || !proofs || B <= 0) return zkc_fail(zk ? zk->ctx : nullptr, ZKC_ERR_BAD_ARG, "zkc_prove_batch_dev: bad argument");
     zkc_ctx* ctx = zk->ctx;
     if (nWitness != zk->nVars) return zkc_fail(ctx, ZKC_ERR_INVALID_WITNESS_LENGTH, "Invalid witness length. Circuit: " + std::to_string(zk->nVars) + ", witness: " + std::to_string(nWitness));
-    uint32_t t[8]; memcpy(t, r32, 32); if (!fp_std_lt_p<FrParams>(t)) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "r >= field order");
-    memcpy(t, s32, 32); if (!fp_std_lt_p<FrParams>(t)) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "s >= field order");
+    for (int b = 0; b < 2 * B; b++) { uint32_t t[8]; memcpy(t, rs + 32 * (size_t)b, 32); if (!fp_std_lt_p<FrParams>(t)) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "r or s >= field order"); }
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    const uint32_t* w = (const uint32_t*)d_wtns;
-    int rc = h_evals_dev(zk, w); if (rc) return rc;
-    if ((rc = msm_g1_run(zk, zk->d_A, w, zk->nVars, 0))) return rc;
-    if ((rc = msm_g1_run(zk, zk->d_B1, w, zk->nVars, 1))) return rc;
-    if ((rc = msm_g2_run(zk, zk->d_B2, w, zk->nVars, 2))) return rc;
-    if ((rc = msm_g1_run(zk, zk->d_C, w + 8ull * (zk->nPub + 1), zk->nVars - zk->nPub - 1, 3))) return rc;
-    if ((rc = msm_g1_run(zk, zk->d_H, zk->d_p, zk->n, 4))) return rc;
-    ZKC_HIP_CHECK(ctx, hipMemcpyAsync(zk->h_results, zk->d_results, 5 * sizeof(G2XYZZ), hipMemcpyDeviceToHost, ctx->stream));
-    if (public_out) ZKC_HIP_CHECK(ctx, hipMemcpyAsync(public_out, w + 8, 32ull * zk->nPub, hipMemcpyDeviceToHost, ctx->stream));
-    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    finalize_proof(zk, (const G2XYZZ*)zk->h_results, r32, s32, proof);
+    const uint32_t nv = zk->nVars, np = zk->nPub, nc = nv - np - 1, n = zk->n;
+    const bool can_fold = zk->nLevels >= 0;
+    WitnessLayout L{}; uint32_t* tmpl = nullptr; int rc;
+    if (can_fold) { L = WitnessLayout::make(zk->nLevels); if ((rc = fold_prepare(zk))) return rc; tmpl = zkc_get_template(ctx, zk->nLevels); if (!tmpl) return ZKC_ERR_HIP; }
+    for (int p0 = 0; p0 < B; p0 += zk->max_inflight) {
+        const int nb = std::min(zk->max_inflight, B - p0);
+        const uint32_t* w0 = (const uint32_t*)d_wtns + (size_t)p0 * nv * 8;
+        int Dc = 0, Ds = 0; bool fold = can_fold;
+        if (can_fold) {       // largest level of this chunk that differs from the template, per tree; n2bOld blocks must match too
+            hipLaunchKernelGGL(zkc_fold_check, dim3(L.n, 2, nb), dim3(64), 0, ctx->stream, L, w0, tmpl, zk->d_flags, nb);
+            ZKC_HIP_CHECK(ctx, hipGetLastError());
+            ZKC_HIP_CHECK(ctx, hipMemcpyAsync(zk->h_flags, zk->d_flags, (size_t)nb * 2 * L.n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        for (int q = 0; q < nb; q++) if ((rc = h_evals_dev(zk, w0 + (size_t)q * nv * 8, q))) return rc;
+        uint32_t* vmap = nullptr; uint32_t nV = nv;
+        if (can_fold) {
+            ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            for (int q = 0; q < nb && fold; q++) for (int t = 0; t < 2; t++) {
+                const uint32_t* f = zk->h_flags + ((size_t)q * 2 + t) * L.n;
+                if (f[L.n - 1]) { fold = false; break; }
+                int D = 0; for (int g = 0; g < L.n - 1; g++) if (f[g]) D = g + 1;
+                if (t == 0) Dc = std::max(Dc, D); else Ds = std::max(Ds, D);
+            }
+            if (fold && (rc = fold_vmap(zk, Dc, Ds, &vmap, &nV))) return rc;
+        }
+        MsmJobList j1{}, j2{}; uint32_t e1 = 0, e2 = 0;
+        for (int q = 0; q < nb; q++) {
+            const uint32_t* w = w0 + (size_t)q * nv * 8;
+            const uint32_t cntC = fold ? nV - (np + 1) : nc;     // wires 0..nPub are never folded, so they are the first nPub+1 map entries
+            j1.entry_off[4 * q + 0] = e1; j1.job[4 * q + 0] = MsmJob{w, vmap, nV, zk->offA, nv, 0}; e1 += nV;
+            j1.entry_off[4 * q + 1] = e1; j1.job[4 * q + 1] = MsmJob{w, vmap, nV, zk->offB1, nv, 0}; e1 += nV;
+            j1.entry_off[4 * q + 2] = e1;
+            j1.job[4 * q + 2] = fold ? MsmJob{w, vmap + (np + 1), cntC, zk->offC, nc, (int32_t)np + 1} : MsmJob{w + 8ull * (np + 1), nullptr, nc, zk->offC, nc, 0};
+            e1 += cntC;
+            j1.entry_off[4 * q + 3] = e1; j1.job[4 * q + 3] = MsmJob{zk->d_p + 8 * (size_t)n * q, nullptr, n, zk->offH, n, 0}; e1 += n;
+            j2.entry_off[q] = e2; j2.job[q] = MsmJob{w, vmap, nV, 0, nv, 0}; e2 += nV;
+        }
+        j1.njobs = 4 * nb; j1.entry_off[4 * nb] = e1; j2.njobs = nb; j2.entry_off[nb] = e2;
+        if ((rc = msm_pass_g1(zk, j1)) || (rc = msm_pass_g2(zk, j2))) return rc;
+        if (publics) for (int q = 0; q < nb; q++)
+            ZKC_HIP_CHECK(ctx, hipMemcpyAsync(publics + 32ull * np * (p0 + q), w0 + (size_t)q * nv * 8 + 8, 32ull * np, hipMemcpyDeviceToHost, ctx->stream));
+        ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        const G1XYZZ* r1 = (const G1XYZZ*)zk->w1.h_results; const G2XYZZ* r2 = (const G2XYZZ*)zk->w2.h_results;
+        G1XYZZ kA = G1XYZZ::inf(), kB1 = kA, kC = kA; G2XYZZ kB2 = G2XYZZ::inf();
+        if (fold) {
+            const auto& f = zk->fold;
+            kA = xyzz_add(f.baseA[0], xyzz_add(f.sufA[0][Dc], f.sufA[1][Ds])); kB1 = xyzz_add(f.baseB1[0], xyzz_add(f.sufB1[0][Dc], f.sufB1[1][Ds]));
+            kC = xyzz_add(f.baseC[0], xyzz_add(f.sufC[0][Dc], f.sufC[1][Ds])); kB2 = xyzz_add(f.baseB2[0], xyzz_add(f.sufB2[0][Dc], f.sufB2[1][Ds]));
+        }
+        for (int q = 0; q < nb; q++)
+            finalize_proof(zk, xyzz_add(r1[4 * q], kA), xyzz_add(r1[4 * q + 1], kB1), xyzz_add(r2[q], kB2), xyzz_add(r1[4 * q + 2], kC), r1[4 * q + 3],
+                           rs + 64ull * (p0 + q), rs + 64ull * (p0 + q) + 32, proofs + 256ull * (p0 + q));
+    }
     return ZKC_OK;
+}
+
+extern "C" int zkc_prove_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, const uint8_t r32[32], const uint8_t s32[32],
+                             uint8_t proof[256], uint8_t* public_out) {
+    if (!r32 || !s32) return zkc_fail(zk ? zk->ctx : nullptr, ZKC_ERR_BAD_ARG, "zkc_prove_dev: bad argument");
+    uint8_t rs[64]; memcpy(rs, r32, 32); memcpy(rs + 32, s32, 32);
+    return zkc_prove_batch_dev(zk, d_wtns, nWitness, 1, rs, proof, public_out);
 }
 
 extern "C" int zkc_prove(zkc_zkey* zk, const void* wtns, uint32_t nWitness, const uint8_t r32[32], const uint8_t s32[32],

@@ -6,37 +6,77 @@
 namespace zkc {
 constexpr int MSM_C = 13;                          // Pippenger window bits (signed digits -> 2^(c-1) buckets per window)
 constexpr int MSM_NW = (254 + MSM_C) / MSM_C;      // 20 windows cover 260 bits
-constexpr int MSM_HALF = 1 << (MSM_C - 1);
-constexpr int MSM_NB = MSM_NW * MSM_HALF;          // buckets per MSM
-constexpr int MSM_HEAVY = 256;                     // buckets with more points go to the block-per-bucket kernel
-constexpr int MSM_MAX_HEAVY = 4096;
-constexpr int MSM_GROUP = 32;                      // buckets per thread in the running-sum reduction
-}
+constexpr int MSM_HALF = 1 << (MSM_C - 1);         // 4096 buckets per window
+constexpr int MSM_NB = MSM_NW * MSM_HALF;          // buckets per MSM job
+constexpr int MSM_SEG = 16;                        // sorted entries per accumulation lane (load balance for repeated scalars)
+constexpr int MSM_MERGE_T = 8;                     // buckets with more segments get a wave of their own before the window pass
+constexpr int MSM_MAX_HEAVY = 1 << 16;
+constexpr int MSM_MAX_JOBS = 64;                   // jobs per pipeline pass (proofs in flight x sections)
+
+// One multi-scalar multiplication inside a pipeline pass: sum_j scalar[j] * P[point(j)]
+struct MsmJob {
+    const uint32_t* scalars;   // standard form, 8 x u32 each
+    const uint32_t* vmap;      // nullptr: scalar j / point j.  else: scalar at scalars + 8*vmap[j], point vmap[j] - pt_shift
+    uint32_t count;            // number of (scalar, point) pairs
+    uint32_t tbl_off;          // first point of this section's pre-shifted table inside the unified point array
+    uint32_t tbl_count;        // points per window in that table
+    int32_t pt_shift;
+};
+struct MsmJobList { MsmJob job[MSM_MAX_JOBS]; uint32_t entry_off[MSM_MAX_JOBS + 1]; int njobs; };
+
+// Work space of one pipeline pass (sized for MSM_MAX_JOBS jobs and max_entries (scalar, window) pairs)
+struct MsmWork {
+    uint32_t *keys = nullptr, *vals = nullptr, *keys2 = nullptr, *vals2 = nullptr;   // max_entries each
+    uint32_t *off = nullptr;        // bucket boundaries, njobs*NB + 1
+    uint32_t *segcnt = nullptr, *segoff = nullptr, *seg2bucket = nullptr, *heavy = nullptr;
+    void *partial = nullptr;        // XYZZ per segment
+    void *wres = nullptr;           // XYZZ per (job, window)
+    void *results = nullptr;        // XYZZ per job (device) ; h_results pinned host mirror
+    void *h_results = nullptr;
+    void *sort_tmp = nullptr; size_t sort_tmp_sz = 0; void* scan_tmp = nullptr; size_t scan_tmp_sz = 0;
+    size_t max_entries = 0, max_segments = 0; int max_jobs = 0; size_t xyzz_size = 0;
+};
+}  // namespace zkc
 
 struct zkc_zkey {
     zkc_ctx* ctx = nullptr;
     uint32_t nVars = 0, nPub = 0, n = 0, logn = 0, nCoeffs = 0;
+    int nLevels = -1;                              // >= 0 when the key's shape matches ZkFranchiseProofCircuit(nLevels): enables folding
     zkc::G1Affine alpha1, beta1, delta1;           // host copies, Montgomery
     zkc::G2Affine beta2, gamma2, delta2;
     std::vector<zkc::G1Affine> ic;
     // device: CSR of section 4 (rows [0,n) = A, [n,2n) = B), values as stored (val * R^2)
     uint32_t *d_rowptr = nullptr, *d_col = nullptr; zkc::Fr* d_val = nullptr;
     zkc::Fr *d_tw_fwd = nullptr, *d_tw_inv = nullptr, *d_coset = nullptr;   // w^j, w^-j (j < n/2), g^i / n
-    // window-shifted base tables: T[w][i] = 2^(c*w) * P_i, affine Montgomery
-    zkc::G1Affine *d_A = nullptr, *d_B1 = nullptr, *d_C = nullptr, *d_H = nullptr; zkc::G2Affine* d_B2 = nullptr;
-    // per-proof work buffers (one proof in flight per zkey handle)
-    zkc::Fr *d_a = nullptr, *d_b = nullptr, *d_c = nullptr, *d_t = nullptr; uint32_t* d_p = nullptr;   // n each
-    uint32_t *d_keys = nullptr, *d_vals = nullptr, *d_keys2 = nullptr, *d_vals2 = nullptr, *d_off = nullptr, *d_heavy = nullptr;
-    void* d_sort_tmp = nullptr; size_t sort_tmp_sz = 0;
-    void *d_buckets = nullptr, *d_partial = nullptr, *d_results = nullptr;   // XYZZ arrays
-    void* h_results = nullptr;                      // pinned host mirror of d_results
+    // pre-shifted base tables, one allocation per group: G1 = [A | B1 | C | H], G2 = [B2]; T[w][i] = 2^(c*w) * P_i
+    zkc::G1Affine* d_g1 = nullptr; zkc::G2Affine* d_g2 = nullptr;
+    uint32_t offA = 0, offB1 = 0, offC = 0, offH = 0;                       // table offsets inside d_g1 (points)
+    // per-proof work buffers
+    int max_inflight = 0;                                                   // proofs per pipeline pass
+    zkc::Fr *d_abc = nullptr, *d_t = nullptr; uint32_t* d_p = nullptr;      // [inflight][3n] , [n] , [inflight][n x 8]
+    zkc::MsmWork w1, w2;                                                    // G1 and G2 pipelines
+    uint32_t *d_flags = nullptr, *h_flags = nullptr;                        // fold check: [inflight][2][n]
+    // constant folding of the voter-independent witness part (SURVEY.md hard part 4)
+    struct Fold {
+        std::vector<zkc::G1XYZZ> baseA, baseB1, baseC; std::vector<zkc::G2XYZZ> baseB2;        // [1]
+        std::vector<zkc::G1XYZZ> sufA[2], sufB1[2], sufC[2]; std::vector<zkc::G2XYZZ> sufB2[2];   // [tree][D] = sum over levels >= D
+        std::map<std::pair<int, int>, std::pair<uint32_t*, uint32_t>> vmaps;                    // (Dc, Ds) -> device wire list, count
+        bool ready = false;
+    } fold;
 };
 
 namespace zkc {
 int ntt_run(zkc_ctx* ctx, const Fr* src, Fr* dst, const Fr* tw, const Fr* scale, int logn);
-// result slot r of zk->d_results receives sum_i scalars[i] * P_i for the table `table` (nw x count points)
-int msm_g1_run(zkc_zkey* zk, const G1Affine* table, const uint32_t* d_scalars_std, uint32_t count, int slot);
-int msm_g2_run(zkc_zkey* zk, const G2Affine* table, const uint32_t* d_scalars_std, uint32_t count, int slot);
-int msm_precompute_g1(zkc_ctx* ctx, const G1Affine* d_base, uint32_t count, G1Affine* d_table);   // d_table[0..count) = base on entry
-int msm_precompute_g2(zkc_ctx* ctx, const G2Affine* d_base, uint32_t count, G2Affine* d_table);
+int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, int max_jobs, bool g2);
+void msm_work_free(MsmWork& w);
+// runs all jobs of `jl` through one pipeline pass; results (XYZZ per job) land in w.h_results after the caller syncs
+int msm_pass_g1(zkc_zkey* zk, const MsmJobList& jl);
+int msm_pass_g2(zkc_zkey* zk, const MsmJobList& jl);
+int msm_precompute_g1(zkc_ctx* ctx, uint32_t count, G1Affine* d_table);   // d_table[0..count) = base on entry
+int msm_precompute_g2(zkc_ctx* ctx, uint32_t count, G2Affine* d_table);
+// out[i] = scalar[wires[i]] * P[wires[i] - pt_shift] (window-0 table), then per-group sums: gsum[g] = sum out[gstart[g]..gstart[g+1])
+int fold_group_sums_g1(zkc_ctx* ctx, const G1Affine* tbl, const uint32_t* d_scalars, const uint32_t* d_wires, uint32_t nw, int32_t pt_shift,
+                       const uint32_t* d_gstart, uint32_t ngroups, G1XYZZ* h_out);
+int fold_group_sums_g2(zkc_ctx* ctx, const G2Affine* tbl, const uint32_t* d_scalars, const uint32_t* d_wires, uint32_t nw, int32_t pt_shift,
+                       const uint32_t* d_gstart, uint32_t ngroups, G2XYZZ* h_out);
 }
