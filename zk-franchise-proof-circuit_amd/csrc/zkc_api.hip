@@ -109,6 +109,7 @@ extern "C" int zkc_ctx_create(int device, zkc_ctx** out) {
     hipError_t e;
     if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+    if ((e = hipStreamCreateWithFlags(&ctx->fin_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate(fin)");
     // Poseidon parameter tables -> Montgomery form -> HBM (about 1.6k Fr = 51 KB; L2/scalar-cache resident)
     std::vector<Fr> all; size_t off[12]; int k = 0;
     off[k++] = all.size(); conv_consts(all, ZKC_POSEIDON_C3); off[k++] = all.size(); conv_consts(all, ZKC_POSEIDON_S3);
@@ -139,6 +140,7 @@ extern "C" void zkc_ctx_destroy(zkc_ctx* ctx) {
     if (ctx->d_scratch_out) (void)hipFree(ctx->d_scratch_out);
     if (ctx->d_status3) (void)hipFree(ctx->d_status3);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->fin_stream) (void)hipStreamDestroy(ctx->fin_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -23,6 +23,7 @@ struct zkc_prof {
 struct zkc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t fin_stream = nullptr;     // blinding kernel + proof D2H, overlapping the next pipeline pass
     std::string err;
     zkc::PoseidonTable ptab{};            // device pointers
     void* d_ptab_mem = nullptr;

@@ -95,7 +95,7 @@ zkc_msm_seg2bucket(const uint32_t* __restrict__ segoff, uint32_t nbuckets, uint3
 
 // ---- K5 ----
 template <class F>
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(128, 2)
 zkc_msm_accumulate(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ off,
                    const uint32_t* __restrict__ segoff, const uint32_t* __restrict__ seg2bucket, uint32_t nbuckets,
                    XYZZ<F>* __restrict__ partial, uint32_t max_segments) {
@@ -278,7 +278,7 @@ int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, int max_jobs, b
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.heavy, (MSM_MAX_HEAVY + 1) * 4));
     ZKC_HIP_CHECK(ctx, hipMalloc(&w.partial, w.max_segments * w.xyzz_size));
     ZKC_HIP_CHECK(ctx, hipMalloc(&w.wres, (size_t)max_jobs * MSM_NW * w.xyzz_size));
-    ZKC_HIP_CHECK(ctx, hipMalloc(&w.results, (size_t)max_jobs * w.xyzz_size));
+    ZKC_HIP_CHECK(ctx, hipMalloc(&w.results, 2 * (size_t)max_jobs * w.xyzz_size));
     ZKC_HIP_CHECK(ctx, hipHostMalloc(&w.h_results, (size_t)max_jobs * w.xyzz_size));
     return ZKC_OK;
 }
@@ -299,7 +299,7 @@ static const bool g_debug_sync = getenv("ZKC_DEBUG_SYNC") != nullptr;   // seria
                     hipGetErrorString(_e)); fflush(stderr); } } while (0)
 
 template <class F>
-static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJobList& jl) {
+static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJobList& jl, int slot, bool to_host) {
     zkc_ctx* ctx = zk->ctx; hipStream_t st = ctx->stream;
     const int nj = jl.njobs;
     if (nj <= 0 || nj > w.max_jobs) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: job count");
@@ -337,7 +337,7 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     }
     XYZZ<F>* partial = reinterpret_cast<XYZZ<F>*>(w.partial);
     XYZZ<F>* wres = reinterpret_cast<XYZZ<F>*>(w.wres);
-    XYZZ<F>* results = reinterpret_cast<XYZZ<F>*>(w.results);
+    XYZZ<F>* results = reinterpret_cast<XYZZ<F>*>(w.results) + (size_t)slot * w.max_jobs;
     const size_t seg_bound = std::min<size_t>(w.max_segments, total / MSM_SEG + nb);     // launch bound on the number of segments
     {
         zkc_prof_scope _ps(ctx, kG2 ? ZKC_PROF_MSM_ACC_G2 : ZKC_PROF_MSM_ACC_G1, alg_bytes);
@@ -356,10 +356,10 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
         hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_final<F>), dim3((nj + 63) / 64), dim3(64), 0, st, wres, nj, results);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_final");
     }
-    ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.h_results, w.results, (size_t)nj * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+    if (to_host) ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.h_results, results, (size_t)nj * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
     return ZKC_OK;
 }
-int msm_pass_g1(zkc_zkey* zk, const MsmJobList& jl) { return msm_pass<Fq>(zk, zk->w1, zk->d_g1, jl); }
-int msm_pass_g2(zkc_zkey* zk, const MsmJobList& jl) { return msm_pass<Fq2>(zk, zk->w2, zk->d_g2, jl); }
+int msm_pass_g1(zkc_zkey* zk, const MsmJobList& jl, int slot, bool to_host) { return msm_pass<Fq>(zk, zk->w1, zk->d_g1, jl, slot, to_host); }
+int msm_pass_g2(zkc_zkey* zk, const MsmJobList& jl, int slot, bool to_host) { return msm_pass<Fq2>(zk, zk->w2, zk->d_g2, jl, slot, to_host); }
 
 }  // namespace zkc

@@ -24,13 +24,20 @@ __device__ __forceinline__ void st_fr(Fr* p, const Fr& r) {
 
 // ---- buildABC1: rows [0,n) = A, [n,2n) = B ; out = sum coef * w[signal].  coef is stored as val*R^2 (the .zkey
 // convention) so one Montgomery product with the standard-form witness lands in Montgomery form. ----
+// K3a is split in two so that every lane has the same amount of multiplier work regardless of row length (rows of the
+// zkCensus R1CS hold between 1 and ~120 coefficients): zkc_matvec_mul forms one product per coefficient, zkc_matvec_rows
+// adds each row's products (additions only).
 extern "C" __global__ void __launch_bounds__(256)
-zkc_matvec(const uint32_t* __restrict__ rowptr, const uint32_t* __restrict__ col, const Fr* __restrict__ val,
-           const Fr* __restrict__ wtns_std, Fr* __restrict__ out, int nrows) {
+zkc_matvec_mul(const uint32_t* __restrict__ col, const Fr* __restrict__ val, const Fr* __restrict__ wtns_std, Fr* __restrict__ prod, uint32_t ncoef) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < ncoef) st_fr(prod + k, ld_fr(val + k) * ld_fr(wtns_std + col[k]));
+}
+extern "C" __global__ void __launch_bounds__(256)
+zkc_matvec_rows(const uint32_t* __restrict__ rowptr, const Fr* __restrict__ prod, Fr* __restrict__ out, int nrows) {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nrows) return;
     Fr acc = Fr::zero();
-    for (uint32_t k = rowptr[r], e = rowptr[r + 1]; k < e; k++) acc = acc + ld_fr(val + k) * ld_fr(wtns_std + col[k]);
+    for (uint32_t k = rowptr[r], e = rowptr[r + 1]; k < e; k++) acc = acc + ld_fr(prod + k);
     st_fr(out + r, acc);
 }
 // c = a * b
@@ -56,8 +63,10 @@ zkc_join_abc(const Fr* __restrict__ a, const Fr* __restrict__ b, const Fr* __res
 // scale != nullptr: multiply element i by scale[i] when storing (used on the last pass of the inverse transform).
 constexpr int NTT_TILE = 1024;        // elements per block tile = 32 KiB of LDS
 extern "C" __global__ void __launch_bounds__(256)
-zkc_ntt_pass(const Fr* __restrict__ src, Fr* __restrict__ dst, const Fr* __restrict__ tw, const Fr* __restrict__ scale,
+zkc_ntt_pass(const Fr* __restrict__ src_all, Fr* __restrict__ dst_all, const Fr* __restrict__ tw, const Fr* __restrict__ scale,
              int logn, int s0, int b, int first) {
+    const Fr* __restrict__ src = src_all + ((size_t)blockIdx.y << logn);      // blockIdx.y = vector of the batch
+    Fr* __restrict__ dst = dst_all + ((size_t)blockIdx.y << logn);
     extern __shared__ uint4 lds4[];
     Fr* tile = reinterpret_cast<Fr*>(lds4);
     const int mid_n = 1 << b;
@@ -98,8 +107,8 @@ zkc_ntt_pass(const Fr* __restrict__ src, Fr* __restrict__ dst, const Fr* __restr
     }
 }
 
-// Full transform src -> dst (src is preserved unless src == dst is not allowed for the first pass).
-int ntt_run(zkc_ctx* ctx, const Fr* src, Fr* dst, const Fr* tw, const Fr* scale, int logn) {
+// Full transform of `nvec` contiguous vectors src -> dst (src must differ from dst: the first pass scatters by bit reversal).
+int ntt_run(zkc_ctx* ctx, const Fr* src, Fr* dst, const Fr* tw, const Fr* scale, int logn, int nvec) {
     int s0 = 0; bool first = true;
     while (s0 < logn) {
         int b = logn - s0 < 9 ? logn - s0 : 9;
@@ -108,7 +117,7 @@ int ntt_run(zkc_ctx* ctx, const Fr* src, Fr* dst, const Fr* tw, const Fr* scale,
         const int lo_t = (NTT_TILE >> b) < (1 << s0) ? (NTT_TILE >> b) : (1 << s0);
         const int nblocks = (1 << logn) / ((1 << b) * lo_t);
         const bool last = s0 + b == logn;
-        hipLaunchKernelGGL(zkc_ntt_pass, dim3(nblocks), dim3(256), (size_t)(1 << b) * lo_t * sizeof(Fr), ctx->stream,
+        hipLaunchKernelGGL(zkc_ntt_pass, dim3(nblocks, nvec), dim3(256), (size_t)(1 << b) * lo_t * sizeof(Fr), ctx->stream,
                            first ? src : dst, dst, tw, last ? scale : nullptr, logn, s0, b, first ? 1 : 0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, std::string("zkc_ntt_pass: ") + hipGetErrorString(e));

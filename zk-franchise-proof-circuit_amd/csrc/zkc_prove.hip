@@ -7,12 +7,14 @@
 // Mirrors snarkjs groth16.prove (ts_inputs/src/example.ts:358-362 via fullProve) / rapidsnark groth16_prover
 // (zk_census_test.go:89).
 #include "zkc_prover.h"
+#include "zkc_fixedbase.h"
 #include <cstring>
 #include <algorithm>
 
 using namespace zkc;
 
-extern "C" __global__ void zkc_matvec(const uint32_t*, const uint32_t*, const Fr*, const Fr*, Fr*, int);
+extern "C" __global__ void zkc_matvec_mul(const uint32_t*, const Fr*, const Fr*, Fr*, uint32_t);
+extern "C" __global__ void zkc_matvec_rows(const uint32_t*, const Fr*, Fr*, int);
 extern "C" __global__ void zkc_pointwise_mul(const Fr*, const Fr*, Fr*, int);
 extern "C" __global__ void zkc_join_abc(const Fr*, const Fr*, const Fr*, uint32_t*, int);
 
@@ -62,10 +64,12 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     if (!zk) return;
     (void)hipSetDevice(zk->ctx->device);
     (void)hipStreamSynchronize(zk->ctx->stream);
-    void* ptrs[] = {zk->d_rowptr, zk->d_col, zk->d_val, zk->d_tw_fwd, zk->d_tw_inv, zk->d_coset, zk->d_g1, zk->d_g2, zk->d_abc, zk->d_t, zk->d_p, zk->d_flags};
+    void* ptrs[] = {zk->d_rowptr, zk->d_col, zk->d_val, zk->d_tw_fwd, zk->d_tw_inv, zk->d_coset, zk->d_g1, zk->d_g2, zk->d_abc, zk->d_t, zk->d_prod, zk->d_p, zk->d_flags,
+                    zk->d_tblDelta1, zk->d_tblAlpha1, zk->d_tblBeta1, zk->d_tblDelta2, zk->d_rs, zk->d_proofs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : zk->fold.vmaps) if (kv.second.first) (void)hipFree(kv.second.first);
     if (zk->h_flags) (void)hipHostFree(zk->h_flags);
+    for (int i = 0; i < 2; i++) { if (zk->ev_msm[i]) (void)hipEventDestroy(zk->ev_msm[i]); if (zk->ev_fin[i]) (void)hipEventDestroy(zk->ev_fin[i]); }
     msm_work_free(zk->w1); msm_work_free(zk->w2);
     delete zk;
 }
@@ -154,16 +158,22 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
         (rc = msm_precompute_g2(ctx, nv, zk->d_g2))) return bail(rc);
     // ---- work buffers: `inflight` proofs share one MSM pipeline pass ----
     const char* e_inf = getenv("ZKC_INFLIGHT");
-    zk->max_inflight = e_inf ? std::max(1, std::min(atoi(e_inf), MSM_MAX_JOBS / 4)) : 8;
+    zk->max_inflight = e_inf ? std::max(1, std::min(atoi(e_inf), MSM_MAX_JOBS / 4)) : 16;
     const size_t per_proof_entries = (size_t)MSM_NW * (3 * (size_t)nv + n);
-    if ((rc = dmalloc(ctx, &zk->d_abc, 3 * (size_t)n * zk->max_inflight)) || (rc = dmalloc(ctx, &zk->d_t, n)) ||
+    if ((rc = dmalloc(ctx, &zk->d_abc, 3 * (size_t)n * zk->max_inflight)) || (rc = dmalloc(ctx, &zk->d_t, 3 * (size_t)n * zk->max_inflight)) || (rc = dmalloc(ctx, &zk->d_prod, (size_t)zk->nCoeffs + 1)) ||
         (rc = dmalloc(ctx, &zk->d_p, 8 * (size_t)n * zk->max_inflight))) return bail(rc);
     if ((rc = msm_work_alloc(ctx, zk->w1, per_proof_entries * zk->max_inflight, 4 * zk->max_inflight, false))) return bail(rc);
     if ((rc = msm_work_alloc(ctx, zk->w2, (size_t)MSM_NW * nv * zk->max_inflight, zk->max_inflight, true))) return bail(rc);
-    if (zk->nLevels >= 0) {
-        const size_t nflags = (size_t)zk->max_inflight * 2 * (zk->nLevels + 1);
-        if ((rc = dmalloc(ctx, &zk->d_flags, nflags))) return bail(rc);
-        ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&zk->h_flags, nflags * 4));
+    {   // fixed-base tables for the blinding step (delta1, alpha1, beta1 in G1; delta2 in G2)
+        FixedBase<Fq> td(zk->delta1), ta(zk->alpha1), tb(zk->beta1); FixedBase<Fq2> t2(zk->delta2);
+        if ((rc = dmalloc(ctx, &zk->d_tblDelta1, td.tab.size())) || (rc = dmalloc(ctx, &zk->d_tblAlpha1, ta.tab.size())) ||
+            (rc = dmalloc(ctx, &zk->d_tblBeta1, tb.tab.size())) || (rc = dmalloc(ctx, &zk->d_tblDelta2, t2.tab.size()))) return bail(rc);
+        ZKC_UP(zk->d_tblDelta1, td.tab.data(), td.tab.size() * sizeof(G1Affine)); ZKC_UP(zk->d_tblAlpha1, ta.tab.data(), ta.tab.size() * sizeof(G1Affine));
+        ZKC_UP(zk->d_tblBeta1, tb.tab.data(), tb.tab.size() * sizeof(G1Affine)); ZKC_UP(zk->d_tblDelta2, t2.tab.data(), t2.tab.size() * sizeof(G2Affine));
+    }
+    for (int i = 0; i < 2; i++) {
+        ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&zk->ev_msm[i], hipEventDisableTiming));
+        ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&zk->ev_fin[i], hipEventDisableTiming));
     }
     ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     *out = zk;
@@ -240,24 +250,27 @@ static int fold_vmap(zkc_zkey* zk, int Dc, int Ds, uint32_t** d_map, uint32_t* c
     return ZKC_OK;
 }
 
-// stages a2..a4 for proof slot q: leaves (A'B' - C') on the odd coset in d_p[q] (standard form)
-static int h_evals_dev(zkc_zkey* zk, const uint32_t* d_wtns, int q) {
-    zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n; hipStream_t st = ctx->stream;
-    Fr *a = zk->d_abc + 3 * (size_t)n * q, *b = a + n, *c = a + 2 * (size_t)n;
+// stages a2..a4 for `nb` proofs: leaves (A'B' - C') on the odd coset in d_p[q] (standard form), q < nb
+static int h_evals_dev(zkc_zkey* zk, const uint32_t* d_wtns0, int nb) {
+    zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n, nv = zk->nVars; hipStream_t st = ctx->stream;
     {
-        zkc_prof_scope _ps(ctx, ZKC_PROF_MATVEC, (uint64_t)zk->nCoeffs * 68 + 3ull * n * 32);
-        hipLaunchKernelGGL(zkc_matvec, dim3((2 * n + 255) / 256), dim3(256), 0, st, zk->d_rowptr, zk->d_col, zk->d_val, (const Fr*)d_wtns, a, (int)(2 * n));
-        ZKC_HIP_CHECK(ctx, hipGetLastError());
-        hipLaunchKernelGGL(zkc_pointwise_mul, dim3((n + 255) / 256), dim3(256), 0, st, a, b, c, (int)n);
+        zkc_prof_scope _ps(ctx, ZKC_PROF_MATVEC, (uint64_t)nb * ((uint64_t)zk->nCoeffs * 68 + 3ull * n * 32));
+        for (int q = 0; q < nb; q++) {
+            Fr *a = zk->d_abc + 3 * (size_t)n * q, *b = a + n, *c = a + 2 * (size_t)n;
+            hipLaunchKernelGGL(zkc_matvec_mul, dim3((zk->nCoeffs + 255) / 256), dim3(256), 0, st, zk->d_col, zk->d_val,
+                               (const Fr*)(d_wtns0 + (size_t)q * nv * 8), zk->d_prod, zk->nCoeffs);
+            hipLaunchKernelGGL(zkc_matvec_rows, dim3((2 * n + 255) / 256), dim3(256), 0, st, zk->d_rowptr, zk->d_prod, a, (int)(2 * n));
+            hipLaunchKernelGGL(zkc_pointwise_mul, dim3((n + 255) / 256), dim3(256), 0, st, a, b, c, (int)n);
+        }
         ZKC_HIP_CHECK(ctx, hipGetLastError());
     }
-    zkc_prof_scope _pn(ctx, ZKC_PROF_NTT, 6ull * 2 * n * 32 + 4ull * n * 32);   // 6 transforms r+w, joinABC
-    Fr* v[3] = {a, b, c};
-    for (int k = 0; k < 3; k++) {
-        int rc = ntt_run(ctx, v[k], zk->d_t, zk->d_tw_inv, zk->d_coset, (int)zk->logn); if (rc) return rc;
-        rc = ntt_run(ctx, zk->d_t, v[k], zk->d_tw_fwd, nullptr, (int)zk->logn); if (rc) return rc;
+    zkc_prof_scope _pn(ctx, ZKC_PROF_NTT, (uint64_t)nb * (6ull * 2 * n * 32 + 4ull * n * 32));   // 6 transforms r+w, joinABC
+    int rc = ntt_run(ctx, zk->d_abc, zk->d_t, zk->d_tw_inv, zk->d_coset, (int)zk->logn, 3 * nb); if (rc) return rc;
+    rc = ntt_run(ctx, zk->d_t, zk->d_abc, zk->d_tw_fwd, nullptr, (int)zk->logn, 3 * nb); if (rc) return rc;
+    for (int q = 0; q < nb; q++) {
+        Fr *a = zk->d_abc + 3 * (size_t)n * q, *b = a + n, *c = a + 2 * (size_t)n;
+        hipLaunchKernelGGL(zkc_join_abc, dim3((n + 255) / 256), dim3(256), 0, st, a, b, c, zk->d_p + 8 * (size_t)n * q, (int)n);
     }
-    hipLaunchKernelGGL(zkc_join_abc, dim3((n + 255) / 256), dim3(256), 0, st, a, b, c, zk->d_p + 8 * (size_t)n * q, (int)n);
     ZKC_HIP_CHECK(ctx, hipGetLastError());
     return ZKC_OK;
 }
@@ -267,12 +280,13 @@ extern "C" int zkc_debug_stage(zkc_zkey* zk, const void* d_wtns, int stage, void
     zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n;
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (stage == 0) {
-        hipLaunchKernelGGL(zkc_matvec, dim3((2 * n + 255) / 256), dim3(256), 0, ctx->stream, zk->d_rowptr, zk->d_col, zk->d_val, (const Fr*)d_wtns, zk->d_abc, (int)(2 * n));
+        hipLaunchKernelGGL(zkc_matvec_mul, dim3((zk->nCoeffs + 255) / 256), dim3(256), 0, ctx->stream, zk->d_col, zk->d_val, (const Fr*)d_wtns, zk->d_prod, zk->nCoeffs);
+        hipLaunchKernelGGL(zkc_matvec_rows, dim3((2 * n + 255) / 256), dim3(256), 0, ctx->stream, zk->d_rowptr, zk->d_prod, zk->d_abc, (int)(2 * n));
         hipLaunchKernelGGL(zkc_pointwise_mul, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, zk->d_abc, zk->d_abc + n, zk->d_abc + 2 * (size_t)n, (int)n);
         ZKC_HIP_CHECK(ctx, hipGetLastError());
         ZKC_HIP_CHECK(ctx, hipMemcpyAsync(host_out, zk->d_abc, 96ull * n, hipMemcpyDeviceToHost, ctx->stream));
     } else {
-        int rc = h_evals_dev(zk, (const uint32_t*)d_wtns, 0); if (rc) return rc;
+        int rc = h_evals_dev(zk, (const uint32_t*)d_wtns, 1); if (rc) return rc;
         ZKC_HIP_CHECK(ctx, hipMemcpyAsync(host_out, zk->d_p, 32ull * n, hipMemcpyDeviceToHost, ctx->stream));
     }
     ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -288,25 +302,11 @@ extern "C" int zkc_msm_debug(zkc_zkey* zk, int which, const void* d_scalars, uin
     MsmJobList jl{}; jl.njobs = 1; jl.entry_off[0] = 0; jl.entry_off[1] = count;
     const uint32_t offs[5] = {zk->offA, zk->offB1, 0, zk->offC, zk->offH};
     jl.job[0] = MsmJob{(const uint32_t*)d_scalars, nullptr, count, offs[which], full, 0};
-    int rc = which == 2 ? msm_pass_g2(zk, jl) : msm_pass_g1(zk, jl); if (rc) return rc;
+    int rc = which == 2 ? msm_pass_g2(zk, jl, 0, true) : msm_pass_g1(zk, jl, 0, true); if (rc) return rc;
     ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (which == 2) g2_to_std((uint8_t*)host_out, xyzz_to_affine(*(G2XYZZ*)zk->w2.h_results));
     else g1_to_std((uint8_t*)host_out, xyzz_to_affine(*(G1XYZZ*)zk->w1.h_results));
     return ZKC_OK;
-}
-
-// a7: piA = alpha + A + r delta ; piB = beta + B + s delta ; piC = C + H + s piA + r piB1 - r s delta   (host, constant work)
-static void finalize_proof(const zkc_zkey* zk, const G1XYZZ& A, const G1XYZZ& B1, const G2XYZZ& B2, const G1XYZZ& C, const G1XYZZ& H,
-                           const uint8_t r32[32], const uint8_t s32[32], uint8_t proof[256]) {
-    uint32_t rk[8], sk[8]; memcpy(rk, r32, 32); memcpy(sk, s32, 32);
-    const G1XYZZ d1 = G1XYZZ::from_affine(zk->delta1); const G2XYZZ d2 = G2XYZZ::from_affine(zk->delta2);
-    G1XYZZ piA = xyzz_add(xyzz_add_affine(A, zk->alpha1), xyzz_mul(d1, rk));
-    G2XYZZ piB = xyzz_add(xyzz_add_affine(B2, zk->beta2), xyzz_mul(d2, sk));
-    G1XYZZ piB1 = xyzz_add(xyzz_add_affine(B1, zk->beta1), xyzz_mul(d1, sk));
-    Fr rf = fp_from_std<FrParams>(rk), sf = fp_from_std<FrParams>(sk);
-    uint32_t nrs[8]; fp_to_std<FrParams>(nrs, Fr::zero() - rf * sf);
-    G1XYZZ piC = xyzz_add(xyzz_add(C, H), xyzz_add(xyzz_add(xyzz_mul(piA, sk), xyzz_mul(piB1, rk)), xyzz_mul(d1, nrs)));
-    g1_to_std(proof, xyzz_to_affine(piA)); g2_to_std(proof + 64, xyzz_to_affine(piB)); g1_to_std(proof + 192, xyzz_to_affine(piC));
 }
 
 // B witnesses resident in HBM -> B proofs.  rs: B x 64 B (r || s).  proofs: B x 256 B, publics: B x nPublic x 32 B (host).
@@ -318,29 +318,42 @@ extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nW
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const uint32_t nv = zk->nVars, np = zk->nPub, nc = nv - np - 1, n = zk->n;
     const bool can_fold = zk->nLevels >= 0;
-    WitnessLayout L{}; uint32_t* tmpl = nullptr; int rc;
-    if (can_fold) { L = WitnessLayout::make(zk->nLevels); if ((rc = fold_prepare(zk))) return rc; tmpl = zkc_get_template(ctx, zk->nLevels); if (!tmpl) return ZKC_ERR_HIP; }
-    for (int p0 = 0; p0 < B; p0 += zk->max_inflight) {
-        const int nb = std::min(zk->max_inflight, B - p0);
+    hipStream_t st = ctx->stream, fin = ctx->fin_stream;
+    WitnessLayout L{}; int rc;
+    if (zk->rs_cap < (size_t)B) {
+        if (zk->d_rs) { ZKC_HIP_CHECK(ctx, hipFree(zk->d_rs)); ZKC_HIP_CHECK(ctx, hipFree(zk->d_proofs)); zk->d_rs = zk->d_proofs = nullptr; }
+        ZKC_HIP_CHECK(ctx, hipMalloc((void**)&zk->d_rs, 64 * (size_t)B)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&zk->d_proofs, 256 * (size_t)B)); zk->rs_cap = B;
+    }
+    ZKC_HIP_CHECK(ctx, hipMemcpyAsync(zk->d_rs, rs, 64 * (size_t)B, hipMemcpyHostToDevice, st));
+    if (can_fold) {       // which levels of every witness differ from the voter-independent template?  one check for the whole batch
+        L = WitnessLayout::make(zk->nLevels);
+        if ((rc = fold_prepare(zk))) return rc;
+        uint32_t* tmpl = zkc_get_template(ctx, zk->nLevels); if (!tmpl) return ZKC_ERR_HIP;
+        const size_t nflags = (size_t)B * 2 * L.n;
+        if (zk->flags_cap < nflags) {
+            if (zk->d_flags) { ZKC_HIP_CHECK(ctx, hipFree(zk->d_flags)); ZKC_HIP_CHECK(ctx, hipHostFree(zk->h_flags)); zk->d_flags = zk->h_flags = nullptr; }
+            ZKC_HIP_CHECK(ctx, hipMalloc((void**)&zk->d_flags, nflags * 4)); ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&zk->h_flags, nflags * 4)); zk->flags_cap = nflags;
+        }
+        hipLaunchKernelGGL(zkc_fold_check, dim3(L.n, 2, B), dim3(64), 0, st, L, (const uint32_t*)d_wtns, tmpl, zk->d_flags, B);
+        ZKC_HIP_CHECK(ctx, hipGetLastError());
+        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(zk->h_flags, zk->d_flags, nflags * 4, hipMemcpyDeviceToHost, st));
+        ZKC_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    }
+    int pass = 0;
+    for (int p0 = 0; p0 < B; p0 += zk->max_inflight, pass++) {
+        const int nb = std::min(zk->max_inflight, B - p0), slot = pass & 1;
         const uint32_t* w0 = (const uint32_t*)d_wtns + (size_t)p0 * nv * 8;
         int Dc = 0, Ds = 0; bool fold = can_fold;
-        if (can_fold) {       // largest level of this chunk that differs from the template, per tree; n2bOld blocks must match too
-            hipLaunchKernelGGL(zkc_fold_check, dim3(L.n, 2, nb), dim3(64), 0, ctx->stream, L, w0, tmpl, zk->d_flags, nb);
-            ZKC_HIP_CHECK(ctx, hipGetLastError());
-            ZKC_HIP_CHECK(ctx, hipMemcpyAsync(zk->h_flags, zk->d_flags, (size_t)nb * 2 * L.n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        for (int q = 0; q < nb && fold; q++) for (int t = 0; t < 2; t++) {
+            const uint32_t* f = zk->h_flags + ((size_t)(p0 + q) * 2 + t) * L.n;
+            if (f[L.n - 1]) { fold = false; break; }                              // n2bOld block differs: not one of our witnesses
+            int D = 0; for (int g = 0; g < L.n - 1; g++) if (f[g]) D = g + 1;
+            if (t == 0) Dc = std::max(Dc, D); else Ds = std::max(Ds, D);
         }
-        for (int q = 0; q < nb; q++) if ((rc = h_evals_dev(zk, w0 + (size_t)q * nv * 8, q))) return rc;
         uint32_t* vmap = nullptr; uint32_t nV = nv;
-        if (can_fold) {
-            ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-            for (int q = 0; q < nb && fold; q++) for (int t = 0; t < 2; t++) {
-                const uint32_t* f = zk->h_flags + ((size_t)q * 2 + t) * L.n;
-                if (f[L.n - 1]) { fold = false; break; }
-                int D = 0; for (int g = 0; g < L.n - 1; g++) if (f[g]) D = g + 1;
-                if (t == 0) Dc = std::max(Dc, D); else Ds = std::max(Ds, D);
-            }
-            if (fold && (rc = fold_vmap(zk, Dc, Ds, &vmap, &nV))) return rc;
-        }
+        if (fold && (rc = fold_vmap(zk, Dc, Ds, &vmap, &nV))) return rc;
+        if (pass >= 2) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, zk->ev_fin[slot], 0));   // result slot still being read by finalize(pass-2)?
+        if ((rc = h_evals_dev(zk, w0, nb))) return rc;
         MsmJobList j1{}, j2{}; uint32_t e1 = 0, e2 = 0;
         for (int q = 0; q < nb; q++) {
             const uint32_t* w = w0 + (size_t)q * nv * 8;
@@ -354,21 +367,28 @@ extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nW
             j2.entry_off[q] = e2; j2.job[q] = MsmJob{w, vmap, nV, 0, nv, 0}; e2 += nV;
         }
         j1.njobs = 4 * nb; j1.entry_off[4 * nb] = e1; j2.njobs = nb; j2.entry_off[nb] = e2;
-        if ((rc = msm_pass_g1(zk, j1)) || (rc = msm_pass_g2(zk, j2))) return rc;
+        if ((rc = msm_pass_g1(zk, j1, slot, false)) || (rc = msm_pass_g2(zk, j2, slot, false))) return rc;
         if (publics) for (int q = 0; q < nb; q++)
-            ZKC_HIP_CHECK(ctx, hipMemcpyAsync(publics + 32ull * np * (p0 + q), w0 + (size_t)q * nv * 8 + 8, 32ull * np, hipMemcpyDeviceToHost, ctx->stream));
-        ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        const G1XYZZ* r1 = (const G1XYZZ*)zk->w1.h_results; const G2XYZZ* r2 = (const G2XYZZ*)zk->w2.h_results;
-        G1XYZZ kA = G1XYZZ::inf(), kB1 = kA, kC = kA; G2XYZZ kB2 = G2XYZZ::inf();
+            ZKC_HIP_CHECK(ctx, hipMemcpyAsync(publics + 32ull * np * (p0 + q), w0 + (size_t)q * nv * 8 + 8, 32ull * np, hipMemcpyDeviceToHost, st));
+        ZKC_HIP_CHECK(ctx, hipEventRecord(zk->ev_msm[slot], st));
+        // a7 on the second stream: overlaps the next pass
+        FinalizeArgs fa{};
+        fa.r1 = (const G1XYZZ*)zk->w1.results + (size_t)slot * zk->w1.max_jobs; fa.r2 = (const G2XYZZ*)zk->w2.results + (size_t)slot * zk->w2.max_jobs;
+        fa.kA = fa.kB1 = fa.kC = G1XYZZ::inf(); fa.kB2 = G2XYZZ::inf();
         if (fold) {
             const auto& f = zk->fold;
-            kA = xyzz_add(f.baseA[0], xyzz_add(f.sufA[0][Dc], f.sufA[1][Ds])); kB1 = xyzz_add(f.baseB1[0], xyzz_add(f.sufB1[0][Dc], f.sufB1[1][Ds]));
-            kC = xyzz_add(f.baseC[0], xyzz_add(f.sufC[0][Dc], f.sufC[1][Ds])); kB2 = xyzz_add(f.baseB2[0], xyzz_add(f.sufB2[0][Dc], f.sufB2[1][Ds]));
+            fa.kA = xyzz_add(f.baseA[0], xyzz_add(f.sufA[0][Dc], f.sufA[1][Ds])); fa.kB1 = xyzz_add(f.baseB1[0], xyzz_add(f.sufB1[0][Dc], f.sufB1[1][Ds]));
+            fa.kC = xyzz_add(f.baseC[0], xyzz_add(f.sufC[0][Dc], f.sufC[1][Ds])); fa.kB2 = xyzz_add(f.baseB2[0], xyzz_add(f.sufB2[0][Dc], f.sufB2[1][Ds]));
         }
-        for (int q = 0; q < nb; q++)
-            finalize_proof(zk, xyzz_add(r1[4 * q], kA), xyzz_add(r1[4 * q + 1], kB1), xyzz_add(r2[q], kB2), xyzz_add(r1[4 * q + 2], kC), r1[4 * q + 3],
-                           rs + 64ull * (p0 + q), rs + 64ull * (p0 + q) + 32, proofs + 256ull * (p0 + q));
+        fa.tblDelta1 = zk->d_tblDelta1; fa.tblAlpha1 = zk->d_tblAlpha1; fa.tblBeta1 = zk->d_tblBeta1; fa.tblDelta2 = zk->d_tblDelta2;
+        fa.alpha1 = zk->alpha1; fa.beta2 = zk->beta2; fa.rs = zk->d_rs + 64 * (size_t)p0; fa.out = zk->d_proofs + 256 * (size_t)p0;
+        ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, zk->ev_msm[slot], 0));
+        if ((rc = finalize_launch(ctx, fin, fa, nb))) return rc;
+        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(proofs + 256ull * p0, zk->d_proofs + 256 * (size_t)p0, 256ull * nb, hipMemcpyDeviceToHost, fin));
+        ZKC_HIP_CHECK(ctx, hipEventRecord(zk->ev_fin[slot], fin));
     }
+    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(fin));
     return ZKC_OK;
 }
 

@@ -22,6 +22,14 @@ struct MsmJob {
     uint32_t tbl_count;        // points per window in that table
     int32_t pt_shift;
 };
+// arguments of the blinding kernel (zkc_finalize.hip); everything except r1/r2/rs/out is constant per proving key
+struct FinalizeArgs {
+    const G1XYZZ* r1; const G2XYZZ* r2;                 // MSM results of this pass: r1[4q + {A,B1,C,H}], r2[q]
+    G1XYZZ kA, kB1, kC; G2XYZZ kB2;                     // folded constants of this pass
+    const G1Affine *tblDelta1, *tblAlpha1, *tblBeta1; const G2Affine* tblDelta2;   // 32 x 255 fixed-base tables
+    G1Affine alpha1; G2Affine beta2;
+    const uint8_t* rs; uint8_t* out;                    // device: nproofs x 64 (r || s) -> nproofs x 256 proof bytes
+};
 struct MsmJobList { MsmJob job[MSM_MAX_JOBS]; uint32_t entry_off[MSM_MAX_JOBS + 1]; int njobs; };
 
 // Work space of one pipeline pass (sized for MSM_MAX_JOBS jobs and max_entries (scalar, window) pairs)
@@ -31,7 +39,7 @@ struct MsmWork {
     uint32_t *segcnt = nullptr, *segoff = nullptr, *seg2bucket = nullptr, *heavy = nullptr;
     void *partial = nullptr;        // XYZZ per segment
     void *wres = nullptr;           // XYZZ per (job, window)
-    void *results = nullptr;        // XYZZ per job (device) ; h_results pinned host mirror
+    void *results = nullptr;        // XYZZ per job, two slots of max_jobs (device) ; h_results pinned host mirror of slot 0
     void *h_results = nullptr;
     void *sort_tmp = nullptr; size_t sort_tmp_sz = 0; void* scan_tmp = nullptr; size_t scan_tmp_sz = 0;
     size_t max_entries = 0, max_segments = 0; int max_jobs = 0; size_t xyzz_size = 0;
@@ -53,9 +61,12 @@ struct zkc_zkey {
     uint32_t offA = 0, offB1 = 0, offC = 0, offH = 0;                       // table offsets inside d_g1 (points)
     // per-proof work buffers
     int max_inflight = 0;                                                   // proofs per pipeline pass
-    zkc::Fr *d_abc = nullptr, *d_t = nullptr; uint32_t* d_p = nullptr;      // [inflight][3n] , [n] , [inflight][n x 8]
+    zkc::Fr *d_abc = nullptr, *d_t = nullptr, *d_prod = nullptr; uint32_t* d_p = nullptr;   // [inflight][3n] x2 (d_t = NTT scratch), [nCoeffs], [inflight][n x 8]
     zkc::MsmWork w1, w2;                                                    // G1 and G2 pipelines
-    uint32_t *d_flags = nullptr, *h_flags = nullptr;                        // fold check: [inflight][2][n]
+    uint32_t *d_flags = nullptr, *h_flags = nullptr; size_t flags_cap = 0;  // fold check: [B][2][n]
+    zkc::G1Affine *d_tblDelta1 = nullptr, *d_tblAlpha1 = nullptr, *d_tblBeta1 = nullptr; zkc::G2Affine* d_tblDelta2 = nullptr;
+    uint8_t *d_rs = nullptr, *d_proofs = nullptr; size_t rs_cap = 0;        // [B][64], [B][256]
+    hipEvent_t ev_msm[2] = {nullptr, nullptr}, ev_fin[2] = {nullptr, nullptr};
     // constant folding of the voter-independent witness part (SURVEY.md hard part 4)
     struct Fold {
         std::vector<zkc::G1XYZZ> baseA, baseB1, baseC; std::vector<zkc::G2XYZZ> baseB2;        // [1]
@@ -66,12 +77,14 @@ struct zkc_zkey {
 };
 
 namespace zkc {
-int ntt_run(zkc_ctx* ctx, const Fr* src, Fr* dst, const Fr* tw, const Fr* scale, int logn);
+int ntt_run(zkc_ctx* ctx, const Fr* src, Fr* dst, const Fr* tw, const Fr* scale, int logn, int nvec);
 int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, int max_jobs, bool g2);
 void msm_work_free(MsmWork& w);
-// runs all jobs of `jl` through one pipeline pass; results (XYZZ per job) land in w.h_results after the caller syncs
-int msm_pass_g1(zkc_zkey* zk, const MsmJobList& jl);
-int msm_pass_g2(zkc_zkey* zk, const MsmJobList& jl);
+// runs all jobs of `jl` through one pipeline pass; results (XYZZ per job) go to device slot `slot` (0/1) of w.results and, when
+// to_host is set, to w.h_results (valid after the caller syncs the stream)
+int msm_pass_g1(zkc_zkey* zk, const MsmJobList& jl, int slot, bool to_host);
+int msm_pass_g2(zkc_zkey* zk, const MsmJobList& jl, int slot, bool to_host);
+int finalize_launch(zkc_ctx* ctx, hipStream_t st, const FinalizeArgs& a, int nproofs);
 int msm_precompute_g1(zkc_ctx* ctx, uint32_t count, G1Affine* d_table);   // d_table[0..count) = base on entry
 int msm_precompute_g2(zkc_ctx* ctx, uint32_t count, G2Affine* d_table);
 // out[i] = scalar[wires[i]] * P[wires[i] - pt_shift] (window-0 table), then per-group sums: gsum[g] = sum out[gstart[g]..gstart[g+1])
