@@ -29,16 +29,16 @@ static hipEvent_t prof_event(zkc_ctx* ctx) {
     if (!ctx->prof.free_events.empty()) { hipEvent_t e = ctx->prof.free_events.back(); ctx->prof.free_events.pop_back(); return e; }
     hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
 }
-zkc_prof_scope::zkc_prof_scope(zkc_ctx* c, int category, uint64_t alg_bytes) : ctx(c), cat(category) {
+zkc_prof_scope::zkc_prof_scope(zkc_ctx* c, int category, uint64_t alg_bytes, hipStream_t stream) : ctx(c), cat(category), st(stream ? stream : (c ? c->stream : nullptr)) {
     on = c && ((c->prof.mask >> category) & 1u);
     if (!on) return;
     a = prof_event(c); b = prof_event(c);
     c->prof.bytes[cat] += alg_bytes; c->prof.launches[cat] += 1;
-    (void)hipEventRecord(a, c->stream);
+    (void)hipEventRecord(a, st);
 }
 zkc_prof_scope::~zkc_prof_scope() {
     if (!on) return;
-    (void)hipEventRecord(b, ctx->stream);
+    (void)hipEventRecord(b, st);
     ctx->prof.pending.push_back({a, b, cat});
 }
 extern "C" int zkc_profile_enable(zkc_ctx* ctx, uint32_t mask) {
@@ -52,7 +52,7 @@ extern "C" int zkc_profile_enable(zkc_ctx* ctx, uint32_t mask) {
 }
 extern "C" int zkc_profile_read(zkc_ctx* ctx, int cat, double* total_ms, uint64_t* launches, uint64_t* alg_bytes) {
     if (!ctx || cat < 0 || cat >= ZKC_PROF_NCAT) return ZKC_ERR_BAD_ARG;
-    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream2));
     for (auto& r : ctx->prof.pending) {
         float ms = 0; (void)hipEventElapsedTime(&ms, r.a, r.b); ctx->prof.ms[r.cat] += ms;
         ctx->prof.free_events.push_back(r.a); ctx->prof.free_events.push_back(r.b);
@@ -109,6 +109,7 @@ extern "C" int zkc_ctx_create(int device, zkc_ctx** out) {
     hipError_t e;
     if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+    if ((e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate(2)");
     if ((e = hipStreamCreateWithFlags(&ctx->fin_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate(fin)");
     // Poseidon parameter tables -> Montgomery form -> HBM (about 1.6k Fr = 51 KB; L2/scalar-cache resident)
     std::vector<Fr> all; size_t off[12]; int k = 0;
@@ -140,6 +141,7 @@ extern "C" void zkc_ctx_destroy(zkc_ctx* ctx) {
     if (ctx->d_scratch_out) (void)hipFree(ctx->d_scratch_out);
     if (ctx->d_status3) (void)hipFree(ctx->d_status3);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->fin_stream) (void)hipStreamDestroy(ctx->fin_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -23,6 +23,7 @@ struct zkc_prof {
 struct zkc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;        // G2 MSM pipeline (independent of buildABC/NTT): overlaps the G1 pipeline
     hipStream_t fin_stream = nullptr;     // blinding kernel + proof D2H, overlapping the next pipeline pass
     std::string err;
     zkc::PoseidonTable ptab{};            // device pointers
@@ -40,7 +41,7 @@ int zkc_fail(zkc_ctx* ctx, int code, const std::string& msg);
 int zkc_ensure(zkc_ctx* ctx, void** p, size_t* cur, size_t need);
 // RAII bracket: records two events around the launches made while it is alive when category `cat` is enabled
 struct zkc_prof_scope {
-    zkc_ctx* ctx; int cat; hipEvent_t a = nullptr, b = nullptr; bool on;
-    zkc_prof_scope(zkc_ctx* c, int category, uint64_t alg_bytes);
+    zkc_ctx* ctx; int cat; hipEvent_t a = nullptr, b = nullptr; bool on; hipStream_t st;
+    zkc_prof_scope(zkc_ctx* c, int category, uint64_t alg_bytes, hipStream_t stream = nullptr);
     ~zkc_prof_scope();
 };

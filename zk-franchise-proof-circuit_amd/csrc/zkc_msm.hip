@@ -106,11 +106,15 @@ zkc_msm_accumulate(const Affine<F>* __restrict__ table, const uint32_t* __restri
     const uint32_t start = off[b] + (s - segoff[b]) * MSM_SEG;
     uint32_t end = start + MSM_SEG; const uint32_t bend = off[b + 1]; if (end > bend) end = bend;
     XYZZ<F> acc = XYZZ<F>::inf();
+    uint32_t v = vals[start];
+    Affine<F> p = PointIO<F>::load(table + (v & 0x7fffffffu));
     for (uint32_t j = start; j < end; j++) {
-        const uint32_t v = vals[j];
-        Affine<F> p = PointIO<F>::load(table + (v & 0x7fffffffu));
+        // issue the next 64-byte gather before the ~10 field products of this addition (the loads are independent of acc)
+        const uint32_t vn = (j + 1 < end) ? vals[j + 1] : v;
+        Affine<F> pn = PointIO<F>::load(table + (vn & 0x7fffffffu));
         if (v >> 31) p.y = fp_neg(p.y);
         acc = xyzz_add_affine(acc, p);
+        v = vn; p = pn;
     }
     partial[s] = acc;
 }
@@ -294,13 +298,13 @@ static const bool g_debug_sync = getenv("ZKC_DEBUG_SYNC") != nullptr;   // seria
     do { hipError_t _e = hipGetLastError(); if (_e != hipSuccess)                                          \
         return zkc_fail((ctx), ZKC_ERR_HIP, std::string(name ": ") + hipGetErrorString(_e));               \
         if (g_debug_sync) { timespec _t0, _t1; clock_gettime(CLOCK_MONOTONIC, &_t0);                        \
-            _e = hipStreamSynchronize((ctx)->stream); clock_gettime(CLOCK_MONOTONIC, &_t1);                \
+            _e = hipStreamSynchronize(st); clock_gettime(CLOCK_MONOTONIC, &_t1);                \
             fprintf(stderr, "[zkc] %-22s %8.3f ms  %s\n", name, (_t1.tv_sec - _t0.tv_sec) * 1e3 + (_t1.tv_nsec - _t0.tv_nsec) * 1e-6, \
                     hipGetErrorString(_e)); fflush(stderr); } } while (0)
 
 template <class F>
-static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJobList& jl, int slot, bool to_host) {
-    zkc_ctx* ctx = zk->ctx; hipStream_t st = ctx->stream;
+static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJobList& jl, int slot, bool to_host, hipStream_t st) {
+    zkc_ctx* ctx = zk->ctx;
     const int nj = jl.njobs;
     if (nj <= 0 || nj > w.max_jobs) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: job count");
     const size_t total = (size_t)jl.entry_off[nj] * MSM_NW;
@@ -310,7 +314,7 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     uint64_t alg_bytes = 0; uint32_t maxcount = 0;
     for (int j = 0; j < nj; j++) { alg_bytes += (uint64_t)jl.job[j].count * (sizeof(Affine<F>) + 32); maxcount = std::max(maxcount, jl.job[j].count); }
     {
-        zkc_prof_scope _ps(ctx, ZKC_PROF_MSM_SORT, 0);
+        zkc_prof_scope _ps(ctx, ZKC_PROF_MSM_SORT, 0, st);
         hipLaunchKernelGGL(zkc_msm_digits, dim3((maxcount + 255) / 256, nj), dim3(256), 0, st, jl, w.keys, w.vals);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_digits");
         int end_bit = 1; while ((1ull << end_bit) <= (uint64_t)nb) end_bit++;
@@ -340,13 +344,13 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     XYZZ<F>* results = reinterpret_cast<XYZZ<F>*>(w.results) + (size_t)slot * w.max_jobs;
     const size_t seg_bound = std::min<size_t>(w.max_segments, total / MSM_SEG + nb);     // launch bound on the number of segments
     {
-        zkc_prof_scope _ps(ctx, kG2 ? ZKC_PROF_MSM_ACC_G2 : ZKC_PROF_MSM_ACC_G1, alg_bytes);
+        zkc_prof_scope _ps(ctx, kG2 ? ZKC_PROF_MSM_ACC_G2 : ZKC_PROF_MSM_ACC_G1, alg_bytes, st);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate<F>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st, table, w.vals2, w.off,
                            w.segoff, w.seg2bucket, nb, partial, (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_accumulate");
     }
     {
-        zkc_prof_scope _pr(ctx, ZKC_PROF_MSM_REDUCE, 0);
+        zkc_prof_scope _pr(ctx, ZKC_PROF_MSM_REDUCE, 0, st);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_merge<F>), dim3(1024), dim3(64), 0, st, partial, w.segoff, w.segcnt, w.heavy, w.heavy + MSM_MAX_HEAVY,
                            (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_merge");
@@ -359,7 +363,7 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     if (to_host) ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.h_results, results, (size_t)nj * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
     return ZKC_OK;
 }
-int msm_pass_g1(zkc_zkey* zk, const MsmJobList& jl, int slot, bool to_host) { return msm_pass<Fq>(zk, zk->w1, zk->d_g1, jl, slot, to_host); }
-int msm_pass_g2(zkc_zkey* zk, const MsmJobList& jl, int slot, bool to_host) { return msm_pass<Fq2>(zk, zk->w2, zk->d_g2, jl, slot, to_host); }
+int msm_pass_g1(zkc_zkey* zk, const MsmJobList& jl, int slot, bool to_host, hipStream_t st) { return msm_pass<Fq>(zk, zk->w1, zk->d_g1, jl, slot, to_host, st); }
+int msm_pass_g2(zkc_zkey* zk, const MsmJobList& jl, int slot, bool to_host, hipStream_t st) { return msm_pass<Fq2>(zk, zk->w2, zk->d_g2, jl, slot, to_host, st); }
 
 }  // namespace zkc

@@ -69,7 +69,8 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : zk->fold.vmaps) if (kv.second.first) (void)hipFree(kv.second.first);
     if (zk->h_flags) (void)hipHostFree(zk->h_flags);
-    for (int i = 0; i < 2; i++) { if (zk->ev_msm[i]) (void)hipEventDestroy(zk->ev_msm[i]); if (zk->ev_fin[i]) (void)hipEventDestroy(zk->ev_fin[i]); }
+    for (int i = 0; i < 2; i++) { if (zk->ev_msm[i]) (void)hipEventDestroy(zk->ev_msm[i]); if (zk->ev_msm2[i]) (void)hipEventDestroy(zk->ev_msm2[i]); if (zk->ev_fin[i]) (void)hipEventDestroy(zk->ev_fin[i]); }
+    if (zk->ev_start) (void)hipEventDestroy(zk->ev_start);
     msm_work_free(zk->w1); msm_work_free(zk->w2);
     delete zk;
 }
@@ -171,8 +172,10 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
         ZKC_UP(zk->d_tblDelta1, td.tab.data(), td.tab.size() * sizeof(G1Affine)); ZKC_UP(zk->d_tblAlpha1, ta.tab.data(), ta.tab.size() * sizeof(G1Affine));
         ZKC_UP(zk->d_tblBeta1, tb.tab.data(), tb.tab.size() * sizeof(G1Affine)); ZKC_UP(zk->d_tblDelta2, t2.tab.data(), t2.tab.size() * sizeof(G2Affine));
     }
+    ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&zk->ev_start, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) {
         ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&zk->ev_msm[i], hipEventDisableTiming));
+        ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&zk->ev_msm2[i], hipEventDisableTiming));
         ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&zk->ev_fin[i], hipEventDisableTiming));
     }
     ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -302,7 +305,7 @@ extern "C" int zkc_msm_debug(zkc_zkey* zk, int which, const void* d_scalars, uin
     MsmJobList jl{}; jl.njobs = 1; jl.entry_off[0] = 0; jl.entry_off[1] = count;
     const uint32_t offs[5] = {zk->offA, zk->offB1, 0, zk->offC, zk->offH};
     jl.job[0] = MsmJob{(const uint32_t*)d_scalars, nullptr, count, offs[which], full, 0};
-    int rc = which == 2 ? msm_pass_g2(zk, jl, 0, true) : msm_pass_g1(zk, jl, 0, true); if (rc) return rc;
+    int rc = which == 2 ? msm_pass_g2(zk, jl, 0, true, ctx->stream) : msm_pass_g1(zk, jl, 0, true, ctx->stream); if (rc) return rc;
     ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (which == 2) g2_to_std((uint8_t*)host_out, xyzz_to_affine(*(G2XYZZ*)zk->w2.h_results));
     else g1_to_std((uint8_t*)host_out, xyzz_to_affine(*(G1XYZZ*)zk->w1.h_results));
@@ -318,7 +321,7 @@ extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nW
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const uint32_t nv = zk->nVars, np = zk->nPub, nc = nv - np - 1, n = zk->n;
     const bool can_fold = zk->nLevels >= 0;
-    hipStream_t st = ctx->stream, fin = ctx->fin_stream;
+    hipStream_t st = ctx->stream, st2 = ctx->stream2, fin = ctx->fin_stream;
     WitnessLayout L{}; int rc;
     if (zk->rs_cap < (size_t)B) {
         if (zk->d_rs) { ZKC_HIP_CHECK(ctx, hipFree(zk->d_rs)); ZKC_HIP_CHECK(ctx, hipFree(zk->d_proofs)); zk->d_rs = zk->d_proofs = nullptr; }
@@ -339,6 +342,7 @@ extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nW
         ZKC_HIP_CHECK(ctx, hipMemcpyAsync(zk->h_flags, zk->d_flags, nflags * 4, hipMemcpyDeviceToHost, st));
         ZKC_HIP_CHECK(ctx, hipStreamSynchronize(st));
     }
+    ZKC_HIP_CHECK(ctx, hipEventRecord(zk->ev_start, st)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st2, zk->ev_start, 0));   // wtns, rs ready
     int pass = 0;
     for (int p0 = 0; p0 < B; p0 += zk->max_inflight, pass++) {
         const int nb = std::min(zk->max_inflight, B - p0), slot = pass & 1;
@@ -352,7 +356,7 @@ extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nW
         }
         uint32_t* vmap = nullptr; uint32_t nV = nv;
         if (fold && (rc = fold_vmap(zk, Dc, Ds, &vmap, &nV))) return rc;
-        if (pass >= 2) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, zk->ev_fin[slot], 0));   // result slot still being read by finalize(pass-2)?
+        if (pass >= 2) { ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, zk->ev_fin[slot], 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st2, zk->ev_fin[slot], 0)); }   // result slot still read by finalize(pass-2)?
         if ((rc = h_evals_dev(zk, w0, nb))) return rc;
         MsmJobList j1{}, j2{}; uint32_t e1 = 0, e2 = 0;
         for (int q = 0; q < nb; q++) {
@@ -367,7 +371,9 @@ extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nW
             j2.entry_off[q] = e2; j2.job[q] = MsmJob{w, vmap, nV, 0, nv, 0}; e2 += nV;
         }
         j1.njobs = 4 * nb; j1.entry_off[4 * nb] = e1; j2.njobs = nb; j2.entry_off[nb] = e2;
-        if ((rc = msm_pass_g1(zk, j1, slot, false)) || (rc = msm_pass_g2(zk, j2, slot, false))) return rc;
+        if ((rc = msm_pass_g2(zk, j2, slot, false, st2))) return rc;          // B2 needs only the witness: runs beside buildABC/NTT/G1
+        ZKC_HIP_CHECK(ctx, hipEventRecord(zk->ev_msm2[slot], st2));
+        if ((rc = msm_pass_g1(zk, j1, slot, false, st))) return rc;
         if (publics) for (int q = 0; q < nb; q++)
             ZKC_HIP_CHECK(ctx, hipMemcpyAsync(publics + 32ull * np * (p0 + q), w0 + (size_t)q * nv * 8 + 8, 32ull * np, hipMemcpyDeviceToHost, st));
         ZKC_HIP_CHECK(ctx, hipEventRecord(zk->ev_msm[slot], st));
@@ -382,12 +388,12 @@ extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nW
         }
         fa.tblDelta1 = zk->d_tblDelta1; fa.tblAlpha1 = zk->d_tblAlpha1; fa.tblBeta1 = zk->d_tblBeta1; fa.tblDelta2 = zk->d_tblDelta2;
         fa.alpha1 = zk->alpha1; fa.beta2 = zk->beta2; fa.rs = zk->d_rs + 64 * (size_t)p0; fa.out = zk->d_proofs + 256 * (size_t)p0;
-        ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, zk->ev_msm[slot], 0));
+        ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, zk->ev_msm[slot], 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, zk->ev_msm2[slot], 0));
         if ((rc = finalize_launch(ctx, fin, fa, nb))) return rc;
         ZKC_HIP_CHECK(ctx, hipMemcpyAsync(proofs + 256ull * p0, zk->d_proofs + 256 * (size_t)p0, 256ull * nb, hipMemcpyDeviceToHost, fin));
         ZKC_HIP_CHECK(ctx, hipEventRecord(zk->ev_fin[slot], fin));
     }
-    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(st)); ZKC_HIP_CHECK(ctx, hipStreamSynchronize(st2));
     ZKC_HIP_CHECK(ctx, hipStreamSynchronize(fin));
     return ZKC_OK;
 }

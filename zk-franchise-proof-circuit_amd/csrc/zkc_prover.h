@@ -66,7 +66,7 @@ struct zkc_zkey {
     uint32_t *d_flags = nullptr, *h_flags = nullptr; size_t flags_cap = 0;  // fold check: [B][2][n]
     zkc::G1Affine *d_tblDelta1 = nullptr, *d_tblAlpha1 = nullptr, *d_tblBeta1 = nullptr; zkc::G2Affine* d_tblDelta2 = nullptr;
     uint8_t *d_rs = nullptr, *d_proofs = nullptr; size_t rs_cap = 0;        // [B][64], [B][256]
-    hipEvent_t ev_msm[2] = {nullptr, nullptr}, ev_fin[2] = {nullptr, nullptr};
+    hipEvent_t ev_msm[2] = {nullptr, nullptr}, ev_msm2[2] = {nullptr, nullptr}, ev_fin[2] = {nullptr, nullptr}, ev_start = nullptr;
     // constant folding of the voter-independent witness part (SURVEY.md hard part 4)
     struct Fold {
         std::vector<zkc::G1XYZZ> baseA, baseB1, baseC; std::vector<zkc::G2XYZZ> baseB2;        // [1]
@@ -82,8 +82,8 @@ int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, int max_jobs, b
 void msm_work_free(MsmWork& w);
 // runs all jobs of `jl` through one pipeline pass; results (XYZZ per job) go to device slot `slot` (0/1) of w.results and, when
 // to_host is set, to w.h_results (valid after the caller syncs the stream)
-int msm_pass_g1(zkc_zkey* zk, const MsmJobList& jl, int slot, bool to_host);
-int msm_pass_g2(zkc_zkey* zk, const MsmJobList& jl, int slot, bool to_host);
+int msm_pass_g1(zkc_zkey* zk, const MsmJobList& jl, int slot, bool to_host, hipStream_t st);
+int msm_pass_g2(zkc_zkey* zk, const MsmJobList& jl, int slot, bool to_host, hipStream_t st);
 int finalize_launch(zkc_ctx* ctx, hipStream_t st, const FinalizeArgs& a, int nproofs);
 int msm_precompute_g1(zkc_ctx* ctx, uint32_t count, G1Affine* d_table);   // d_table[0..count) = base on entry
 int msm_precompute_g2(zkc_ctx* ctx, uint32_t count, G2Affine* d_table);
