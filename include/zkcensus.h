@@ -78,6 +78,27 @@ int zkc_prove_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, const uin
  * pipeline pass.  Mirrors what a rapidsnark / snarkjs caller would loop over (zk_census_test.go:89 per voter). */
 int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, int B, const uint8_t* rs, uint8_t* proofs, uint8_t* publics);
 
+/* ---- the rapidsnark entry point (go-rapidsnark prover.h `groth16_prover`, reached from prover.Prove at
+ * zk_census_test.go:89): whole .zkey and .wtns file images in, NUL-terminated proof / public-signal JSON out.
+ * Returns 0 OK, 1 ERROR, 2 SHORT_BUFFER (required sizes written back), 3 INVALID_WITNESS_LENGTH.  r, s are random. */
+int groth16_prover(const void* zkey_buffer, unsigned long zkey_size, const void* wtns_buffer, unsigned long wtns_size,
+                   char* proof_buffer, unsigned long* proof_size, char* public_buffer, unsigned long* public_size,
+                   char* error_msg, unsigned long error_msg_maxsize);
+
+/* ---- a9: verification on the CPU (replaces proof.Verify(vkey) zk_census_test.go:122 / snarkjs groth16.verify).
+ * zkc_verify takes the texts of verification_key.json, signals.json and proof.json: 1 valid, 0 invalid, <0 = -ZKC_ERR_*.
+ * zkc_verify_bin takes vk = alpha1(64) beta2(128) gamma2(128) delta2(128) IC[nPublic+1](64 each), standard form. */
+int zkc_verify(const char* vkey_json, const char* public_json, const char* proof_json);
+int zkc_verify_bin(const uint8_t* vk, int nPublic, const uint8_t* pub, const uint8_t* proof);
+const char* zkc_verify_last_error(void);
+
+/* ---- a8: artifact codecs.  proof/public JSON exactly as snarkjs prints them (proof.json, signals.json);
+ * .wtns = iden3 binfile "wtns" v2 (section 1: n8, prime, nWitness; section 2: nWitness x 32 B LE). */
+int zkc_proof_to_json(const uint8_t proof[256], const uint8_t* pub, int nPublic, char* proof_buf, unsigned long* proof_size,
+                      char* public_buf, unsigned long* public_size);
+int zkc_wtns_parse(const void* wtns_bytes, unsigned long size, const uint8_t** payload, uint32_t* nWitness);
+unsigned long zkc_wtns_write(const void* payload, uint32_t nWitness, void* out, unsigned long out_size);   /* returns bytes needed/written */
+
 /* ---- test hooks (stage outputs for parity tests against the oracle; not part of the drop-in surface) ----
  * zkc_debug_stage: stage 0 -> A_w | B_w | C_w after buildABC (3 x domainSize x 32 B, Montgomery form);
  *                  stage 1 -> joinABC output (A'B' - C') on the odd coset (domainSize x 32 B, standard form).

@@ -43,12 +43,23 @@ def test_r1cs_rejects_mutated_witnesses(circuit160):
     rng = random.Random(5)
     # wires no constraint touches: voteHash (census.circom:54-57) -- every other wire must be pinned
     free = {4, 5}
+    # ... and IsZero.inv hints whose input is zero (any value satisfies in*inv = 1 - out when in = 0, exactly as in circomlib),
+    # plus the three inv wires of ForceEqualIfEnabled / isZero[nLevels] whose input is identically zero
+    inp = VEC['vectors'][1]['inputs']
+    for blk, sib in ((L.off_census, inp['censusSiblings']), (L.off_sikver, inp['sikSiblings'])):
+        sib = list(sib) + ['0'] * (L.n - len(sib))
+        oz = blk + L.off_iszero
+        for i in range(L.n - 1):
+            if int(sib[i]) == 0:
+                free.add(oz + 2 * i + 1 if i < L.n - 2 else oz + 2 * (L.n - 2))
+        free.add(blk + 2); free.add(oz + 2 * (L.n - 2) + 1)
+    free.add(L.off_checknull)
     for k in rng.sample(range(1, L.nWires), 300):
         if k in free:
             continue
         m = list(base); m[k] = (m[k] + 1 + rng.randrange(5)) % ol.R
         assert cs.check(m) != -1, 'wire %d is unconstrained' % k
-    for k in free:
+    for k in (4, 5):
         m = list(base); m[k] = (m[k] + 1) % ol.R
         assert cs.check(m) == -1
 
@@ -91,3 +102,41 @@ def test_setup_prove_verify_nl10(tmp_path):
     # same seed -> same key (deterministic toxic waste); other seed -> other key
     _, zp2, _ = setup.ensure_test_artifacts(10, seed=7, directory=str(tmp_path))
     assert open(zp2, 'rb').read() != zk
+
+
+def test_product_verifier_on_reference_triple():
+    """zkc_verify (product, CPU) against the reference's committed proof / signals / verification key."""
+    from zkcensus_amd import groth16
+    vk = ol.load_json('ref/verification_key.json'); pr = ol.load_json('ref/proof.json'); sig = ol.load_json('ref/signals.json')
+    assert groth16.verify(vk, sig, pr) is True
+    assert groth16.verify(open(ol.golden('ref/verification_key.json')).read(), sig, open(ol.golden('ref/proof.json')).read()) is True
+    for i in (0, 5, 7):
+        s2 = list(sig); s2[i] = str((int(s2[i]) + 1) % ol.R)
+        assert groth16.verify(vk, s2, pr) is False
+    bad = json.loads(json.dumps(pr)); bad['pi_a'][0] = str((int(bad['pi_a'][0]) + 1) % ol.Q)
+    assert groth16.verify(vk, sig, bad) is False
+    bad = json.loads(json.dumps(pr)); bad['pi_b'][1][0] = str((int(bad['pi_b'][1][0]) + 1) % ol.Q)
+    assert groth16.verify(vk, sig, bad) is False
+    # binary form agrees with the oracle's verifier on the same inputs
+    lib = _native.load()
+    assert lib.zkc_verify_bin(ol.vk_bytes(vk), 8, b''.join(ol.le32(x) for x in sig), ol.proof_bytes(pr)) == 1
+
+
+def test_codecs_roundtrip():
+    lib = _native.load()
+    from zkcensus_amd import groth16
+    pr = ol.load_json('ref/proof.json'); sig = ol.load_json('ref/signals.json')
+    pj, sj = groth16.proof_to_json(ol.proof_bytes(pr), b''.join(ol.le32(x) for x in sig))
+    assert sj == sig and pj['pi_a'] == pr['pi_a'] and pj['pi_b'] == pr['pi_b'] and pj['pi_c'] == pr['pi_c']
+    assert pj['protocol'] == 'groth16' and pj['curve'] == 'bn128'
+    payload = b''.join(ol.le32(i * 7919 % ol.R) for i in range(100))
+    need = lib.zkc_wtns_write(payload, 100, None, 0)
+    buf = ctypes.create_string_buffer(need)
+    assert lib.zkc_wtns_write(payload, 100, buf, need) == need and buf.raw[:4] == b'wtns'
+    assert groth16._wtns_payload(buf.raw) == payload
+    assert lib.zkc_wtns_parse(b'nope' + buf.raw[4:], need, None, None) != 0
+    # short-buffer protocol of the rapidsnark-shaped surface
+    ps, us = ctypes.c_ulong(8), ctypes.c_ulong(8)
+    rc = lib.zkc_proof_to_json(ol.proof_bytes(pr), b''.join(ol.le32(x) for x in sig), 8, ctypes.create_string_buffer(8), ctypes.byref(ps),
+                               ctypes.create_string_buffer(8), ctypes.byref(us))
+    assert rc == 2 and ps.value > 600 and us.value > 300

@@ -9,7 +9,7 @@ from . import _native
 from ._native import ZkcError
 from .inputs import INPUT_KEYS, flatten_inputs, R_MOD
 
-__all__ = ['Context', 'ProvingKey', 'ZkcError', 'INPUT_KEYS', 'flatten_inputs', 'R_MOD']
+__all__ = ['Context', 'ProvingKey', 'groth16', 'ZkcError', 'INPUT_KEYS', 'flatten_inputs', 'R_MOD']
 
 
 class Context:
@@ -23,9 +23,12 @@ class Context:
             raise ZkcError(rc, (self._lib.zkc_last_error(None) or b'').decode())
         self._h = h
         self.device = device
+        self._keys = []            # ProvingKey handles living on this context: freed before the context itself
 
     def close(self):
         if getattr(self, '_h', None):
+            for k in list(self._keys):
+                k.close()
             self._lib.zkc_ctx_destroy(self._h)
             self._h = None
 
@@ -74,14 +77,18 @@ class ProvingKey:
         h = ctypes.c_void_p()
         ctx._check(self._lib.zkc_zkey_load(ctx._h, zkey_bytes, len(zkey_bytes), ctypes.byref(h)))
         self._h = h
+        ctx._keys.append(self)
         a, b, c = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
         self._lib.zkc_zkey_info(h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
         self.n_vars, self.n_public, self.domain_size = a.value, b.value, c.value
 
     def close(self):
         if getattr(self, '_h', None):
-            self._lib.zkc_zkey_free(self._h)
+            if getattr(self.ctx, '_h', None):          # the context frees its keys when it closes first
+                self._lib.zkc_zkey_free(self._h)
             self._h = None
+            if self in self.ctx._keys:
+                self.ctx._keys.remove(self)
 
     def __del__(self):
         try:
@@ -119,3 +126,6 @@ class ProvingKey:
         out = ctypes.create_string_buffer(128 if which == 2 else 64)
         self.ctx._check(self._lib.zkc_msm_debug(self._h, which, d_scalars_ptr, count, out))
         return out.raw
+
+
+from . import groth16  # noqa: E402  (snarkjs-shaped surface: groth16.fullProve / prove / verify, groth16.wtns.calculate)

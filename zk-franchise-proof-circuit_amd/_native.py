@@ -45,6 +45,14 @@ def load():
     L.zkc_prove_batch_dev.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
     L.zkc_debug_stage.argtypes = [vp, vp, ctypes.c_int, ctypes.c_char_p]
     L.zkc_msm_debug.argtypes = [vp, ctypes.c_int, vp, ctypes.c_uint32, ctypes.c_char_p]
+    ulp = ctypes.POINTER(ctypes.c_ulong)
+    L.groth16_prover.argtypes = [ctypes.c_char_p, ctypes.c_ulong, ctypes.c_char_p, ctypes.c_ulong, ctypes.c_char_p, ulp, ctypes.c_char_p, ulp, ctypes.c_char_p, ctypes.c_ulong]
+    L.zkc_verify.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
+    L.zkc_verify_bin.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p]
+    L.zkc_verify_last_error.restype = ctypes.c_char_p
+    L.zkc_proof_to_json.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ulp, ctypes.c_char_p, ulp]
+    L.zkc_wtns_parse.argtypes = [ctypes.c_char_p, ctypes.c_ulong, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint32)]
+    L.zkc_wtns_write.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_ulong]; L.zkc_wtns_write.restype = ctypes.c_ulong
     L.zkc_poseidon_batch.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
     L.zkc_profile_enable.argtypes = [vp, ctypes.c_uint32]
     L.zkc_profile_read.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
