@@ -140,3 +140,16 @@ def test_codecs_roundtrip():
     rc = lib.zkc_proof_to_json(ol.proof_bytes(pr), b''.join(ol.le32(x) for x in sig), 8, ctypes.create_string_buffer(8), ctypes.byref(ps),
                                ctypes.create_string_buffer(8), ctypes.byref(us))
     assert rc == 2 and ps.value > 600 and us.value > 300
+
+
+def test_napi_shim_loads_and_verifies_reference_triple():
+    """The Node N-API surface (napi/): groth16.verify on the reference triple, and fullProve failing loudly without a GPU."""
+    import shutil, subprocess
+    node = shutil.which('node')
+    if not node or not os.path.exists(os.path.join(ol.ROOT, 'napi', 'zkcensus.node')):
+        pytest.skip('node or the built addon is not available')
+    js = ("const z=require('./napi');const vk=require('./tests/golden/ref/verification_key.json'),pr=require('./tests/golden/ref/proof.json'),"
+          "sg=require('./tests/golden/ref/signals.json');(async()=>{const a=await z.groth16.verify(vk,sg,pr);sg[1]=(BigInt(sg[1])+1n).toString();"
+          "const b=await z.groth16.verify(vk,sg,pr);console.log(JSON.stringify([a,b,z.flatten(require('./tests/golden/ref/inputs_example.json'),160).length]))})()")
+    out = subprocess.check_output([node, '-e', js], cwd=ol.ROOT, timeout=120).decode()
+    assert json.loads(out.strip().splitlines()[-1]) == [True, False, 334 * 32]
