@@ -102,8 +102,14 @@ def main():
     dom = 'msm_accumulate_g1'
     d = prof[dom]
     achieved = d['alg_bytes'] / (d['ms'] * 1e-3) / 1e9 if d['ms'] > 0 else 0.0
+    traffic, traffic_src = None, None
+    try:      # HBM bytes per launch of the same kernel/geometry from the committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
+        pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')))
+        traffic = int(pm['hbm_bytes_per_launch_uncorrected']); traffic_src = 'profiles/r01_pmc_hbm_traffic.json (separate --pmc run, %d proofs per launch)' % pm['proofs_per_launch']
+    except Exception:
+        pass
     roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBPS, 6), 'traffic': None,
+                'frac': round(achieved / HBM_PEAK_GBPS, 6), 'traffic': traffic, 'traffic_source': traffic_src,
                 'avg_launch_ms': round(d['ms'] / max(1, d['launches']), 4), 'alg_bytes_per_launch': d['alg_bytes'] // max(1, d['launches']),
                 'note': 'MSM bucket accumulation is integer-ALU bound (about 10 Fq products per 96 B streamed), not HBM bound; see DESIGN.md'}
 
