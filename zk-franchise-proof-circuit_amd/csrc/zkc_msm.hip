@@ -44,9 +44,10 @@ template <> struct PointIO<Fq2> {
 
 // ---- K4 ----
 extern "C" __global__ void __launch_bounds__(256)
-zkc_msm_digits(MsmJobList jl, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+zkc_msm_digits(const MsmJobList* __restrict__ jlp, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     const int j = blockIdx.y;
-    const MsmJob& job = jl.job[j];
+    const MsmJobList& jl = *jlp;
+    const MsmJob job = jl.job[j];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= job.count) return;
     const uint32_t wire = job.vmap ? job.vmap[i] : i;
@@ -280,6 +281,7 @@ int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, int max_jobs, b
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.off, (nb + 2) * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.segcnt, (nb + 2) * 4));
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.segoff, (nb + 2) * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.seg2bucket, w.max_segments * 4));
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.heavy, (MSM_MAX_HEAVY + 1) * 4));
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.d_jobs, sizeof(MsmJobList)));
     ZKC_HIP_CHECK(ctx, hipMalloc(&w.partial, w.max_segments * w.xyzz_size));
     ZKC_HIP_CHECK(ctx, hipMalloc(&w.wres, (size_t)max_jobs * MSM_NW * w.xyzz_size));
     ZKC_HIP_CHECK(ctx, hipMalloc(&w.results, 2 * (size_t)max_jobs * w.xyzz_size));
@@ -287,7 +289,7 @@ int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, int max_jobs, b
     return ZKC_OK;
 }
 void msm_work_free(MsmWork& w) {
-    void* p[] = {w.keys, w.vals, w.keys2, w.vals2, w.off, w.segcnt, w.segoff, w.seg2bucket, w.heavy, w.partial, w.wres, w.results, w.sort_tmp, w.scan_tmp};
+    void* p[] = {w.keys, w.vals, w.keys2, w.vals2, w.off, w.segcnt, w.segoff, w.seg2bucket, w.heavy, w.d_jobs, w.partial, w.wres, w.results, w.sort_tmp, w.scan_tmp};
     for (void* q : p) if (q) (void)hipFree(q);
     if (w.h_results) (void)hipHostFree(w.h_results);
     w = MsmWork();
@@ -315,7 +317,8 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     for (int j = 0; j < nj; j++) { alg_bytes += (uint64_t)jl.job[j].count * (sizeof(Affine<F>) + 32); maxcount = std::max(maxcount, jl.job[j].count); }
     {
         zkc_prof_scope _ps(ctx, ZKC_PROF_MSM_SORT, 0, st);
-        hipLaunchKernelGGL(zkc_msm_digits, dim3((maxcount + 255) / 256, nj), dim3(256), 0, st, jl, w.keys, w.vals);
+        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.d_jobs, &jl, sizeof(MsmJobList), hipMemcpyHostToDevice, st));   // pageable source: staged before return
+        hipLaunchKernelGGL(zkc_msm_digits, dim3((maxcount + 255) / 256, nj), dim3(256), 0, st, (const MsmJobList*)w.d_jobs, w.keys, w.vals);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_digits");
         int end_bit = 1; while ((1ull << end_bit) <= (uint64_t)nb) end_bit++;
         size_t need = 0;

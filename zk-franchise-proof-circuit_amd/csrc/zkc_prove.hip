@@ -159,7 +159,7 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
         (rc = msm_precompute_g2(ctx, nv, zk->d_g2))) return bail(rc);
     // ---- work buffers: `inflight` proofs share one MSM pipeline pass ----
     const char* e_inf = getenv("ZKC_INFLIGHT");
-    zk->max_inflight = e_inf ? std::max(1, std::min(atoi(e_inf), MSM_MAX_JOBS / 4)) : 16;
+    zk->max_inflight = e_inf ? std::max(1, std::min(atoi(e_inf), MSM_MAX_JOBS / 4)) : 32;
     const size_t per_proof_entries = (size_t)MSM_NW * (3 * (size_t)nv + n);
     if ((rc = dmalloc(ctx, &zk->d_abc, 3 * (size_t)n * zk->max_inflight)) || (rc = dmalloc(ctx, &zk->d_t, 3 * (size_t)n * zk->max_inflight)) || (rc = dmalloc(ctx, &zk->d_prod, (size_t)zk->nCoeffs + 1)) ||
         (rc = dmalloc(ctx, &zk->d_p, 8 * (size_t)n * zk->max_inflight))) return bail(rc);
@@ -358,7 +358,7 @@ extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nW
         if (fold && (rc = fold_vmap(zk, Dc, Ds, &vmap, &nV))) return rc;
         if (pass >= 2) { ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, zk->ev_fin[slot], 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st2, zk->ev_fin[slot], 0)); }   // result slot still read by finalize(pass-2)?
         if ((rc = h_evals_dev(zk, w0, nb))) return rc;
-        MsmJobList j1{}, j2{}; uint32_t e1 = 0, e2 = 0;
+        static thread_local MsmJobList j1, j2; uint32_t e1 = 0, e2 = 0;   // 4.6 KB each: kept off the stack frame of a C-ABI entry point
         for (int q = 0; q < nb; q++) {
             const uint32_t* w = w0 + (size_t)q * nv * 8;
             const uint32_t cntC = fold ? nV - (np + 1) : nc;     // wires 0..nPub are never folded, so they are the first nPub+1 map entries

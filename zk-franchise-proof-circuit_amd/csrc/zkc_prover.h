@@ -11,7 +11,7 @@ constexpr int MSM_NB = MSM_NW * MSM_HALF;          // buckets per MSM job
 constexpr int MSM_SEG = 16;                        // sorted entries per accumulation lane (load balance for repeated scalars)
 constexpr int MSM_MERGE_T = 8;                     // buckets with more segments get a wave of their own before the window pass
 constexpr int MSM_MAX_HEAVY = 1 << 16;
-constexpr int MSM_MAX_JOBS = 64;                   // jobs per pipeline pass (proofs in flight x sections)
+constexpr int MSM_MAX_JOBS = 128;                  // jobs per pipeline pass (proofs in flight x sections)
 
 // One multi-scalar multiplication inside a pipeline pass: sum_j scalar[j] * P[point(j)]
 struct MsmJob {
@@ -41,6 +41,7 @@ struct MsmWork {
     void *wres = nullptr;           // XYZZ per (job, window)
     void *results = nullptr;        // XYZZ per job, two slots of max_jobs (device) ; h_results pinned host mirror of slot 0
     void *h_results = nullptr;
+    MsmJobList* d_jobs = nullptr;   // device copy of the pass' job list (too large for kernel arguments)
     void *sort_tmp = nullptr; size_t sort_tmp_sz = 0; void* scan_tmp = nullptr; size_t scan_tmp_sz = 0;
     size_t max_entries = 0, max_segments = 0; int max_jobs = 0; size_t xyzz_size = 0;
 };
