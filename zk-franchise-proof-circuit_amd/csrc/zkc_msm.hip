@@ -52,20 +52,22 @@ zkc_msm_digits(const MsmJobList* __restrict__ jlp, uint32_t* __restrict__ keys, 
     if (i >= job.count) return;
     const uint32_t wire = job.vmap ? job.vmap[i] : i;
     const uint4* sp = reinterpret_cast<const uint4*>(job.scalars + 8 * (size_t)wire); uint4 a = sp[0], b = sp[1];
-    const uint32_t s[9] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, 0};
+    const uint32_t s[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     const uint32_t pt = job.tbl_off + (uint32_t)((int32_t)wire - job.pt_shift);
-    const size_t base = (size_t)jl.entry_off[j] * MSM_NW;
+    const uint32_t c = job.c, half = 1u << (c - 1), mask = (1u << c) - 1;
     uint32_t carry = 0;
+    for (uint32_t w = 0; w < job.nw; w++) {
+        const uint32_t bit = w * c, li = bit >> 5, sh = bit & 31;
+        uint32_t lo = 0, hi = 0;
 #pragma unroll
-    for (int w = 0; w < MSM_NW; w++) {
-        const int bit = w * MSM_C, li = bit >> 5, sh = bit & 31;
-        uint64_t two = (li < 8) ? ((uint64_t)s[li] | ((uint64_t)s[li + 1] << 32)) : 0;
-        uint32_t d = (uint32_t)((two >> sh) & ((1u << MSM_C) - 1)) + carry;
+        for (int q = 0; q < 8; q++) { lo = ((uint32_t)q == li) ? s[q] : lo; hi = ((uint32_t)q == li + 1) ? s[q] : hi; }
+        const uint64_t two = (uint64_t)lo | ((uint64_t)hi << 32);
+        uint32_t d = (uint32_t)((two >> sh) & mask) + carry;
         uint32_t neg = 0;
-        if (d > (uint32_t)MSM_HALF) { d = (1u << MSM_C) - d; neg = 1; carry = 1; } else carry = 0;
-        const size_t o = base + (size_t)w * job.count + i;
-        keys[o] = d ? (uint32_t)(j * MSM_NB + w * MSM_HALF) + d - 1 : (uint32_t)(jl.njobs * MSM_NB);      // zero digits sort to the end
-        vals[o] = (pt + (uint32_t)w * job.tbl_count) | (neg << 31);
+        if (d > half) { d = (1u << c) - d; neg = 1; carry = 1; } else carry = 0;
+        const size_t o = (size_t)job.ent_off + (size_t)w * job.count + i;
+        keys[o] = d ? job.boff + w * half + d - 1 : jl.total_buckets;                 // zero digits sort to the end
+        vals[o] = (pt + w * job.tbl_count) | (neg << 31);
     }
 }
 // off[b] = first sorted position with key >= b
@@ -144,18 +146,19 @@ zkc_msm_merge(XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ segoff
     }
 }
 
-// ---- K6 ---- one workgroup per (job, window); lane t owns buckets 16t .. 16t+15 (digits 16t+1 .. 16t+16)
+// ---- K6 ---- one workgroup per (job, window); lane t owns buckets PER*t .. PER*t+PER-1 (digits PER*t+1 ..), PER = half/256
 template <class F>
 __global__ void __launch_bounds__(256)
 zkc_msm_window(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ segoff, const uint32_t* __restrict__ segcnt,
-               XYZZ<F>* __restrict__ wres, uint32_t max_segments) {
+               const MsmWindow* __restrict__ windows, XYZZ<F>* __restrict__ wres, uint32_t max_segments) {
     extern __shared__ uint4 lds4[];
     XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds4);
-    constexpr int PER = MSM_HALF / 256;                                   // 16
-    const uint32_t first = blockIdx.x * MSM_HALF + threadIdx.x * PER;     // blockIdx.x = job * NW + window
-    // run = sum of the lane's buckets from the top; loc = sum_k k * B_k (k = 1..PER)
+    const MsmWindow win = windows[blockIdx.x];
+    const int per = (int)(win.half >> 8);                                 // 16 (c = 13) or 2 (c = 10)
+    const uint32_t first = win.bucket0 + threadIdx.x * per;
+    // run = sum of the lane's buckets from the top; loc = sum_k k * B_k (k = 1..per)
     XYZZ<F> run = XYZZ<F>::inf(), loc = XYZZ<F>::inf();
-    for (int k = PER - 1; k >= 0; k--) {
+    for (int k = per - 1; k >= 0; k--) {
         uint32_t s0 = segoff[first + k], s1 = s0 + segcnt[first + k];
         if (s1 > max_segments) s1 = max_segments;
         for (uint32_t s = s0; s < s1; s++) run = xyzz_add(run, partial[s]);
@@ -170,9 +173,9 @@ zkc_msm_window(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__
         if ((int)threadIdx.x + o < 256) sh[threadIdx.x] = xyzz_add(sh[threadIdx.x], v);
         __syncthreads();
     }
-    // sum_d d B_d = sum_t loc_t + PER * sum_{t>=1} R_t
+    // sum_d d B_d = sum_t loc_t + per * sum_{t>=1} R_t
     XYZZ<F> y = XYZZ<F>::inf();
-    if (threadIdx.x >= 1) { y = sh[threadIdx.x]; for (int k = 0; k < 4; k++) y = xyzz_dbl(y); }   // x16
+    if (threadIdx.x >= 1) { y = sh[threadIdx.x]; for (int k = per; k > 1; k >>= 1) y = xyzz_dbl(y); }   // x per (a power of two)
     y = xyzz_add(y, loc);
     __syncthreads();
     sh[threadIdx.x] = y; __syncthreads();
@@ -184,37 +187,37 @@ zkc_msm_window(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__
 }
 template <class F>
 __global__ void __launch_bounds__(64)
-zkc_msm_final(const XYZZ<F>* __restrict__ wres, int njobs, XYZZ<F>* __restrict__ results) {
+zkc_msm_final(const XYZZ<F>* __restrict__ wres, const MsmJobList* __restrict__ jl, XYZZ<F>* __restrict__ results) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= njobs) return;
+    if (j >= jl->njobs) return;
     XYZZ<F> acc = XYZZ<F>::inf();
-    for (int w = 0; w < MSM_NW; w++) acc = xyzz_add(acc, wres[j * MSM_NW + w]);
+    for (uint32_t w = 0; w < jl->job[j].nw; w++) acc = xyzz_add(acc, wres[jl->job[j].win_off + w]);
     results[j] = acc;
 }
 
 // ---- one-time base table: table[w][i] = 2^c * table[w-1][i] ----
 template <class F>
 __global__ void __launch_bounds__(128)
-zkc_msm_shift_bases(const Affine<F>* __restrict__ prev, Affine<F>* __restrict__ next, uint32_t count) {
+zkc_msm_shift_bases(const Affine<F>* __restrict__ prev, Affine<F>* __restrict__ next, uint32_t count, int c) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     Affine<F> a = PointIO<F>::load(prev + i);
     XYZZ<F> p = xyzz_dbl_affine(a);
-    for (int k = 1; k < MSM_C; k++) p = xyzz_dbl(p);
+    for (int k = 1; k < c; k++) p = xyzz_dbl(p);
     next[i] = xyzz_to_affine(p);
 }
 template <class F>
-static int precompute(zkc_ctx* ctx, uint32_t count, Affine<F>* d_table) {
-    for (int w = 1; w < MSM_NW; w++) {
+static int precompute(zkc_ctx* ctx, uint32_t count, Affine<F>* d_table, int c) {
+    for (int w = 1; w < msm_nw(c); w++) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_shift_bases<F>), dim3((count + 127) / 128), dim3(128), 0, ctx->stream,
-                           d_table + (size_t)(w - 1) * count, d_table + (size_t)w * count, count);
+                           d_table + (size_t)(w - 1) * count, d_table + (size_t)w * count, count, c);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, std::string("zkc_msm_shift_bases: ") + hipGetErrorString(e));
     }
     return ZKC_OK;
 }
-int msm_precompute_g1(zkc_ctx* ctx, uint32_t count, G1Affine* d_table) { return precompute<Fq>(ctx, count, d_table); }
-int msm_precompute_g2(zkc_ctx* ctx, uint32_t count, G2Affine* d_table) { return precompute<Fq2>(ctx, count, d_table); }
+int msm_precompute_g1(zkc_ctx* ctx, uint32_t count, G1Affine* d_table, int c) { return precompute<Fq>(ctx, count, d_table, c); }
+int msm_precompute_g2(zkc_ctx* ctx, uint32_t count, G2Affine* d_table, int c) { return precompute<Fq2>(ctx, count, d_table, c); }
 
 // ---- constant folding support: out[i] = scalar[wire_i] * P[wire_i - shift] by double-and-add, then per-group sums ----
 __device__ __forceinline__ uint32_t limb_of(const uint32_t k[8], int i) {
@@ -272,9 +275,9 @@ int fold_group_sums_g2(zkc_ctx* ctx, const G2Affine* tbl, const uint32_t* s, con
 }
 
 // ---- work space ----
-int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, int max_jobs, bool g2) {
-    w.max_entries = max_entries; w.max_jobs = max_jobs; w.xyzz_size = g2 ? sizeof(G2XYZZ) : sizeof(G1XYZZ);
-    const size_t nb = (size_t)max_jobs * MSM_NB;
+int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, size_t max_buckets, int max_jobs, bool g2) {
+    w.max_entries = max_entries; w.max_jobs = max_jobs; w.max_buckets = max_buckets; w.xyzz_size = g2 ? sizeof(G2XYZZ) : sizeof(G1XYZZ);
+    const size_t nb = max_buckets;
     w.max_segments = max_entries / MSM_SEG + nb;        // every non-empty bucket has at most one short segment
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.keys, max_entries * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.vals, max_entries * 4));
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.keys2, max_entries * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.vals2, max_entries * 4));
@@ -283,13 +286,14 @@ int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, int max_jobs, b
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.heavy, (MSM_MAX_HEAVY + 1) * 4));
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.d_jobs, sizeof(MsmJobList)));
     ZKC_HIP_CHECK(ctx, hipMalloc(&w.partial, w.max_segments * w.xyzz_size));
-    ZKC_HIP_CHECK(ctx, hipMalloc(&w.wres, (size_t)max_jobs * MSM_NW * w.xyzz_size));
+    ZKC_HIP_CHECK(ctx, hipMalloc(&w.wres, (size_t)max_jobs * MSM_NW_MAX * w.xyzz_size));
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.d_windows, (size_t)max_jobs * MSM_NW_MAX * sizeof(MsmWindow)));
     ZKC_HIP_CHECK(ctx, hipMalloc(&w.results, 2 * (size_t)max_jobs * w.xyzz_size));
     ZKC_HIP_CHECK(ctx, hipHostMalloc(&w.h_results, (size_t)max_jobs * w.xyzz_size));
     return ZKC_OK;
 }
 void msm_work_free(MsmWork& w) {
-    void* p[] = {w.keys, w.vals, w.keys2, w.vals2, w.off, w.segcnt, w.segoff, w.seg2bucket, w.heavy, w.d_jobs, w.partial, w.wres, w.results, w.sort_tmp, w.scan_tmp};
+    void* p[] = {w.keys, w.vals, w.keys2, w.vals2, w.off, w.segcnt, w.segoff, w.seg2bucket, w.heavy, w.d_jobs, w.d_windows, w.partial, w.wres, w.results, w.sort_tmp, w.scan_tmp};
     for (void* q : p) if (q) (void)hipFree(q);
     if (w.h_results) (void)hipHostFree(w.h_results);
     w = MsmWork();
@@ -309,15 +313,20 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     zkc_ctx* ctx = zk->ctx;
     const int nj = jl.njobs;
     if (nj <= 0 || nj > w.max_jobs) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: job count");
-    const size_t total = (size_t)jl.entry_off[nj] * MSM_NW;
-    if (total > w.max_entries) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: too many entries for the work space");
-    const uint32_t nb = (uint32_t)nj * MSM_NB;
+    const size_t total = jl.total_entries;
+    const uint32_t nb = jl.total_buckets;
+    if (total > w.max_entries || nb > w.max_buckets) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: too many entries for the work space");
     constexpr bool kG2 = sizeof(F) == sizeof(Fq2);
     uint64_t alg_bytes = 0; uint32_t maxcount = 0;
     for (int j = 0; j < nj; j++) { alg_bytes += (uint64_t)jl.job[j].count * (sizeof(Affine<F>) + 32); maxcount = std::max(maxcount, jl.job[j].count); }
     {
         zkc_prof_scope _ps(ctx, ZKC_PROF_MSM_SORT, 0, st);
+        static thread_local std::vector<MsmWindow> wins;
+        wins.clear();
+        for (int j = 0; j < nj; j++) for (uint32_t wdw = 0; wdw < jl.job[j].nw; wdw++)
+            wins.push_back(MsmWindow{jl.job[j].boff + wdw * (uint32_t)msm_half((int)jl.job[j].c), (uint32_t)msm_half((int)jl.job[j].c), (uint32_t)j});
         ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.d_jobs, &jl, sizeof(MsmJobList), hipMemcpyHostToDevice, st));   // pageable source: staged before return
+        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.d_windows, wins.data(), wins.size() * sizeof(MsmWindow), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(zkc_msm_digits, dim3((maxcount + 255) / 256, nj), dim3(256), 0, st, (const MsmJobList*)w.d_jobs, w.keys, w.vals);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_digits");
         int end_bit = 1; while ((1ull << end_bit) <= (uint64_t)nb) end_bit++;
@@ -357,10 +366,10 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
         hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_merge<F>), dim3(1024), dim3(64), 0, st, partial, w.segoff, w.segcnt, w.heavy, w.heavy + MSM_MAX_HEAVY,
                            (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_merge");
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_window<F>), dim3(nj * MSM_NW), dim3(256), 256 * sizeof(XYZZ<F>), st, partial, w.segoff, w.segcnt, wres,
-                           (uint32_t)w.max_segments);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_window<F>), dim3(jl.total_windows), dim3(256), 256 * sizeof(XYZZ<F>), st, partial, w.segoff, w.segcnt,
+                           (const MsmWindow*)w.d_windows, wres, (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_window");
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_final<F>), dim3((nj + 63) / 64), dim3(64), 0, st, wres, nj, results);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_final<F>), dim3((nj + 63) / 64), dim3(64), 0, st, wres, (const MsmJobList*)w.d_jobs, results);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_final");
     }
     if (to_host) ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.h_results, results, (size_t)nj * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));

@@ -147,24 +147,26 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
     }
     // ---- bases: one G1 array [A | B1 | C | H] and one G2 array [B2]; window 0 = the zkey points as stored (affine,
     //      Montgomery), windows 1..19 pre-shifted on the device ----
-    zk->offA = 0; zk->offB1 = MSM_NW * nv; zk->offC = 2 * MSM_NW * nv; zk->offH = 2 * MSM_NW * nv + MSM_NW * nc;
-    const size_t g1_points = (size_t)MSM_NW * (2 * (size_t)nv + nc + n);
+    constexpr int NWS = msm_nw(MSM_C_SMALL), NWB = msm_nw(MSM_C_BIG);
+    zk->offA = 0; zk->offB1 = NWS * nv; zk->offC = 2 * NWS * nv; zk->offH = 2 * NWS * nv + NWS * nc;
+    const size_t g1_points = (size_t)NWS * (2 * (size_t)nv + nc) + (size_t)NWB * n;
     if (g1_points >= (1ull << 31)) return bail(zkc_fail(ctx, ZKC_ERR_FORMAT, "zkey too large for 31-bit point indices"));
-    if ((rc = dmalloc(ctx, &zk->d_g1, g1_points)) || (rc = dmalloc(ctx, &zk->d_g2, (size_t)MSM_NW * nv))) return bail(rc);
+    if ((rc = dmalloc(ctx, &zk->d_g1, g1_points)) || (rc = dmalloc(ctx, &zk->d_g2, (size_t)NWS * nv))) return bail(rc);
     ZKC_UP(zk->d_g1 + zk->offA, sec[5], 64ull * nv); ZKC_UP(zk->d_g1 + zk->offB1, sec[6], 64ull * nv);
     ZKC_UP(zk->d_g1 + zk->offC, sec[8], 64ull * nc); ZKC_UP(zk->d_g1 + zk->offH, sec[9], 64ull * n);
     ZKC_UP(zk->d_g2, sec[7], 128ull * nv);
-    if ((rc = msm_precompute_g1(ctx, nv, zk->d_g1 + zk->offA)) || (rc = msm_precompute_g1(ctx, nv, zk->d_g1 + zk->offB1)) ||
-        (rc = msm_precompute_g1(ctx, nc, zk->d_g1 + zk->offC)) || (rc = msm_precompute_g1(ctx, n, zk->d_g1 + zk->offH)) ||
-        (rc = msm_precompute_g2(ctx, nv, zk->d_g2))) return bail(rc);
+    if ((rc = msm_precompute_g1(ctx, nv, zk->d_g1 + zk->offA, MSM_C_SMALL)) || (rc = msm_precompute_g1(ctx, nv, zk->d_g1 + zk->offB1, MSM_C_SMALL)) ||
+        (rc = msm_precompute_g1(ctx, nc, zk->d_g1 + zk->offC, MSM_C_SMALL)) || (rc = msm_precompute_g1(ctx, n, zk->d_g1 + zk->offH, MSM_C_BIG)) ||
+        (rc = msm_precompute_g2(ctx, nv, zk->d_g2, MSM_C_SMALL))) return bail(rc);
     // ---- work buffers: `inflight` proofs share one MSM pipeline pass ----
     const char* e_inf = getenv("ZKC_INFLIGHT");
     zk->max_inflight = e_inf ? std::max(1, std::min(atoi(e_inf), MSM_MAX_JOBS / 4)) : 32;
-    const size_t per_proof_entries = (size_t)MSM_NW * (3 * (size_t)nv + n);
+    const size_t per_proof_entries = (size_t)NWS * 3 * nv + (size_t)NWB * n;
+    const size_t per_proof_buckets = 3 * (size_t)msm_nb(MSM_C_SMALL) + msm_nb(MSM_C_BIG);
     if ((rc = dmalloc(ctx, &zk->d_abc, 3 * (size_t)n * zk->max_inflight)) || (rc = dmalloc(ctx, &zk->d_t, 3 * (size_t)n * zk->max_inflight)) || (rc = dmalloc(ctx, &zk->d_prod, (size_t)zk->nCoeffs + 1)) ||
         (rc = dmalloc(ctx, &zk->d_p, 8 * (size_t)n * zk->max_inflight))) return bail(rc);
-    if ((rc = msm_work_alloc(ctx, zk->w1, per_proof_entries * zk->max_inflight, 4 * zk->max_inflight, false))) return bail(rc);
-    if ((rc = msm_work_alloc(ctx, zk->w2, (size_t)MSM_NW * nv * zk->max_inflight, zk->max_inflight, true))) return bail(rc);
+    if ((rc = msm_work_alloc(ctx, zk->w1, per_proof_entries * zk->max_inflight, per_proof_buckets * zk->max_inflight, 4 * zk->max_inflight, false))) return bail(rc);
+    if ((rc = msm_work_alloc(ctx, zk->w2, (size_t)NWS * nv * zk->max_inflight, (size_t)msm_nb(MSM_C_SMALL) * zk->max_inflight, zk->max_inflight, true))) return bail(rc);
     {   // fixed-base tables for the blinding step (delta1, alpha1, beta1 in G1; delta2 in G2)
         FixedBase<Fq> td(zk->delta1), ta(zk->alpha1), tb(zk->beta1); FixedBase<Fq2> t2(zk->delta2);
         if ((rc = dmalloc(ctx, &zk->d_tblDelta1, td.tab.size())) || (rc = dmalloc(ctx, &zk->d_tblAlpha1, ta.tab.size())) ||
@@ -302,9 +304,9 @@ extern "C" int zkc_msm_debug(zkc_zkey* zk, int which, const void* d_scalars, uin
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const uint32_t full = which == 3 ? zk->nVars - zk->nPub - 1 : which == 4 ? zk->n : zk->nVars;
     if (count != full) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_msm_debug: count must equal the section size");
-    MsmJobList jl{}; jl.njobs = 1; jl.entry_off[0] = 0; jl.entry_off[1] = count;
+    static thread_local MsmJobList jl; jl.clear();
     const uint32_t offs[5] = {zk->offA, zk->offB1, 0, zk->offC, zk->offH};
-    jl.job[0] = MsmJob{(const uint32_t*)d_scalars, nullptr, count, offs[which], full, 0};
+    jl.add((const uint32_t*)d_scalars, nullptr, count, offs[which], full, 0, which == 4 ? MSM_C_BIG : MSM_C_SMALL);
     int rc = which == 2 ? msm_pass_g2(zk, jl, 0, true, ctx->stream) : msm_pass_g1(zk, jl, 0, true, ctx->stream); if (rc) return rc;
     ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (which == 2) g2_to_std((uint8_t*)host_out, xyzz_to_affine(*(G2XYZZ*)zk->w2.h_results));
@@ -358,19 +360,18 @@ extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nW
         if (fold && (rc = fold_vmap(zk, Dc, Ds, &vmap, &nV))) return rc;
         if (pass >= 2) { ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, zk->ev_fin[slot], 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st2, zk->ev_fin[slot], 0)); }   // result slot still read by finalize(pass-2)?
         if ((rc = h_evals_dev(zk, w0, nb))) return rc;
-        static thread_local MsmJobList j1, j2; uint32_t e1 = 0, e2 = 0;   // 4.6 KB each: kept off the stack frame of a C-ABI entry point
+        static thread_local MsmJobList j1, j2;     // 6 KB each: kept off the stack frame of a C-ABI entry point
+        j1.clear(); j2.clear();
         for (int q = 0; q < nb; q++) {
             const uint32_t* w = w0 + (size_t)q * nv * 8;
-            const uint32_t cntC = fold ? nV - (np + 1) : nc;     // wires 0..nPub are never folded, so they are the first nPub+1 map entries
-            j1.entry_off[4 * q + 0] = e1; j1.job[4 * q + 0] = MsmJob{w, vmap, nV, zk->offA, nv, 0}; e1 += nV;
-            j1.entry_off[4 * q + 1] = e1; j1.job[4 * q + 1] = MsmJob{w, vmap, nV, zk->offB1, nv, 0}; e1 += nV;
-            j1.entry_off[4 * q + 2] = e1;
-            j1.job[4 * q + 2] = fold ? MsmJob{w, vmap + (np + 1), cntC, zk->offC, nc, (int32_t)np + 1} : MsmJob{w + 8ull * (np + 1), nullptr, nc, zk->offC, nc, 0};
-            e1 += cntC;
-            j1.entry_off[4 * q + 3] = e1; j1.job[4 * q + 3] = MsmJob{zk->d_p + 8 * (size_t)n * q, nullptr, n, zk->offH, n, 0}; e1 += n;
-            j2.entry_off[q] = e2; j2.job[q] = MsmJob{w, vmap, nV, 0, nv, 0}; e2 += nV;
+            j1.add(w, vmap, nV, zk->offA, nv, 0, MSM_C_SMALL);
+            j1.add(w, vmap, nV, zk->offB1, nv, 0, MSM_C_SMALL);
+            // wires 0..nPub are never folded, so they are the first nPub+1 map entries: section C skips them
+            if (fold) j1.add(w, vmap + (np + 1), nV - (np + 1), zk->offC, nc, (int32_t)np + 1, MSM_C_SMALL);
+            else j1.add(w + 8ull * (np + 1), nullptr, nc, zk->offC, nc, 0, MSM_C_SMALL);
+            j1.add(zk->d_p + 8 * (size_t)n * q, nullptr, n, zk->offH, n, 0, MSM_C_BIG);
+            j2.add(w, vmap, nV, 0, nv, 0, MSM_C_SMALL);
         }
-        j1.njobs = 4 * nb; j1.entry_off[4 * nb] = e1; j2.njobs = nb; j2.entry_off[nb] = e2;
         if ((rc = msm_pass_g2(zk, j2, slot, false, st2))) return rc;          // B2 needs only the witness: runs beside buildABC/NTT/G1
         ZKC_HIP_CHECK(ctx, hipEventRecord(zk->ev_msm2[slot], st2));
         if ((rc = msm_pass_g1(zk, j1, slot, false, st))) return rc;

@@ -4,10 +4,14 @@
 #include "zkc_curve.h"
 
 namespace zkc {
-constexpr int MSM_C = 13;                          // Pippenger window bits (signed digits -> 2^(c-1) buckets per window)
-constexpr int MSM_NW = (254 + MSM_C) / MSM_C;      // 20 windows cover 260 bits
-constexpr int MSM_HALF = 1 << (MSM_C - 1);         // 4096 buckets per window
-constexpr int MSM_NB = MSM_NW * MSM_HALF;          // buckets per MSM job
+// Pippenger window bits per section (signed digits -> 2^(c-1) buckets per window).  H (2^17 random scalars) uses 13-bit
+// windows; the witness sections A, B1, C, B2 run over the ~13 k wires left after constant folding, where 10-bit windows
+// minimise additions + bucket reduction.
+constexpr int MSM_C_BIG = 13, MSM_C_SMALL = 10;
+constexpr int msm_nw(int c) { return (254 + c) / c; }          // 13 -> 20 windows (260 bits), 10 -> 26 windows (260 bits)
+constexpr int msm_half(int c) { return 1 << (c - 1); }
+constexpr int msm_nb(int c) { return msm_nw(c) * msm_half(c); } // buckets per job: 81920 / 13312
+constexpr int MSM_NW_MAX = msm_nw(MSM_C_SMALL);
 constexpr int MSM_SEG = 16;                        // sorted entries per accumulation lane (load balance for repeated scalars)
 constexpr int MSM_MERGE_T = 8;                     // buckets with more segments get a wave of their own before the window pass
 constexpr int MSM_MAX_HEAVY = 1 << 16;
@@ -21,6 +25,8 @@ struct MsmJob {
     uint32_t tbl_off;          // first point of this section's pre-shifted table inside the unified point array
     uint32_t tbl_count;        // points per window in that table
     int32_t pt_shift;
+    uint32_t c, nw;            // window bits / windows of this job's table
+    uint32_t boff, ent_off, win_off;   // first bucket / first (scalar, window) entry / first window of this job inside the pass
 };
 // arguments of the blinding kernel (zkc_finalize.hip); everything except r1/r2/rs/out is constant per proving key
 struct FinalizeArgs {
@@ -30,7 +36,16 @@ struct FinalizeArgs {
     G1Affine alpha1; G2Affine beta2;
     const uint8_t* rs; uint8_t* out;                    // device: nproofs x 64 (r || s) -> nproofs x 256 proof bytes
 };
-struct MsmJobList { MsmJob job[MSM_MAX_JOBS]; uint32_t entry_off[MSM_MAX_JOBS + 1]; int njobs; };
+struct MsmJobList {
+    MsmJob job[MSM_MAX_JOBS]; int njobs; uint32_t total_buckets, total_entries, total_windows;
+    void add(const uint32_t* scalars, const uint32_t* vmap, uint32_t count, uint32_t tbl_off, uint32_t tbl_count, int32_t pt_shift, int c) {
+        MsmJob& j = job[njobs++];
+        j = MsmJob{scalars, vmap, count, tbl_off, tbl_count, pt_shift, (uint32_t)c, (uint32_t)msm_nw(c), total_buckets, total_entries, total_windows};
+        total_buckets += (uint32_t)msm_nb(c); total_entries += count * (uint32_t)msm_nw(c); total_windows += (uint32_t)msm_nw(c);
+    }
+    void clear() { njobs = 0; total_buckets = total_entries = total_windows = 0; }
+};
+struct MsmWindow { uint32_t bucket0, half, job; };   // one workgroup of zkc_msm_window
 
 // Work space of one pipeline pass (sized for MSM_MAX_JOBS jobs and max_entries (scalar, window) pairs)
 struct MsmWork {
@@ -42,6 +57,7 @@ struct MsmWork {
     void *results = nullptr;        // XYZZ per job, two slots of max_jobs (device) ; h_results pinned host mirror of slot 0
     void *h_results = nullptr;
     MsmJobList* d_jobs = nullptr;   // device copy of the pass' job list (too large for kernel arguments)
+    MsmWindow* d_windows = nullptr; size_t max_buckets = 0;
     void *sort_tmp = nullptr; size_t sort_tmp_sz = 0; void* scan_tmp = nullptr; size_t scan_tmp_sz = 0;
     size_t max_entries = 0, max_segments = 0; int max_jobs = 0; size_t xyzz_size = 0;
 };
@@ -79,15 +95,15 @@ struct zkc_zkey {
 
 namespace zkc {
 int ntt_run(zkc_ctx* ctx, const Fr* src, Fr* dst, const Fr* tw, const Fr* scale, int logn, int nvec);
-int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, int max_jobs, bool g2);
+int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, size_t max_buckets, int max_jobs, bool g2);
 void msm_work_free(MsmWork& w);
 // runs all jobs of `jl` through one pipeline pass; results (XYZZ per job) go to device slot `slot` (0/1) of w.results and, when
 // to_host is set, to w.h_results (valid after the caller syncs the stream)
 int msm_pass_g1(zkc_zkey* zk, const MsmJobList& jl, int slot, bool to_host, hipStream_t st);
 int msm_pass_g2(zkc_zkey* zk, const MsmJobList& jl, int slot, bool to_host, hipStream_t st);
 int finalize_launch(zkc_ctx* ctx, hipStream_t st, const FinalizeArgs& a, int nproofs);
-int msm_precompute_g1(zkc_ctx* ctx, uint32_t count, G1Affine* d_table);   // d_table[0..count) = base on entry
-int msm_precompute_g2(zkc_ctx* ctx, uint32_t count, G2Affine* d_table);
+int msm_precompute_g1(zkc_ctx* ctx, uint32_t count, G1Affine* d_table, int c);   // d_table[0..count) = base on entry
+int msm_precompute_g2(zkc_ctx* ctx, uint32_t count, G2Affine* d_table, int c);
 // out[i] = scalar[wires[i]] * P[wires[i] - pt_shift] (window-0 table), then per-group sums: gsum[g] = sum out[gstart[g]..gstart[g+1])
 int fold_group_sums_g1(zkc_ctx* ctx, const G1Affine* tbl, const uint32_t* d_scalars, const uint32_t* d_wires, uint32_t nw, int32_t pt_shift,
                        const uint32_t* d_gstart, uint32_t ngroups, G1XYZZ* h_out);
