@@ -201,8 +201,11 @@ extern "C" int zkc_proof_to_json(const uint8_t proof[256], const uint8_t* pub, i
     for (int i = 0; i < nPublic; i++) sj += (i ? ",\"" : "\"") + dec_of(pub + 32 * i) + "\"";
     sj += "]";
     const bool shortbuf = !proof_buf || !public_buf || *proof_size < pj.size() + 1 || *public_size < sj.size() + 1;
+    if (shortbuf) {      // report sizes that hold ANY proof of this shape (77 decimal digits per coordinate): r, s differ between calls
+        *proof_size = 8 * 80 + 128; *public_size = (unsigned long)nPublic * 80 + 8;
+        return ZKC_ERR_SHORT_BUFFER;
+    }
     *proof_size = pj.size() + 1; *public_size = sj.size() + 1;
-    if (shortbuf) return ZKC_ERR_SHORT_BUFFER;
     memcpy(proof_buf, pj.c_str(), pj.size() + 1); memcpy(public_buf, sj.c_str(), sj.size() + 1);
     return ZKC_OK;
 }
