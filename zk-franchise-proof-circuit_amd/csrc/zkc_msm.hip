@@ -25,7 +25,8 @@
 namespace zkc {
 
 template <class F> struct PointIO;
-template <> struct PointIO<Fq> {
+template <class PP> struct PointIO<Fp<PP>> {
+    typedef Fp<PP> Fq;
     static __device__ __forceinline__ Affine<Fq> load(const Affine<Fq>* p) {
         const uint4* d = reinterpret_cast<const uint4*>(p); uint4 a = d[0], b = d[1], c = d[2], e = d[3];
         Affine<Fq> r;
@@ -37,7 +38,7 @@ template <> struct PointIO<Fq> {
 template <> struct PointIO<Fq2> {
     static __device__ __forceinline__ Affine<Fq2> load(const Affine<Fq2>* p) {
         const Affine<Fq>* q = reinterpret_cast<const Affine<Fq>*>(p);
-        Affine<Fq> lo = PointIO<Fq>::load(q), hi = PointIO<Fq>::load(q + 1);
+        Affine<Fq> lo = PointIO<zkc::Fq>::load(q), hi = PointIO<zkc::Fq>::load(q + 1);
         return {{lo.x, lo.y}, {hi.x, hi.y}};        // memory order x.c0, x.c1, y.c0, y.c1
     }
 };
@@ -357,8 +358,13 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     const size_t seg_bound = std::min<size_t>(w.max_segments, total / MSM_SEG + nb);     // launch bound on the number of segments
     {
         zkc_prof_scope _ps(ctx, kG2 ? ZKC_PROF_MSM_ACC_G2 : ZKC_PROF_MSM_ACC_G1, alg_bytes, st);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate<F>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st, table, w.vals2, w.off,
-                           w.segoff, w.seg2bucket, nb, partial, (uint32_t)w.max_segments);
+        if constexpr (kG2)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate<F>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st, table, w.vals2, w.off,
+                               w.segoff, w.seg2bucket, nb, partial, (uint32_t)w.max_segments);
+        else      // G1: same layout, field type with the inlined product
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate<FqI>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
+                               reinterpret_cast<const Affine<FqI>*>(table), w.vals2, w.off, w.segoff, w.seg2bucket, nb,
+                               reinterpret_cast<XYZZ<FqI>*>(partial), (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_accumulate");
     }
     {
