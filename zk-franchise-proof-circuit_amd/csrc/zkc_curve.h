@@ -9,31 +9,34 @@
 
 namespace zkc {
 
-struct Fq2 {
-    Fq c0, c1;
-    ZKC_HD static Fq2 zero() { return {Fq::zero(), Fq::zero()}; }
-    ZKC_HD static Fq2 one() { return {Fq::one(), Fq::zero()}; }
+template <class B>
+struct Fq2T {                       // B[u]/(u^2 + 1)
+    B c0, c1;
+    ZKC_HD static Fq2T zero() { return {B::zero(), B::zero()}; }
+    ZKC_HD static Fq2T one() { return {B::one(), B::zero()}; }
     ZKC_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
-    ZKC_HD bool operator==(const Fq2& b) const { return c0 == b.c0 && c1 == b.c1; }
-    ZKC_HD bool operator!=(const Fq2& b) const { return !(*this == b); }
+    ZKC_HD bool operator==(const Fq2T& b) const { return c0 == b.c0 && c1 == b.c1; }
+    ZKC_HD bool operator!=(const Fq2T& b) const { return !(*this == b); }
 };
-ZKC_HD Fq2 operator+(const Fq2& a, const Fq2& b) { return {a.c0 + b.c0, a.c1 + b.c1}; }
-ZKC_HD Fq2 operator-(const Fq2& a, const Fq2& b) { return {a.c0 - b.c0, a.c1 - b.c1}; }
-ZKC_HD Fq2 operator*(const Fq2& a, const Fq2& b) {      // Karatsuba: 3 Fq multiplications
-    Fq t0 = a.c0 * b.c0, t1 = a.c1 * b.c1;
-    Fq t2 = (a.c0 + a.c1) * (b.c0 + b.c1);
+template <class B> ZKC_HD Fq2T<B> operator+(const Fq2T<B>& a, const Fq2T<B>& b) { return {a.c0 + b.c0, a.c1 + b.c1}; }
+template <class B> ZKC_HD Fq2T<B> operator-(const Fq2T<B>& a, const Fq2T<B>& b) { return {a.c0 - b.c0, a.c1 - b.c1}; }
+template <class B> ZKC_HD Fq2T<B> operator*(const Fq2T<B>& a, const Fq2T<B>& b) {      // Karatsuba: 3 base-field multiplications
+    B t0 = a.c0 * b.c0, t1 = a.c1 * b.c1;
+    B t2 = (a.c0 + a.c1) * (b.c0 + b.c1);
     return {t0 - t1, t2 - t0 - t1};
 }
-ZKC_HD Fq2 fp_sqr(const Fq2& a) {                        // (c0+c1)(c0-c1), 2 c0 c1
-    Fq t = a.c0 * a.c1;
+template <class B> ZKC_HD Fq2T<B> fp_sqr(const Fq2T<B>& a) {                        // (c0+c1)(c0-c1), 2 c0 c1
+    B t = a.c0 * a.c1;
     return {(a.c0 + a.c1) * (a.c0 - a.c1), t + t};
 }
-ZKC_HD Fq2 fp_dbl(const Fq2& a) { return {a.c0 + a.c0, a.c1 + a.c1}; }
-ZKC_HD Fq2 fp_neg(const Fq2& a) { return {fp_neg(a.c0), fp_neg(a.c1)}; }
-ZKC_HD Fq2 fp_inv(const Fq2& a) {
-    Fq n = fp_inv(a.c0 * a.c0 + a.c1 * a.c1);
+template <class B> ZKC_HD Fq2T<B> fp_dbl(const Fq2T<B>& a) { return {a.c0 + a.c0, a.c1 + a.c1}; }
+template <class B> ZKC_HD Fq2T<B> fp_neg(const Fq2T<B>& a) { return {fp_neg(a.c0), fp_neg(a.c1)}; }
+template <class B> ZKC_HD Fq2T<B> fp_inv(const Fq2T<B>& a) {
+    B n = fp_inv(a.c0 * a.c0 + a.c1 * a.c1);
     return {a.c0 * n, fp_neg(a.c1 * n)};
 }
+using Fq2 = Fq2T<Fq>;
+using Fq2I = Fq2T<FqI>;             // layout-identical; inlined base-field products (G2 bucket accumulation)
 
 template <class F>
 struct Affine {

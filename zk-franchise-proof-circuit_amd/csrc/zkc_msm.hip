@@ -35,10 +35,11 @@ template <class PP> struct PointIO<Fp<PP>> {
         return r;
     }
 };
-template <> struct PointIO<Fq2> {
+template <class BB> struct PointIO<Fq2T<BB>> {
+    typedef Fq2T<BB> Fq2; typedef BB Fq;
     static __device__ __forceinline__ Affine<Fq2> load(const Affine<Fq2>* p) {
         const Affine<Fq>* q = reinterpret_cast<const Affine<Fq>*>(p);
-        Affine<Fq> lo = PointIO<zkc::Fq>::load(q), hi = PointIO<zkc::Fq>::load(q + 1);
+        Affine<Fq> lo = PointIO<Fq>::load(q), hi = PointIO<Fq>::load(q + 1);
         return {{lo.x, lo.y}, {hi.x, hi.y}};        // memory order x.c0, x.c1, y.c0, y.c1
     }
 };
@@ -359,8 +360,9 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     {
         zkc_prof_scope _ps(ctx, kG2 ? ZKC_PROF_MSM_ACC_G2 : ZKC_PROF_MSM_ACC_G1, alg_bytes, st);
         if constexpr (kG2)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate<F>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st, table, w.vals2, w.off,
-                               w.segoff, w.seg2bucket, nb, partial, (uint32_t)w.max_segments);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate<Fq2I>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
+                               reinterpret_cast<const Affine<Fq2I>*>(table), w.vals2, w.off, w.segoff, w.seg2bucket, nb,
+                               reinterpret_cast<XYZZ<Fq2I>*>(partial), (uint32_t)w.max_segments);
         else      // G1: same layout, field type with the inlined product
             hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate<FqI>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
                                reinterpret_cast<const Affine<FqI>*>(table), w.vals2, w.off, w.segoff, w.seg2bucket, nb,
