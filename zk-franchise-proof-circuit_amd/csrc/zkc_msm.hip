@@ -148,7 +148,9 @@ zkc_msm_merge(XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ segoff
     }
 }
 
-// ---- K6 ---- one workgroup per (job, window); lane t owns buckets PER*t .. PER*t+PER-1 (digits PER*t+1 ..), PER = half/256
+// ---- K6 ---- one workgroup per (job, window); lane t owns buckets PER*t .. PER*t+PER-1 (digits PER*t+1 ..), PER = half/blockDim.
+// 13-bit windows (4096 buckets) run with 256 lanes x 16 buckets, 10-bit windows (512 buckets) with one wave x 8 buckets: the
+// scan and the tree cost log2(lanes) additions per lane whatever the window holds, so small windows get fewer lanes.
 template <class F>
 __global__ void __launch_bounds__(256)
 zkc_msm_window(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ segoff, const uint32_t* __restrict__ segcnt,
@@ -156,7 +158,7 @@ zkc_msm_window(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__
     extern __shared__ uint4 lds4[];
     XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds4);
     const MsmWindow win = windows[blockIdx.x];
-    const int per = (int)(win.half >> 8);                                 // 16 (c = 13) or 2 (c = 10)
+    const int nt = (int)blockDim.x, per = (int)win.half / nt;
     const uint32_t first = win.bucket0 + threadIdx.x * per;
     // run = sum of the lane's buckets from the top; loc = sum_k k * B_k (k = 1..per)
     XYZZ<F> run = XYZZ<F>::inf(), loc = XYZZ<F>::inf();
@@ -168,11 +170,11 @@ zkc_msm_window(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__
     }
     // suffix sums R_t = sum_{t' >= t} S_t' across lanes (Hillis-Steele in LDS)
     sh[threadIdx.x] = run; __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
+    for (int o = 1; o < nt; o <<= 1) {
         XYZZ<F> v = XYZZ<F>::inf();
-        if ((int)threadIdx.x + o < 256) v = sh[threadIdx.x + o];
+        if ((int)threadIdx.x + o < nt) v = sh[threadIdx.x + o];
         __syncthreads();
-        if ((int)threadIdx.x + o < 256) sh[threadIdx.x] = xyzz_add(sh[threadIdx.x], v);
+        if ((int)threadIdx.x + o < nt) sh[threadIdx.x] = xyzz_add(sh[threadIdx.x], v);
         __syncthreads();
     }
     // sum_d d B_d = sum_t loc_t + per * sum_{t>=1} R_t
@@ -181,11 +183,11 @@ zkc_msm_window(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__
     y = xyzz_add(y, loc);
     __syncthreads();
     sh[threadIdx.x] = y; __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
+    for (int st = nt / 2; st > 0; st >>= 1) {
         if ((int)threadIdx.x < st) sh[threadIdx.x] = xyzz_add(sh[threadIdx.x], sh[threadIdx.x + st]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) wres[blockIdx.x] = sh[0];
+    if (threadIdx.x == 0) wres[win.out] = sh[0];
 }
 template <class F>
 __global__ void __launch_bounds__(64)
@@ -319,14 +321,18 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     const uint32_t nb = jl.total_buckets;
     if (total > w.max_entries || nb > w.max_buckets) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: too many entries for the work space");
     constexpr bool kG2 = sizeof(F) == sizeof(Fq2);
-    uint64_t alg_bytes = 0; uint32_t maxcount = 0;
+    uint64_t alg_bytes = 0; uint32_t maxcount = 0, n_small = 0;
     for (int j = 0; j < nj; j++) { alg_bytes += (uint64_t)jl.job[j].count * (sizeof(Affine<F>) + 32); maxcount = std::max(maxcount, jl.job[j].count); }
     {
         zkc_prof_scope _ps(ctx, ZKC_PROF_MSM_SORT, 0, st);
-        static thread_local std::vector<MsmWindow> wins;
-        wins.clear();
-        for (int j = 0; j < nj; j++) for (uint32_t wdw = 0; wdw < jl.job[j].nw; wdw++)
-            wins.push_back(MsmWindow{jl.job[j].boff + wdw * (uint32_t)msm_half((int)jl.job[j].c), (uint32_t)msm_half((int)jl.job[j].c), (uint32_t)j});
+        static thread_local std::vector<MsmWindow> wins;      // small (10-bit) windows first, then the 13-bit ones
+        wins.clear(); n_small = 0;
+        for (int big = 0; big < 2; big++) for (int j = 0; j < nj; j++) {
+            if ((jl.job[j].c == (uint32_t)MSM_C_BIG) != (big == 1)) continue;
+            for (uint32_t wdw = 0; wdw < jl.job[j].nw; wdw++)
+                wins.push_back(MsmWindow{jl.job[j].boff + wdw * (uint32_t)msm_half((int)jl.job[j].c), (uint32_t)msm_half((int)jl.job[j].c), jl.job[j].win_off + wdw});
+            if (!big) n_small += jl.job[j].nw;
+        }
         ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.d_jobs, &jl, sizeof(MsmJobList), hipMemcpyHostToDevice, st));   // pageable source: staged before return
         ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.d_windows, wins.data(), wins.size() * sizeof(MsmWindow), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(zkc_msm_digits, dim3((maxcount + 255) / 256, nj), dim3(256), 0, st, (const MsmJobList*)w.d_jobs, w.keys, w.vals);
@@ -374,8 +380,11 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
         hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_merge<F>), dim3(1024), dim3(64), 0, st, partial, w.segoff, w.segcnt, w.heavy, w.heavy + MSM_MAX_HEAVY,
                            (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_merge");
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_window<F>), dim3(jl.total_windows), dim3(256), 256 * sizeof(XYZZ<F>), st, partial, w.segoff, w.segcnt,
-                           (const MsmWindow*)w.d_windows, wres, (uint32_t)w.max_segments);
+        if (n_small) hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_window<F>), dim3(n_small), dim3(64), 64 * sizeof(XYZZ<F>), st, partial, w.segoff, w.segcnt,
+                                        (const MsmWindow*)w.d_windows, wres, (uint32_t)w.max_segments);
+        if (jl.total_windows > n_small)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_window<F>), dim3(jl.total_windows - n_small), dim3(256), 256 * sizeof(XYZZ<F>), st, partial, w.segoff,
+                               w.segcnt, (const MsmWindow*)w.d_windows + n_small, wres, (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_window");
         hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_final<F>), dim3((nj + 63) / 64), dim3(64), 0, st, wres, (const MsmJobList*)w.d_jobs, results);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_final");

@@ -45,7 +45,7 @@ struct MsmJobList {
     }
     void clear() { njobs = 0; total_buckets = total_entries = total_windows = 0; }
 };
-struct MsmWindow { uint32_t bucket0, half, job; };   // one workgroup of zkc_msm_window
+struct MsmWindow { uint32_t bucket0, half, out; };   // one workgroup of zkc_msm_window: buckets [bucket0, bucket0+half) -> wres[out]
 
 // Work space of one pipeline pass (sized for MSM_MAX_JOBS jobs and max_entries (scalar, window) pairs)
 struct MsmWork {
