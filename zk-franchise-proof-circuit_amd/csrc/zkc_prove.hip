@@ -67,7 +67,7 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     void* ptrs[] = {zk->d_rowptr, zk->d_col, zk->d_val, zk->d_tw_fwd, zk->d_tw_inv, zk->d_coset, zk->d_g1, zk->d_g2, zk->d_abc, zk->d_t, zk->d_prod, zk->d_p, zk->d_flags,
                     zk->d_tblDelta1, zk->d_tblAlpha1, zk->d_tblBeta1, zk->d_tblDelta2, zk->d_rs, zk->d_proofs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    for (auto& kv : zk->fold.vmaps) if (kv.second.first) (void)hipFree(kv.second.first);
+    for (auto& kv : zk->fold.vmaps) if (kv.second.d) (void)hipFree(kv.second.d);
     if (zk->h_flags) (void)hipHostFree(zk->h_flags);
     for (int i = 0; i < 2; i++) { if (zk->ev_msm[i]) (void)hipEventDestroy(zk->ev_msm[i]); if (zk->ev_msm2[i]) (void)hipEventDestroy(zk->ev_msm2[i]); if (zk->ev_fin[i]) (void)hipEventDestroy(zk->ev_fin[i]); }
     if (zk->ev_start) (void)hipEventDestroy(zk->ev_start);
@@ -104,6 +104,11 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
     zk->delta1 = rd_g1(h + 468); zk->delta2 = rd_g2(h + 532);
     for (uint32_t i = 0; i <= np; i++) zk->ic.push_back(rd_g1(sec[3] + 64ull * i));
     zk->nCoeffs = rd32(sec[4]);
+    {   // wires whose A / B / C polynomial is zero have the point at infinity as base: they never enter an MSM
+        auto zero64 = [](const uint8_t* q) { for (int i = 0; i < 64; i++) if (q[i]) return false; return true; };
+        zk->fold.infA.resize(nv); zk->fold.infB.resize(nv); zk->fold.infC.assign(nv, 0);
+        for (uint32_t i = 0; i < nv; i++) { zk->fold.infA[i] = zero64(sec[5] + 64ull * i); zk->fold.infB[i] = zero64(sec[6] + 64ull * i); if (i > np) zk->fold.infC[i] = zero64(sec[8] + 64ull * (i - np - 1)); }
+    }
     if (ssz[4] != 4 + 44ull * zk->nCoeffs) { delete zk; return zkc_fail(ctx, ZKC_ERR_FORMAT, "zkey: coefficient section size"); }
     // a key whose shape is ZkFranchiseProofCircuit(nLevels) can use the voter-independent witness template
     if (np == 8 && !getenv("ZKC_NO_FOLD")) for (int nl = 3; nl <= 252; nl++) if ((uint32_t)WitnessLayout::make(nl).nWires == nv) { zk->nLevels = nl; break; }
@@ -234,10 +239,11 @@ static int fold_prepare(zkc_zkey* zk) {
     f.ready = true;
     return ZKC_OK;
 }
-// device list of the wires that stay in the MSMs when levels >= Dc (census) / >= Ds (sik) and the n2bOld blocks are folded
-static int fold_vmap(zkc_zkey* zk, int Dc, int Ds, uint32_t** d_map, uint32_t* count) {
+// device lists of the wires that stay in the MSMs of each section when levels >= Dc (census) / >= Ds (sik) and the n2bOld
+// blocks are folded into constants; wires whose base is the point at infinity are dropped per section
+static int fold_vmap(zkc_zkey* zk, int Dc, int Ds, zkc_zkey::Fold::VMap* out) {
     auto it = zk->fold.vmaps.find({Dc, Ds});
-    if (it != zk->fold.vmaps.end()) { *d_map = it->second.first; *count = it->second.second; return ZKC_OK; }
+    if (it != zk->fold.vmaps.end()) { *out = it->second; return ZKC_OK; }
     zkc_ctx* ctx = zk->ctx; const WitnessLayout L = WitnessLayout::make(zk->nLevels); const int n = L.n;
     std::vector<uint8_t> folded(L.nWires, 0);
     for (int tree = 0; tree < 2; tree++) {
@@ -245,13 +251,14 @@ static int fold_vmap(zkc_zkey* zk, int Dc, int Ds, uint32_t** d_map, uint32_t* c
         for (int g = D; g < n - 1; g++) for (int w = rg[g].first; w < rg[g].second; w++) folded[w] = 1;
         for (int w = rg[n - 1].first; w < rg[n - 1].second; w++) folded[w] = 1;
     }
-    std::vector<uint32_t> v; for (int w = 0; w < L.nWires; w++) if (!folded[w]) v.push_back((uint32_t)w);
-    uint32_t* d = nullptr;
-    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&d, v.size() * 4));
-    ZKC_HIP_CHECK(ctx, hipMemcpyAsync(d, v.data(), v.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<uint32_t> v; zkc_zkey::Fold::VMap m;
+    m.offA = 0; for (int w = 0; w < L.nWires; w++) if (!folded[w] && !zk->fold.infA[w]) v.push_back((uint32_t)w); m.nA = (uint32_t)v.size();
+    m.offB = (uint32_t)v.size(); for (int w = 0; w < L.nWires; w++) if (!folded[w] && !zk->fold.infB[w]) v.push_back((uint32_t)w); m.nB = (uint32_t)v.size() - m.offB;
+    m.offC = (uint32_t)v.size(); for (int w = (int)zk->nPub + 1; w < L.nWires; w++) if (!folded[w] && !zk->fold.infC[w]) v.push_back((uint32_t)w); m.nC = (uint32_t)v.size() - m.offC;
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&m.d, v.size() * 4 + 4));
+    ZKC_HIP_CHECK(ctx, hipMemcpyAsync(m.d, v.data(), v.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    zk->fold.vmaps[{Dc, Ds}] = {d, (uint32_t)v.size()};
-    *d_map = d; *count = (uint32_t)v.size();
+    zk->fold.vmaps[{Dc, Ds}] = m; *out = m;
     return ZKC_OK;
 }
 
@@ -356,21 +363,26 @@ extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nW
             int D = 0; for (int g = 0; g < L.n - 1; g++) if (f[g]) D = g + 1;
             if (t == 0) Dc = std::max(Dc, D); else Ds = std::max(Ds, D);
         }
-        uint32_t* vmap = nullptr; uint32_t nV = nv;
-        if (fold && (rc = fold_vmap(zk, Dc, Ds, &vmap, &nV))) return rc;
+        zkc_zkey::Fold::VMap vm;
+        if (fold && (rc = fold_vmap(zk, Dc, Ds, &vm))) return rc;
         if (pass >= 2) { ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, zk->ev_fin[slot], 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st2, zk->ev_fin[slot], 0)); }   // result slot still read by finalize(pass-2)?
         if ((rc = h_evals_dev(zk, w0, nb))) return rc;
         static thread_local MsmJobList j1, j2;     // 6 KB each: kept off the stack frame of a C-ABI entry point
         j1.clear(); j2.clear();
         for (int q = 0; q < nb; q++) {
             const uint32_t* w = w0 + (size_t)q * nv * 8;
-            j1.add(w, vmap, nV, zk->offA, nv, 0, MSM_C_SMALL);
-            j1.add(w, vmap, nV, zk->offB1, nv, 0, MSM_C_SMALL);
-            // wires 0..nPub are never folded, so they are the first nPub+1 map entries: section C skips them
-            if (fold) j1.add(w, vmap + (np + 1), nV - (np + 1), zk->offC, nc, (int32_t)np + 1, MSM_C_SMALL);
-            else j1.add(w + 8ull * (np + 1), nullptr, nc, zk->offC, nc, 0, MSM_C_SMALL);
+            if (fold) {
+                j1.add(w, vm.d + vm.offA, vm.nA, zk->offA, nv, 0, MSM_C_SMALL);
+                j1.add(w, vm.d + vm.offB, vm.nB, zk->offB1, nv, 0, MSM_C_SMALL);
+                j1.add(w, vm.d + vm.offC, vm.nC, zk->offC, nc, (int32_t)np + 1, MSM_C_SMALL);
+                j2.add(w, vm.d + vm.offB, vm.nB, 0, nv, 0, MSM_C_SMALL);
+            } else {
+                j1.add(w, nullptr, nv, zk->offA, nv, 0, MSM_C_SMALL);
+                j1.add(w, nullptr, nv, zk->offB1, nv, 0, MSM_C_SMALL);
+                j1.add(w + 8ull * (np + 1), nullptr, nc, zk->offC, nc, 0, MSM_C_SMALL);
+                j2.add(w, nullptr, nv, 0, nv, 0, MSM_C_SMALL);
+            }
             j1.add(zk->d_p + 8 * (size_t)n * q, nullptr, n, zk->offH, n, 0, MSM_C_BIG);
-            j2.add(w, vmap, nV, 0, nv, 0, MSM_C_SMALL);
         }
         if ((rc = msm_pass_g2(zk, j2, slot, false, st2))) return rc;          // B2 needs only the witness: runs beside buildABC/NTT/G1
         ZKC_HIP_CHECK(ctx, hipEventRecord(zk->ev_msm2[slot], st2));

@@ -88,7 +88,9 @@ struct zkc_zkey {
     struct Fold {
         std::vector<zkc::G1XYZZ> baseA, baseB1, baseC; std::vector<zkc::G2XYZZ> baseB2;        // [1]
         std::vector<zkc::G1XYZZ> sufA[2], sufB1[2], sufC[2]; std::vector<zkc::G2XYZZ> sufB2[2];   // [tree][D] = sum over levels >= D
-        std::map<std::pair<int, int>, std::pair<uint32_t*, uint32_t>> vmaps;                    // (Dc, Ds) -> device wire list, count
+        struct VMap { uint32_t* d = nullptr; uint32_t offA = 0, nA = 0, offB = 0, nB = 0, offC = 0, nC = 0; };   // three lists in one allocation
+        std::map<std::pair<int, int>, VMap> vmaps;                                              // (Dc, Ds) -> surviving wires per section
+        std::vector<uint8_t> infA, infB, infC;                                                  // base point is the point at infinity (zero polynomial)
         bool ready = false;
     } fold;
 };
