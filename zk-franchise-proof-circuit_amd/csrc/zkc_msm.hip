@@ -99,8 +99,8 @@ zkc_msm_seg2bucket(const uint32_t* __restrict__ segoff, uint32_t nbuckets, uint3
 }
 
 // ---- K5 ----
-template <class F>
-__global__ void __launch_bounds__(128, 2)
+template <class F, int MINW>
+__global__ void __launch_bounds__(128, MINW)
 zkc_msm_accumulate(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ off,
                    const uint32_t* __restrict__ segoff, const uint32_t* __restrict__ seg2bucket, uint32_t nbuckets,
                    XYZZ<F>* __restrict__ partial, uint32_t max_segments) {
@@ -366,11 +366,11 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     {
         zkc_prof_scope _ps(ctx, kG2 ? ZKC_PROF_MSM_ACC_G2 : ZKC_PROF_MSM_ACC_G1, alg_bytes, st);
         if constexpr (kG2)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate<Fq2I>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate<Fq2I, 1>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
                                reinterpret_cast<const Affine<Fq2I>*>(table), w.vals2, w.off, w.segoff, w.seg2bucket, nb,
                                reinterpret_cast<XYZZ<Fq2I>*>(partial), (uint32_t)w.max_segments);
         else      // G1: same layout, field type with the inlined product
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate<FqI>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate<FqI, 2>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
                                reinterpret_cast<const Affine<FqI>*>(table), w.vals2, w.off, w.segoff, w.seg2bucket, nb,
                                reinterpret_cast<XYZZ<FqI>*>(partial), (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_accumulate");
