@@ -27,33 +27,39 @@ __device__ __forceinline__ void st_fr(Fr* p, const Fr& r) {
 // K3a is split in two so that every lane has the same amount of multiplier work regardless of row length (rows of the
 // zkCensus R1CS hold between 1 and ~120 coefficients): zkc_matvec_mul forms one product per coefficient, zkc_matvec_rows
 // adds each row's products (additions only).
+// All four are batched over the proofs of a pass: blockIdx.y = proof.
 extern "C" __global__ void __launch_bounds__(256)
-zkc_matvec_mul(const uint32_t* __restrict__ col, const Fr* __restrict__ val, const Fr* __restrict__ wtns_std, Fr* __restrict__ prod, uint32_t ncoef) {
+zkc_matvec_mul(const uint32_t* __restrict__ col, const Fr* __restrict__ val, const Fr* __restrict__ wtns_std, size_t wtns_stride,
+               Fr* __restrict__ prod, uint32_t ncoef) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < ncoef) st_fr(prod + k, ld_fr(val + k) * ld_fr(wtns_std + col[k]));
+    if (k < ncoef) st_fr(prod + (size_t)blockIdx.y * ncoef + k, ld_fr(val + k) * ld_fr(wtns_std + (size_t)blockIdx.y * wtns_stride + col[k]));
 }
 extern "C" __global__ void __launch_bounds__(256)
-zkc_matvec_rows(const uint32_t* __restrict__ rowptr, const Fr* __restrict__ prod, Fr* __restrict__ out, int nrows) {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrows) return;
+zkc_matvec_rows(const uint32_t* __restrict__ rowptr, const Fr* __restrict__ prod, uint32_t ncoef, Fr* __restrict__ abc, int n) {
+    // rows [0,n) = A, [n,2n) = B of proof blockIdx.y; abc layout [proof][3][n]
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= 2 * n) return;
+    const Fr* __restrict__ p = prod + (size_t)blockIdx.y * ncoef;
     Fr acc = Fr::zero();
-    for (uint32_t k = rowptr[r], e = rowptr[r + 1]; k < e; k++) acc = acc + ld_fr(prod + k);
-    st_fr(out + r, acc);
+    for (uint32_t k = rowptr[r], e = rowptr[r + 1]; k < e; k++) acc = acc + ld_fr(p + k);
+    st_fr(abc + (size_t)blockIdx.y * 3 * n + r, acc);
 }
 // c = a * b
 extern "C" __global__ void __launch_bounds__(256)
-zkc_pointwise_mul(const Fr* __restrict__ a, const Fr* __restrict__ b, Fr* __restrict__ c, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) st_fr(c + i, ld_fr(a + i) * ld_fr(b + i));
+zkc_pointwise_mul(Fr* __restrict__ abc, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    Fr* a = abc + (size_t)blockIdx.y * 3 * n;
+    if (i < n) st_fr(a + 2 * (size_t)n + i, ld_fr(a + i) * ld_fr(a + n + i));
 }
 // joinABC: p = a*b - c, written in STANDARD form (the H-MSM reads scalar digits from it)
 extern "C" __global__ void __launch_bounds__(256)
-zkc_join_abc(const Fr* __restrict__ a, const Fr* __restrict__ b, const Fr* __restrict__ c, uint32_t* __restrict__ p_std, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+zkc_join_abc(const Fr* __restrict__ abc, uint32_t* __restrict__ p_std, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fr r = ld_fr(a + i) * ld_fr(b + i) - ld_fr(c + i);
+    const Fr* a = abc + (size_t)blockIdx.y * 3 * n;
+    Fr r = ld_fr(a + i) * ld_fr(a + n + i) - ld_fr(a + 2 * (size_t)n + i);
     uint32_t s[8]; fp_to_std<FrParams>(s, r);
-    uint4* d = reinterpret_cast<uint4*>(p_std + 8 * (size_t)i);
+    uint4* d = reinterpret_cast<uint4*>(p_std + 8 * ((size_t)blockIdx.y * n + i));
     d[0] = make_uint4(s[0], s[1], s[2], s[3]); d[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
 

@@ -13,10 +13,10 @@
 
 using namespace zkc;
 
-extern "C" __global__ void zkc_matvec_mul(const uint32_t*, const Fr*, const Fr*, Fr*, uint32_t);
-extern "C" __global__ void zkc_matvec_rows(const uint32_t*, const Fr*, Fr*, int);
-extern "C" __global__ void zkc_pointwise_mul(const Fr*, const Fr*, Fr*, int);
-extern "C" __global__ void zkc_join_abc(const Fr*, const Fr*, const Fr*, uint32_t*, int);
+extern "C" __global__ void zkc_matvec_mul(const uint32_t*, const Fr*, const Fr*, size_t, Fr*, uint32_t);
+extern "C" __global__ void zkc_matvec_rows(const uint32_t*, const Fr*, uint32_t, Fr*, int);
+extern "C" __global__ void zkc_pointwise_mul(Fr*, int);
+extern "C" __global__ void zkc_join_abc(const Fr*, uint32_t*, int);
 
 namespace {
 uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
@@ -168,7 +168,7 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
     zk->max_inflight = e_inf ? std::max(1, std::min(atoi(e_inf), MSM_MAX_JOBS / 4)) : 32;
     const size_t per_proof_entries = (size_t)NWS * 3 * nv + (size_t)NWB * n;
     const size_t per_proof_buckets = 3 * (size_t)msm_nb(MSM_C_SMALL) + msm_nb(MSM_C_BIG);
-    if ((rc = dmalloc(ctx, &zk->d_abc, 3 * (size_t)n * zk->max_inflight)) || (rc = dmalloc(ctx, &zk->d_t, 3 * (size_t)n * zk->max_inflight)) || (rc = dmalloc(ctx, &zk->d_prod, (size_t)zk->nCoeffs + 1)) ||
+    if ((rc = dmalloc(ctx, &zk->d_abc, 3 * (size_t)n * zk->max_inflight)) || (rc = dmalloc(ctx, &zk->d_t, 3 * (size_t)n * zk->max_inflight)) || (rc = dmalloc(ctx, &zk->d_prod, (size_t)zk->nCoeffs * zk->max_inflight + 1)) ||
         (rc = dmalloc(ctx, &zk->d_p, 8 * (size_t)n * zk->max_inflight))) return bail(rc);
     if ((rc = msm_work_alloc(ctx, zk->w1, per_proof_entries * zk->max_inflight, per_proof_buckets * zk->max_inflight, 4 * zk->max_inflight, false))) return bail(rc);
     if ((rc = msm_work_alloc(ctx, zk->w2, (size_t)NWS * nv * zk->max_inflight, (size_t)msm_nb(MSM_C_SMALL) * zk->max_inflight, zk->max_inflight, true))) return bail(rc);
@@ -267,22 +267,16 @@ static int h_evals_dev(zkc_zkey* zk, const uint32_t* d_wtns0, int nb) {
     zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n, nv = zk->nVars; hipStream_t st = ctx->stream;
     {
         zkc_prof_scope _ps(ctx, ZKC_PROF_MATVEC, (uint64_t)nb * ((uint64_t)zk->nCoeffs * 68 + 3ull * n * 32));
-        for (int q = 0; q < nb; q++) {
-            Fr *a = zk->d_abc + 3 * (size_t)n * q, *b = a + n, *c = a + 2 * (size_t)n;
-            hipLaunchKernelGGL(zkc_matvec_mul, dim3((zk->nCoeffs + 255) / 256), dim3(256), 0, st, zk->d_col, zk->d_val,
-                               (const Fr*)(d_wtns0 + (size_t)q * nv * 8), zk->d_prod, zk->nCoeffs);
-            hipLaunchKernelGGL(zkc_matvec_rows, dim3((2 * n + 255) / 256), dim3(256), 0, st, zk->d_rowptr, zk->d_prod, a, (int)(2 * n));
-            hipLaunchKernelGGL(zkc_pointwise_mul, dim3((n + 255) / 256), dim3(256), 0, st, a, b, c, (int)n);
-        }
+        hipLaunchKernelGGL(zkc_matvec_mul, dim3((zk->nCoeffs + 255) / 256, nb), dim3(256), 0, st, zk->d_col, zk->d_val, (const Fr*)d_wtns0, (size_t)nv,
+                           zk->d_prod, zk->nCoeffs);
+        hipLaunchKernelGGL(zkc_matvec_rows, dim3((2 * n + 255) / 256, nb), dim3(256), 0, st, zk->d_rowptr, zk->d_prod, zk->nCoeffs, zk->d_abc, (int)n);
+        hipLaunchKernelGGL(zkc_pointwise_mul, dim3((n + 255) / 256, nb), dim3(256), 0, st, zk->d_abc, (int)n);
         ZKC_HIP_CHECK(ctx, hipGetLastError());
     }
     zkc_prof_scope _pn(ctx, ZKC_PROF_NTT, (uint64_t)nb * (6ull * 2 * n * 32 + 4ull * n * 32));   // 6 transforms r+w, joinABC
     int rc = ntt_run(ctx, zk->d_abc, zk->d_t, zk->d_tw_inv, zk->d_coset, (int)zk->logn, 3 * nb); if (rc) return rc;
     rc = ntt_run(ctx, zk->d_t, zk->d_abc, zk->d_tw_fwd, nullptr, (int)zk->logn, 3 * nb); if (rc) return rc;
-    for (int q = 0; q < nb; q++) {
-        Fr *a = zk->d_abc + 3 * (size_t)n * q, *b = a + n, *c = a + 2 * (size_t)n;
-        hipLaunchKernelGGL(zkc_join_abc, dim3((n + 255) / 256), dim3(256), 0, st, a, b, c, zk->d_p + 8 * (size_t)n * q, (int)n);
-    }
+    hipLaunchKernelGGL(zkc_join_abc, dim3((n + 255) / 256, nb), dim3(256), 0, st, zk->d_abc, zk->d_p, (int)n);
     ZKC_HIP_CHECK(ctx, hipGetLastError());
     return ZKC_OK;
 }
@@ -292,9 +286,9 @@ extern "C" int zkc_debug_stage(zkc_zkey* zk, const void* d_wtns, int stage, void
     zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n;
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (stage == 0) {
-        hipLaunchKernelGGL(zkc_matvec_mul, dim3((zk->nCoeffs + 255) / 256), dim3(256), 0, ctx->stream, zk->d_col, zk->d_val, (const Fr*)d_wtns, zk->d_prod, zk->nCoeffs);
-        hipLaunchKernelGGL(zkc_matvec_rows, dim3((2 * n + 255) / 256), dim3(256), 0, ctx->stream, zk->d_rowptr, zk->d_prod, zk->d_abc, (int)(2 * n));
-        hipLaunchKernelGGL(zkc_pointwise_mul, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, zk->d_abc, zk->d_abc + n, zk->d_abc + 2 * (size_t)n, (int)n);
+        hipLaunchKernelGGL(zkc_matvec_mul, dim3((zk->nCoeffs + 255) / 256, 1), dim3(256), 0, ctx->stream, zk->d_col, zk->d_val, (const Fr*)d_wtns, (size_t)zk->nVars, zk->d_prod, zk->nCoeffs);
+        hipLaunchKernelGGL(zkc_matvec_rows, dim3((2 * n + 255) / 256, 1), dim3(256), 0, ctx->stream, zk->d_rowptr, zk->d_prod, zk->nCoeffs, zk->d_abc, (int)n);
+        hipLaunchKernelGGL(zkc_pointwise_mul, dim3((n + 255) / 256, 1), dim3(256), 0, ctx->stream, zk->d_abc, (int)n);
         ZKC_HIP_CHECK(ctx, hipGetLastError());
         ZKC_HIP_CHECK(ctx, hipMemcpyAsync(host_out, zk->d_abc, 96ull * n, hipMemcpyDeviceToHost, ctx->stream));
     } else {
