@@ -189,14 +189,16 @@ zkc_msm_window(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__
     }
     if (threadIdx.x == 0) wres[win.out] = sh[0];
 }
+// one wave per job: lane w holds window w's result, shuffle tree over the (at most 26) windows
 template <class F>
 __global__ void __launch_bounds__(64)
 zkc_msm_final(const XYZZ<F>* __restrict__ wres, const MsmJobList* __restrict__ jl, XYZZ<F>* __restrict__ results) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= jl->njobs) return;
+    const int j = blockIdx.x;
+    const uint32_t nw = jl->job[j].nw, w0 = jl->job[j].win_off;
     XYZZ<F> acc = XYZZ<F>::inf();
-    for (uint32_t w = 0; w < jl->job[j].nw; w++) acc = xyzz_add(acc, wres[jl->job[j].win_off + w]);
-    results[j] = acc;
+    if (threadIdx.x < nw) acc = wres[w0 + threadIdx.x];
+    for (int d = 16; d > 0; d >>= 1) acc = xyzz_add(acc, shfl_down_xyzz(acc, d));      // nw <= 32
+    if (threadIdx.x == 0) results[j] = acc;
 }
 
 // ---- one-time base table: table[w][i] = 2^c * table[w-1][i] ----
@@ -386,7 +388,7 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
             hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_window<F>), dim3(jl.total_windows - n_small), dim3(256), 256 * sizeof(XYZZ<F>), st, partial, w.segoff,
                                w.segcnt, (const MsmWindow*)w.d_windows + n_small, wres, (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_window");
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_final<F>), dim3((nj + 63) / 64), dim3(64), 0, st, wres, (const MsmJobList*)w.d_jobs, results);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_final<F>), dim3(nj), dim3(64), 0, st, wres, (const MsmJobList*)w.d_jobs, results);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_final");
     }
     if (to_host) ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.h_results, results, (size_t)nj * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
