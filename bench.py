@@ -13,7 +13,8 @@ import argparse, ctypes, json, os, sys, time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (6.3 TB/s achievable)
-CATS = {0: 'witness', 1: 'buildABC_matvec', 2: 'ntt_joinABC', 3: 'msm_digits_sort', 4: 'msm_accumulate_g1', 5: 'msm_accumulate_g2', 6: 'msm_reduce'}
+CATS = {0: 'witness', 1: 'buildABC_matvec', 2: 'ntt_joinABC', 3: 'msm_digits_sort', 4: 'msm_accumulate_g1', 5: 'msm_accumulate_g2', 6: 'msm_reduce',
+        7: 'msm_g1_streamed'}
 
 
 def main():
@@ -111,7 +112,9 @@ def main():
     roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBPS, 6), 'traffic': traffic, 'traffic_source': traffic_src,
                 'avg_launch_ms': round(d['ms'] / max(1, d['launches']), 4), 'alg_bytes_per_launch': d['alg_bytes'] // max(1, d['launches']),
-                'note': 'MSM bucket accumulation is integer-ALU bound (about 10 Fq products per 96 B streamed), not HBM bound; see DESIGN.md'}
+                'streamed_pair_bytes_per_launch': prof['msm_g1_streamed']['alg_bytes'] // max(1, d['launches']),
+                'note': 'achieved = algorithmic bytes (whole A,B1,C,H sections, SURVEY.md 8d) / kernel time; constant folding streams only streamed_pair_bytes. '
+                        'The kernel is bound by the 32-bit integer multiplier (about 10 Fq products = 1620 v_mad_u64_u32 per 96 B), not by HBM; see DESIGN.md'}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -142,7 +145,7 @@ def main():
                                    'own test zkey seed 0x5A4B43454E535553, synthetic %d-voter census' % (args.nlevels, B, B * world),
                        'batch_per_gpu': B, 'nVars': pk.n_vars, 'domainSize': pk.domain_size, 'parallelism': 'independent proofs per GPU, RCCL all_gather of 512 B/proof'},
             'roofline': roofline, 'cpu_baseline': cpu,
-            'stage_ms_per_proof': {k: round(v['ms'] / (args.steps * B), 4) for k, v in prof.items()},
+            'stage_ms_per_proof': {k: round(v['ms'] / (args.steps * B), 4) for k, v in prof.items() if k != 'msm_g1_streamed'},
         }
         print(json.dumps(line))
     if world > 1:

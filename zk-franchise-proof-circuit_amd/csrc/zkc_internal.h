@@ -13,7 +13,7 @@
 
 // Per-kernel-category HIP-event timing on the context's own stream (bench.py's roofline figure reads it).
 enum { ZKC_PROF_WITNESS = 0, ZKC_PROF_MATVEC = 1, ZKC_PROF_NTT = 2, ZKC_PROF_MSM_SORT = 3, ZKC_PROF_MSM_ACC_G1 = 4, ZKC_PROF_MSM_ACC_G2 = 5,
-       ZKC_PROF_MSM_REDUCE = 6, ZKC_PROF_NCAT = 8 };
+       ZKC_PROF_MSM_REDUCE = 6, ZKC_PROF_MSM_G1_STREAMED = 7 /* bytes only: pairs left after constant folding */, ZKC_PROF_NCAT = 8 };
 struct zkc_prof {
     uint32_t mask = 0;
     struct Rec { hipEvent_t a, b; int cat; };

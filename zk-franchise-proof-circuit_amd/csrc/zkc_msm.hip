@@ -324,7 +324,12 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     if (total > w.max_entries || nb > w.max_buckets) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: too many entries for the work space");
     constexpr bool kG2 = sizeof(F) == sizeof(Fq2);
     uint64_t alg_bytes = 0; uint32_t maxcount = 0, n_small = 0;
-    for (int j = 0; j < nj; j++) { alg_bytes += (uint64_t)jl.job[j].count * (sizeof(Affine<F>) + 32); maxcount = std::max(maxcount, jl.job[j].count); }
+    uint64_t streamed_bytes = 0;
+    for (int j = 0; j < nj; j++) {
+        alg_bytes += (uint64_t)jl.job[j].tbl_count * (sizeof(Affine<F>) + 32);     // the whole section, folded or not
+        streamed_bytes += (uint64_t)jl.job[j].count * (sizeof(Affine<F>) + 32);     // (scalar, base) pairs that actually enter the MSM
+        maxcount = std::max(maxcount, jl.job[j].count);
+    }
     {
         zkc_prof_scope _ps(ctx, ZKC_PROF_MSM_SORT, 0, st);
         static thread_local std::vector<MsmWindow> wins;      // small (10-bit) windows first, then the 13-bit ones
@@ -367,6 +372,7 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     const size_t seg_bound = std::min<size_t>(w.max_segments, total / MSM_SEG + nb);     // launch bound on the number of segments
     {
         zkc_prof_scope _ps(ctx, kG2 ? ZKC_PROF_MSM_ACC_G2 : ZKC_PROF_MSM_ACC_G1, alg_bytes, st);
+        if (!kG2 && ((ctx->prof.mask >> ZKC_PROF_MSM_ACC_G1) & 1)) ctx->prof.bytes[ZKC_PROF_MSM_G1_STREAMED] += streamed_bytes;
         if constexpr (kG2)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate<Fq2I, 1>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
                                reinterpret_cast<const Affine<Fq2I>*>(table), w.vals2, w.off, w.segoff, w.seg2bucket, nb,
