@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Single-proof latency (BASELINE configs[1]): inputs_example.json verbatim through the C ABI, per stage, on one MI355X."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch, numpy as np
+import zkcensus_amd
+from zkcensus_amd import setup
+
+def main():
+    ex = json.load(open(os.path.join(ROOT, 'tests/golden/ref/inputs_example.json')))
+    _, zp, _ = setup.ensure_test_artifacts(160)
+    t0 = time.perf_counter(); ctx = zkcensus_amd.Context(0); pk = zkcensus_amd.ProvingKey(ctx, open(zp, 'rb').read()); t_load = time.perf_counter() - t0
+    flat = zkcensus_amd.flatten_inputs(ex)
+    d_in = torch.from_numpy(np.frombuffer(flat, dtype=np.uint8).copy()).cuda()
+    nW = ctx.n_wires(160)
+    d_w = torch.empty(nW * 32, dtype=torch.uint8, device='cuda'); d_s = torch.zeros(1, dtype=torch.int32, device='cuda')
+    res = {}
+    for it in range(4):
+        t0 = time.perf_counter()
+        ws, st = ctx.witness([flat])                       # host buffers in and out (2.6 MB witness over PCIe)
+        t1 = time.perf_counter()
+        pk.prove(ws[0], 11 + it, 17 + it)                  # host witness in, 256-byte proof out
+        t2 = time.perf_counter()
+        ctx.witness_dev(d_in.data_ptr(), 1, d_w.data_ptr(), d_s.data_ptr()); pk.prove_dev(d_w.data_ptr(), 11 + it, 17 + it)   # device-resident path
+        t3 = time.perf_counter()
+        res = {'witness_host_ms': round((t1 - t0) * 1e3, 2), 'prove_host_ms': round((t2 - t1) * 1e3, 2), 'fullprove_device_resident_ms': round((t3 - t2) * 1e3, 2), 'status': st[0]}
+    res['key_load_and_precompute_s'] = round(t_load, 2)
+    print(json.dumps(res))
+
+if __name__ == '__main__':
+    main()

@@ -400,7 +400,7 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     if (to_host) ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.h_results, results, (size_t)nj * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
     return ZKC_OK;
 }
-int msm_pass_g1(zkc_zkey* zk, const MsmJobList& jl, int slot, bool to_host, hipStream_t st) { return msm_pass<Fq>(zk, zk->w1, zk->d_g1, jl, slot, to_host, st); }
-int msm_pass_g2(zkc_zkey* zk, const MsmJobList& jl, int slot, bool to_host, hipStream_t st) { return msm_pass<Fq2>(zk, zk->w2, zk->d_g2, jl, slot, to_host, st); }
+int msm_pass_g1(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st) { return msm_pass<Fq>(zk, w, zk->d_g1, jl, slot, to_host, st); }
+int msm_pass_g2(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st) { return msm_pass<Fq2>(zk, w, zk->d_g2, jl, slot, to_host, st); }
 
 }  // namespace zkc

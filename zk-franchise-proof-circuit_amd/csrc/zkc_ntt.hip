@@ -114,7 +114,7 @@ zkc_ntt_pass(const Fr* __restrict__ src_all, Fr* __restrict__ dst_all, const Fr*
 }
 
 // Full transform of `nvec` contiguous vectors src -> dst (src must differ from dst: the first pass scatters by bit reversal).
-int ntt_run(zkc_ctx* ctx, const Fr* src, Fr* dst, const Fr* tw, const Fr* scale, int logn, int nvec) {
+int ntt_run(zkc_ctx* ctx, hipStream_t st, const Fr* src, Fr* dst, const Fr* tw, const Fr* scale, int logn, int nvec) {
     int s0 = 0; bool first = true;
     while (s0 < logn) {
         int b = logn - s0 < 9 ? logn - s0 : 9;
@@ -123,7 +123,7 @@ int ntt_run(zkc_ctx* ctx, const Fr* src, Fr* dst, const Fr* tw, const Fr* scale,
         const int lo_t = (NTT_TILE >> b) < (1 << s0) ? (NTT_TILE >> b) : (1 << s0);
         const int nblocks = (1 << logn) / ((1 << b) * lo_t);
         const bool last = s0 + b == logn;
-        hipLaunchKernelGGL(zkc_ntt_pass, dim3(nblocks, nvec), dim3(256), (size_t)(1 << b) * lo_t * sizeof(Fr), ctx->stream,
+        hipLaunchKernelGGL(zkc_ntt_pass, dim3(nblocks, nvec), dim3(256), (size_t)(1 << b) * lo_t * sizeof(Fr), st,
                            first ? src : dst, dst, tw, last ? scale : nullptr, logn, s0, b, first ? 1 : 0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, std::string("zkc_ntt_pass: ") + hipGetErrorString(e));

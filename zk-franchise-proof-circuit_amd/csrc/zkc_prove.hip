@@ -64,14 +64,18 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     if (!zk) return;
     (void)hipSetDevice(zk->ctx->device);
     (void)hipStreamSynchronize(zk->ctx->stream);
-    void* ptrs[] = {zk->d_rowptr, zk->d_col, zk->d_val, zk->d_tw_fwd, zk->d_tw_inv, zk->d_coset, zk->d_g1, zk->d_g2, zk->d_abc, zk->d_t, zk->d_prod, zk->d_p, zk->d_flags,
+    void* ptrs[] = {zk->d_rowptr, zk->d_col, zk->d_val, zk->d_tw_fwd, zk->d_tw_inv, zk->d_coset, zk->d_g1, zk->d_g2, zk->d_flags,
                     zk->d_tblDelta1, zk->d_tblAlpha1, zk->d_tblBeta1, zk->d_tblDelta2, zk->d_rs, zk->d_proofs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : zk->fold.vmaps) if (kv.second.d) (void)hipFree(kv.second.d);
     if (zk->h_flags) (void)hipHostFree(zk->h_flags);
-    for (int i = 0; i < 2; i++) { if (zk->ev_msm[i]) (void)hipEventDestroy(zk->ev_msm[i]); if (zk->ev_msm2[i]) (void)hipEventDestroy(zk->ev_msm2[i]); if (zk->ev_fin[i]) (void)hipEventDestroy(zk->ev_fin[i]); }
     if (zk->ev_start) (void)hipEventDestroy(zk->ev_start);
-    msm_work_free(zk->w1); msm_work_free(zk->w2);
+    for (auto& L : zk->lane) {
+        for (hipStream_t q : {L.st, L.st2, L.fin}) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+        for (void* q : {(void*)L.d_abc, (void*)L.d_t, (void*)L.d_prod, (void*)L.d_p}) if (q) (void)hipFree(q);
+        for (hipEvent_t e : {L.ev_msm, L.ev_msm2, L.ev_fin}) if (e) (void)hipEventDestroy(e);
+        msm_work_free(L.w1); msm_work_free(L.w2);
+    }
     delete zk;
 }
 
@@ -168,10 +172,19 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
     zk->max_inflight = e_inf ? std::max(1, std::min(atoi(e_inf), MSM_MAX_JOBS / 4)) : 32;
     const size_t per_proof_entries = (size_t)NWS * 3 * nv + (size_t)NWB * n;
     const size_t per_proof_buckets = 3 * (size_t)msm_nb(MSM_C_SMALL) + msm_nb(MSM_C_BIG);
-    if ((rc = dmalloc(ctx, &zk->d_abc, 3 * (size_t)n * zk->max_inflight)) || (rc = dmalloc(ctx, &zk->d_t, 3 * (size_t)n * zk->max_inflight)) || (rc = dmalloc(ctx, &zk->d_prod, (size_t)zk->nCoeffs * zk->max_inflight + 1)) ||
-        (rc = dmalloc(ctx, &zk->d_p, 8 * (size_t)n * zk->max_inflight))) return bail(rc);
-    if ((rc = msm_work_alloc(ctx, zk->w1, per_proof_entries * zk->max_inflight, per_proof_buckets * zk->max_inflight, 4 * zk->max_inflight, false))) return bail(rc);
-    if ((rc = msm_work_alloc(ctx, zk->w2, (size_t)NWS * nv * zk->max_inflight, (size_t)msm_nb(MSM_C_SMALL) * zk->max_inflight, zk->max_inflight, true))) return bail(rc);
+    // ZKC_LANES=2 lets two lanes take alternate passes; measured no gain (the GPU is already saturated), so one lane is the default
+    { const char* e_l = getenv("ZKC_LANES"); zk->nlanes = e_l ? std::max(1, std::min(atoi(e_l), 2)) : 1; }
+    for (int l = 0; l < zk->nlanes; l++) {
+        zkc_lane& L = zk->lane[l];
+        ZKC_HIP_CHECK(ctx, hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking)); ZKC_HIP_CHECK(ctx, hipStreamCreateWithFlags(&L.st2, hipStreamNonBlocking));
+        ZKC_HIP_CHECK(ctx, hipStreamCreateWithFlags(&L.fin, hipStreamNonBlocking));
+        ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&L.ev_msm, hipEventDisableTiming)); ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&L.ev_msm2, hipEventDisableTiming));
+        ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&L.ev_fin, hipEventDisableTiming));
+        if ((rc = dmalloc(ctx, &L.d_abc, 3 * (size_t)n * zk->max_inflight)) || (rc = dmalloc(ctx, &L.d_t, 3 * (size_t)n * zk->max_inflight)) ||
+            (rc = dmalloc(ctx, &L.d_prod, (size_t)zk->nCoeffs * zk->max_inflight + 1)) || (rc = dmalloc(ctx, &L.d_p, 8 * (size_t)n * zk->max_inflight))) return bail(rc);
+        if ((rc = msm_work_alloc(ctx, L.w1, per_proof_entries * zk->max_inflight, per_proof_buckets * zk->max_inflight, 4 * zk->max_inflight, false))) return bail(rc);
+        if ((rc = msm_work_alloc(ctx, L.w2, (size_t)NWS * nv * zk->max_inflight, (size_t)msm_nb(MSM_C_SMALL) * zk->max_inflight, zk->max_inflight, true))) return bail(rc);
+    }
     {   // fixed-base tables for the blinding step (delta1, alpha1, beta1 in G1; delta2 in G2)
         FixedBase<Fq> td(zk->delta1), ta(zk->alpha1), tb(zk->beta1); FixedBase<Fq2> t2(zk->delta2);
         if ((rc = dmalloc(ctx, &zk->d_tblDelta1, td.tab.size())) || (rc = dmalloc(ctx, &zk->d_tblAlpha1, ta.tab.size())) ||
@@ -180,11 +193,6 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
         ZKC_UP(zk->d_tblBeta1, tb.tab.data(), tb.tab.size() * sizeof(G1Affine)); ZKC_UP(zk->d_tblDelta2, t2.tab.data(), t2.tab.size() * sizeof(G2Affine));
     }
     ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&zk->ev_start, hipEventDisableTiming));
-    for (int i = 0; i < 2; i++) {
-        ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&zk->ev_msm[i], hipEventDisableTiming));
-        ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&zk->ev_msm2[i], hipEventDisableTiming));
-        ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&zk->ev_fin[i], hipEventDisableTiming));
-    }
     ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     *out = zk;
     return ZKC_OK;
@@ -263,55 +271,55 @@ static int fold_vmap(zkc_zkey* zk, int Dc, int Ds, zkc_zkey::Fold::VMap* out) {
 }
 
 // stages a2..a4 for `nb` proofs: leaves (A'B' - C') on the odd coset in d_p[q] (standard form), q < nb
-static int h_evals_dev(zkc_zkey* zk, const uint32_t* d_wtns0, int nb) {
-    zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n, nv = zk->nVars; hipStream_t st = ctx->stream;
+static int h_evals_dev(zkc_zkey* zk, zkc_lane& L, const uint32_t* d_wtns0, int nb) {
+    zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n, nv = zk->nVars; hipStream_t st = L.st;
     {
-        zkc_prof_scope _ps(ctx, ZKC_PROF_MATVEC, (uint64_t)nb * ((uint64_t)zk->nCoeffs * 68 + 3ull * n * 32));
+        zkc_prof_scope _ps(ctx, ZKC_PROF_MATVEC, (uint64_t)nb * ((uint64_t)zk->nCoeffs * 68 + 3ull * n * 32), st);
         hipLaunchKernelGGL(zkc_matvec_mul, dim3((zk->nCoeffs + 255) / 256, nb), dim3(256), 0, st, zk->d_col, zk->d_val, (const Fr*)d_wtns0, (size_t)nv,
-                           zk->d_prod, zk->nCoeffs);
-        hipLaunchKernelGGL(zkc_matvec_rows, dim3((2 * n + 255) / 256, nb), dim3(256), 0, st, zk->d_rowptr, zk->d_prod, zk->nCoeffs, zk->d_abc, (int)n);
-        hipLaunchKernelGGL(zkc_pointwise_mul, dim3((n + 255) / 256, nb), dim3(256), 0, st, zk->d_abc, (int)n);
+                           L.d_prod, zk->nCoeffs);
+        hipLaunchKernelGGL(zkc_matvec_rows, dim3((2 * n + 255) / 256, nb), dim3(256), 0, st, zk->d_rowptr, L.d_prod, zk->nCoeffs, L.d_abc, (int)n);
+        hipLaunchKernelGGL(zkc_pointwise_mul, dim3((n + 255) / 256, nb), dim3(256), 0, st, L.d_abc, (int)n);
         ZKC_HIP_CHECK(ctx, hipGetLastError());
     }
-    zkc_prof_scope _pn(ctx, ZKC_PROF_NTT, (uint64_t)nb * (6ull * 2 * n * 32 + 4ull * n * 32));   // 6 transforms r+w, joinABC
-    int rc = ntt_run(ctx, zk->d_abc, zk->d_t, zk->d_tw_inv, zk->d_coset, (int)zk->logn, 3 * nb); if (rc) return rc;
-    rc = ntt_run(ctx, zk->d_t, zk->d_abc, zk->d_tw_fwd, nullptr, (int)zk->logn, 3 * nb); if (rc) return rc;
-    hipLaunchKernelGGL(zkc_join_abc, dim3((n + 255) / 256, nb), dim3(256), 0, st, zk->d_abc, zk->d_p, (int)n);
+    zkc_prof_scope _pn(ctx, ZKC_PROF_NTT, (uint64_t)nb * (6ull * 2 * n * 32 + 4ull * n * 32), st);   // 6 transforms r+w, joinABC
+    int rc = ntt_run(ctx, st, L.d_abc, L.d_t, zk->d_tw_inv, zk->d_coset, (int)zk->logn, 3 * nb); if (rc) return rc;
+    rc = ntt_run(ctx, st, L.d_t, L.d_abc, zk->d_tw_fwd, nullptr, (int)zk->logn, 3 * nb); if (rc) return rc;
+    hipLaunchKernelGGL(zkc_join_abc, dim3((n + 255) / 256, nb), dim3(256), 0, st, L.d_abc, L.d_p, (int)n);
     ZKC_HIP_CHECK(ctx, hipGetLastError());
     return ZKC_OK;
 }
 
 extern "C" int zkc_debug_stage(zkc_zkey* zk, const void* d_wtns, int stage, void* host_out) {
     if (!zk || !d_wtns || !host_out) return ZKC_ERR_BAD_ARG;
-    zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n;
-    ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n; zkc_lane& L0 = zk->lane[0];
+    ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device)); ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (stage == 0) {
-        hipLaunchKernelGGL(zkc_matvec_mul, dim3((zk->nCoeffs + 255) / 256, 1), dim3(256), 0, ctx->stream, zk->d_col, zk->d_val, (const Fr*)d_wtns, (size_t)zk->nVars, zk->d_prod, zk->nCoeffs);
-        hipLaunchKernelGGL(zkc_matvec_rows, dim3((2 * n + 255) / 256, 1), dim3(256), 0, ctx->stream, zk->d_rowptr, zk->d_prod, zk->nCoeffs, zk->d_abc, (int)n);
-        hipLaunchKernelGGL(zkc_pointwise_mul, dim3((n + 255) / 256, 1), dim3(256), 0, ctx->stream, zk->d_abc, (int)n);
+        hipLaunchKernelGGL(zkc_matvec_mul, dim3((zk->nCoeffs + 255) / 256, 1), dim3(256), 0, L0.st, zk->d_col, zk->d_val, (const Fr*)d_wtns, (size_t)zk->nVars, L0.d_prod, zk->nCoeffs);
+        hipLaunchKernelGGL(zkc_matvec_rows, dim3((2 * n + 255) / 256, 1), dim3(256), 0, L0.st, zk->d_rowptr, L0.d_prod, zk->nCoeffs, L0.d_abc, (int)n);
+        hipLaunchKernelGGL(zkc_pointwise_mul, dim3((n + 255) / 256, 1), dim3(256), 0, L0.st, L0.d_abc, (int)n);
         ZKC_HIP_CHECK(ctx, hipGetLastError());
-        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(host_out, zk->d_abc, 96ull * n, hipMemcpyDeviceToHost, ctx->stream));
+        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(host_out, L0.d_abc, 96ull * n, hipMemcpyDeviceToHost, L0.st));
     } else {
-        int rc = h_evals_dev(zk, (const uint32_t*)d_wtns, 1); if (rc) return rc;
-        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(host_out, zk->d_p, 32ull * n, hipMemcpyDeviceToHost, ctx->stream));
+        int rc = h_evals_dev(zk, L0, (const uint32_t*)d_wtns, 1); if (rc) return rc;
+        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(host_out, L0.d_p, 32ull * n, hipMemcpyDeviceToHost, L0.st));
     }
-    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(L0.st));
     return ZKC_OK;
 }
 
 extern "C" int zkc_msm_debug(zkc_zkey* zk, int which, const void* d_scalars, uint32_t count, void* host_out) {
     if (!zk || !d_scalars || !host_out || which < 0 || which > 4) return ZKC_ERR_BAD_ARG;
-    zkc_ctx* ctx = zk->ctx;
-    ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    zkc_ctx* ctx = zk->ctx; zkc_lane& L0 = zk->lane[0];
+    ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device)); ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t full = which == 3 ? zk->nVars - zk->nPub - 1 : which == 4 ? zk->n : zk->nVars;
     if (count != full) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_msm_debug: count must equal the section size");
     static thread_local MsmJobList jl; jl.clear();
     const uint32_t offs[5] = {zk->offA, zk->offB1, 0, zk->offC, zk->offH};
     jl.add((const uint32_t*)d_scalars, nullptr, count, offs[which], full, 0, which == 4 ? MSM_C_BIG : MSM_C_SMALL);
-    int rc = which == 2 ? msm_pass_g2(zk, jl, 0, true, ctx->stream) : msm_pass_g1(zk, jl, 0, true, ctx->stream); if (rc) return rc;
-    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (which == 2) g2_to_std((uint8_t*)host_out, xyzz_to_affine(*(G2XYZZ*)zk->w2.h_results));
-    else g1_to_std((uint8_t*)host_out, xyzz_to_affine(*(G1XYZZ*)zk->w1.h_results));
+    int rc = which == 2 ? msm_pass_g2(zk, L0.w2, jl, 0, true, L0.st) : msm_pass_g1(zk, L0.w1, jl, 0, true, L0.st); if (rc) return rc;
+    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(L0.st));
+    if (which == 2) g2_to_std((uint8_t*)host_out, xyzz_to_affine(*(G2XYZZ*)L0.w2.h_results));
+    else g1_to_std((uint8_t*)host_out, xyzz_to_affine(*(G1XYZZ*)L0.w1.h_results));
     return ZKC_OK;
 }
 
@@ -324,13 +332,13 @@ extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nW
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const uint32_t nv = zk->nVars, np = zk->nPub, nc = nv - np - 1, n = zk->n;
     const bool can_fold = zk->nLevels >= 0;
-    hipStream_t st = ctx->stream, st2 = ctx->stream2, fin = ctx->fin_stream;
+    hipStream_t st0 = ctx->stream;
     WitnessLayout L{}; int rc;
     if (zk->rs_cap < (size_t)B) {
         if (zk->d_rs) { ZKC_HIP_CHECK(ctx, hipFree(zk->d_rs)); ZKC_HIP_CHECK(ctx, hipFree(zk->d_proofs)); zk->d_rs = zk->d_proofs = nullptr; }
         ZKC_HIP_CHECK(ctx, hipMalloc((void**)&zk->d_rs, 64 * (size_t)B)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&zk->d_proofs, 256 * (size_t)B)); zk->rs_cap = B;
     }
-    ZKC_HIP_CHECK(ctx, hipMemcpyAsync(zk->d_rs, rs, 64 * (size_t)B, hipMemcpyHostToDevice, st));
+    ZKC_HIP_CHECK(ctx, hipMemcpyAsync(zk->d_rs, rs, 64 * (size_t)B, hipMemcpyHostToDevice, st0));
     if (can_fold) {       // which levels of every witness differ from the voter-independent template?  one check for the whole batch
         L = WitnessLayout::make(zk->nLevels);
         if ((rc = fold_prepare(zk))) return rc;
@@ -340,15 +348,17 @@ extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nW
             if (zk->d_flags) { ZKC_HIP_CHECK(ctx, hipFree(zk->d_flags)); ZKC_HIP_CHECK(ctx, hipHostFree(zk->h_flags)); zk->d_flags = zk->h_flags = nullptr; }
             ZKC_HIP_CHECK(ctx, hipMalloc((void**)&zk->d_flags, nflags * 4)); ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&zk->h_flags, nflags * 4)); zk->flags_cap = nflags;
         }
-        hipLaunchKernelGGL(zkc_fold_check, dim3(L.n, 2, B), dim3(64), 0, st, L, (const uint32_t*)d_wtns, tmpl, zk->d_flags, B);
+        hipLaunchKernelGGL(zkc_fold_check, dim3(L.n, 2, B), dim3(64), 0, st0, L, (const uint32_t*)d_wtns, tmpl, zk->d_flags, B);
         ZKC_HIP_CHECK(ctx, hipGetLastError());
-        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(zk->h_flags, zk->d_flags, nflags * 4, hipMemcpyDeviceToHost, st));
-        ZKC_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(zk->h_flags, zk->d_flags, nflags * 4, hipMemcpyDeviceToHost, st0));
+        ZKC_HIP_CHECK(ctx, hipStreamSynchronize(st0));
     }
-    ZKC_HIP_CHECK(ctx, hipEventRecord(zk->ev_start, st)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st2, zk->ev_start, 0));   // wtns, rs ready
+    ZKC_HIP_CHECK(ctx, hipEventRecord(zk->ev_start, st0));                      // wtns, rs ready
+    for (int l = 0; l < zk->nlanes; l++) { ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(zk->lane[l].st, zk->ev_start, 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(zk->lane[l].st2, zk->ev_start, 0)); zk->lane[l].used = false; }
     int pass = 0;
     for (int p0 = 0; p0 < B; p0 += zk->max_inflight, pass++) {
-        const int nb = std::min(zk->max_inflight, B - p0), slot = pass & 1;
+        const int nb = std::min(zk->max_inflight, B - p0), slot = 0;
+        zkc_lane& LN = zk->lane[pass % zk->nlanes]; hipStream_t st = LN.st, st2 = LN.st2, fin = LN.fin;
         const uint32_t* w0 = (const uint32_t*)d_wtns + (size_t)p0 * nv * 8;
         int Dc = 0, Ds = 0; bool fold = can_fold;
         for (int q = 0; q < nb && fold; q++) for (int t = 0; t < 2; t++) {
@@ -359,8 +369,9 @@ extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nW
         }
         zkc_zkey::Fold::VMap vm;
         if (fold && (rc = fold_vmap(zk, Dc, Ds, &vm))) return rc;
-        if (pass >= 2) { ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, zk->ev_fin[slot], 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st2, zk->ev_fin[slot], 0)); }   // result slot still read by finalize(pass-2)?
-        if ((rc = h_evals_dev(zk, w0, nb))) return rc;
+        if (LN.used) { ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, LN.ev_fin, 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st2, LN.ev_fin, 0)); }   // lane's result slot still read by its previous blinding?
+        LN.used = true;
+        if ((rc = h_evals_dev(zk, LN, w0, nb))) return rc;
         static thread_local MsmJobList j1, j2;     // 6 KB each: kept off the stack frame of a C-ABI entry point
         j1.clear(); j2.clear();
         for (int q = 0; q < nb; q++) {
@@ -376,17 +387,17 @@ extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nW
                 j1.add(w + 8ull * (np + 1), nullptr, nc, zk->offC, nc, 0, MSM_C_SMALL);
                 j2.add(w, nullptr, nv, 0, nv, 0, MSM_C_SMALL);
             }
-            j1.add(zk->d_p + 8 * (size_t)n * q, nullptr, n, zk->offH, n, 0, MSM_C_BIG);
+            j1.add(LN.d_p + 8 * (size_t)n * q, nullptr, n, zk->offH, n, 0, MSM_C_BIG);
         }
-        if ((rc = msm_pass_g2(zk, j2, slot, false, st2))) return rc;          // B2 needs only the witness: runs beside buildABC/NTT/G1
-        ZKC_HIP_CHECK(ctx, hipEventRecord(zk->ev_msm2[slot], st2));
-        if ((rc = msm_pass_g1(zk, j1, slot, false, st))) return rc;
+        if ((rc = msm_pass_g2(zk, LN.w2, j2, slot, false, st2))) return rc;          // B2 needs only the witness: runs beside buildABC/NTT/G1
+        ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_msm2, st2));
+        if ((rc = msm_pass_g1(zk, LN.w1, j1, slot, false, st))) return rc;
         if (publics) for (int q = 0; q < nb; q++)
             ZKC_HIP_CHECK(ctx, hipMemcpyAsync(publics + 32ull * np * (p0 + q), w0 + (size_t)q * nv * 8 + 8, 32ull * np, hipMemcpyDeviceToHost, st));
-        ZKC_HIP_CHECK(ctx, hipEventRecord(zk->ev_msm[slot], st));
+        ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_msm, st));
         // a7 on the second stream: overlaps the next pass
         FinalizeArgs fa{};
-        fa.r1 = (const G1XYZZ*)zk->w1.results + (size_t)slot * zk->w1.max_jobs; fa.r2 = (const G2XYZZ*)zk->w2.results + (size_t)slot * zk->w2.max_jobs;
+        fa.r1 = (const G1XYZZ*)LN.w1.results; fa.r2 = (const G2XYZZ*)LN.w2.results;
         fa.kA = fa.kB1 = fa.kC = G1XYZZ::inf(); fa.kB2 = G2XYZZ::inf();
         if (fold) {
             const auto& f = zk->fold;
@@ -395,13 +406,12 @@ extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nW
         }
         fa.tblDelta1 = zk->d_tblDelta1; fa.tblAlpha1 = zk->d_tblAlpha1; fa.tblBeta1 = zk->d_tblBeta1; fa.tblDelta2 = zk->d_tblDelta2;
         fa.alpha1 = zk->alpha1; fa.beta2 = zk->beta2; fa.rs = zk->d_rs + 64 * (size_t)p0; fa.out = zk->d_proofs + 256 * (size_t)p0;
-        ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, zk->ev_msm[slot], 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, zk->ev_msm2[slot], 0));
+        ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm, 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm2, 0));
         if ((rc = finalize_launch(ctx, fin, fa, nb))) return rc;
         ZKC_HIP_CHECK(ctx, hipMemcpyAsync(proofs + 256ull * p0, zk->d_proofs + 256 * (size_t)p0, 256ull * nb, hipMemcpyDeviceToHost, fin));
-        ZKC_HIP_CHECK(ctx, hipEventRecord(zk->ev_fin[slot], fin));
+        ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_fin, fin));
     }
-    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(st)); ZKC_HIP_CHECK(ctx, hipStreamSynchronize(st2));
-    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(fin));
+    for (int l = 0; l < zk->nlanes; l++) { ZKC_HIP_CHECK(ctx, hipStreamSynchronize(zk->lane[l].st)); ZKC_HIP_CHECK(ctx, hipStreamSynchronize(zk->lane[l].st2)); ZKC_HIP_CHECK(ctx, hipStreamSynchronize(zk->lane[l].fin)); }
     return ZKC_OK;
 }
 

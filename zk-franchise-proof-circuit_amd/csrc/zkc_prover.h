@@ -63,6 +63,15 @@ struct MsmWork {
 };
 }  // namespace zkc
 
+// One pipeline lane: its own three streams and every per-pass buffer.  Two lanes take alternate passes so that the
+// latency-bound tail of a pass (window reduce, final sums, blinding) overlaps the throughput-bound head of the next one.
+struct zkc_lane {
+    hipStream_t st = nullptr, st2 = nullptr, fin = nullptr;               // buildABC/NTT/G1 MSM ; G2 MSM ; blinding + D2H
+    zkc::Fr *d_abc = nullptr, *d_t = nullptr, *d_prod = nullptr; uint32_t* d_p = nullptr;   // [inflight][3n] x2 (d_t = NTT scratch), [inflight][nCoeffs], [inflight][n x 8]
+    zkc::MsmWork w1, w2;                                                  // G1 and G2 pipelines
+    hipEvent_t ev_msm = nullptr, ev_msm2 = nullptr, ev_fin = nullptr; bool used = false;
+};
+
 struct zkc_zkey {
     zkc_ctx* ctx = nullptr;
     uint32_t nVars = 0, nPub = 0, n = 0, logn = 0, nCoeffs = 0;
@@ -78,12 +87,11 @@ struct zkc_zkey {
     uint32_t offA = 0, offB1 = 0, offC = 0, offH = 0;                       // table offsets inside d_g1 (points)
     // per-proof work buffers
     int max_inflight = 0;                                                   // proofs per pipeline pass
-    zkc::Fr *d_abc = nullptr, *d_t = nullptr, *d_prod = nullptr; uint32_t* d_p = nullptr;   // [inflight][3n] x2 (d_t = NTT scratch), [nCoeffs], [inflight][n x 8]
-    zkc::MsmWork w1, w2;                                                    // G1 and G2 pipelines
+    zkc_lane lane[2]; int nlanes = 2;
     uint32_t *d_flags = nullptr, *h_flags = nullptr; size_t flags_cap = 0;  // fold check: [B][2][n]
     zkc::G1Affine *d_tblDelta1 = nullptr, *d_tblAlpha1 = nullptr, *d_tblBeta1 = nullptr; zkc::G2Affine* d_tblDelta2 = nullptr;
     uint8_t *d_rs = nullptr, *d_proofs = nullptr; size_t rs_cap = 0;        // [B][64], [B][256]
-    hipEvent_t ev_msm[2] = {nullptr, nullptr}, ev_msm2[2] = {nullptr, nullptr}, ev_fin[2] = {nullptr, nullptr}, ev_start = nullptr;
+    hipEvent_t ev_start = nullptr;
     // constant folding of the voter-independent witness part (SURVEY.md hard part 4)
     struct Fold {
         std::vector<zkc::G1XYZZ> baseA, baseB1, baseC; std::vector<zkc::G2XYZZ> baseB2;        // [1]
@@ -96,13 +104,13 @@ struct zkc_zkey {
 };
 
 namespace zkc {
-int ntt_run(zkc_ctx* ctx, const Fr* src, Fr* dst, const Fr* tw, const Fr* scale, int logn, int nvec);
+int ntt_run(zkc_ctx* ctx, hipStream_t st, const Fr* src, Fr* dst, const Fr* tw, const Fr* scale, int logn, int nvec);
 int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, size_t max_buckets, int max_jobs, bool g2);
 void msm_work_free(MsmWork& w);
 // runs all jobs of `jl` through one pipeline pass; results (XYZZ per job) go to device slot `slot` (0/1) of w.results and, when
 // to_host is set, to w.h_results (valid after the caller syncs the stream)
-int msm_pass_g1(zkc_zkey* zk, const MsmJobList& jl, int slot, bool to_host, hipStream_t st);
-int msm_pass_g2(zkc_zkey* zk, const MsmJobList& jl, int slot, bool to_host, hipStream_t st);
+int msm_pass_g1(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st);
+int msm_pass_g2(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st);
 int finalize_launch(zkc_ctx* ctx, hipStream_t st, const FinalizeArgs& a, int nproofs);
 int msm_precompute_g1(zkc_ctx* ctx, uint32_t count, G1Affine* d_table, int c);   // d_table[0..count) = base on entry
 int msm_precompute_g2(zkc_ctx* ctx, uint32_t count, G2Affine* d_table, int c);
