@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string.h>
+#include <vector>
 #include "zkc_prover.h"
 #include <rocprim/rocprim.hpp>
 
@@ -68,7 +69,7 @@ zkc_msm_digits(const MsmJobList* __restrict__ jlp, uint32_t* __restrict__ keys, 
         uint32_t neg = 0;
         if (d > half) { d = (1u << c) - d; neg = 1; carry = 1; } else carry = 0;
         const size_t o = (size_t)job.ent_off + (size_t)w * job.count + i;
-        keys[o] = d ? job.boff + w * half + d - 1 : jl.total_buckets;                 // zero digits sort to the end
+        keys[o] = d ? job.boff + d - 1 : jl.total_buckets;     // pre-shifted bases: digit d of every window shares bucket d; zero digits sort to the end
         vals[o] = (pt + w * job.tbl_count) | (neg << 31);
     }
 }
@@ -148,57 +149,74 @@ zkc_msm_merge(XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ segoff
     }
 }
 
-// ---- K6 ---- one workgroup per (job, window); lane t owns buckets PER*t .. PER*t+PER-1 (digits PER*t+1 ..), PER = half/blockDim.
-// 13-bit windows (4096 buckets) run with 256 lanes x 16 buckets, 10-bit windows (512 buckets) with one wave x 8 buckets: the
-// scan and the tree cost log2(lanes) additions per lane whatever the window holds, so small windows get fewer lanes.
+// ---- K6 ---- one wave per virtual window of MSM_VW = 512 consecutive buckets of a job; lane t owns buckets 8t .. 8t+7.
+// Output per virtual window: W = sum_{j=1..512} j * B_{j} (local weights) and S = sum B_j; zkc_msm_final applies the window's offset.
 template <class F>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 zkc_msm_window(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ segoff, const uint32_t* __restrict__ segcnt,
                const MsmWindow* __restrict__ windows, XYZZ<F>* __restrict__ wres, uint32_t max_segments) {
     extern __shared__ uint4 lds4[];
     XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds4);
     const MsmWindow win = windows[blockIdx.x];
-    const int nt = (int)blockDim.x, per = (int)win.half / nt;
-    const uint32_t first = win.bucket0 + threadIdx.x * per;
-    // run = sum of the lane's buckets from the top; loc = sum_k k * B_k (k = 1..per)
-    XYZZ<F> run = XYZZ<F>::inf(), loc = XYZZ<F>::inf();
-    for (int k = per - 1; k >= 0; k--) {
+    constexpr int PER = MSM_VW / 64;                                      // 8
+    const uint32_t first = win.bucket0 + threadIdx.x * PER;
+    XYZZ<F> run = XYZZ<F>::inf(), loc = XYZZ<F>::inf();                   // run = sum of the lane's buckets from the top; loc = sum_k k * B_k
+    for (int k = PER - 1; k >= 0; k--) {
         uint32_t s0 = segoff[first + k], s1 = s0 + segcnt[first + k];
         if (s1 > max_segments) s1 = max_segments;
         for (uint32_t s = s0; s < s1; s++) run = xyzz_add(run, partial[s]);
         loc = xyzz_add(loc, run);
     }
-    // suffix sums R_t = sum_{t' >= t} S_t' across lanes (Hillis-Steele in LDS)
+    // suffix sums R_t = sum_{t' >= t} S_t' across the 64 lanes (Hillis-Steele in LDS)
     sh[threadIdx.x] = run; __syncthreads();
-    for (int o = 1; o < nt; o <<= 1) {
+    for (int o = 1; o < 64; o <<= 1) {
+        XYZZ<F> v = XYZZ<F>::inf();
+        if ((int)threadIdx.x + o < 64) v = sh[threadIdx.x + o];
+        __syncthreads();
+        if ((int)threadIdx.x + o < 64) sh[threadIdx.x] = xyzz_add(sh[threadIdx.x], v);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) wres[2 * win.out + 1] = sh[0];                   // S = R_0
+    // W = sum_t loc_t + PER * sum_{t>=1} R_t
+    XYZZ<F> y = XYZZ<F>::inf();
+    if (threadIdx.x >= 1) { y = sh[threadIdx.x]; for (int k = PER; k > 1; k >>= 1) y = xyzz_dbl(y); }
+    y = xyzz_add(y, loc);
+    __syncthreads();
+    sh[threadIdx.x] = y; __syncthreads();
+    for (int st = 32; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sh[threadIdx.x] = xyzz_add(sh[threadIdx.x], sh[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) wres[2 * win.out] = sh[0];
+}
+// one workgroup per job: result = sum_k W_k + MSM_VW * sum_k k * S_k over the job's virtual windows k (digit = MSM_VW*k + local index)
+template <class F, int NT>
+__global__ void __launch_bounds__(NT)
+zkc_msm_final(const XYZZ<F>* __restrict__ wres, const MsmJobList* __restrict__ jl, XYZZ<F>* __restrict__ results) {
+    extern __shared__ uint4 lds4[];
+    XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds4);
+    const int j = blockIdx.x; constexpr int nt = NT;                          // NT >= virtual windows of the largest job
+    const uint32_t nvw = (1u << (jl->job[j].c - 1)) / MSM_VW, w0 = jl->job[j].win_off;
+    XYZZ<F> Wk = XYZZ<F>::inf(), Sk = XYZZ<F>::inf();
+    if (threadIdx.x < nvw) { Wk = wres[2 * (w0 + threadIdx.x)]; Sk = wres[2 * (w0 + threadIdx.x) + 1]; }
+    sh[threadIdx.x] = Sk; __syncthreads();
+    for (int o = 1; o < nt; o <<= 1) {                                     // suffix sums of S over k
         XYZZ<F> v = XYZZ<F>::inf();
         if ((int)threadIdx.x + o < nt) v = sh[threadIdx.x + o];
         __syncthreads();
         if ((int)threadIdx.x + o < nt) sh[threadIdx.x] = xyzz_add(sh[threadIdx.x], v);
         __syncthreads();
     }
-    // sum_d d B_d = sum_t loc_t + per * sum_{t>=1} R_t
     XYZZ<F> y = XYZZ<F>::inf();
-    if (threadIdx.x >= 1) { y = sh[threadIdx.x]; for (int k = per; k > 1; k >>= 1) y = xyzz_dbl(y); }   // x per (a power of two)
-    y = xyzz_add(y, loc);
+    if (threadIdx.x >= 1) { y = sh[threadIdx.x]; for (int k = MSM_VW; k > 1; k >>= 1) y = xyzz_dbl(y); }   // sum_{k>=1} R_k = sum_k k S_k, times 512
+    y = xyzz_add(y, Wk);
     __syncthreads();
     sh[threadIdx.x] = y; __syncthreads();
     for (int st = nt / 2; st > 0; st >>= 1) {
         if ((int)threadIdx.x < st) sh[threadIdx.x] = xyzz_add(sh[threadIdx.x], sh[threadIdx.x + st]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) wres[win.out] = sh[0];
-}
-// one wave per job: lane w holds window w's result, shuffle tree over the (at most 26) windows
-template <class F>
-__global__ void __launch_bounds__(64)
-zkc_msm_final(const XYZZ<F>* __restrict__ wres, const MsmJobList* __restrict__ jl, XYZZ<F>* __restrict__ results) {
-    const int j = blockIdx.x;
-    const uint32_t nw = jl->job[j].nw, w0 = jl->job[j].win_off;
-    XYZZ<F> acc = XYZZ<F>::inf();
-    if (threadIdx.x < nw) acc = wres[w0 + threadIdx.x];
-    for (int d = 16; d > 0; d >>= 1) acc = xyzz_add(acc, shfl_down_xyzz(acc, d));      // nw <= 32
-    if (threadIdx.x == 0) results[j] = acc;
+    if (threadIdx.x == 0) results[j] = sh[0];
 }
 
 // ---- one-time base table: table[w][i] = 2^c * table[w-1][i] ----
@@ -292,8 +310,9 @@ int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, size_t max_buck
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.heavy, (MSM_MAX_HEAVY + 1) * 4));
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.d_jobs, sizeof(MsmJobList)));
     ZKC_HIP_CHECK(ctx, hipMalloc(&w.partial, w.max_segments * w.xyzz_size));
-    ZKC_HIP_CHECK(ctx, hipMalloc(&w.wres, (size_t)max_jobs * MSM_NW_MAX * w.xyzz_size));
-    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.d_windows, (size_t)max_jobs * MSM_NW_MAX * sizeof(MsmWindow)));
+    const size_t max_vw = max_buckets / MSM_VW + (size_t)max_jobs;
+    ZKC_HIP_CHECK(ctx, hipMalloc(&w.wres, 2 * max_vw * w.xyzz_size));
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.d_windows, max_vw * sizeof(MsmWindow)));
     ZKC_HIP_CHECK(ctx, hipMalloc(&w.results, 2 * (size_t)max_jobs * w.xyzz_size));
     ZKC_HIP_CHECK(ctx, hipHostMalloc(&w.h_results, (size_t)max_jobs * w.xyzz_size));
     return ZKC_OK;
@@ -323,7 +342,7 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     const uint32_t nb = jl.total_buckets;
     if (total > w.max_entries || nb > w.max_buckets) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: too many entries for the work space");
     constexpr bool kG2 = sizeof(F) == sizeof(Fq2);
-    uint64_t alg_bytes = 0; uint32_t maxcount = 0, n_small = 0;
+    uint64_t alg_bytes = 0; uint32_t maxcount = 0;
     uint64_t streamed_bytes = 0;
     for (int j = 0; j < nj; j++) {
         alg_bytes += (uint64_t)jl.job[j].tbl_count * (sizeof(Affine<F>) + 32);     // the whole section, folded or not
@@ -332,14 +351,10 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     }
     {
         zkc_prof_scope _ps(ctx, ZKC_PROF_MSM_SORT, 0, st);
-        static thread_local std::vector<MsmWindow> wins;      // small (10-bit) windows first, then the 13-bit ones
-        wins.clear(); n_small = 0;
-        for (int big = 0; big < 2; big++) for (int j = 0; j < nj; j++) {
-            if ((jl.job[j].c == (uint32_t)MSM_C_BIG) != (big == 1)) continue;
-            for (uint32_t wdw = 0; wdw < jl.job[j].nw; wdw++)
-                wins.push_back(MsmWindow{jl.job[j].boff + wdw * (uint32_t)msm_half((int)jl.job[j].c), (uint32_t)msm_half((int)jl.job[j].c), jl.job[j].win_off + wdw});
-            if (!big) n_small += jl.job[j].nw;
-        }
+        static thread_local std::vector<MsmWindow> wins;
+        wins.clear();
+        for (int j = 0; j < nj; j++) for (uint32_t k = 0; k < (uint32_t)msm_half((int)jl.job[j].c) / MSM_VW; k++)
+            wins.push_back(MsmWindow{jl.job[j].boff + k * MSM_VW, jl.job[j].win_off + k});
         ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.d_jobs, &jl, sizeof(MsmJobList), hipMemcpyHostToDevice, st));   // pageable source: staged before return
         ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.d_windows, wins.data(), wins.size() * sizeof(MsmWindow), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(zkc_msm_digits, dim3((maxcount + 255) / 256, nj), dim3(256), 0, st, (const MsmJobList*)w.d_jobs, w.keys, w.vals);
@@ -388,14 +403,24 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
         hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_merge<F>), dim3(1024), dim3(64), 0, st, partial, w.segoff, w.segcnt, w.heavy, w.heavy + MSM_MAX_HEAVY,
                            (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_merge");
-        if (n_small) hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_window<F>), dim3(n_small), dim3(64), 64 * sizeof(XYZZ<F>), st, partial, w.segoff, w.segcnt,
-                                        (const MsmWindow*)w.d_windows, wres, (uint32_t)w.max_segments);
-        if (jl.total_windows > n_small)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_window<F>), dim3(jl.total_windows - n_small), dim3(256), 256 * sizeof(XYZZ<F>), st, partial, w.segoff,
-                               w.segcnt, (const MsmWindow*)w.d_windows + n_small, wres, (uint32_t)w.max_segments);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_window<F>), dim3(jl.total_windows), dim3(64), 64 * sizeof(XYZZ<F>), st, partial, w.segoff, w.segcnt,
+                           (const MsmWindow*)w.d_windows, wres, (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_window");
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_final<F>), dim3(nj), dim3(64), 0, st, wres, (const MsmJobList*)w.d_jobs, results);
+        uint32_t max_vw = 64; for (int j = 0; j < nj; j++) max_vw = std::max<uint32_t>(max_vw, (uint32_t)msm_half((int)jl.job[j].c) / MSM_VW);     // 64 or 128 lanes
+        if (max_vw == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_final<F, 64>), dim3(nj), dim3(64), 64 * sizeof(XYZZ<F>), st, wres, (const MsmJobList*)w.d_jobs, results);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_final<F, 128>), dim3(nj), dim3(128), 128 * sizeof(XYZZ<F>), st, wres, (const MsmJobList*)w.d_jobs, results);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_final");
+    }
+    if (g_debug_sync && getenv("ZKC_DEBUG_DUMP")) {
+        ZKC_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        std::vector<uint32_t> hb(64 * 8); uint32_t seg[4] = {0, 0, 0, 0};
+        auto dump = [&](const char* name, const void* dptr) {
+            (void)hipMemcpy(hb.data(), dptr, sizeof(XYZZ<F>), hipMemcpyDeviceToHost);
+            fprintf(stderr, "[zkc] %-10s", name); for (unsigned i = 0; i < 8; i++) fprintf(stderr, " %08x", hb[i]); fprintf(stderr, "\n");
+        };
+        (void)hipMemcpy(seg, w.segoff, 16, hipMemcpyDeviceToHost); fprintf(stderr, "[zkc] segoff %u %u %u %u\n", seg[0], seg[1], seg[2], seg[3]);
+        (void)hipMemcpy(seg, w.segcnt, 16, hipMemcpyDeviceToHost); fprintf(stderr, "[zkc] segcnt %u %u %u %u\n", seg[0], seg[1], seg[2], seg[3]);
+        dump("table0", table); dump("partial0", partial); dump("wres0(W)", wres); dump("wres1(S)", wres + 1); dump("result0", results);
     }
     if (to_host) ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.h_results, results, (size_t)nj * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
     return ZKC_OK;

@@ -171,7 +171,7 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
     const char* e_inf = getenv("ZKC_INFLIGHT");
     zk->max_inflight = e_inf ? std::max(1, std::min(atoi(e_inf), MSM_MAX_JOBS / 4)) : 32;
     const size_t per_proof_entries = (size_t)NWS * 3 * nv + (size_t)NWB * n;
-    const size_t per_proof_buckets = 3 * (size_t)msm_nb(MSM_C_SMALL) + msm_nb(MSM_C_BIG);
+    const size_t per_proof_buckets = 3 * (size_t)msm_half(MSM_C_SMALL) + msm_half(MSM_C_BIG);
     // ZKC_LANES=2 lets two lanes take alternate passes; measured no gain (the GPU is already saturated), so one lane is the default
     { const char* e_l = getenv("ZKC_LANES"); zk->nlanes = e_l ? std::max(1, std::min(atoi(e_l), 2)) : 1; }
     for (int l = 0; l < zk->nlanes; l++) {
@@ -183,7 +183,7 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
         if ((rc = dmalloc(ctx, &L.d_abc, 3 * (size_t)n * zk->max_inflight)) || (rc = dmalloc(ctx, &L.d_t, 3 * (size_t)n * zk->max_inflight)) ||
             (rc = dmalloc(ctx, &L.d_prod, (size_t)zk->nCoeffs * zk->max_inflight + 1)) || (rc = dmalloc(ctx, &L.d_p, 8 * (size_t)n * zk->max_inflight))) return bail(rc);
         if ((rc = msm_work_alloc(ctx, L.w1, per_proof_entries * zk->max_inflight, per_proof_buckets * zk->max_inflight, 4 * zk->max_inflight, false))) return bail(rc);
-        if ((rc = msm_work_alloc(ctx, L.w2, (size_t)NWS * nv * zk->max_inflight, (size_t)msm_nb(MSM_C_SMALL) * zk->max_inflight, zk->max_inflight, true))) return bail(rc);
+        if ((rc = msm_work_alloc(ctx, L.w2, (size_t)NWS * nv * zk->max_inflight, (size_t)msm_half(MSM_C_SMALL) * zk->max_inflight, zk->max_inflight, true))) return bail(rc);
     }
     {   // fixed-base tables for the blinding step (delta1, alpha1, beta1 in G1; delta2 in G2)
         FixedBase<Fq> td(zk->delta1), ta(zk->alpha1), tb(zk->beta1); FixedBase<Fq2> t2(zk->delta2);
@@ -318,6 +318,8 @@ extern "C" int zkc_msm_debug(zkc_zkey* zk, int which, const void* d_scalars, uin
     jl.add((const uint32_t*)d_scalars, nullptr, count, offs[which], full, 0, which == 4 ? MSM_C_BIG : MSM_C_SMALL);
     int rc = which == 2 ? msm_pass_g2(zk, L0.w2, jl, 0, true, L0.st) : msm_pass_g1(zk, L0.w1, jl, 0, true, L0.st); if (rc) return rc;
     ZKC_HIP_CHECK(ctx, hipStreamSynchronize(L0.st));
+    if (getenv("ZKC_DEBUG_DUMP")) { const uint32_t* h = (const uint32_t*)(which == 2 ? L0.w2.h_results : L0.w1.h_results);
+        fprintf(stderr, "[zkc] h_results "); for (int i = 0; i < (which == 2 ? 64 : 32); i++) fprintf(stderr, "%s%08x", i % 8 ? "" : " ", h[i]); fprintf(stderr, "\n"); }
     if (which == 2) g2_to_std((uint8_t*)host_out, xyzz_to_affine(*(G2XYZZ*)L0.w2.h_results));
     else g1_to_std((uint8_t*)host_out, xyzz_to_affine(*(G1XYZZ*)L0.w1.h_results));
     return ZKC_OK;

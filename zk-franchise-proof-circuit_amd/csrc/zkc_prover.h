@@ -4,17 +4,17 @@
 #include "zkc_curve.h"
 
 namespace zkc {
-// Pippenger window bits per section (signed digits -> 2^(c-1) buckets per window).  H (2^17 random scalars) uses 13-bit
-// windows; the witness sections A, B1, C, B2 run over the ~13 k wires left after constant folding, where 10-bit windows
-// minimise additions + bucket reduction.
-constexpr int MSM_C_BIG = 13, MSM_C_SMALL = 10;
-constexpr int msm_nw(int c) { return (254 + c) / c; }          // 13 -> 20 windows (260 bits), 10 -> 26 windows (260 bits)
-constexpr int msm_half(int c) { return 1 << (c - 1); }
-constexpr int msm_nb(int c) { return msm_nw(c) * msm_half(c); } // buckets per job: 81920 / 13312
-constexpr int MSM_NW_MAX = msm_nw(MSM_C_SMALL);
+// Pippenger window bits per section (signed digits).  Because the bases are pre-shifted per window (T[w][i] = 2^(c w) P_i), a
+// digit d of ANY window lands in the same bucket d: a job has 2^(c-1) buckets in total, not per window, so large windows are cheap.
+// H (2^17 random scalars): c = 17 -> 15 additions per scalar into 65536 buckets (about 30 entries each); the witness sections A, B1,
+// C, B2 (8-11 k wires after constant folding): c = 13 -> 20 additions per scalar into 4096 buckets.
+constexpr int MSM_C_BIG = 17, MSM_C_SMALL = 13;
+constexpr int msm_nw(int c) { return (254 + c) / c; }          // 17 -> 15 windows (255 bits), 13 -> 20 windows (260 bits)
+constexpr int msm_half(int c) { return 1 << (c - 1); }         // buckets per job
+constexpr int MSM_VW = 512;                                    // buckets per workgroup of the reduction ("virtual window")
 constexpr int MSM_SEG = 16;                        // sorted entries per accumulation lane (load balance for repeated scalars)
 constexpr int MSM_MERGE_T = 8;                     // buckets with more segments get a wave of their own before the window pass
-constexpr int MSM_MAX_HEAVY = 1 << 16;
+constexpr int MSM_MAX_HEAVY = 1 << 20;
 constexpr int MSM_MAX_JOBS = 128;                  // jobs per pipeline pass (proofs in flight x sections)
 
 // One multi-scalar multiplication inside a pipeline pass: sum_j scalar[j] * P[point(j)]
@@ -26,7 +26,7 @@ struct MsmJob {
     uint32_t tbl_count;        // points per window in that table
     int32_t pt_shift;
     uint32_t c, nw;            // window bits / windows of this job's table
-    uint32_t boff, ent_off, win_off;   // first bucket / first (scalar, window) entry / first window of this job inside the pass
+    uint32_t boff, ent_off, win_off;   // first bucket / first (scalar, window) entry / first virtual window of this job inside the pass
 };
 // arguments of the blinding kernel (zkc_finalize.hip); everything except r1/r2/rs/out is constant per proving key
 struct FinalizeArgs {
@@ -41,11 +41,11 @@ struct MsmJobList {
     void add(const uint32_t* scalars, const uint32_t* vmap, uint32_t count, uint32_t tbl_off, uint32_t tbl_count, int32_t pt_shift, int c) {
         MsmJob& j = job[njobs++];
         j = MsmJob{scalars, vmap, count, tbl_off, tbl_count, pt_shift, (uint32_t)c, (uint32_t)msm_nw(c), total_buckets, total_entries, total_windows};
-        total_buckets += (uint32_t)msm_nb(c); total_entries += count * (uint32_t)msm_nw(c); total_windows += (uint32_t)msm_nw(c);
+        total_buckets += (uint32_t)msm_half(c); total_entries += count * (uint32_t)msm_nw(c); total_windows += (uint32_t)(msm_half(c) / MSM_VW);
     }
     void clear() { njobs = 0; total_buckets = total_entries = total_windows = 0; }
 };
-struct MsmWindow { uint32_t bucket0, half, out; };   // one workgroup of zkc_msm_window: buckets [bucket0, bucket0+half) -> wres[out]
+struct MsmWindow { uint32_t bucket0, out; };   // one wave of zkc_msm_window: buckets [bucket0, bucket0 + MSM_VW) -> wres[2*out] (weighted), wres[2*out+1] (plain sum)
 
 // Work space of one pipeline pass (sized for MSM_MAX_JOBS jobs and max_entries (scalar, window) pairs)
 struct MsmWork {
