@@ -69,11 +69,12 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : zk->fold.vmaps) if (kv.second.d) (void)hipFree(kv.second.d);
     if (zk->h_flags) (void)hipHostFree(zk->h_flags);
+    if (zk->h_out) (void)hipHostFree(zk->h_out);
     if (zk->ev_start) (void)hipEventDestroy(zk->ev_start);
     for (auto& L : zk->lane) {
         for (hipStream_t q : {L.st, L.st2, L.fin}) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
         for (void* q : {(void*)L.d_abc, (void*)L.d_t, (void*)L.d_prod, (void*)L.d_p}) if (q) (void)hipFree(q);
-        for (hipEvent_t e : {L.ev_msm, L.ev_msm2, L.ev_fin}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {L.ev_msm, L.ev_msm2, L.ev_fin[0], L.ev_fin[1]}) if (e) (void)hipEventDestroy(e);
         msm_work_free(L.w1); msm_work_free(L.w2);
     }
     delete zk;
@@ -179,7 +180,7 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
         ZKC_HIP_CHECK(ctx, hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking)); ZKC_HIP_CHECK(ctx, hipStreamCreateWithFlags(&L.st2, hipStreamNonBlocking));
         ZKC_HIP_CHECK(ctx, hipStreamCreateWithFlags(&L.fin, hipStreamNonBlocking));
         ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&L.ev_msm, hipEventDisableTiming)); ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&L.ev_msm2, hipEventDisableTiming));
-        ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&L.ev_fin, hipEventDisableTiming));
+        ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&L.ev_fin[0], hipEventDisableTiming)); ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&L.ev_fin[1], hipEventDisableTiming));
         if ((rc = dmalloc(ctx, &L.d_abc, 3 * (size_t)n * zk->max_inflight)) || (rc = dmalloc(ctx, &L.d_t, 3 * (size_t)n * zk->max_inflight)) ||
             (rc = dmalloc(ctx, &L.d_prod, (size_t)zk->nCoeffs * zk->max_inflight + 1)) || (rc = dmalloc(ctx, &L.d_p, 8 * (size_t)n * zk->max_inflight))) return bail(rc);
         if ((rc = msm_work_alloc(ctx, L.w1, per_proof_entries * zk->max_inflight, per_proof_buckets * zk->max_inflight, 4 * zk->max_inflight, false))) return bail(rc);
@@ -337,9 +338,11 @@ extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nW
     hipStream_t st0 = ctx->stream;
     WitnessLayout L{}; int rc;
     if (zk->rs_cap < (size_t)B) {
-        if (zk->d_rs) { ZKC_HIP_CHECK(ctx, hipFree(zk->d_rs)); ZKC_HIP_CHECK(ctx, hipFree(zk->d_proofs)); zk->d_rs = zk->d_proofs = nullptr; }
-        ZKC_HIP_CHECK(ctx, hipMalloc((void**)&zk->d_rs, 64 * (size_t)B)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&zk->d_proofs, 256 * (size_t)B)); zk->rs_cap = B;
+        if (zk->d_rs) { ZKC_HIP_CHECK(ctx, hipFree(zk->d_rs)); ZKC_HIP_CHECK(ctx, hipFree(zk->d_proofs)); ZKC_HIP_CHECK(ctx, hipHostFree(zk->h_out)); zk->d_rs = zk->d_proofs = zk->h_out = nullptr; }
+        ZKC_HIP_CHECK(ctx, hipMalloc((void**)&zk->d_rs, 64 * (size_t)B)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&zk->d_proofs, 256 * (size_t)B));
+        ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&zk->h_out, (256 + 32 * (size_t)zk->nPub) * B)); zk->rs_cap = B;
     }
+    uint8_t* const h_pub = zk->h_out + 256ull * zk->rs_cap;      // results land in pinned memory so that no copy blocks the enqueueing thread
     ZKC_HIP_CHECK(ctx, hipMemcpyAsync(zk->d_rs, rs, 64 * (size_t)B, hipMemcpyHostToDevice, st0));
     if (can_fold) {       // which levels of every witness differ from the voter-independent template?  one check for the whole batch
         L = WitnessLayout::make(zk->nLevels);
@@ -356,11 +359,12 @@ extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nW
         ZKC_HIP_CHECK(ctx, hipStreamSynchronize(st0));
     }
     ZKC_HIP_CHECK(ctx, hipEventRecord(zk->ev_start, st0));                      // wtns, rs ready
-    for (int l = 0; l < zk->nlanes; l++) { ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(zk->lane[l].st, zk->ev_start, 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(zk->lane[l].st2, zk->ev_start, 0)); zk->lane[l].used = false; }
+    for (int l = 0; l < zk->nlanes; l++) { ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(zk->lane[l].st, zk->ev_start, 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(zk->lane[l].st2, zk->ev_start, 0)); zk->lane[l].npass = 0; }
     int pass = 0;
     for (int p0 = 0; p0 < B; p0 += zk->max_inflight, pass++) {
-        const int nb = std::min(zk->max_inflight, B - p0), slot = 0;
-        zkc_lane& LN = zk->lane[pass % zk->nlanes]; hipStream_t st = LN.st, st2 = LN.st2, fin = LN.fin;
+        const int nb = std::min(zk->max_inflight, B - p0);
+        zkc_lane& LN = zk->lane[pass % zk->nlanes]; const int slot = LN.npass & 1;       // MSM results are double-buffered: the blinding of pass k overlaps pass k+1
+        hipStream_t st = LN.st, st2 = LN.st2, fin = LN.fin;
         const uint32_t* w0 = (const uint32_t*)d_wtns + (size_t)p0 * nv * 8;
         int Dc = 0, Ds = 0; bool fold = can_fold;
         for (int q = 0; q < nb && fold; q++) for (int t = 0; t < 2; t++) {
@@ -371,8 +375,8 @@ extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nW
         }
         zkc_zkey::Fold::VMap vm;
         if (fold && (rc = fold_vmap(zk, Dc, Ds, &vm))) return rc;
-        if (LN.used) { ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, LN.ev_fin, 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st2, LN.ev_fin, 0)); }   // lane's result slot still read by its previous blinding?
-        LN.used = true;
+        if (LN.npass >= 2) { ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, LN.ev_fin[slot], 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st2, LN.ev_fin[slot], 0)); }   // slot still read by the blinding two passes back?
+        LN.npass++;
         if ((rc = h_evals_dev(zk, LN, w0, nb))) return rc;
         static thread_local MsmJobList j1, j2;     // 6 KB each: kept off the stack frame of a C-ABI entry point
         j1.clear(); j2.clear();
@@ -394,12 +398,12 @@ extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nW
         if ((rc = msm_pass_g2(zk, LN.w2, j2, slot, false, st2))) return rc;          // B2 needs only the witness: runs beside buildABC/NTT/G1
         ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_msm2, st2));
         if ((rc = msm_pass_g1(zk, LN.w1, j1, slot, false, st))) return rc;
-        if (publics) for (int q = 0; q < nb; q++)
-            ZKC_HIP_CHECK(ctx, hipMemcpyAsync(publics + 32ull * np * (p0 + q), w0 + (size_t)q * nv * 8 + 8, 32ull * np, hipMemcpyDeviceToHost, st));
+        if (publics)       // wires 1..nPublic of every witness, one strided copy
+            ZKC_HIP_CHECK(ctx, hipMemcpy2DAsync(h_pub + 32ull * np * p0, 32ull * np, w0 + 8, 32ull * nv, 32ull * np, nb, hipMemcpyDeviceToHost, st));
         ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_msm, st));
         // a7 on the second stream: overlaps the next pass
         FinalizeArgs fa{};
-        fa.r1 = (const G1XYZZ*)LN.w1.results; fa.r2 = (const G2XYZZ*)LN.w2.results;
+        fa.r1 = (const G1XYZZ*)LN.w1.results + (size_t)slot * LN.w1.max_jobs; fa.r2 = (const G2XYZZ*)LN.w2.results + (size_t)slot * LN.w2.max_jobs;
         fa.kA = fa.kB1 = fa.kC = G1XYZZ::inf(); fa.kB2 = G2XYZZ::inf();
         if (fold) {
             const auto& f = zk->fold;
@@ -410,10 +414,12 @@ extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nW
         fa.alpha1 = zk->alpha1; fa.beta2 = zk->beta2; fa.rs = zk->d_rs + 64 * (size_t)p0; fa.out = zk->d_proofs + 256 * (size_t)p0;
         ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm, 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm2, 0));
         if ((rc = finalize_launch(ctx, fin, fa, nb))) return rc;
-        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(proofs + 256ull * p0, zk->d_proofs + 256 * (size_t)p0, 256ull * nb, hipMemcpyDeviceToHost, fin));
-        ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_fin, fin));
+        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(zk->h_out + 256ull * p0, zk->d_proofs + 256 * (size_t)p0, 256ull * nb, hipMemcpyDeviceToHost, fin));
+        ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_fin[slot], fin));
     }
     for (int l = 0; l < zk->nlanes; l++) { ZKC_HIP_CHECK(ctx, hipStreamSynchronize(zk->lane[l].st)); ZKC_HIP_CHECK(ctx, hipStreamSynchronize(zk->lane[l].st2)); ZKC_HIP_CHECK(ctx, hipStreamSynchronize(zk->lane[l].fin)); }
+    memcpy(proofs, zk->h_out, 256ull * B);
+    if (publics) memcpy(publics, h_pub, 32ull * np * B);
     return ZKC_OK;
 }
 

@@ -69,7 +69,7 @@ struct zkc_lane {
     hipStream_t st = nullptr, st2 = nullptr, fin = nullptr;               // buildABC/NTT/G1 MSM ; G2 MSM ; blinding + D2H
     zkc::Fr *d_abc = nullptr, *d_t = nullptr, *d_prod = nullptr; uint32_t* d_p = nullptr;   // [inflight][3n] x2 (d_t = NTT scratch), [inflight][nCoeffs], [inflight][n x 8]
     zkc::MsmWork w1, w2;                                                  // G1 and G2 pipelines
-    hipEvent_t ev_msm = nullptr, ev_msm2 = nullptr, ev_fin = nullptr; bool used = false;
+    hipEvent_t ev_msm = nullptr, ev_msm2 = nullptr, ev_fin[2] = {nullptr, nullptr}; int npass = 0;      // ev_fin[slot]: blinding of the pass that used result slot `slot`
 };
 
 struct zkc_zkey {
@@ -91,6 +91,7 @@ struct zkc_zkey {
     uint32_t *d_flags = nullptr, *h_flags = nullptr; size_t flags_cap = 0;  // fold check: [B][2][n]
     zkc::G1Affine *d_tblDelta1 = nullptr, *d_tblAlpha1 = nullptr, *d_tblBeta1 = nullptr; zkc::G2Affine* d_tblDelta2 = nullptr;
     uint8_t *d_rs = nullptr, *d_proofs = nullptr; size_t rs_cap = 0;        // [B][64], [B][256]
+    uint8_t* h_out = nullptr;                                               // pinned: [B][256] proofs then [B][nPub][32] public signals (async D2H target)
     hipEvent_t ev_start = nullptr;
     // constant folding of the voter-independent witness part (SURVEY.md hard part 4)
     struct Fold {
