@@ -21,6 +21,7 @@
 #include <string.h>
 #include <vector>
 #include "zkc_prover.h"
+#include "zkc_f29.h"
 #include <rocprim/rocprim.hpp>
 
 namespace zkc {
@@ -123,6 +124,83 @@ zkc_msm_accumulate(const Affine<F>* __restrict__ table, const uint32_t* __restri
         v = vn; p = pn;
     }
     partial[s] = acc;
+}
+
+// ---- K5, G1: the same segment walk with the accumulator kept in radix 2^29 (zkc_f29.h) ----
+// Magnitudes (multiples of p; products contract by 169 = 2^261 / p): table coordinates enter as 32 x value (< 32 p), the accumulator
+// keeps X, Y < 10.5 p (carried limbs, top limb < 2^25) and ZZ, ZZZ < 4 p.  With D25 < 11.6 p and D24, D24x3 < 6.3 p:
+//   U2 = x2 ZZ, S2 = y2 ZZZ < 1.8 p ; P = U2 - X + D25, R = S2 - Y + D25 < 13.4 p ; PP, RR < 2.1 p ; PPP, Q < 1.2 p
+//   X3 = RR - PPP - 2Q + D24x3 < 8.4 p ; W = Q - X3 + D25 < 12.7 p ; Y3 = R W - Y PPP + D24 < 8.3 p ; ZZ PP, ZZZ PPP < 1.1 p
+struct Acc29 { uint32_t X[9], Y[9], ZZ[9], ZZZ[9]; };
+struct Dom29 {
+    static constexpr L9 D25 = f29_dominator<FqParams>(1u << 29, 1u << 25);
+    static constexpr L9 D24 = f29_dominator<FqParams>(1u << 29, 1u << 24);
+    static constexpr L9 D24x3 = f29_dominator<FqParams>(3u << 29, 1u << 24);
+};
+// acc += (x2, y2).  Returns false and leaves acc alone when the two points share their x coordinate (same_y tells which case)
+__device__ __forceinline__ bool f29_madd(Acc29& acc, const uint32_t x2[9], const uint32_t y2[9], bool& same_y) {
+    typedef FqParams P;
+    uint32_t U2[9], S2[9], Pn[9], Rn[9];
+    f29_mul<P>(U2, x2, acc.ZZ); f29_mul<P>(S2, y2, acc.ZZZ);
+    f29_sub(Pn, U2, acc.X, Dom29::D25); f29_carry(Pn);
+    f29_sub(Rn, S2, acc.Y, Dom29::D25); f29_carry(Rn);
+    if (f29_is_zero_mod_p<P>(Pn)) { same_y = f29_is_zero_mod_p<P>(Rn); return false; }
+    uint32_t PP[9], PPP[9], Q[9], RR[9], W[9], T[9], V[9];
+    f29_sqr<P>(PP, Pn); f29_mul<P>(PPP, Pn, PP); f29_mul<P>(Q, acc.X, PP); f29_sqr<P>(RR, Rn);
+#pragma unroll
+    for (int k = 0; k < 9; k++) acc.X[k] = RR[k] + Dom29::D24x3.l[k] - PPP[k] - 2 * Q[k];
+    f29_carry(acc.X);
+    f29_sub(W, Q, acc.X, Dom29::D25);
+    f29_mul<P>(T, Rn, W); f29_mul<P>(V, acc.Y, PPP);
+    f29_sub(acc.Y, T, V, Dom29::D24); f29_carry(acc.Y);
+    f29_mul<P>(T, acc.ZZ, PP); f29_mul<P>(V, acc.ZZZ, PPP);
+#pragma unroll
+    for (int k = 0; k < 9; k++) { acc.ZZ[k] = T[k]; acc.ZZZ[k] = V[k]; }
+    return true;
+}
+// an 8 x u32 element -> R' form below 1.2 p
+__device__ __forceinline__ void f29_enter(uint32_t r[9], const uint32_t w[8]) {
+    uint32_t t[9]; f29_from_fp_shl5(t, w); f29_mul<FqParams>(r, t, F29K<FqParams>::one.l);
+}
+template <int MINW>
+__global__ void __launch_bounds__(128, MINW)
+zkc_msm_accumulate29(const Affine<Fq>* __restrict__ table, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ off,
+                     const uint32_t* __restrict__ segoff, const uint32_t* __restrict__ seg2bucket, uint32_t nbuckets,
+                     XYZZ<Fq>* __restrict__ partial, uint32_t max_segments) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t nseg = segoff[nbuckets]; if (nseg > max_segments) nseg = max_segments;
+    if (s >= nseg) return;
+    const uint32_t b = seg2bucket[s];
+    const uint32_t start = off[b] + (s - segoff[b]) * MSM_SEG;
+    uint32_t end = start + MSM_SEG; const uint32_t bend = off[b + 1]; if (end > bend) end = bend;
+    Acc29 acc; bool inf = true;
+    uint32_t v = vals[start];
+    Affine<Fq> p = PointIO<Fq>::load(table + (v & 0x7fffffffu));
+    for (uint32_t j = start; j < end; j++) {
+        const uint32_t vn = (j + 1 < end) ? vals[j + 1] : v;
+        Affine<Fq> pn = PointIO<Fq>::load(table + (vn & 0x7fffffffu));      // next gather in flight during this addition
+        if (!p.is_inf()) {
+            if (v >> 31) p.y = fp_neg(p.y);
+            uint32_t x2[9], y2[9];
+            f29_from_fp_shl5(x2, p.x.v); f29_from_fp_shl5(y2, p.y.v);
+            bool same_y = false;
+            if (inf) {
+                f29_mul<FqParams>(acc.X, x2, F29K<FqParams>::one.l); f29_mul<FqParams>(acc.Y, y2, F29K<FqParams>::one.l);
+#pragma unroll
+                for (int k = 0; k < 9; k++) acc.ZZ[k] = acc.ZZZ[k] = F29K<FqParams>::one.l[k];
+                inf = false;
+            } else if (!f29_madd(acc, x2, y2, same_y)) {
+                if (same_y) {                                               // the bucket holds this very point: double it (rare; generic code)
+                    const XYZZ<Fq> d = xyzz_dbl_affine(p);
+                    f29_enter(acc.X, d.X.v); f29_enter(acc.Y, d.Y.v); f29_enter(acc.ZZ, d.ZZ.v); f29_enter(acc.ZZZ, d.ZZZ.v);
+                } else inf = true;                                          // P + (-P)
+            }
+        }
+        v = vn; p = pn;
+    }
+    XYZZ<Fq> out = XYZZ<Fq>::inf();
+    if (!inf) { out.X = f29_to_fp<FqParams>(acc.X); out.Y = f29_to_fp<FqParams>(acc.Y); out.ZZ = f29_to_fp<FqParams>(acc.ZZ); out.ZZZ = f29_to_fp<FqParams>(acc.ZZZ); }
+    partial[s] = out;
 }
 
 // buckets with many segments (the 7-bit top window holds n/97 entries per bucket; repeated witness values) are summed by
@@ -393,9 +471,9 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
                                reinterpret_cast<const Affine<Fq2I>*>(table), w.vals2, w.off, w.segoff, w.seg2bucket, nb,
                                reinterpret_cast<XYZZ<Fq2I>*>(partial), (uint32_t)w.max_segments);
         else      // G1: same layout, field type with the inlined product
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate<FqI, 2>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
-                               reinterpret_cast<const Affine<FqI>*>(table), w.vals2, w.off, w.segoff, w.seg2bucket, nb,
-                               reinterpret_cast<XYZZ<FqI>*>(partial), (uint32_t)w.max_segments);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate29<2>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
+                               reinterpret_cast<const Affine<Fq>*>(table), w.vals2, w.off, w.segoff, w.seg2bucket, nb,
+                               reinterpret_cast<XYZZ<Fq>*>(partial), (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_accumulate");
     }
     {

@@ -15,7 +15,7 @@ constexpr int MSM_VW = 512;                                    // buckets per wo
 constexpr int MSM_SEG = 16;                        // sorted entries per accumulation lane (load balance for repeated scalars)
 constexpr int MSM_MERGE_T = 8;                     // buckets with more segments get a wave of their own before the window pass
 constexpr int MSM_MAX_HEAVY = 1 << 20;
-constexpr int MSM_MAX_JOBS = 128;                  // jobs per pipeline pass (proofs in flight x sections)
+constexpr int MSM_MAX_JOBS = 512;                  // jobs per pipeline pass (proofs in flight x sections)
 
 // One multi-scalar multiplication inside a pipeline pass: sum_j scalar[j] * P[point(j)]
 struct MsmJob {
