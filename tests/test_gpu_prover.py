@@ -82,6 +82,41 @@ def test_each_msm_nl10(env):
         assert got == exp, 'MSM section %d' % which
 
 
+def test_msm_equal_and_opposite_bases_nl10(env):
+    """Wires that share a base point (same polynomial in the key) land in one bucket when their digits agree: the accumulation
+    then has to double a point, or cancel P + (-P), instead of adding.  The radix-2^29 kernel detects both from the carried
+    difference; sections A (G1) and B2 (G2) of the test key hold groups of up to 127 identical points."""
+    ctx, get, torch = env
+    zk, pk, _ = get(10)
+    z = ol.zkey_parse(zk)
+    import ctypes, collections
+    q, qinv = ol.Q, pow(1 << 256, -1, ol.Q)
+    rng = random.Random(11)
+    for which, ptr, psz in ((0, z.pointsA, 64), (1, z.pointsB1, 64), (2, z.pointsB2, 128)):
+        cnt = pk.n_vars
+        raw = ctypes.string_at(ptr, cnt * psz)
+        std = b''.join((int.from_bytes(raw[32 * i:32 * i + 32], 'little') * qinv % q).to_bytes(32, 'little') for i in range(len(raw) // 32))
+        groups = collections.defaultdict(list)
+        for i in range(cnt):
+            pt = raw[psz * i:psz * i + psz]
+            if any(pt): groups[pt].append(i)
+        dup = max(groups.values(), key=len)
+        assert len(dup) >= 3, 'test key lost its duplicated base points'
+        a, b, c = dup[:3]
+        cases = [{a: 3, b: 3}, {a: 3, b: (1 << 13) - 3}, {a: 5, b: 5, c: 5}, {a: 7, b: R - 7}, {a: 1, b: 1, c: R - 1},
+                 {i: 9 for i in dup},                                         # a whole group in one bucket (doubling, then additions of 2P + P ...)
+                 {i: (9 if k % 2 else (1 << 13) - 9) for k, i in enumerate(dup)}]
+        base = [rng.randrange(R) for _ in range(cnt)]
+        cases.append(dict(enumerate(base)) | {i: base[dup[0]] for i in dup})   # random everywhere, the group shares one full-size scalar
+        for vals in cases:
+            sc = [0] * cnt
+            for k, v in vals.items(): sc[k] = v
+            scb = b''.join(x.to_bytes(32, 'little') for x in sc)
+            got = pk.msm_debug(which, dev_bytes(torch, scb).data_ptr(), cnt)
+            exp = ol.msm_g2(std, scb) if which == 2 else ol.msm_g1(std, scb)
+            assert got == exp, 'MSM section %d with equal bases' % which
+
+
 @pytest.mark.parametrize('nl', [10, 160])
 def test_prove_matches_oracle_and_verifies(env, nl):
     ctx, get, torch = env
