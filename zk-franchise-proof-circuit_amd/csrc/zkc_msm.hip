@@ -227,7 +227,7 @@ zkc_msm_merge(XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ segoff
     }
 }
 
-// ---- K6 ---- one wave per virtual window of MSM_VW = 512 consecutive buckets of a job; lane t owns buckets 8t .. 8t+7.
+// ---- K6 ---- one wave per virtual window of MSM_VW = 1024 consecutive buckets of a job; lane t owns buckets 16t .. 16t+15 (512: 1496, 1024: 1548, 2048: 1505 proofs/s).
 // Output per virtual window: W = sum_{j=1..512} j * B_{j} (local weights) and S = sum B_j; zkc_msm_final applies the window's offset.
 template <class F>
 __global__ void __launch_bounds__(64)
@@ -236,7 +236,7 @@ zkc_msm_window(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__
     extern __shared__ uint4 lds4[];
     XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds4);
     const MsmWindow win = windows[blockIdx.x];
-    constexpr int PER = MSM_VW / 64;                                      // 8
+    constexpr int PER = MSM_VW / 64;                                      // 16
     const uint32_t first = win.bucket0 + threadIdx.x * PER;
     XYZZ<F> run = XYZZ<F>::inf(), loc = XYZZ<F>::inf();                   // run = sum of the lane's buckets from the top; loc = sum_k k * B_k
     for (int k = PER - 1; k >= 0; k--) {

@@ -11,7 +11,7 @@ namespace zkc {
 constexpr int MSM_C_BIG = 17, MSM_C_SMALL = 13;
 constexpr int msm_nw(int c) { return (254 + c) / c; }          // 17 -> 15 windows (255 bits), 13 -> 20 windows (260 bits)
 constexpr int msm_half(int c) { return 1 << (c - 1); }         // buckets per job
-constexpr int MSM_VW = 512;                                    // buckets per workgroup of the reduction ("virtual window")
+constexpr int MSM_VW = 1024;                                   // buckets per workgroup of the reduction ("virtual window")
 constexpr int MSM_SEG = 16;                        // sorted entries per accumulation lane (load balance for repeated scalars)
 constexpr int MSM_MERGE_T = 8;                     // buckets with more segments get a wave of their own before the window pass
 constexpr int MSM_MAX_HEAVY = 1 << 20;
