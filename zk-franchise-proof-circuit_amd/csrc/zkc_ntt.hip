@@ -24,25 +24,36 @@ __device__ __forceinline__ void st_fr(Fr* p, const Fr& r) {
 
 // ---- buildABC1: rows [0,n) = A, [n,2n) = B ; out = sum coef * w[signal].  coef is stored as val*R^2 (the .zkey
 // convention) so one Montgomery product with the standard-form witness lands in Montgomery form. ----
-// K3a is split in two so that every lane has the same amount of multiplier work regardless of row length (rows of the
-// zkCensus R1CS hold between 1 and ~120 coefficients): zkc_matvec_mul forms one product per coefficient, zkc_matvec_rows
-// adds each row's products (additions only).
-// All four are batched over the proofs of a pass: blockIdx.y = proof.
+// The matrix is kept in jagged-diagonal order (zkc_zkey_load): rows sorted by length, the k-th coefficients of all rows that have one
+// stored contiguously.  Lane r walks row perm[r]: its loads of (col, val) are coalesced across the wave, neighbouring lanes have rows
+// of (nearly) equal length (the zkCensus R1CS has rows of 1 to ~120 coefficients), and no per-coefficient product is ever written out.
+// Batched over the proofs of a pass: blockIdx.y = proof.
+// The first `nlong` rows (more than MATVEC_LONG coefficients; up to 319 in the zkCensus R1CS) get a wave each: a lane walking such a row
+// alone is a 319-deep chain of dependent gathers and held the whole kernel for 2 ms.
 extern "C" __global__ void __launch_bounds__(256)
-zkc_matvec_mul(const uint32_t* __restrict__ col, const Fr* __restrict__ val, const Fr* __restrict__ wtns_std, size_t wtns_stride,
-               Fr* __restrict__ prod, uint32_t ncoef) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < ncoef) st_fr(prod + (size_t)blockIdx.y * ncoef + k, ld_fr(val + k) * ld_fr(wtns_std + (size_t)blockIdx.y * wtns_stride + col[k]));
-}
-extern "C" __global__ void __launch_bounds__(256)
-zkc_matvec_rows(const uint32_t* __restrict__ rowptr, const Fr* __restrict__ prod, uint32_t ncoef, Fr* __restrict__ abc, int n) {
-    // rows [0,n) = A, [n,2n) = B of proof blockIdx.y; abc layout [proof][3][n]
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= 2 * n) return;
-    const Fr* __restrict__ p = prod + (size_t)blockIdx.y * ncoef;
+zkc_matvec_jds(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ rowlen, const uint32_t* __restrict__ jdptr,
+               const uint32_t* __restrict__ col, const Fr* __restrict__ val, const Fr* __restrict__ wtns_std, size_t wtns_stride,
+               Fr* __restrict__ abc, int n, uint32_t nlong) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;      // rows [0,n) = A, [n,2n) = B ; abc layout [proof][3][n]
+    const Fr* __restrict__ w = wtns_std + (size_t)blockIdx.y * wtns_stride;
     Fr acc = Fr::zero();
-    for (uint32_t k = rowptr[r], e = rowptr[r + 1]; k < e; k++) acc = acc + ld_fr(p + k);
-    st_fr(abc + (size_t)blockIdx.y * 3 * n + r, acc);
+    if ((t >> 6) < nlong) {                         // wave-uniform
+        const uint32_t r = t >> 6, len = rowlen[r];
+        for (uint32_t k = lane; k < len; k += 64) { const uint32_t idx = jdptr[k] + r; acc = acc + ld_fr(val + idx) * ld_fr(w + col[idx]); }
+        for (int d = 32; d > 0; d >>= 1) {
+            Fr o;
+#pragma unroll
+            for (int i = 0; i < 8; i++) o.v[i] = (uint32_t)__shfl_down((int)acc.v[i], d, 64);
+            acc = acc + o;
+        }
+        if (lane == 0) st_fr(abc + (size_t)blockIdx.y * 3 * n + perm[r], acc);
+        return;
+    }
+    const uint32_t r = t - nlong * 63u;             // = nlong + (t - 64 nlong)
+    if (r >= 2u * (uint32_t)n) return;
+    const uint32_t len = rowlen[r];
+    for (uint32_t k = 0; k < len; k++) { const uint32_t idx = jdptr[k] + r; acc = acc + ld_fr(val + idx) * ld_fr(w + col[idx]); }
+    st_fr(abc + (size_t)blockIdx.y * 3 * n + perm[r], acc);
 }
 // c = a * b
 extern "C" __global__ void __launch_bounds__(256)

@@ -13,8 +13,8 @@
 
 using namespace zkc;
 
-extern "C" __global__ void zkc_matvec_mul(const uint32_t*, const Fr*, const Fr*, size_t, Fr*, uint32_t);
-extern "C" __global__ void zkc_matvec_rows(const uint32_t*, const Fr*, uint32_t, Fr*, int);
+extern "C" __global__ void zkc_matvec_jds(const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, const Fr*, const Fr*, size_t, Fr*, int, uint32_t);
+static constexpr uint32_t MATVEC_LONG = 16;      // rows with more coefficients are summed by a whole wave
 extern "C" __global__ void zkc_pointwise_mul(Fr*, int);
 extern "C" __global__ void zkc_join_abc(const Fr*, uint32_t*, int);
 
@@ -64,7 +64,7 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     if (!zk) return;
     (void)hipSetDevice(zk->ctx->device);
     (void)hipStreamSynchronize(zk->ctx->stream);
-    void* ptrs[] = {zk->d_rowptr, zk->d_col, zk->d_val, zk->d_tw_fwd, zk->d_tw_inv, zk->d_coset, zk->d_g1, zk->d_g2, zk->d_flags,
+    void* ptrs[] = {zk->d_perm, zk->d_rowlen, zk->d_jdptr, zk->d_col, zk->d_val, zk->d_tw_fwd, zk->d_tw_inv, zk->d_coset, zk->d_g1, zk->d_g2, zk->d_flags,
                     zk->d_tblDelta1, zk->d_tblAlpha1, zk->d_tblBeta1, zk->d_tblDelta2, zk->d_rs, zk->d_proofs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : zk->fold.vmaps) if (kv.second.d) (void)hipFree(kv.second.d);
@@ -73,7 +73,7 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     if (zk->ev_start) (void)hipEventDestroy(zk->ev_start);
     for (auto& L : zk->lane) {
         for (hipStream_t q : {L.st, L.st2, L.fin}) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
-        for (void* q : {(void*)L.d_abc, (void*)L.d_t, (void*)L.d_prod, (void*)L.d_p}) if (q) (void)hipFree(q);
+        for (void* q : {(void*)L.d_abc, (void*)L.d_t, (void*)L.d_p}) if (q) (void)hipFree(q);
         for (hipEvent_t e : {L.ev_msm, L.ev_msm2, L.ev_fin[0], L.ev_fin[1]}) if (e) (void)hipEventDestroy(e);
         msm_work_free(L.w1); msm_work_free(L.w2);
     }
@@ -138,10 +138,26 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
             uint32_t k = fill[(size_t)m * n + cc]++;
             col[k] = s; memcpy(val[k].v, c + 44ull * i + 12, 32);
         }
-        if ((rc = dmalloc(ctx, &zk->d_rowptr, rowptr.size())) || (rc = dmalloc(ctx, &zk->d_col, col.size() + 1)) || (rc = dmalloc(ctx, &zk->d_val, val.size() + 1))) return bail(rc);
-        ZKC_UP(zk->d_rowptr, rowptr.data(), rowptr.size() * 4);
-        ZKC_UP(zk->d_col, col.data(), col.size() * 4);
-        ZKC_UP(zk->d_val, val.data(), val.size() * sizeof(Fr));
+        // jagged-diagonal order: rows by decreasing length; slot jdptr[k] + r holds the k-th coefficient of the r-th longest row
+        const size_t nrows = 2 * (size_t)n;
+        std::vector<uint32_t> perm(nrows), rowlen(nrows);
+        for (size_t r = 0; r < nrows; r++) perm[r] = (uint32_t)r;
+        std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return rowptr[a + 1] - rowptr[a] > rowptr[b + 1] - rowptr[b]; });
+        for (size_t r = 0; r < nrows; r++) rowlen[r] = rowptr[perm[r] + 1] - rowptr[perm[r]];
+        const uint32_t maxlen = nrows ? rowlen[0] : 0;
+        zk->nlong = 0; while (zk->nlong < nrows && rowlen[zk->nlong] > MATVEC_LONG) zk->nlong++;
+        std::vector<uint32_t> jdptr(maxlen + 1, 0);
+        { size_t live = nrows; for (uint32_t k = 0; k < maxlen; k++) { while (live > 0 && rowlen[live - 1] <= k) live--; jdptr[k + 1] = jdptr[k] + (uint32_t)live; } }
+        std::vector<uint32_t> jcol(zk->nCoeffs); std::vector<Fr> jval(zk->nCoeffs);
+        for (size_t r = 0; r < nrows; r++) for (uint32_t k = 0; k < rowlen[r]; k++) {
+            const size_t dst = (size_t)jdptr[k] + r, src = (size_t)rowptr[perm[r]] + k;
+            jcol[dst] = col[src]; jval[dst] = val[src];
+        }
+        if ((rc = dmalloc(ctx, &zk->d_perm, nrows)) || (rc = dmalloc(ctx, &zk->d_rowlen, nrows)) || (rc = dmalloc(ctx, &zk->d_jdptr, jdptr.size())) ||
+            (rc = dmalloc(ctx, &zk->d_col, jcol.size() + 1)) || (rc = dmalloc(ctx, &zk->d_val, jval.size() + 1))) return bail(rc);
+        ZKC_UP(zk->d_perm, perm.data(), nrows * 4); ZKC_UP(zk->d_rowlen, rowlen.data(), nrows * 4); ZKC_UP(zk->d_jdptr, jdptr.data(), jdptr.size() * 4);
+        ZKC_UP(zk->d_col, jcol.data(), jcol.size() * 4);
+        ZKC_UP(zk->d_val, jval.data(), jval.size() * sizeof(Fr));
     }
     // ---- twiddles and the coset/1-over-n scale ----
     {
@@ -182,7 +198,7 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
         ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&L.ev_msm, hipEventDisableTiming)); ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&L.ev_msm2, hipEventDisableTiming));
         ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&L.ev_fin[0], hipEventDisableTiming)); ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&L.ev_fin[1], hipEventDisableTiming));
         if ((rc = dmalloc(ctx, &L.d_abc, 3 * (size_t)n * zk->max_inflight)) || (rc = dmalloc(ctx, &L.d_t, 3 * (size_t)n * zk->max_inflight)) ||
-            (rc = dmalloc(ctx, &L.d_prod, (size_t)zk->nCoeffs * zk->max_inflight + 1)) || (rc = dmalloc(ctx, &L.d_p, 8 * (size_t)n * zk->max_inflight))) return bail(rc);
+            (rc = dmalloc(ctx, &L.d_p, 8 * (size_t)n * zk->max_inflight))) return bail(rc);
         if ((rc = msm_work_alloc(ctx, L.w1, per_proof_entries * zk->max_inflight, per_proof_buckets * zk->max_inflight, 4 * zk->max_inflight, false))) return bail(rc);
         if ((rc = msm_work_alloc(ctx, L.w2, (size_t)NWS * nv * zk->max_inflight, (size_t)msm_half(MSM_C_SMALL) * zk->max_inflight, zk->max_inflight, true))) return bail(rc);
     }
@@ -276,9 +292,8 @@ static int h_evals_dev(zkc_zkey* zk, zkc_lane& L, const uint32_t* d_wtns0, int n
     zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n, nv = zk->nVars; hipStream_t st = L.st;
     {
         zkc_prof_scope _ps(ctx, ZKC_PROF_MATVEC, (uint64_t)nb * ((uint64_t)zk->nCoeffs * 68 + 3ull * n * 32), st);
-        hipLaunchKernelGGL(zkc_matvec_mul, dim3((zk->nCoeffs + 255) / 256, nb), dim3(256), 0, st, zk->d_col, zk->d_val, (const Fr*)d_wtns0, (size_t)nv,
-                           L.d_prod, zk->nCoeffs);
-        hipLaunchKernelGGL(zkc_matvec_rows, dim3((2 * n + 255) / 256, nb), dim3(256), 0, st, zk->d_rowptr, L.d_prod, zk->nCoeffs, L.d_abc, (int)n);
+        hipLaunchKernelGGL(zkc_matvec_jds, dim3((2 * n + 63 * zk->nlong + 255) / 256, nb), dim3(256), 0, st, zk->d_perm, zk->d_rowlen, zk->d_jdptr, zk->d_col, zk->d_val,
+                           (const Fr*)d_wtns0, (size_t)nv, L.d_abc, (int)n, zk->nlong);
         hipLaunchKernelGGL(zkc_pointwise_mul, dim3((n + 255) / 256, nb), dim3(256), 0, st, L.d_abc, (int)n);
         ZKC_HIP_CHECK(ctx, hipGetLastError());
     }
@@ -295,8 +310,8 @@ extern "C" int zkc_debug_stage(zkc_zkey* zk, const void* d_wtns, int stage, void
     zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n; zkc_lane& L0 = zk->lane[0];
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device)); ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (stage == 0) {
-        hipLaunchKernelGGL(zkc_matvec_mul, dim3((zk->nCoeffs + 255) / 256, 1), dim3(256), 0, L0.st, zk->d_col, zk->d_val, (const Fr*)d_wtns, (size_t)zk->nVars, L0.d_prod, zk->nCoeffs);
-        hipLaunchKernelGGL(zkc_matvec_rows, dim3((2 * n + 255) / 256, 1), dim3(256), 0, L0.st, zk->d_rowptr, L0.d_prod, zk->nCoeffs, L0.d_abc, (int)n);
+        hipLaunchKernelGGL(zkc_matvec_jds, dim3((2 * n + 63 * zk->nlong + 255) / 256, 1), dim3(256), 0, L0.st, zk->d_perm, zk->d_rowlen, zk->d_jdptr, zk->d_col, zk->d_val,
+                           (const Fr*)d_wtns, (size_t)zk->nVars, L0.d_abc, (int)n, zk->nlong);
         hipLaunchKernelGGL(zkc_pointwise_mul, dim3((n + 255) / 256, 1), dim3(256), 0, L0.st, L0.d_abc, (int)n);
         ZKC_HIP_CHECK(ctx, hipGetLastError());
         ZKC_HIP_CHECK(ctx, hipMemcpyAsync(host_out, L0.d_abc, 96ull * n, hipMemcpyDeviceToHost, L0.st));

@@ -67,7 +67,7 @@ struct MsmWork {
 // latency-bound tail of a pass (window reduce, final sums, blinding) overlaps the throughput-bound head of the next one.
 struct zkc_lane {
     hipStream_t st = nullptr, st2 = nullptr, fin = nullptr;               // buildABC/NTT/G1 MSM ; G2 MSM ; blinding + D2H
-    zkc::Fr *d_abc = nullptr, *d_t = nullptr, *d_prod = nullptr; uint32_t* d_p = nullptr;   // [inflight][3n] x2 (d_t = NTT scratch), [inflight][nCoeffs], [inflight][n x 8]
+    zkc::Fr *d_abc = nullptr, *d_t = nullptr; uint32_t* d_p = nullptr;   // [inflight][3n] x2 (d_t = NTT scratch), [inflight][n x 8]
     zkc::MsmWork w1, w2;                                                  // G1 and G2 pipelines
     hipEvent_t ev_msm = nullptr, ev_msm2 = nullptr, ev_fin[2] = {nullptr, nullptr}; int npass = 0;      // ev_fin[slot]: blinding of the pass that used result slot `slot`
 };
@@ -79,8 +79,8 @@ struct zkc_zkey {
     zkc::G1Affine alpha1, beta1, delta1;           // host copies, Montgomery
     zkc::G2Affine beta2, gamma2, delta2;
     std::vector<zkc::G1Affine> ic;
-    // device: CSR of section 4 (rows [0,n) = A, [n,2n) = B), values as stored (val * R^2)
-    uint32_t *d_rowptr = nullptr, *d_col = nullptr; zkc::Fr* d_val = nullptr;
+    // device: section 4 in jagged-diagonal order (rows [0,n) = A, [n,2n) = B, sorted by length), values as stored (val * R^2)
+    uint32_t *d_perm = nullptr, *d_rowlen = nullptr, *d_jdptr = nullptr, *d_col = nullptr; zkc::Fr* d_val = nullptr; uint32_t nlong = 0;
     zkc::Fr *d_tw_fwd = nullptr, *d_tw_inv = nullptr, *d_coset = nullptr;   // w^j, w^-j (j < n/2), g^i / n
     // pre-shifted base tables, one allocation per group: G1 = [A | B1 | C | H], G2 = [B2]; T[w][i] = 2^(c*w) * P_i
     zkc::G1Affine* d_g1 = nullptr; zkc::G2Affine* d_g2 = nullptr;
