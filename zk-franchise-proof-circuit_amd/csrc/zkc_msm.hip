@@ -22,6 +22,7 @@
 #include <vector>
 #include "zkc_prover.h"
 #include "zkc_f29.h"
+#include "zkc_f29_g2.h"
 #include <rocprim/rocprim.hpp>
 
 namespace zkc {
@@ -200,6 +201,82 @@ zkc_msm_accumulate29(const Affine<Fq>* __restrict__ table, const uint32_t* __res
     }
     XYZZ<Fq> out = XYZZ<Fq>::inf();
     if (!inf) { out.X = f29_to_fp<FqParams>(acc.X); out.Y = f29_to_fp<FqParams>(acc.Y); out.ZZ = f29_to_fp<FqParams>(acc.ZZ); out.ZZZ = f29_to_fp<FqParams>(acc.ZZZ); }
+    partial[s] = out;
+}
+
+// ---- K5, G2: radix-2^29 accumulator over Fq2 (zkc_f29_g2.h).  The table is a second copy of the pre-shifted G2 bases in R' form:
+// 60 words per point = x (9 + 9 limbs, word 18 = 1 for the point at infinity, word 19 pad), y, -y, so a signed digit only picks
+// which 80-byte chunk to load. ----
+constexpr int G2T29_WORDS = 60;
+__global__ void __launch_bounds__(128)
+zkc_g2_table29(const Affine<Fq2>* __restrict__ tbl, uint32_t* __restrict__ out, size_t count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const Affine<Fq2> a = PointIO<Fq2>::load(tbl + i);
+    uint32_t* o = out + i * G2T29_WORDS;
+    const Fq2 ny = fp_neg(a.y);
+    f29_enter_fq(o, a.x.c0.v); f29_enter_fq(o + 9, a.x.c1.v); o[18] = a.is_inf() ? 1u : 0u; o[19] = 0;
+    f29_enter_fq(o + 20, a.y.c0.v); f29_enter_fq(o + 29, a.y.c1.v); o[38] = o[39] = 0;
+    f29_enter_fq(o + 40, ny.c0.v); f29_enter_fq(o + 49, ny.c1.v); o[58] = o[59] = 0;
+}
+int msm_g2_table29(zkc_ctx* ctx, const G2Affine* d_table, uint32_t* d_out, size_t count) {
+    hipLaunchKernelGGL(zkc_g2_table29, dim3((unsigned)((count + 127) / 128)), dim3(128), 0, ctx->stream, d_table, d_out, count);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, std::string("zkc_g2_table29: ") + hipGetErrorString(e));
+    return ZKC_OK;
+}
+struct G2Chunk { uint32_t w[20]; };
+__device__ __forceinline__ G2Chunk g2_chunk_load(const uint32_t* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p); G2Chunk c;
+#pragma unroll
+    for (int i = 0; i < 5; i++) { const uint4 v = q[i]; c.w[4 * i] = v.x; c.w[4 * i + 1] = v.y; c.w[4 * i + 2] = v.z; c.w[4 * i + 3] = v.w; }
+    return c;
+}
+template <int MINW>
+__global__ void __launch_bounds__(128, MINW)
+zkc_msm_accumulate29_g2(const uint32_t* __restrict__ table29, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ off,
+                        const uint32_t* __restrict__ segoff, const uint32_t* __restrict__ seg2bucket, uint32_t nbuckets,
+                        XYZZ<Fq2>* __restrict__ partial, uint32_t max_segments) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t nseg = segoff[nbuckets]; if (nseg > max_segments) nseg = max_segments;
+    if (s >= nseg) return;
+    const uint32_t b = seg2bucket[s];
+    const uint32_t start = off[b] + (s - segoff[b]) * MSM_SEG;
+    uint32_t end = start + MSM_SEG; const uint32_t bend = off[b + 1]; if (end > bend) end = bend;
+    Acc29G2 acc; bool inf = true;
+    uint32_t v = vals[start];
+    const uint32_t* pp = table29 + (size_t)(v & 0x7fffffffu) * G2T29_WORDS;
+    G2Chunk cx = g2_chunk_load(pp), cy = g2_chunk_load(pp + ((v >> 31) ? 40 : 20));
+    for (uint32_t j = start; j < end; j++) {
+        const uint32_t vn = (j + 1 < end) ? vals[j + 1] : v;
+        const uint32_t* pn = table29 + (size_t)(vn & 0x7fffffffu) * G2T29_WORDS;
+        const G2Chunk nx = g2_chunk_load(pn), ny = g2_chunk_load(pn + ((vn >> 31) ? 40 : 20));      // next gather in flight during this addition
+        if (!cx.w[18]) {
+            F2x29 x2, y2;
+#pragma unroll
+            for (int k = 0; k < 9; k++) { x2.c0[k] = cx.w[k]; x2.c1[k] = cx.w[9 + k]; y2.c0[k] = cy.w[k]; y2.c1[k] = cy.w[9 + k]; }
+            bool same_y = false;
+            if (inf) {
+                acc.X = x2; acc.Y = y2;
+#pragma unroll
+                for (int k = 0; k < 9; k++) { acc.ZZ.c0[k] = acc.ZZZ.c0[k] = F29K<FqParams>::one.l[k]; acc.ZZ.c1[k] = acc.ZZZ.c1[k] = 0; }
+                inf = false;
+            } else if (!f29g2_madd(acc, x2, y2, same_y)) {
+                if (same_y) {                                               // the bucket holds this very point: double it (rare; generic code)
+                    Affine<Fq2> a; a.x = {f29_to_fp<FqParams>(x2.c0), f29_to_fp<FqParams>(x2.c1)}; a.y = {f29_to_fp<FqParams>(y2.c0), f29_to_fp<FqParams>(y2.c1)};
+                    const XYZZ<Fq2> d = xyzz_dbl_affine(a);
+                    f29_enter_fq(acc.X.c0, d.X.c0.v); f29_enter_fq(acc.X.c1, d.X.c1.v); f29_enter_fq(acc.Y.c0, d.Y.c0.v); f29_enter_fq(acc.Y.c1, d.Y.c1.v);
+                    f29_enter_fq(acc.ZZ.c0, d.ZZ.c0.v); f29_enter_fq(acc.ZZ.c1, d.ZZ.c1.v); f29_enter_fq(acc.ZZZ.c0, d.ZZZ.c0.v); f29_enter_fq(acc.ZZZ.c1, d.ZZZ.c1.v);
+                } else inf = true;                                          // P + (-P)
+            }
+        }
+        v = vn; cx = nx; cy = ny;
+    }
+    XYZZ<Fq2> out = XYZZ<Fq2>::inf();
+    if (!inf) {
+        out.X = {f29_to_fp<FqParams>(acc.X.c0), f29_to_fp<FqParams>(acc.X.c1)}; out.Y = {f29_to_fp<FqParams>(acc.Y.c0), f29_to_fp<FqParams>(acc.Y.c1)};
+        out.ZZ = {f29_to_fp<FqParams>(acc.ZZ.c0), f29_to_fp<FqParams>(acc.ZZ.c1)}; out.ZZZ = {f29_to_fp<FqParams>(acc.ZZZ.c0), f29_to_fp<FqParams>(acc.ZZZ.c1)};
+    }
     partial[s] = out;
 }
 
@@ -467,9 +544,8 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
         zkc_prof_scope _ps(ctx, kG2 ? ZKC_PROF_MSM_ACC_G2 : ZKC_PROF_MSM_ACC_G1, alg_bytes, st);
         if (!kG2 && ((ctx->prof.mask >> ZKC_PROF_MSM_ACC_G1) & 1)) ctx->prof.bytes[ZKC_PROF_MSM_G1_STREAMED] += streamed_bytes;
         if constexpr (kG2)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate<Fq2I, 1>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
-                               reinterpret_cast<const Affine<Fq2I>*>(table), w.vals2, w.off, w.segoff, w.seg2bucket, nb,
-                               reinterpret_cast<XYZZ<Fq2I>*>(partial), (uint32_t)w.max_segments);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate29_g2<1>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
+                               zk->d_g2_29, w.vals2, w.off, w.segoff, w.seg2bucket, nb, reinterpret_cast<XYZZ<Fq2>*>(partial), (uint32_t)w.max_segments);
         else      // G1: same layout, field type with the inlined product
             hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate29<2>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
                                reinterpret_cast<const Affine<Fq>*>(table), w.vals2, w.off, w.segoff, w.seg2bucket, nb,

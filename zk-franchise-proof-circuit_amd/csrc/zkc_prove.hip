@@ -64,7 +64,7 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     if (!zk) return;
     (void)hipSetDevice(zk->ctx->device);
     (void)hipStreamSynchronize(zk->ctx->stream);
-    void* ptrs[] = {zk->d_perm, zk->d_rowlen, zk->d_jdptr, zk->d_col, zk->d_val, zk->d_tw_fwd, zk->d_tw_inv, zk->d_coset, zk->d_g1, zk->d_g2, zk->d_flags,
+    void* ptrs[] = {zk->d_perm, zk->d_rowlen, zk->d_jdptr, zk->d_col, zk->d_val, zk->d_tw_fwd, zk->d_tw_inv, zk->d_coset, zk->d_g1, zk->d_g2, zk->d_g2_29, zk->d_flags,
                     zk->d_tblDelta1, zk->d_tblAlpha1, zk->d_tblBeta1, zk->d_tblDelta2, zk->d_rs, zk->d_proofs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : zk->fold.vmaps) if (kv.second.d) (void)hipFree(kv.second.d);
@@ -184,6 +184,7 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
     if ((rc = msm_precompute_g1(ctx, nv, zk->d_g1 + zk->offA, MSM_C_SMALL)) || (rc = msm_precompute_g1(ctx, nv, zk->d_g1 + zk->offB1, MSM_C_SMALL)) ||
         (rc = msm_precompute_g1(ctx, nc, zk->d_g1 + zk->offC, MSM_C_SMALL)) || (rc = msm_precompute_g1(ctx, n, zk->d_g1 + zk->offH, MSM_C_BIG)) ||
         (rc = msm_precompute_g2(ctx, nv, zk->d_g2, MSM_C_SMALL))) return bail(rc);
+    if ((rc = dmalloc(ctx, &zk->d_g2_29, 60 * (size_t)NWS * nv)) || (rc = msm_g2_table29(ctx, zk->d_g2, zk->d_g2_29, (size_t)NWS * nv))) return bail(rc);
     // ---- work buffers: `inflight` proofs share one MSM pipeline pass ----
     const char* e_inf = getenv("ZKC_INFLIGHT");
     zk->max_inflight = e_inf ? std::max(1, std::min(atoi(e_inf), MSM_MAX_JOBS / 4)) : 64;      // measured: 16 -> 730, 32 -> 1365, 64 -> 1444, 96 -> 1435 proofs/s
