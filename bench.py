@@ -64,7 +64,8 @@ def main():
 
     def step():
         ctx.witness_dev(d_inputs.data_ptr(), B, d_wtns.data_ptr(), d_status.data_ptr(), args.nlevels)
-        rsb = b''.join(rs.bytes(31) + b'\0' for _ in range(2 * B))       # r, s < 2^248 < field order
+        rsa = rs.integers(0, 256, size=(2 * B, 32), dtype=np.uint8); rsa[:, 31] = 0     # r, s < 2^248 < field order
+        rsb = rsa.tobytes()
         p, pub = pk.prove_batch_dev(d_wtns.data_ptr(), B, rsb)
         rec = parallel.pack_records(p, pub, d_status.cpu().tolist())      # 256 B proof + 8 x 32 B signals + status per voter
         # RCCL over xGMI: the only collective -- finished proofs to every rank (513 B per voter)

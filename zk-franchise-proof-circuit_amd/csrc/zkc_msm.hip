@@ -304,7 +304,7 @@ zkc_msm_merge(XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ segoff
     }
 }
 
-// ---- K6 ---- one wave per virtual window of MSM_VW = 1024 consecutive buckets of a job; lane t owns buckets 16t .. 16t+15 (512: 1496, 1024: 1548, 2048: 1505 proofs/s).
+// ---- K6 ---- one wave per virtual window of 64 x per consecutive buckets of a job; lane t owns buckets per t .. per t + per - 1.
 // Output per virtual window: W = sum_{j=1..512} j * B_{j} (local weights) and S = sum B_j; zkc_msm_final applies the window's offset.
 template <class F>
 __global__ void __launch_bounds__(64)
@@ -313,7 +313,7 @@ zkc_msm_window(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__
     extern __shared__ uint4 lds4[];
     XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds4);
     const MsmWindow win = windows[blockIdx.x];
-    constexpr int PER = MSM_VW / 64;                                      // 16
+    const int PER = (int)win.per;                                         // 16 (H) or 4 (witness sections)
     const uint32_t first = win.bucket0 + threadIdx.x * PER;
     XYZZ<F> run = XYZZ<F>::inf(), loc = XYZZ<F>::inf();                   // run = sum of the lane's buckets from the top; loc = sum_k k * B_k
     for (int k = PER - 1; k >= 0; k--) {
@@ -344,14 +344,14 @@ zkc_msm_window(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__
     }
     if (threadIdx.x == 0) wres[2 * win.out] = sh[0];
 }
-// one workgroup per job: result = sum_k W_k + MSM_VW * sum_k k * S_k over the job's virtual windows k (digit = MSM_VW*k + local index)
+// one workgroup per job: result = sum_k W_k + vw * sum_k k * S_k over the job's virtual windows k (digit = vw k + local index)
 template <class F, int NT>
 __global__ void __launch_bounds__(NT)
 zkc_msm_final(const XYZZ<F>* __restrict__ wres, const MsmJobList* __restrict__ jl, XYZZ<F>* __restrict__ results) {
     extern __shared__ uint4 lds4[];
     XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds4);
     const int j = blockIdx.x; constexpr int nt = NT;                          // NT >= virtual windows of the largest job
-    const uint32_t nvw = (1u << (jl->job[j].c - 1)) / MSM_VW, w0 = jl->job[j].win_off;
+    const uint32_t vw = jl->job[j].vw, nvw = (1u << (jl->job[j].c - 1)) / vw, w0 = jl->job[j].win_off;
     XYZZ<F> Wk = XYZZ<F>::inf(), Sk = XYZZ<F>::inf();
     if (threadIdx.x < nvw) { Wk = wres[2 * (w0 + threadIdx.x)]; Sk = wres[2 * (w0 + threadIdx.x) + 1]; }
     sh[threadIdx.x] = Sk; __syncthreads();
@@ -363,7 +363,7 @@ zkc_msm_final(const XYZZ<F>* __restrict__ wres, const MsmJobList* __restrict__ j
         __syncthreads();
     }
     XYZZ<F> y = XYZZ<F>::inf();
-    if (threadIdx.x >= 1) { y = sh[threadIdx.x]; for (int k = MSM_VW; k > 1; k >>= 1) y = xyzz_dbl(y); }   // sum_{k>=1} R_k = sum_k k S_k, times 512
+    if (threadIdx.x >= 1) { y = sh[threadIdx.x]; for (uint32_t k = vw; k > 1; k >>= 1) y = xyzz_dbl(y); }   // sum_{k>=1} R_k = sum_k k S_k, times vw
     y = xyzz_add(y, Wk);
     __syncthreads();
     sh[threadIdx.x] = y; __syncthreads();
@@ -465,7 +465,7 @@ int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, size_t max_buck
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.heavy, (MSM_MAX_HEAVY + 1) * 4));
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.d_jobs, sizeof(MsmJobList)));
     ZKC_HIP_CHECK(ctx, hipMalloc(&w.partial, w.max_segments * w.xyzz_size));
-    const size_t max_vw = max_buckets / MSM_VW + (size_t)max_jobs;
+    const size_t max_vw = max_buckets / MSM_VW_MIN + (size_t)max_jobs;
     ZKC_HIP_CHECK(ctx, hipMalloc(&w.wres, 2 * max_vw * w.xyzz_size));
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.d_windows, max_vw * sizeof(MsmWindow)));
     ZKC_HIP_CHECK(ctx, hipMalloc(&w.results, 2 * (size_t)max_jobs * w.xyzz_size));
@@ -508,8 +508,8 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
         zkc_prof_scope _ps(ctx, ZKC_PROF_MSM_SORT, 0, st);
         static thread_local std::vector<MsmWindow> wins;
         wins.clear();
-        for (int j = 0; j < nj; j++) for (uint32_t k = 0; k < (uint32_t)msm_half((int)jl.job[j].c) / MSM_VW; k++)
-            wins.push_back(MsmWindow{jl.job[j].boff + k * MSM_VW, jl.job[j].win_off + k});
+        for (int j = 0; j < nj; j++) for (uint32_t k = 0; k < (uint32_t)msm_half((int)jl.job[j].c) / jl.job[j].vw; k++)
+            wins.push_back(MsmWindow{jl.job[j].boff + k * jl.job[j].vw, jl.job[j].win_off + k, jl.job[j].vw / 64});
         ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.d_jobs, &jl, sizeof(MsmJobList), hipMemcpyHostToDevice, st));   // pageable source: staged before return
         ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.d_windows, wins.data(), wins.size() * sizeof(MsmWindow), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(zkc_msm_digits, dim3((maxcount + 255) / 256, nj), dim3(256), 0, st, (const MsmJobList*)w.d_jobs, w.keys, w.vals);
@@ -560,9 +560,9 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
         hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_window<F>), dim3(jl.total_windows), dim3(64), 64 * sizeof(XYZZ<F>), st, partial, w.segoff, w.segcnt,
                            (const MsmWindow*)w.d_windows, wres, (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_window");
-        uint32_t max_vw = 64; for (int j = 0; j < nj; j++) max_vw = std::max<uint32_t>(max_vw, (uint32_t)msm_half((int)jl.job[j].c) / MSM_VW);     // 64 or 128 lanes
-        if (max_vw == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_final<F, 64>), dim3(nj), dim3(64), 64 * sizeof(XYZZ<F>), st, wres, (const MsmJobList*)w.d_jobs, results);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_final<F, 128>), dim3(nj), dim3(128), 128 * sizeof(XYZZ<F>), st, wres, (const MsmJobList*)w.d_jobs, results);
+        static_assert(msm_half(MSM_C_BIG) / msm_vw(MSM_C_BIG) <= MSM_MAX_VW_PER_JOB && msm_half(MSM_C_SMALL) / msm_vw(MSM_C_SMALL) <= MSM_MAX_VW_PER_JOB, "final kernel: one lane per virtual window");
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_final<F, MSM_MAX_VW_PER_JOB>), dim3(nj), dim3(MSM_MAX_VW_PER_JOB), MSM_MAX_VW_PER_JOB * sizeof(XYZZ<F>), st, wres,
+                           (const MsmJobList*)w.d_jobs, results);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_final");
     }
     if (g_debug_sync && getenv("ZKC_DEBUG_DUMP")) {

@@ -11,7 +11,10 @@ namespace zkc {
 constexpr int MSM_C_BIG = 17, MSM_C_SMALL = 13;
 constexpr int msm_nw(int c) { return (254 + c) / c; }          // 17 -> 15 windows (255 bits), 13 -> 20 windows (260 bits)
 constexpr int msm_half(int c) { return 1 << (c - 1); }         // buckets per job
-constexpr int MSM_VW = 1024;                                   // buckets per workgroup of the reduction ("virtual window")
+// buckets per workgroup of the reduction ("virtual window"): 1024 for H (64 waves per job; 512: 1496, 1024: 1548, 2048: 1505 proofs/s),
+// 256 for the witness sections (16 waves per job instead of 4: their reduction is a latency chain, not a throughput problem)
+constexpr int msm_vw(int c) { return c >= 16 ? 1024 : 256; }
+constexpr int MSM_VW_MIN = 256, MSM_MAX_VW_PER_JOB = 64;
 constexpr int MSM_SEG = 16;                        // sorted entries per accumulation lane (load balance for repeated scalars)
 constexpr int MSM_MERGE_T = 8;                     // buckets with more segments get a wave of their own before the window pass
 constexpr int MSM_MAX_HEAVY = 1 << 20;
@@ -25,7 +28,7 @@ struct MsmJob {
     uint32_t tbl_off;          // first point of this section's pre-shifted table inside the unified point array
     uint32_t tbl_count;        // points per window in that table
     int32_t pt_shift;
-    uint32_t c, nw;            // window bits / windows of this job's table
+    uint32_t c, nw, vw;        // window bits / windows of this job's table / buckets per virtual window
     uint32_t boff, ent_off, win_off;   // first bucket / first (scalar, window) entry / first virtual window of this job inside the pass
 };
 // arguments of the blinding kernel (zkc_finalize.hip); everything except r1/r2/rs/out is constant per proving key
@@ -40,12 +43,12 @@ struct MsmJobList {
     MsmJob job[MSM_MAX_JOBS]; int njobs; uint32_t total_buckets, total_entries, total_windows;
     void add(const uint32_t* scalars, const uint32_t* vmap, uint32_t count, uint32_t tbl_off, uint32_t tbl_count, int32_t pt_shift, int c) {
         MsmJob& j = job[njobs++];
-        j = MsmJob{scalars, vmap, count, tbl_off, tbl_count, pt_shift, (uint32_t)c, (uint32_t)msm_nw(c), total_buckets, total_entries, total_windows};
-        total_buckets += (uint32_t)msm_half(c); total_entries += count * (uint32_t)msm_nw(c); total_windows += (uint32_t)(msm_half(c) / MSM_VW);
+        j = MsmJob{scalars, vmap, count, tbl_off, tbl_count, pt_shift, (uint32_t)c, (uint32_t)msm_nw(c), (uint32_t)msm_vw(c), total_buckets, total_entries, total_windows};
+        total_buckets += (uint32_t)msm_half(c); total_entries += count * (uint32_t)msm_nw(c); total_windows += (uint32_t)(msm_half(c) / msm_vw(c));
     }
     void clear() { njobs = 0; total_buckets = total_entries = total_windows = 0; }
 };
-struct MsmWindow { uint32_t bucket0, out; };   // one wave of zkc_msm_window: buckets [bucket0, bucket0 + MSM_VW) -> wres[2*out] (weighted), wres[2*out+1] (plain sum)
+struct MsmWindow { uint32_t bucket0, out, per; };   // one wave of zkc_msm_window: buckets [bucket0, bucket0 + 64 per) -> wres[2*out] (weighted), wres[2*out+1] (plain sum)
 
 // Work space of one pipeline pass (sized for MSM_MAX_JOBS jobs and max_entries (scalar, window) pairs)
 struct MsmWork {
