@@ -110,12 +110,22 @@ def main():
         traffic = int(pm['hbm_bytes_per_launch_uncorrected']); traffic_src = 'profiles/r01_pmc_hbm_traffic.json (separate --pmc run, %d proofs per launch)' % pm['proofs_per_launch']
     except Exception:
         pass
-    roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+    # the bound that actually holds: VALU issue.  tools/probe/rate_probe.hip measures 35.4e12 lane-instructions/s for v_mad_u64_u32 (and every
+    # other full-rate VALU op) on this part; one mixed addition of the radix-2^29 kernel is 2700 instructions, 1566 of them v_mad_u64_u32.
+    nproofs = args.steps * B
+    pairs_per_proof = prof['msm_g1_streamed']['alg_bytes'] / 96.0 / nproofs             # (scalar, base) pairs entering the G1 MSMs of one proof
+    madds_per_proof = 15.0 * pk.domain_size + 20.0 * (pairs_per_proof - pk.domain_size)  # c = 17: 15 windows for H; c = 13: 20 windows for A, B1, C
+    madd_rate = madds_per_proof * nproofs / (d['ms'] * 1e-3) if d['ms'] > 0 else 0.0
+    alu = {'unit': 'mixed additions/s', 'achieved': round(madd_rate / 1e9, 3), 'achieved_unit': 'G madd/s', 'instr_per_madd': 2700,
+           'peak_lane_instr_per_s': 35.4e12, 'frac': round(madd_rate * 2700 / 35.4e12, 4),
+           'note': 'VALU issue bound (measured full-rate v_mad_u64_u32 throughput, tools/probe/rate_probe.hip); this, not HBM, limits the kernel'}
+    roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'valu': alu,
                 'frac': round(achieved / HBM_PEAK_GBPS, 6), 'traffic': traffic, 'traffic_source': traffic_src,
                 'avg_launch_ms': round(d['ms'] / max(1, d['launches']), 4), 'alg_bytes_per_launch': d['alg_bytes'] // max(1, d['launches']),
                 'streamed_pair_bytes_per_launch': prof['msm_g1_streamed']['alg_bytes'] // max(1, d['launches']),
                 'note': 'achieved = algorithmic bytes (whole A,B1,C,H sections, SURVEY.md 8d) / kernel time; constant folding streams only streamed_pair_bytes. '
-                        'The kernel is bound by the 32-bit integer multiplier (about 10 Fq products = 1620 v_mad_u64_u32 per 96 B), not by HBM; see DESIGN.md'}
+                        'The kernel is bound by VALU issue (2700 instructions per mixed addition, see valu), not by HBM; traffic exceeds the algorithmic bytes because '
+                        'every (scalar, window) digit gathers its own pre-shifted 64-byte base (15-20 table rows per base point) -- see DESIGN.md'}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,33 @@
+"""Summarise two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into profiles/rNN_pmc_hbm_traffic.json.
+
+usage: python tools/pmc_summary.py <dir with *_counter_collection.csv of the FETCH pass> <dir of the WRITE pass> <proofs per launch> <out.json>
+The roofline kernel is the G1 bucket accumulation (zkc_msm_accumulate29); bench.py reads hbm_bytes_per_launch_uncorrected from the file.
+"""
+import csv, glob, json, os, sys, collections
+
+
+def load(d):
+    f = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)[0]
+    acc = collections.defaultdict(lambda: [0, 0.0]); seen = collections.defaultdict(set)
+    for r in csv.DictReader(open(f)):
+        k = r['Kernel_Name']; acc[k][1] += float(r['Counter_Value']); seen[k].add(r['Dispatch_Id'])
+    return {k: {'launches': len(seen[k]), 'counter_sum': v[1], 'per_launch': v[1] / max(1, len(seen[k]))} for k, v in acc.items() if k.startswith('zkc') or 'zkc::' in k}
+
+
+def main():
+    fdir, wdir, ppl, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    fe, wr = load(fdir), load(wdir)
+    kern = [k for k in fe if 'zkc_msm_accumulate29<' in k][0]
+    doc = {'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --batch %d --steps 1 --warmup 0 --no-cpu-baseline' % ppl,
+           'kernel': kern, 'proofs_per_launch': ppl,
+           'FETCH_SIZE_per_launch': fe[kern]['per_launch'], 'WRITE_SIZE_per_launch': wr[kern]['per_launch'],
+           'hbm_bytes_per_launch_uncorrected': (fe[kern]['per_launch'] + wr[kern]['per_launch']) * 1024,
+           'note': 'counters are in KiB (guide: hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024).  The gfx950 x2 FETCH correction of the guide is calibrated for wide '
+                   'coalesced streams; this kernel gathers 64-byte points at random, so the uncorrected figure is reported and 2x is the upper bound.',
+           'all_zkc_kernels': {'pmc_fetch': fe, 'pmc_write': wr}}
+    json.dump(doc, open(out, 'w'), indent=1)
+    print(kern[:60], 'FETCH %.0f KiB WRITE %.0f KiB per launch -> %.3f GB' % (fe[kern]['per_launch'], wr[kern]['per_launch'], doc['hbm_bytes_per_launch_uncorrected'] / 1e9))
+
+
+if __name__ == '__main__':
+    main()
