@@ -194,3 +194,25 @@ def test_batch_prove_nl160_verifies(env):
     # one of them against the oracle prover, byte for byte
     rc, op, _ = ol.prove(zk, ws[7], int.from_bytes(rsb[64 * 7:64 * 7 + 32], 'little'), int.from_bytes(rsb[64 * 7 + 32:64 * 7 + 64], 'little'))
     assert rc == 0 and op == proofs[256 * 7:256 * 8]
+
+
+def test_max_levels_nl252_config5(env):
+    """the circuit at the largest nLevels this build's generator supports (252: 128 386 wires, domain 2^17).
+    Witness and proof bytes equal the oracle's, the pinned verifier accepts -- for a shallow voter (most levels fold) and for a voter at
+    the maximum depth (nothing folds)."""
+    ctx, get, torch = env
+    nl = 252
+    zk, pk, vk = get(nl)
+    assert pk.n_vars == ol.lib().zko_n_wires(nl) == 128386 and pk.domain_size == 1 << 17
+    from census_gen import random_voter
+    rng = random.Random(5)
+    voters = [random_voter(rng, ol.poseidon, nLevels=nl, depth_c=7, depth_s=5), random_voter(rng, ol.poseidon, nLevels=nl, depth_c=nl, depth_s=nl)]
+    ws, st = ctx.witness(voters, nLevels=nl)
+    assert st == [0, 0]
+    for v, w in zip(voters, ws):
+        rc, ow = ol.witness(v, nLevels=nl)
+        assert rc == 0 and w == ow
+        p, pub = pk.prove(w, 111, 222)
+        rc, op, opub = ol.prove(zk, w, 111, 222)
+        assert rc == 0 and p == op and pub == opub
+        assert ol.verify(vk, pub, p)
