@@ -90,6 +90,13 @@ int groth16_prover(const void* zkey_buffer, unsigned long zkey_size, const void*
  * zkc_verify_bin takes vk = alpha1(64) beta2(128) gamma2(128) delta2(128) IC[nPublic+1](64 each), standard form. */
 int zkc_verify(const char* vkey_json, const char* public_json, const char* proof_json);
 int zkc_verify_bin(const uint8_t* vk, int nPublic, const uint8_t* pub, const uint8_t* proof);
+
+/* ---- f4: batch verification of N proofs under one key (what a vote-counting node does after zk_census_test.go:103-124 per vote).
+ * One random-linear-combination pairing check: N + 3 Miller loops and one final exponentiation; the G1 scalar multiplications run on
+ * the GPU of `ctx`, Miller loops on host threads.  vk as for zkc_verify_bin; pubs: N x nPublic x 32 B; proofs: N x 256 B (standard
+ * form).  seed32: 32 bytes of FRESH randomness for the weights (NULL: taken from the OS); soundness error about 2^-128.
+ * Returns 1 when every proof is valid, 0 when at least one is not (verify singly to find it), <0 = -ZKC_ERR_*. */
+int zkc_verify_batch(zkc_ctx* ctx, const uint8_t* vk, int nPublic, const uint8_t* pubs, const uint8_t* proofs, int N, const uint8_t* seed32);
 const char* zkc_verify_last_error(void);
 
 /* ---- a8: artifact codecs.  proof/public JSON exactly as snarkjs prints them (proof.json, signals.json);

@@ -1,0 +1,59 @@
+"""GPU: batch verifier -- N proofs folded into one pairing-product check.  The oracle verifies each proof
+singly (pinned pairing verifier); the batch result must be the AND of those verdicts, for honest batches and for batches with one
+tampered member (proof point swapped for another valid curve point, public signal changed, point off the curve)."""
+import json, os, random, sys
+import pytest
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(ol.ROOT, 'tools'))
+
+
+def test_batch_verify_matches_single_verdicts():
+    import torch, numpy as np  # noqa: F401
+    import zkcensus_amd
+    from zkcensus_amd import groth16, setup
+    from census_gen import random_voter
+    nl, N = 10, 24
+    ctx = zkcensus_amd.Context(0)
+    _, zp, vp = setup.ensure_test_artifacts(nl)
+    zk = open(zp, 'rb').read(); pk = zkcensus_amd.ProvingKey(ctx, zk); vk = json.load(open(vp))
+    rng = random.Random(42)
+    voters = [random_voter(rng, ol.poseidon, nLevels=nl, depth_c=rng.randint(1, nl), depth_s=rng.randint(1, nl)) for _ in range(N)]
+    ws, st = ctx.witness(voters, nLevels=nl)
+    assert st == [0] * N
+    d = torch.from_numpy(np.frombuffer(b''.join(ws), dtype=np.uint8).copy()).cuda()
+    rs = b''.join(rng.randrange(1 << 248).to_bytes(32, 'little') for _ in range(2 * N))
+    proofs, pubs = pk.prove_batch_dev(d.data_ptr(), N, rs)
+    npub = 8
+    single = [ol.verify(vk, pubs[32 * npub * i:32 * npub * (i + 1)], proofs[256 * i:256 * (i + 1)]) for i in range(N)]
+    assert all(single)
+    seed = bytes(range(32))
+    assert groth16.verify_batch(ctx, vk, pubs, proofs, seed) is True
+    assert groth16.verify_batch(ctx, vk, pubs, proofs) is True                       # weights from the OS
+    assert groth16.verify_batch(ctx, vk, pubs[:32 * npub], proofs[:256], seed) is True   # N = 1
+
+    def with_patch(buf, off, new):
+        b = bytearray(buf); b[off:off + len(new)] = new; return bytes(b)
+    # (1) proof 5 gets proof 7's C: every point is still on the curve, only the pairing equation can tell
+    bad = with_patch(proofs, 256 * 5 + 192, proofs[256 * 7 + 192:256 * 7 + 256])
+    assert not ol.verify(vk, pubs[32 * npub * 5:32 * npub * 6], bad[256 * 5:256 * 6])
+    assert groth16.verify_batch(ctx, vk, pubs, bad, seed) is False
+    # (2) proofs 2 and 3 exchange their A points
+    a2, a3 = proofs[256 * 2:256 * 2 + 64], proofs[256 * 3:256 * 3 + 64]
+    bad = with_patch(with_patch(proofs, 256 * 2, a3), 256 * 3, a2)
+    assert groth16.verify_batch(ctx, vk, pubs, bad, seed) is False
+    # (3) one bit of one public signal
+    off = 32 * npub * 11 + 32 * 2
+    badpub = with_patch(pubs, off, bytes([pubs[off] ^ 1]))
+    assert not ol.verify(vk, badpub[32 * npub * 11:32 * npub * 12], proofs[256 * 11:256 * 12])
+    assert groth16.verify_batch(ctx, vk, badpub, proofs, seed) is False
+    # (4) a point off the curve, a coordinate >= q, a public signal >= r: rejected before any pairing
+    assert groth16.verify_batch(ctx, vk, pubs, with_patch(proofs, 256 * 9, bytes([proofs[256 * 9] ^ 1])), seed) is False
+    assert groth16.verify_batch(ctx, vk, pubs, with_patch(proofs, 256 * 9, b'\xff' * 32), seed) is False
+    assert groth16.verify_batch(ctx, vk, with_patch(pubs, 0, b'\xff' * 32), proofs, seed) is False
+    # (5) the negation of a valid A (still in G1): e(-A, B) flips
+    q = ol.Q
+    y = int.from_bytes(proofs[32:64], 'little')
+    assert groth16.verify_batch(ctx, vk, pubs, with_patch(proofs, 32, ((q - y) % q).to_bytes(32, 'little')), seed) is False
+    pk.close(); ctx.close()

@@ -49,6 +49,7 @@ def load():
     L.groth16_prover.argtypes = [ctypes.c_char_p, ctypes.c_ulong, ctypes.c_char_p, ctypes.c_ulong, ctypes.c_char_p, ulp, ctypes.c_char_p, ulp, ctypes.c_char_p, ctypes.c_ulong]
     L.zkc_verify.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
     L.zkc_verify_bin.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p]
+    L.zkc_verify_batch.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
     L.zkc_verify_last_error.restype = ctypes.c_char_p
     L.zkc_proof_to_json.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ulp, ctypes.c_char_p, ulp]
     L.zkc_wtns_parse.argtypes = [ctypes.c_char_p, ctypes.c_ulong, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint32)]

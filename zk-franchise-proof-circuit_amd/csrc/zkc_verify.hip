@@ -10,6 +10,8 @@
 #include <string>
 #include <vector>
 #include <random>
+#include <thread>
+#include <algorithm>
 #include "zkc_prover.h"
 
 using namespace zkc;
@@ -167,6 +169,86 @@ extern "C" int zkc_verify_bin(const uint8_t* vk, int nPublic, const uint8_t* pub
     }
     const G1Affine vkx = xyzz_to_affine(acc);
     Fq12 f = miller(affine_neg(A), B) * miller(alpha, beta) * miller(vkx, gamma) * miller(C, delta);
+    return is_one12(final_exp(f)) ? 1 : 0;
+}
+
+// ---- f4: batch verification (the step on the other side of the path, zk_census_test.go:103-124 run per vote) ----
+// N proofs under one key are folded into one pairing-product check with random 128-bit weights rho_i:
+//     prod_i e(-rho_i A_i, B_i) * e((sum rho_i) alpha, beta) * e(sum_i rho_i vk_x_i, gamma) * e(sum_i rho_i C_i, delta) == 1
+// i.e. N + 3 Miller loops and ONE final exponentiation instead of 4 N and N.  The G1 work (rho_i A_i for every proof and the MSM
+// sum rho_i C_i) runs on the GPU with the prover's double-and-add / group-sum kernels; Miller loops run on host threads.
+// A cheating prover passes with probability about 2^-128 provided the weights are unpredictable to it: `seed32` must be fresh
+// randomness (NULL: std::random_device).  Each B_i is checked to lie in the order-r subgroup of the twist (G2 has a cofactor; the
+// single-proof check, like snarkjs, does not need that).  Returns 1 all valid / 0 at least one invalid / <0 = -ZKC_ERR_*.
+namespace {
+struct Xoshiro { uint64_t s[4]; uint64_t next() { auto rotl = [](uint64_t x, int k) { return (x << k) | (x >> (64 - k)); };
+    const uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17; s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45); return r; } };
+}
+extern "C" int zkc_verify_batch(zkc_ctx* ctx, const uint8_t* vk, int nPublic, const uint8_t* pubs, const uint8_t* proofs, int N, const uint8_t* seed32) {
+    if (!ctx || !vk || !pubs || !proofs || nPublic < 0 || N <= 0) return vfail(-ZKC_ERR_BAD_ARG, "zkc_verify_batch: bad argument");
+    G1Affine alpha; G2Affine beta, gamma, delta; std::vector<G1Affine> ic(nPublic + 1);
+    if (!rd_g1_std(alpha, vk) || !rd_g2_std(beta, vk + 64) || !rd_g2_std(gamma, vk + 192) || !rd_g2_std(delta, vk + 320)) return vfail(-ZKC_ERR_FORMAT, "verification key coordinate >= q");
+    for (int j = 0; j <= nPublic; j++) if (!rd_g1_std(ic[j], vk + 448 + 64 * (size_t)j)) return vfail(-ZKC_ERR_FORMAT, "IC coordinate >= q");
+    Xoshiro rng;
+    if (seed32) memcpy(rng.s, seed32, 32); else { std::random_device rd; for (auto& x : rng.s) x = ((uint64_t)rd() << 32) | rd(); }
+    if (!(rng.s[0] | rng.s[1] | rng.s[2] | rng.s[3])) rng.s[0] = 1;
+    // ---- parse, per-proof membership checks, weights ----
+    std::vector<G1Affine> pts(2 * (size_t)N); std::vector<G2Affine> Bs(N); std::vector<uint32_t> rho(8 * 2 * (size_t)N, 0);
+    std::vector<Fr> xsum(nPublic, Fr::zero()); Fr rsum = Fr::zero();
+    for (int i = 0; i < N; i++) {
+        const uint8_t* pr = proofs + 256 * (size_t)i;
+        if (!rd_g1_std(pts[i], pr) || !rd_g2_std(Bs[i], pr + 64) || !rd_g1_std(pts[N + i], pr + 192)) return 0;
+        if (!g1_on_curve(pts[i]) || !g1_on_curve(pts[N + i]) || !g2_on_curve(Bs[i])) return 0;
+        uint32_t* r = rho.data() + 8 * (size_t)i;
+        const uint64_t lo = rng.next(), hi = rng.next(); r[0] = (uint32_t)lo; r[1] = (uint32_t)(lo >> 32); r[2] = (uint32_t)hi; r[3] = (uint32_t)(hi >> 32);
+        memcpy(rho.data() + 8 * ((size_t)N + i), r, 32);
+        const Fr rm = fp_from_std<FrParams>(r); rsum = rsum + rm;
+        for (int j = 0; j < nPublic; j++) {
+            uint32_t k[8]; memcpy(k, pubs + 32 * ((size_t)i * nPublic + j), 32);
+            if (!fp_std_lt_p<FrParams>(k)) return 0;
+            xsum[j] = xsum[j] + rm * fp_from_std<FrParams>(k);
+        }
+    }
+    // ---- G1 side on the GPU: rho_i A_i (N single-element groups) and sum rho_i C_i (one group) ----
+    std::vector<G1XYZZ> gout(N + 1);
+    {
+        ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+        G1Affine* d_pts = nullptr; uint32_t *d_rho = nullptr, *d_idx = nullptr, *d_gs = nullptr;
+        std::vector<uint32_t> idx(2 * (size_t)N), gs(N + 2);
+        for (size_t i = 0; i < idx.size(); i++) idx[i] = (uint32_t)i;
+        for (int i = 0; i <= N; i++) gs[i] = (uint32_t)i; gs[N + 1] = 2 * (uint32_t)N;
+        int rc = ZKC_OK;
+        auto cleanup = [&]() { for (void* q : {(void*)d_pts, (void*)d_rho, (void*)d_idx, (void*)d_gs}) if (q) (void)hipFree(q); };
+        if (hipMalloc((void**)&d_pts, pts.size() * sizeof(G1Affine)) != hipSuccess || hipMalloc((void**)&d_rho, rho.size() * 4) != hipSuccess ||
+            hipMalloc((void**)&d_idx, idx.size() * 4) != hipSuccess || hipMalloc((void**)&d_gs, gs.size() * 4) != hipSuccess) { cleanup(); return vfail(-ZKC_ERR_HIP, "zkc_verify_batch: hipMalloc failed"); }
+        if (hipMemcpy(d_pts, pts.data(), pts.size() * sizeof(G1Affine), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_rho, rho.data(), rho.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_gs, gs.data(), gs.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return vfail(-ZKC_ERR_HIP, "zkc_verify_batch: hipMemcpy failed"); }
+        rc = fold_group_sums_g1(ctx, d_pts, d_rho, d_idx, 2 * (uint32_t)N, 0, d_gs, (uint32_t)N + 1, gout.data());
+        cleanup();
+        if (rc) return vfail(-rc, std::string("zkc_verify_batch: ") + zkc_last_error(ctx));
+    }
+    // ---- vk_x side: (sum rho) IC0 + sum_j (sum_i rho_i x_ij) IC_j ----
+    uint32_t k[8]; fp_to_std<FrParams>(k, rsum);
+    G1XYZZ vx = xyzz_mul(G1XYZZ::from_affine(ic[0]), k);
+    const G1Affine ralpha = xyzz_to_affine(xyzz_mul(G1XYZZ::from_affine(alpha), k));
+    for (int j = 0; j < nPublic; j++) { fp_to_std<FrParams>(k, xsum[j]); vx = xyzz_add(vx, xyzz_mul(G1XYZZ::from_affine(ic[j + 1]), k)); }
+    // ---- Miller loops on host threads (and the subgroup check of every B_i) ----
+    const unsigned nthr = std::max(1u, std::min({std::thread::hardware_concurrency(), 32u, (unsigned)N}));
+    std::vector<Fq12> part(nthr, one12()); std::vector<int> bad(nthr, 0);
+    auto work = [&](unsigned t) {
+        uint32_t rord[8]; for (int q = 0; q < 8; q++) rord[q] = FrParams::p[q];
+        Fq12 f = one12();
+        for (int i = (int)t; i < N; i += (int)nthr) {
+            if (!xyzz_mul(G2XYZZ::from_affine(Bs[i]), rord).is_inf()) { bad[t] = 1; return; }
+            f = f * miller(affine_neg(xyzz_to_affine(gout[i])), Bs[i]);
+        }
+        part[t] = f;
+    };
+    std::vector<std::thread> th; for (unsigned t = 1; t < nthr; t++) th.emplace_back(work, t);
+    work(0); for (auto& x : th) x.join();
+    for (unsigned t = 0; t < nthr; t++) if (bad[t]) return 0;
+    Fq12 f = miller(ralpha, beta) * miller(xyzz_to_affine(vx), gamma) * miller(xyzz_to_affine(gout[N]), delta);
+    for (unsigned t = 0; t < nthr; t++) f = f * part[t];
     return is_one12(final_exp(f)) ? 1 : 0;
 }
 

@@ -101,3 +101,27 @@ def verify(vk, public_signals, proof):
     if rc < 0:
         raise _native.ZkcError(-rc, (lib.zkc_verify_last_error() or b'').decode())
     return rc == 1
+
+
+def vk_to_bytes(vk):
+    """verification_key.json object -> the binary layout of zkc_verify_bin / zkc_verify_batch (standard form, little endian)."""
+    le = lambda d: int(d).to_bytes(32, 'little')
+    g1 = lambda p: le(p[0]) + le(p[1])
+    g2 = lambda p: le(p[0][0]) + le(p[0][1]) + le(p[1][0]) + le(p[1][1])
+    return g1(vk['vk_alpha_1']) + g2(vk['vk_beta_2']) + g2(vk['vk_gamma_2']) + g2(vk['vk_delta_2']) + b''.join(g1(p) for p in vk['IC'])
+
+
+def verify_batch(ctx, vk, publics, proofs, seed=None):
+    """Batch counterpart of verify (no snarkjs equivalent): N proofs under one key in one random-linear-combination pairing check.
+    vk: parsed verification_key.json (or its binary form); publics: N x nPublic x 32 bytes, proofs: N x 256 bytes, as returned by
+    ProvingKey.prove_batch_dev.  seed: 32 bytes of fresh randomness (None: OS).  True iff every proof is valid."""
+    lib = _native.load()
+    vkb = vk if isinstance(vk, (bytes, bytearray)) else vk_to_bytes(vk)
+    n = len(proofs) // 256
+    npub = (len(vkb) - 448) // 64 - 1
+    if n == 0 or len(proofs) != 256 * n or len(publics) != 32 * npub * n:
+        raise ValueError('verify_batch: proofs must be N x 256 bytes and publics N x nPublic x 32 bytes')
+    rc = lib.zkc_verify_batch(ctx._h, bytes(vkb), npub, bytes(publics), bytes(proofs), n, seed)
+    if rc < 0:
+        raise _native.ZkcError(-rc, (lib.zkc_verify_last_error() or b'').decode())
+    return rc == 1
