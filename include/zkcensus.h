@@ -106,6 +106,20 @@ int zkc_proof_to_json(const uint8_t proof[256], const uint8_t* pub, int nPublic,
 int zkc_wtns_parse(const void* wtns_bytes, unsigned long size, const uint8_t** payload, uint32_t* nWitness);
 unsigned long zkc_wtns_write(const void* payload, uint32_t nWitness, void* out, unsigned long out_size);   /* returns bytes needed/written */
 
+/* ---- the NTT and G1 MSM engines on their own (what ffjavascript's Fr.fft / Fr.ifft and G1.multiExpAffine are to snarkjs'
+ * groth16.prove, ts_inputs/src/example.ts:358).  Used by SURVEY.md 8(d) config 5 (ii): 2^20-point synthetic stress (tools/stress.py).
+ * zkc_ntt_dev        : nvec contiguous vectors of 2^logn Fr elements in Montgomery form (R = 2^256), natural order in and out,
+ *                      d_src != d_dst; inverse != 0 includes the 1/n factor.
+ * zkc_g1_mul_batch_dev: d_out[i] = k_i * base (scalars 32 B standard form on the device; points affine standard form, 64 B).
+ * zkc_msm_g1_load_dev : n bases (device, affine standard form; checked to be on the curve) -> resident pre-shifted window tables.
+ * zkc_msm_g1_dev      : sum_i s_i P_i, scalars n x 32 B standard form on the device; out = affine standard form (zero = infinity). */
+typedef struct zkc_msm zkc_msm;
+int zkc_ntt_dev(zkc_ctx* ctx, const void* d_src, void* d_dst, int logn, int nvec, int inverse);
+int zkc_g1_mul_batch_dev(zkc_ctx* ctx, const uint8_t base_std[64], const void* d_scalars, uint32_t n, void* d_out);
+int zkc_msm_g1_load_dev(zkc_ctx* ctx, const void* d_bases_std, uint32_t n, zkc_msm** out);
+int zkc_msm_g1_dev(zkc_msm* m, const void* d_scalars, uint8_t out[64]);
+void zkc_msm_g1_free(zkc_msm* m);
+
 /* ---- test hooks (stage outputs for parity tests against the oracle; not part of the drop-in surface) ----
  * zkc_debug_stage: stage 0 -> A_w | B_w | C_w after buildABC (3 x domainSize x 32 B, Montgomery form);
  *                  stage 1 -> joinABC output (A'B' - C') on the odd coset (domainSize x 32 B, standard form).

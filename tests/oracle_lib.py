@@ -106,7 +106,8 @@ def ntt(vals, inverse=False):
     n = len(vals); logn = n.bit_length() - 1
     buf = ctypes.create_string_buffer(b''.join(le32(v) for v in vals), n * 32)
     lib().zko_ntt(buf, logn, 1 if inverse else 0)
-    return [int.from_bytes(buf.raw[32 * i:32 * i + 32], 'little') for i in range(n)]
+    raw = buf.raw                                   # one copy (buf.raw inside the loop copied the whole buffer per element)
+    return [int.from_bytes(raw[32 * i:32 * i + 32], 'little') for i in range(n)]
 
 
 def root_of_unity(logn):

@@ -56,6 +56,11 @@ def load():
     L.zkc_wtns_write.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_ulong]; L.zkc_wtns_write.restype = ctypes.c_ulong
     L.zkc_poseidon_batch.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
     L.zkc_profile_enable.argtypes = [vp, ctypes.c_uint32]
+    L.zkc_ntt_dev.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.zkc_g1_mul_batch_dev.argtypes = [vp, ctypes.c_char_p, vp, ctypes.c_uint32, vp]
+    L.zkc_msm_g1_load_dev.argtypes = [vp, vp, ctypes.c_uint32, ctypes.POINTER(vp)]
+    L.zkc_msm_g1_dev.argtypes = [vp, vp, ctypes.c_char_p]
+    L.zkc_msm_g1_free.argtypes = [vp]; L.zkc_msm_g1_free.restype = None
     L.zkc_profile_read.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     L.zkc_setup_from_r1cs.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
     _lib = L
