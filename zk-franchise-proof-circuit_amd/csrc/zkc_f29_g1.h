@@ -1,0 +1,114 @@
+// zkc_f29_g1.h -- G1 group operations on radix-2^29 coordinates (zkc_f29.h): the mixed addition of the bucket accumulation (K5) and the
+// full addition / doubling of the bucket reduction (K6).  Magnitudes are multiples of p; products contract by 169 = 2^261 / p.
+// Dominators: D24 < 6.3 p (dominates carried values below 5.29 p), D25 < 11.6 p (below 10.58 p), D26 < 22.2 p (21.1 p), D27 < 43.3 p (42.3 p);
+// "x2"/"x3" variants have limbs 0..7 above 2 or 3 times 2^29 (dominate a sum of two / three carried values).
+#pragma once
+#include "zkc_f29.h"
+#include "zkc_curve.h"
+
+namespace zkc {
+
+struct Acc29 { uint32_t X[9], Y[9], ZZ[9], ZZZ[9]; };
+struct Dom29 {
+    static constexpr L9 D25 = f29_dominator<FqParams>(1u << 29, 1u << 25);
+    static constexpr L9 D24 = f29_dominator<FqParams>(1u << 29, 1u << 24);
+    static constexpr L9 D24x3 = f29_dominator<FqParams>(3u << 29, 1u << 24);
+    static constexpr L9 D26x2 = f29_dominator<FqParams>(2u << 29, 1u << 26);
+    static constexpr L9 D27 = f29_dominator<FqParams>(1u << 29, 1u << 27);
+};
+// an 8 x u32 element (R = 2^256 form) -> R' form below 1.2 p
+ZKC_HD void f29_enter_fq(uint32_t r[9], const uint32_t w[8]) {
+    uint32_t t[9]; f29_from_fp_shl5(t, w); f29_mul<FqParams>(r, t, F29K<FqParams>::one.l);
+}
+
+// ---- mixed addition acc += (x2, y2); x2, y2 = 32 x table coordinate (< 32 p).  Accumulator invariant: X, Y < 10.5 p carried, ZZ, ZZZ < 4 p.
+//   U2 = x2 ZZ, S2 = y2 ZZZ < 1.8 p ; P = U2 - X + D25, R = S2 - Y + D25 < 13.4 p ; PP, RR < 2.1 p ; PPP, Q < 1.2 p
+//   X3 = RR - PPP - 2Q + D24x3 < 8.4 p ; W = Q - X3 + D25 < 12.7 p ; Y3 = R W - Y PPP + D24 < 8.3 p ; ZZ PP, ZZZ PPP < 1.1 p
+// Returns false and leaves acc alone when the two points share their x coordinate (same_y tells which case).
+ZKC_HD bool f29_madd(Acc29& acc, const uint32_t x2[9], const uint32_t y2[9], bool& same_y) {
+    typedef FqParams P;
+    uint32_t U2[9], S2[9], Pn[9], Rn[9];
+    f29_mul<P>(U2, x2, acc.ZZ); f29_mul<P>(S2, y2, acc.ZZZ);
+    f29_sub(Pn, U2, acc.X, Dom29::D25); f29_carry(Pn);
+    f29_sub(Rn, S2, acc.Y, Dom29::D25); f29_carry(Rn);
+    if (f29_is_zero_mod_p<P>(Pn)) { same_y = f29_is_zero_mod_p<P>(Rn); return false; }
+    uint32_t PP[9], PPP[9], Q[9], RR[9], W[9], T[9], V[9];
+    f29_sqr<P>(PP, Pn); f29_mul<P>(PPP, Pn, PP); f29_mul<P>(Q, acc.X, PP); f29_sqr<P>(RR, Rn);
+#pragma unroll
+    for (int k = 0; k < 9; k++) acc.X[k] = RR[k] + Dom29::D24x3.l[k] - PPP[k] - 2 * Q[k];
+    f29_carry(acc.X);
+    f29_sub(W, Q, acc.X, Dom29::D25);
+    f29_mul<P>(T, Rn, W); f29_mul<P>(V, acc.Y, PPP);
+    f29_sub(acc.Y, T, V, Dom29::D24); f29_carry(acc.Y);
+    f29_mul<P>(T, acc.ZZ, PP); f29_mul<P>(V, acc.ZZZ, PPP);
+#pragma unroll
+    for (int k = 0; k < 9; k++) { acc.ZZ[k] = T[k]; acc.ZZZ[k] = V[k]; }
+    return true;
+}
+
+// ---- bucket reduction: points with all four coordinates carried and below 32 p ("loose": what slicing an 8 x u32 point gives, and what
+// the operations below return).  Infinity is ZZ with all limbs zero (a finite point never has ZZ = 0 mod p, and infinity is only ever
+// stored as exact zeros).
+ZKC_HD bool f29_pt_is_inf(const Acc29& a) { uint32_t o = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) o |= a.ZZ[k]; return o == 0; }
+ZKC_HD void f29_pt_set_inf(Acc29& a) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) a.X[k] = a.Y[k] = a.ZZ[k] = a.ZZZ[k] = 0; }
+ZKC_HD Acc29 f29_pt_from_xyzz(const XYZZ<Fq>& p) {       // canonical 8 x u32 -> loose
+    Acc29 a; f29_from_fp_shl5(a.X, p.X.v); f29_from_fp_shl5(a.Y, p.Y.v); f29_from_fp_shl5(a.ZZ, p.ZZ.v); f29_from_fp_shl5(a.ZZZ, p.ZZZ.v); return a; }
+ZKC_HD XYZZ<Fq> f29_pt_to_xyzz(const Acc29& a) {
+    XYZZ<Fq> p; p.X = f29_to_fp<FqParams>(a.X); p.Y = f29_to_fp<FqParams>(a.Y); p.ZZ = f29_to_fp<FqParams>(a.ZZ); p.ZZZ = f29_to_fp<FqParams>(a.ZZZ); return p; }
+
+// doubling (dbl-2008-s-1), a finite.  U = 2Y < 64 p ; V = U^2 < 25.3 p ; W = U V < 10.6 p ; S = X V < 5.8 p ; M = 3 X^2 < 21.2 p ;
+// X3 = M^2 - 2S + D26x2 < 25.9 p ; Y3 = M (S - X3 + D27) - W Y + D25 < 18.7 p ; ZZ3 = V ZZ < 5.8 p ; ZZZ3 = W ZZZ < 3.1 p
+ZKC_HD void f29_pt_dbl(Acc29& r, const Acc29& a) {
+    typedef FqParams P;
+    uint32_t U[9], V[9], W[9], S[9], M[9], T[9], X3[9], Y3[9];
+    f29_add(U, a.Y, a.Y);
+    f29_mul<P>(V, U, U); f29_mul<P>(W, U, V); f29_mul<P>(S, a.X, V);
+    f29_sqr<P>(T, a.X);
+#pragma unroll
+    for (int k = 0; k < 9; k++) M[k] = 3 * T[k];
+    f29_carry(M);
+    f29_sqr<P>(T, M);
+#pragma unroll
+    for (int k = 0; k < 9; k++) X3[k] = T[k] + Dom29::D26x2.l[k] - 2 * S[k];
+    f29_carry(X3);
+    f29_sub(T, S, X3, Dom29::D27);                        // limbs < 1.5 * 2^30, times carried M
+    f29_mul<P>(Y3, M, T); f29_mul<P>(T, W, a.Y);
+    f29_sub(Y3, Y3, T, Dom29::D25); f29_carry(Y3);
+    f29_mul<P>(T, V, a.ZZ); f29_mul<P>(S, W, a.ZZZ);
+#pragma unroll
+    for (int k = 0; k < 9; k++) { r.X[k] = X3[k]; r.Y[k] = Y3[k]; r.ZZ[k] = T[k]; r.ZZZ[k] = S[k]; }
+}
+// full addition (add-2008-s), complete.  U1, U2, S1, S2 < 7.1 p ; P, R (+ D25) < 18.7 p ; PP, RR < 3.1 p ; PPP < 1.4 p ; Q < 1.2 p ;
+// X3 = RR - PPP - 2Q + D24x3 < 9.4 p ; W = Q - X3 + D25 < 12.8 p ; Y3 = R W - S1 PPP + D24 < 8.7 p ; ZZ3, ZZZ3 < 1.2 p
+ZKC_HD void f29_pt_add(Acc29& r, const Acc29& a, const Acc29& b) {
+    typedef FqParams P;
+    if (f29_pt_is_inf(b)) { r = a; return; }
+    if (f29_pt_is_inf(a)) { r = b; return; }
+    uint32_t U1[9], S1[9], Pn[9], Rn[9], T[9];
+    f29_mul<P>(U1, a.X, b.ZZ); f29_mul<P>(T, b.X, a.ZZ);
+    f29_sub(Pn, T, U1, Dom29::D25); f29_carry(Pn);
+    f29_mul<P>(S1, a.Y, b.ZZZ); f29_mul<P>(T, b.Y, a.ZZZ);
+    f29_sub(Rn, T, S1, Dom29::D25); f29_carry(Rn);
+    if (f29_is_zero_mod_p<P>(Pn)) {
+        if (f29_is_zero_mod_p<P>(Rn)) f29_pt_dbl(r, a); else f29_pt_set_inf(r);
+        return;
+    }
+    uint32_t PP[9], PPP[9], Q[9], X3[9], Y3[9], V[9];
+    f29_sqr<P>(PP, Pn); f29_mul<P>(PPP, Pn, PP); f29_mul<P>(Q, U1, PP); f29_sqr<P>(T, Rn);
+#pragma unroll
+    for (int k = 0; k < 9; k++) X3[k] = T[k] + Dom29::D24x3.l[k] - PPP[k] - 2 * Q[k];
+    f29_carry(X3);
+    f29_sub(T, Q, X3, Dom29::D25);
+    f29_mul<P>(Y3, Rn, T); f29_mul<P>(V, S1, PPP);
+    f29_sub(Y3, Y3, V, Dom29::D24); f29_carry(Y3);
+    f29_mul<P>(T, a.ZZ, b.ZZ); f29_mul<P>(V, T, PP);
+    f29_mul<P>(T, a.ZZZ, b.ZZZ); f29_mul<P>(Q, T, PPP);
+#pragma unroll
+    for (int k = 0; k < 9; k++) { r.X[k] = X3[k]; r.Y[k] = Y3[k]; r.ZZ[k] = V[k]; r.ZZZ[k] = Q[k]; }
+}
+
+}  // namespace zkc

@@ -11,6 +11,8 @@
 // next addition stay small; the table holds x, y and -y below 1.2 p in R' form (zkc_g2_table29), 9 limbs each.
 #pragma once
 #include "zkc_f29.h"
+#include "zkc_curve.h"
+#include "zkc_f29_g1.h"
 
 namespace zkc {
 
@@ -90,11 +92,6 @@ ZKC_HD bool f29g2_madd(Acc29G2& acc, const F2x29& x2, const F2x29& y2, bool& sam
     f29g2_mul(U, acc.ZZ, PP); acc.ZZ = U;
     f29g2_mul(U, acc.ZZZ, PPP); acc.ZZZ = U;
     return true;
-}
-
-// an 8 x u32 element (R = 2^256 form) -> R' form below 1.2 p
-ZKC_HD void f29_enter_fq(uint32_t r[9], const uint32_t w[8]) {
-    uint32_t t[9]; f29_from_fp_shl5(t, w); f29_mul<FqParams>(r, t, F29K<FqParams>::one.l);
 }
 
 }  // namespace zkc
