@@ -163,6 +163,23 @@ ZKC_HD bool f29_is_zero_mod_p(const uint32_t a[9]) {
     return diff == 0;
 }
 
+// carried value below 2^261  ->  carried value below 3 p, same residue: subtract q p with q = floor(top limb / (floor(p / 2^232) + 1)),
+// which never exceeds floor(value / p) and falls short of it by at most 2
+template <class P>
+ZKC_HD void f29_reduce_small(uint32_t a[9]) {
+    constexpr L9 Pl = F29K<P>::p;
+    constexpr uint32_t ptop1 = (P::p[7] >> 8) + 1;
+    constexpr uint32_t qmagic = (uint32_t)((1ull << 50) / ptop1);
+    const uint32_t q = (uint32_t)(((uint64_t)a[8] * qmagic) >> 50);
+    int64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const int64_t v = (int64_t)a[k] - (int64_t)((uint64_t)q * Pl.l[k]) + carry;
+        a[k] = k < 8 ? (uint32_t)v & F29_MASK : (uint32_t)v;
+        carry = v >> 29;
+    }
+}
+
 // bits [LO, LO+32) of the integer with normalised base-2^29 digits d[0..8]
 template <int LO>
 ZKC_HD uint32_t f29_word(const uint32_t d[9]) {

@@ -25,22 +25,7 @@ struct Dom29G2 {
     static constexpr L9 D25 = f29_dominator<P>(1u << 29, 1u << 25);
     static constexpr L9 D26 = f29_dominator<P>(1u << 29, 1u << 26);
     static constexpr L9 D27x3 = f29_dominator<P>(3u << 29, 1u << 27);
-    static constexpr uint32_t ptop1 = (FqParams::p[7] >> 8) + 1;                    // floor(p / 2^232) + 1
-    static constexpr uint32_t qmagic = (uint32_t)((1ull << 50) / ptop1);           // q = t * qmagic >> 50 <= floor(t / ptop1)
 };
-
-// carried value below 64 p  ->  carried value below 3 p, same residue
-ZKC_HD void f29_reduce_small(uint32_t a[9]) {
-    constexpr L9 Pl = F29K<FqParams>::p;
-    const uint32_t q = (uint32_t)(((uint64_t)a[8] * Dom29G2::qmagic) >> 50);      // never above floor(value / p)
-    int64_t carry = 0;
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-        const int64_t v = (int64_t)a[k] - (int64_t)((uint64_t)q * Pl.l[k]) + carry;
-        a[k] = k < 8 ? (uint32_t)v & F29_MASK : (uint32_t)v;
-        carry = v >> 29;
-    }
-}
 
 ZKC_HD void f29g2_mul(F2x29& r, const F2x29& a, const F2x29& b) {
     typedef FqParams P;
@@ -83,12 +68,12 @@ ZKC_HD bool f29g2_madd(Acc29G2& acc, const F2x29& x2, const F2x29& y2, bool& sam
         acc.X.c0[k] = U.c0[k] + Dom29G2::D27x3.l[k] - PPP.c0[k] - 2 * Q.c0[k];
         acc.X.c1[k] = U.c1[k] + Dom29G2::D27x3.l[k] - PPP.c1[k] - 2 * Q.c1[k];
     }
-    f29_carry(acc.X.c0); f29_reduce_small(acc.X.c0); f29_carry(acc.X.c1); f29_reduce_small(acc.X.c1);
+    f29_carry(acc.X.c0); f29_reduce_small<FqParams>(acc.X.c0); f29_carry(acc.X.c1); f29_reduce_small<FqParams>(acc.X.c1);
     f29_sub(W.c0, Q.c0, acc.X.c0, Dom29G2::D24); f29_carry(W.c0); f29_sub(W.c1, Q.c1, acc.X.c1, Dom29G2::D24); f29_carry(W.c1);
     f29g2_mul(U, Rn, W);                                                // T
     f29g2_mul(Q, acc.Y, PPP);                                           // V
-    f29_sub(acc.Y.c0, U.c0, Q.c0, Dom29G2::D25); f29_carry(acc.Y.c0); f29_reduce_small(acc.Y.c0);
-    f29_sub(acc.Y.c1, U.c1, Q.c1, Dom29G2::D25); f29_carry(acc.Y.c1); f29_reduce_small(acc.Y.c1);
+    f29_sub(acc.Y.c0, U.c0, Q.c0, Dom29G2::D25); f29_carry(acc.Y.c0); f29_reduce_small<FqParams>(acc.Y.c0);
+    f29_sub(acc.Y.c1, U.c1, Q.c1, Dom29G2::D25); f29_carry(acc.Y.c1); f29_reduce_small<FqParams>(acc.Y.c1);
     f29g2_mul(U, acc.ZZ, PP); acc.ZZ = U;
     f29g2_mul(U, acc.ZZZ, PPP); acc.ZZZ = U;
     return true;

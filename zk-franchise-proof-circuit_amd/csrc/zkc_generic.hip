@@ -19,7 +19,7 @@ Fr root_of_unity(int logn) {            // 5^((r-1)/2^28) squared down to order 
     for (int i = 28; i > logn; i--) w = w * w;
     return w;
 }
-struct TwiddleSet { Fr *fwd = nullptr, *inv = nullptr, *ninv = nullptr; };
+struct TwiddleSet { uint32_t *fwd = nullptr, *inv = nullptr; Fr* ninv = nullptr; };
 std::map<std::pair<zkc_ctx*, int>, TwiddleSet> g_tw;      // per (context, log n); lives as long as the process (a few MB)
 
 __global__ void __launch_bounds__(256) zkc_fill_fr(Fr* __restrict__ dst, Fr v, uint32_t n) {
@@ -70,10 +70,14 @@ extern "C" int zkc_ntt_dev(zkc_ctx* ctx, const void* d_src, void* d_dst, int log
         const Fr w = root_of_unity(logn), wi = fp_inv<FrParams>(w);
         std::vector<Fr> f(n / 2), b(n / 2);
         f[0] = b[0] = Fr::one(); for (uint32_t i = 1; i < n / 2; i++) { f[i] = f[i - 1] * w; b[i] = b[i - 1] * wi; }
-        ZKC_HIP_CHECK(ctx, hipMalloc((void**)&t.fwd, (size_t)(n / 2) * sizeof(Fr))); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&t.inv, (size_t)(n / 2) * sizeof(Fr)));
+        Fr* d_tmp = nullptr; int rc;
+        ZKC_HIP_CHECK(ctx, hipMalloc((void**)&d_tmp, (size_t)(n / 2) * sizeof(Fr)));
         ZKC_HIP_CHECK(ctx, hipMalloc((void**)&t.ninv, (size_t)n * sizeof(Fr)));
-        ZKC_HIP_CHECK(ctx, hipMemcpy(t.fwd, f.data(), f.size() * sizeof(Fr), hipMemcpyHostToDevice));
-        ZKC_HIP_CHECK(ctx, hipMemcpy(t.inv, b.data(), b.size() * sizeof(Fr), hipMemcpyHostToDevice));
+        ZKC_HIP_CHECK(ctx, hipMemcpy(d_tmp, f.data(), f.size() * sizeof(Fr), hipMemcpyHostToDevice));
+        if ((rc = ntt_make_tw29(ctx, d_tmp, n / 2, &t.fwd))) return rc;
+        ZKC_HIP_CHECK(ctx, hipMemcpy(d_tmp, b.data(), b.size() * sizeof(Fr), hipMemcpyHostToDevice));
+        if ((rc = ntt_make_tw29(ctx, d_tmp, n / 2, &t.inv))) return rc;
+        ZKC_HIP_CHECK(ctx, hipFree(d_tmp));
         hipLaunchKernelGGL(zkc_fill_fr, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, t.ninv, fp_inv<FrParams>(fp_from_u32<FrParams>(n)), n);
         ZKC_HIP_CHECK(ctx, hipGetLastError());
     }

@@ -10,6 +10,7 @@
 // All vectors are Montgomery-form Fr, 32 B per element, natural order in HBM.
 #include "zkc_internal.h"
 #include "zkc_prover.h"
+#include "zkc_f29.h"
 
 namespace zkc {
 
@@ -76,16 +77,31 @@ zkc_join_abc(const Fr* __restrict__ abc, uint32_t* __restrict__ p_std, int n) {
 
 // ---- one NTT pass: stages s0+1 .. s0+b of a DIT transform of size 2^logn ----
 // index i = (hi | mid | lo), mid = b bits at position s0, lo = s0 bits.  A block owns tile (hi, lo in [lo0, lo0+LO_T)).
-// tw[j] = w_n^j (or w_n^-j), j < n/2.  first pass (s0 == 0): loads src[bitrev(i)]; otherwise loads src[i] (src may == dst).
+// first pass (s0 == 0): loads src[bitrev(i)]; otherwise loads src[i] (src may == dst).
 // scale != nullptr: multiply element i by scale[i] when storing (used on the last pass of the inverse transform).
-constexpr int NTT_TILE = 1024;        // elements per block tile = 32 KiB of LDS
+//
+// Inside the tile every element is nine 29-bit limbs in R' = 2^261 form (zkc_f29.h): a loaded element enters as 32 x value (< 32 p); a
+// butterfly is t = v w (81 + 81 mads, < 1.7 p because the twiddle is < 1.2 p), u + t and u - t + D24, each carried -- no conditional
+// subtraction anywhere; magnitudes grow by at most 6.3 p per stage (< 90 p after nine, capacity 169 p) and are brought back below 3 p
+// (or multiplied by the scale factor) before the exact division by 32 that returns the 8 x u32 form.  tw29[j] = w^j (or w^-j), j < n/2,
+// in that limb form, 12 words per entry (zkc_tw29).
+constexpr int NTT_TILE = 1024;        // elements per block tile = 36 KiB of LDS
+constexpr int TW29_WORDS = 12;
+extern "C" __global__ void __launch_bounds__(256) zkc_tw29(const Fr* __restrict__ tw, uint32_t* __restrict__ out, uint32_t count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const Fr x = ld_fr(tw + i);
+    uint32_t t[9], r[9]; f29_from_fp_shl5(t, x.v); f29_mul<FrParams>(r, t, F29K<FrParams>::one.l);       // < 1.2 p
+    uint4* o = reinterpret_cast<uint4*>(out + (size_t)TW29_WORDS * i);
+    o[0] = make_uint4(r[0], r[1], r[2], r[3]); o[1] = make_uint4(r[4], r[5], r[6], r[7]); o[2] = make_uint4(r[8], 0, 0, 0);
+}
+struct NttDom { static constexpr L9 D24 = f29_dominator<FrParams>(1u << 29, 1u << 24); };
 extern "C" __global__ void __launch_bounds__(256)
-zkc_ntt_pass(const Fr* __restrict__ src_all, Fr* __restrict__ dst_all, const Fr* __restrict__ tw, const Fr* __restrict__ scale,
+zkc_ntt_pass(const Fr* __restrict__ src_all, Fr* __restrict__ dst_all, const uint32_t* __restrict__ tw29, const Fr* __restrict__ scale,
              int logn, int s0, int b, int first) {
     const Fr* __restrict__ src = src_all + ((size_t)blockIdx.y << logn);      // blockIdx.y = vector of the batch
     Fr* __restrict__ dst = dst_all + ((size_t)blockIdx.y << logn);
-    extern __shared__ uint4 lds4[];
-    Fr* tile = reinterpret_cast<Fr*>(lds4);
+    extern __shared__ uint32_t tile[];                                      // 9 words per element (odd stride: conflict-free)
     const int mid_n = 1 << b;
     const int lo_bits = s0;
     const int lo_t = (NTT_TILE >> b) < (1 << lo_bits) ? (NTT_TILE >> b) : (1 << lo_bits);   // neighbouring lo per tile
@@ -98,7 +114,10 @@ zkc_ntt_pass(const Fr* __restrict__ src_all, Fr* __restrict__ dst_all, const Fr*
         const int mid = e / lo_t, l = e - mid * lo_t;
         size_t gi = base + ((size_t)mid << s0) + lo0 + l;
         if (first) gi = __brev((unsigned)gi) >> (32 - logn);
-        tile[e] = ld_fr(src + gi);
+        const Fr x = ld_fr(src + gi);
+        uint32_t t[9]; f29_from_fp_shl5(t, x.v);
+#pragma unroll
+        for (int k = 0; k < 9; k++) tile[9 * e + k] = t[k];
     }
     __syncthreads();
     for (int t = 1; t <= b; t++) {
@@ -109,23 +128,47 @@ zkc_ntt_pass(const Fr* __restrict__ src_all, Fr* __restrict__ dst_all, const Fr*
             const int j = pr & (half - 1), blk = pr >> (t - 1);
             const int m0 = (blk << t) + j, m1 = m0 + half;
             const unsigned k = ((unsigned)j << s0) + lo0 + l;     // butterfly index within the half-block of size 2^(s-1)
-            const Fr w = ld_fr(tw + ((size_t)k << (logn - s)));
-            Fr u = tile[m0 * lo_t + l], v = tile[m1 * lo_t + l] * w;
-            tile[m0 * lo_t + l] = u + v; tile[m1 * lo_t + l] = u - v;
+            const uint4* wp = reinterpret_cast<const uint4*>(tw29 + (size_t)TW29_WORDS * ((size_t)k << (logn - s)));
+            const uint4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+            const uint32_t w[9] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x};
+            uint32_t* pu = tile + 9 * (m0 * lo_t + l); uint32_t* pv = tile + 9 * (m1 * lo_t + l);
+            uint32_t u[9], v[9], tt[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) { u[i] = pu[i]; v[i] = pv[i]; }
+            f29_mul<FrParams>(tt, v, w);
+#pragma unroll
+            for (int i = 0; i < 9; i++) { v[i] = u[i] + NttDom::D24.l[i] - tt[i]; u[i] += tt[i]; }
+            f29_carry(u); f29_carry(v);
+#pragma unroll
+            for (int i = 0; i < 9; i++) { pu[i] = u[i]; pv[i] = v[i]; }
         }
         __syncthreads();
     }
     for (int e = threadIdx.x; e < elems; e += blockDim.x) {
         const int mid = e / lo_t, l = e - mid * lo_t;
         const size_t gi = base + ((size_t)mid << s0) + lo0 + l;
-        Fr r = tile[e];
-        if (scale) r = r * ld_fr(scale + gi);
-        st_fr(dst + gi, r);
+        uint32_t r[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) r[k] = tile[9 * e + k];
+        if (scale) { const Fr sc = ld_fr(scale + gi); uint32_t s29[9], o[9]; f29_from_fp_shl5(s29, sc.v); f29_mul<FrParams>(o, r, s29);
+#pragma unroll
+            for (int k = 0; k < 9; k++) r[k] = o[k]; }
+        else f29_reduce_small<FrParams>(r);
+        st_fr(dst + gi, f29_to_fp<FrParams>(r));
     }
 }
 
+// twiddle table (n/2 Montgomery-form Fr, device) -> the 12-word limb form the pass kernel reads
+int ntt_make_tw29(zkc_ctx* ctx, const Fr* d_tw, uint32_t count, uint32_t** out) {
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)out, (size_t)count * TW29_WORDS * 4));
+    hipLaunchKernelGGL(zkc_tw29, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, d_tw, *out, count);
+    ZKC_HIP_CHECK(ctx, hipGetLastError());
+    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKC_OK;
+}
+
 // Full transform of `nvec` contiguous vectors src -> dst (src must differ from dst: the first pass scatters by bit reversal).
-int ntt_run(zkc_ctx* ctx, hipStream_t st, const Fr* src, Fr* dst, const Fr* tw, const Fr* scale, int logn, int nvec) {
+int ntt_run(zkc_ctx* ctx, hipStream_t st, const Fr* src, Fr* dst, const uint32_t* tw29, const Fr* scale, int logn, int nvec) {
     int s0 = 0; bool first = true;
     while (s0 < logn) {
         int b = logn - s0 < 9 ? logn - s0 : 9;
@@ -134,8 +177,8 @@ int ntt_run(zkc_ctx* ctx, hipStream_t st, const Fr* src, Fr* dst, const Fr* tw, 
         const int lo_t = (NTT_TILE >> b) < (1 << s0) ? (NTT_TILE >> b) : (1 << s0);
         const int nblocks = (1 << logn) / ((1 << b) * lo_t);
         const bool last = s0 + b == logn;
-        hipLaunchKernelGGL(zkc_ntt_pass, dim3(nblocks, nvec), dim3(256), (size_t)(1 << b) * lo_t * sizeof(Fr), st,
-                           first ? src : dst, dst, tw, last ? scale : nullptr, logn, s0, b, first ? 1 : 0);
+        hipLaunchKernelGGL(zkc_ntt_pass, dim3(nblocks, nvec), dim3(256), (size_t)(1 << b) * lo_t * 36, st,
+                           first ? src : dst, dst, tw29, last ? scale : nullptr, logn, s0, b, first ? 1 : 0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, std::string("zkc_ntt_pass: ") + hipGetErrorString(e));
         s0 += b; first = false;
