@@ -65,10 +65,10 @@ def main():
     rs = np.random.default_rng(0x5A4B43454E535553 + rank)
 
     def step():
-        ctx.witness_dev(d_inputs.data_ptr(), B, d_wtns.data_ptr(), d_status.data_ptr(), args.nlevels)
         rsa = rs.integers(0, 256, size=(2 * B, 32), dtype=np.uint8); rsa[:, 31] = 0     # r, s < 2^248 < field order
         rsb = rsa.tobytes()
-        p, pub = pk.prove_batch_dev(d_wtns.data_ptr(), B, rsb)
+        # inputs -> witness -> proof for the whole batch (groth16.fullProve per voter, ts_inputs/src/example.ts:358): one C-ABI call
+        p, pub = pk.fullprove_batch_dev(d_inputs.data_ptr(), B, d_wtns.data_ptr(), d_status.data_ptr(), rsb)
         rec = parallel.pack_records(p, pub, d_status.cpu().tolist())      # 256 B proof + 8 x 32 B signals + status per voter
         # RCCL over xGMI: the only collective -- finished proofs to every rank (513 B per voter)
         out['records'] = parallel.gather_records(rec.cuda(local), world, dist, B * world) if world > 1 else rec

@@ -74,9 +74,15 @@ int zkc_prove_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, const uin
                   uint8_t proof[256], uint8_t* public_out);
 
 /* batch form: B witnesses resident in HBM (B x nWitness x 32 B), rs = B x 64 B (r || s per proof), outputs on the host:
- * proofs B x 256 B, publics B x nPublic x 32 B (may be NULL).  Up to ZKC_INFLIGHT (default 8) proofs share one MSM
+ * proofs B x 256 B, publics B x nPublic x 32 B (may be NULL).  Up to ZKC_INFLIGHT (default 64) proofs share one MSM
  * pipeline pass.  Mirrors what a rapidsnark / snarkjs caller would loop over (zk_census_test.go:89 per voter). */
 int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, int B, const uint8_t* rs, uint8_t* proofs, uint8_t* publics);
+
+/* groth16.fullProve (ts_inputs/src/example.ts:358-362) for a batch, everything on the device: B input blocks (zkc_circuit_n_inputs x 32 B
+ * each, census.circom:51-67 order) -> witnesses (left in d_wtns: B x nWires x 32 B), per-voter circuit status in d_status (ZKC_W_*; a voter
+ * whose inputs fail a circuit assert still yields bytes in `proofs`, to be discarded by the caller) and the proofs.  The witness kernels
+ * of one pass run underneath the MSMs of the previous one.  Needs a key of ZkFranchiseProofCircuit(nLevels) shape. */
+int zkc_fullprove_batch_dev(zkc_zkey* zk, const void* d_inputs, int B, void* d_wtns, int32_t* d_status, const uint8_t* rs, uint8_t* proofs, uint8_t* publics);
 
 /* ---- the rapidsnark entry point (go-rapidsnark prover.h `groth16_prover`, reached from prover.Prove at
  * zk_census_test.go:89): whole .zkey and .wtns file images in, NUL-terminated proof / public-signal JSON out.

@@ -216,3 +216,39 @@ def test_max_levels_nl252_config5(env):
         rc, op, opub = ol.prove(zk, w, 111, 222)
         assert rc == 0 and p == op and pub == opub
         assert ol.verify(vk, pub, p)
+
+
+def test_fullprove_batch_equals_witness_then_prove(env):
+    """zkc_fullprove_batch_dev pipelines witness generation under the MSMs; bytes must equal the two-step path (and so the oracle's),
+    statuses must report a voter whose inputs fail a circuit assert, and that voter must not disturb its neighbours."""
+    ctx, get, torch = env
+    import numpy as np, zkcensus_amd
+    nl, B = 10, 150                                     # 3 passes of 64: chunk boundaries inside the batch
+    zk, pk, vk = get(nl)
+    from census_gen import random_voter
+    rng = random.Random(77)
+    voters = [random_voter(rng, ol.poseidon, nLevels=nl, depth_c=rng.randint(1, nl), depth_s=rng.randint(1, nl)) for _ in range(B)]
+    bad = 70
+    voters[bad] = dict(voters[bad]); voters[bad]['nullifier'] = str(int(voters[bad]['nullifier']) ^ 1)      # census.circom:111 assert
+    flat = b''.join(zkcensus_amd.flatten_inputs(v, nl) for v in voters)
+    d_in = dev_bytes(torch, flat)
+    nW = ctx.n_wires(nl)
+    d_w = torch.zeros(B * nW * 32, dtype=torch.uint8, device='cuda'); d_st = torch.zeros(B, dtype=torch.int32, device='cuda')
+    rs = b''.join(rng.randrange(1 << 248).to_bytes(32, 'little') for _ in range(2 * B))
+    p1, pub1 = pk.fullprove_batch_dev(d_in.data_ptr(), B, d_w.data_ptr(), d_st.data_ptr(), rs)
+    st = d_st.cpu().tolist()
+    assert st[bad] != 0 and all(x == 0 for i, x in enumerate(st) if i != bad)
+    ws, st2 = ctx.witness(voters, nLevels=nl)
+    assert st2 == st
+    got_w = d_w.cpu().numpy().tobytes()
+    for i in (0, 63, 64, 127, 128, B - 1):
+        assert got_w[i * nW * 32:(i + 1) * nW * 32] == ws[i]
+    d_w2 = dev_bytes(torch, b''.join(ws))
+    p2, pub2 = pk.prove_batch_dev(d_w2.data_ptr(), B, rs)
+    good = [i for i in range(B) if i != bad]
+    assert all(p1[256 * i:256 * i + 256] == p2[256 * i:256 * i + 256] and pub1[256 * i:256 * i + 256] == pub2[256 * i:256 * i + 256] for i in good)
+    for i in (0, 64, B - 1):
+        assert ol.verify(vk, pub1[256 * i:256 * i + 256], p1[256 * i:256 * i + 256])
+        r_i = int.from_bytes(rs[64 * i:64 * i + 32], 'little'); s_i = int.from_bytes(rs[64 * i + 32:64 * i + 64], 'little')
+        rc, op, opub = ol.prove(zk, ws[i], r_i, s_i)
+        assert rc == 0 and op == p1[256 * i:256 * i + 256]

@@ -117,6 +117,13 @@ class ProvingKey:
         self.ctx._check(self._lib.zkc_prove_batch_dev(self._h, d_wtns_ptr, self.n_vars, B, bytes(rs), proofs, pubs))
         return proofs.raw, pubs.raw
 
+    def fullprove_batch_dev(self, d_inputs_ptr, B, d_wtns_ptr, d_status_ptr, rs):
+        """groth16.fullProve for a batch on the device: inputs (B x 334 x 32 B) -> witnesses (left in d_wtns), status (d_status) and proofs;
+        witness generation of one pass overlaps the MSMs of the previous one.  Returns (proofs, publics) like prove_batch_dev."""
+        proofs = ctypes.create_string_buffer(256 * B); pubs = ctypes.create_string_buffer(32 * self.n_public * B)
+        self.ctx._check(self._lib.zkc_fullprove_batch_dev(self._h, d_inputs_ptr, B, d_wtns_ptr, d_status_ptr, bytes(rs), proofs, pubs))
+        return proofs.raw, pubs.raw
+
     def debug_stage(self, d_wtns_ptr, stage):
         out = ctypes.create_string_buffer((96 if stage == 0 else 32) * self.domain_size)
         self.ctx._check(self._lib.zkc_debug_stage(self._h, d_wtns_ptr, stage, out))

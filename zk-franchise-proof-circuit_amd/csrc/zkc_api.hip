@@ -189,6 +189,15 @@ static int witness_dev3(zkc_ctx* ctx, const WitnessLayout& L, const void* d_inpu
     return ZKC_OK;
 }
 
+// one chunk of voters, enqueued on ctx->stream without any synchronisation (the full-prove pipeline of zkc_prove.hip issues a chunk per pass)
+int zkc_witness_chunk_async(zkc_ctx* ctx, int nLevels, const void* d_inputs, int B, void* d_wtns, int32_t* d_status3, int32_t* d_status) {
+    WitnessLayout L = WitnessLayout::make(nLevels);
+    int rc = witness_dev3(ctx, L, d_inputs, B, d_wtns, d_status3); if (rc) return rc;
+    hipLaunchKernelGGL(zkc_status_combine, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, d_status3, d_status, B);
+    ZKC_HIP_CHECK(ctx, hipGetLastError());
+    return ZKC_OK;
+}
+
 extern "C" int zkc_witness_dev(zkc_ctx* ctx, int nLevels, const void* d_inputs, int B, void* d_wtns, int32_t* d_status) {
     if (!ctx || !d_inputs || !d_wtns || !d_status || B <= 0 || nLevels < 3 || nLevels > 252) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_witness_dev: bad argument");
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));

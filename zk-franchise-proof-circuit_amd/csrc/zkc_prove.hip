@@ -71,6 +71,7 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     if (zk->h_flags) (void)hipHostFree(zk->h_flags);
     if (zk->h_out) (void)hipHostFree(zk->h_out);
     if (zk->ev_start) (void)hipEventDestroy(zk->ev_start);
+    for (hipEvent_t e : zk->ev_chunk) (void)hipEventDestroy(e);
     for (auto& L : zk->lane) {
         for (hipStream_t q : {L.st, L.st2, L.fin}) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
         for (void* q : {(void*)L.d_abc, (void*)L.d_t, (void*)L.d_p}) if (q) (void)hipFree(q);
@@ -343,8 +344,11 @@ extern "C" int zkc_msm_debug(zkc_zkey* zk, int which, const void* d_scalars, uin
     return ZKC_OK;
 }
 
-// B witnesses resident in HBM -> B proofs.  rs: B x 64 B (r || s).  proofs: B x 256 B, publics: B x nPublic x 32 B (host).
-extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, int B, const uint8_t* rs, uint8_t* proofs, uint8_t* publics) {
+// d_inputs != nullptr: the witnesses are computed here as well, a chunk per pass on ctx->stream, so that the (latency-bound, few-wave)
+// witness kernels of pass p+1 run underneath the MSMs of pass p
+int zkc_witness_chunk_async(zkc_ctx* ctx, int nLevels, const void* d_inputs, int B, void* d_wtns, int32_t* d_status3, int32_t* d_status);
+static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, int B, const uint8_t* rs, uint8_t* proofs, uint8_t* publics,
+                            const void* d_inputs, int32_t* d_status) {
     if (!zk || !d_wtns || !rs || !proofs || B <= 0) return zkc_fail(zk ? zk->ctx : nullptr, ZKC_ERR_BAD_ARG, "zkc_prove_batch_dev: bad argument");
     zkc_ctx* ctx = zk->ctx;
     if (nWitness != zk->nVars) return zkc_fail(ctx, ZKC_ERR_INVALID_WITNESS_LENGTH, "Invalid witness length. Circuit: " + std::to_string(zk->nVars) + ", witness: " + std::to_string(nWitness));
@@ -361,26 +365,51 @@ extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nW
     }
     uint8_t* const h_pub = zk->h_out + 256ull * zk->rs_cap;      // results land in pinned memory so that no copy blocks the enqueueing thread
     ZKC_HIP_CHECK(ctx, hipMemcpyAsync(zk->d_rs, rs, 64 * (size_t)B, hipMemcpyHostToDevice, st0));
-    if (can_fold) {       // which levels of every witness differ from the voter-independent template?  one check for the whole batch
+    // per pass (chunk of max_inflight proofs), all enqueued now on st0: [witness kernels] -> fold check (which levels of the witness differ
+    // from the voter-independent template?) -> flags to the host -> event.  The pass loop below waits for a chunk's event only.
+    uint32_t* tmpl = nullptr;
+    if (can_fold) {
         L = WitnessLayout::make(zk->nLevels);
         if ((rc = fold_prepare(zk))) return rc;
-        uint32_t* tmpl = zkc_get_template(ctx, zk->nLevels); if (!tmpl) return ZKC_ERR_HIP;
+        tmpl = zkc_get_template(ctx, zk->nLevels); if (!tmpl) return ZKC_ERR_HIP;
         const size_t nflags = (size_t)B * 2 * L.n;
         if (zk->flags_cap < nflags) {
             if (zk->d_flags) { ZKC_HIP_CHECK(ctx, hipFree(zk->d_flags)); ZKC_HIP_CHECK(ctx, hipHostFree(zk->h_flags)); zk->d_flags = zk->h_flags = nullptr; }
             ZKC_HIP_CHECK(ctx, hipMalloc((void**)&zk->d_flags, nflags * 4)); ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&zk->h_flags, nflags * 4)); zk->flags_cap = nflags;
         }
-        hipLaunchKernelGGL(zkc_fold_check, dim3(L.n, 2, B), dim3(64), 0, st0, L, (const uint32_t*)d_wtns, tmpl, zk->d_flags, B);
-        ZKC_HIP_CHECK(ctx, hipGetLastError());
-        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(zk->h_flags, zk->d_flags, nflags * 4, hipMemcpyDeviceToHost, st0));
-        ZKC_HIP_CHECK(ctx, hipStreamSynchronize(st0));
     }
-    ZKC_HIP_CHECK(ctx, hipEventRecord(zk->ev_start, st0));                      // wtns, rs ready
-    for (int l = 0; l < zk->nlanes; l++) { ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(zk->lane[l].st, zk->ev_start, 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(zk->lane[l].st2, zk->ev_start, 0)); zk->lane[l].npass = 0; }
+    const int npasses = (B + zk->max_inflight - 1) / zk->max_inflight;
+    while ((int)zk->ev_chunk.size() < npasses) { hipEvent_t e; ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); zk->ev_chunk.push_back(e); }
+    int32_t* d_status3 = nullptr;
+    if (d_inputs) {
+        if ((rc = zkc_ensure(ctx, (void**)&ctx->d_status3, &ctx->status3_n, (size_t)B * 3 * sizeof(int32_t)))) return rc;
+        d_status3 = ctx->d_status3;
+    }
+    static const int wgroup = [] { const char* e = getenv("ZKC_WITNESS_GROUP"); return e ? std::max(1, atoi(e)) : 4; }();
+    for (int c = 0; c < npasses; c++) {
+        const int p0 = c * zk->max_inflight, nb = std::min(zk->max_inflight, B - p0);
+        uint32_t* wc = (uint32_t*)d_wtns + (size_t)p0 * nv * 8;
+        // the chain kernel is a latency chain (one lane per Merkle path, ~14 ms alone whatever the batch, several times that while the MSMs
+        // own the SIMDs): one launch covers the voters of ZKC_WITNESS_GROUP passes so that it never becomes the pipeline's pace
+        if (d_inputs && c % wgroup == 0) {
+            const int g0 = p0, gn = std::min(wgroup * zk->max_inflight, B - g0);
+            if ((rc = zkc_witness_chunk_async(ctx, zk->nLevels, (const uint8_t*)d_inputs + (size_t)g0 * L.nInputs * 32, gn, wc, d_status3 + 3 * (size_t)g0, d_status + g0))) return rc;
+        }
+        if (can_fold) {
+            uint32_t* fl = zk->d_flags + (size_t)p0 * 2 * L.n;
+            hipLaunchKernelGGL(zkc_fold_check, dim3(L.n, 2, nb), dim3(64), 0, st0, L, (const uint32_t*)wc, tmpl, fl, nb);
+            ZKC_HIP_CHECK(ctx, hipGetLastError());
+            ZKC_HIP_CHECK(ctx, hipMemcpyAsync(zk->h_flags + (size_t)p0 * 2 * L.n, fl, (size_t)nb * 2 * L.n * 4, hipMemcpyDeviceToHost, st0));
+        }
+        ZKC_HIP_CHECK(ctx, hipEventRecord(zk->ev_chunk[c], st0));                // wtns of this chunk (and rs) ready, flags on the host
+    }
+    for (int l = 0; l < zk->nlanes; l++) zk->lane[l].npass = 0;
     int pass = 0;
     for (int p0 = 0; p0 < B; p0 += zk->max_inflight, pass++) {
         const int nb = std::min(zk->max_inflight, B - p0);
         zkc_lane& LN = zk->lane[pass % zk->nlanes]; const int slot = LN.npass & 1;       // MSM results are double-buffered: the blinding of pass k overlaps pass k+1
+        ZKC_HIP_CHECK(ctx, hipEventSynchronize(zk->ev_chunk[pass]));              // host: this chunk's fold flags have arrived
+        ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(LN.st, zk->ev_chunk[pass], 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(LN.st2, zk->ev_chunk[pass], 0));
         hipStream_t st = LN.st, st2 = LN.st2, fin = LN.fin;
         const uint32_t* w0 = (const uint32_t*)d_wtns + (size_t)p0 * nv * 8;
         int Dc = 0, Ds = 0; bool fold = can_fold;
@@ -438,6 +467,18 @@ extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nW
     memcpy(proofs, zk->h_out, 256ull * B);
     if (publics) memcpy(publics, h_pub, 32ull * np * B);
     return ZKC_OK;
+}
+
+// B witnesses resident in HBM -> B proofs.  rs: B x 64 B (r || s).  proofs: B x 256 B, publics: B x nPublic x 32 B (host).
+extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, int B, const uint8_t* rs, uint8_t* proofs, uint8_t* publics) {
+    return prove_batch_impl(zk, d_wtns, nWitness, B, rs, proofs, publics, nullptr, nullptr);
+}
+// groth16.fullProve for a batch: B input blocks (334 x 32 B each, census.circom:51-67 order) resident in HBM -> witnesses (left in d_wtns,
+// B x nWires x 32 B), per-voter circuit status (d_status, ZKC_W_*) and proofs.  Witness generation of pass p+1 overlaps the MSMs of pass p.
+extern "C" int zkc_fullprove_batch_dev(zkc_zkey* zk, const void* d_inputs, int B, void* d_wtns, int32_t* d_status, const uint8_t* rs, uint8_t* proofs, uint8_t* publics) {
+    if (!zk || !d_inputs || !d_status) return zkc_fail(zk ? zk->ctx : nullptr, ZKC_ERR_BAD_ARG, "zkc_fullprove_batch_dev: bad argument");
+    if (zk->nLevels < 0) return zkc_fail(zk->ctx, ZKC_ERR_BAD_ARG, "zkc_fullprove_batch_dev: the key is not a ZkFranchiseProofCircuit(nLevels) key; compute the witness elsewhere and call zkc_prove_batch_dev");
+    return prove_batch_impl(zk, d_wtns, zk->nVars, B, rs, proofs, publics, d_inputs, d_status);
 }
 
 extern "C" int zkc_prove_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, const uint8_t r32[32], const uint8_t s32[32],

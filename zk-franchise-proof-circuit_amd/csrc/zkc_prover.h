@@ -97,7 +97,7 @@ struct zkc_zkey {
     zkc::G1Affine *d_tblDelta1 = nullptr, *d_tblAlpha1 = nullptr, *d_tblBeta1 = nullptr; zkc::G2Affine* d_tblDelta2 = nullptr;
     uint8_t *d_rs = nullptr, *d_proofs = nullptr; size_t rs_cap = 0;        // [B][64], [B][256]
     uint8_t* h_out = nullptr;                                               // pinned: [B][256] proofs then [B][nPub][32] public signals (async D2H target)
-    hipEvent_t ev_start = nullptr;
+    hipEvent_t ev_start = nullptr; std::vector<hipEvent_t> ev_chunk;        // ev_chunk[p]: witness (if made here) and fold flags of pass p are ready
     // constant folding of the voter-independent witness part (SURVEY.md hard part 4)
     struct Fold {
         std::vector<zkc::G1XYZZ> baseA, baseB1, baseC; std::vector<zkc::G2XYZZ> baseB2;        // [1]
