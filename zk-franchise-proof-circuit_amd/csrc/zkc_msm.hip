@@ -491,7 +491,7 @@ static const bool g_debug_sync = getenv("ZKC_DEBUG_SYNC") != nullptr;   // seria
                     hipGetErrorString(_e)); fflush(stderr); } } while (0)
 
 template <class F>
-static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJobList& jl, int slot, bool to_host, hipStream_t st) {
+static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJobList& jl, int slot, bool to_host, hipStream_t st, hipEvent_t ev_sorted) {
     zkc_ctx* ctx = zk->ctx;
     const int nj = jl.njobs;
     if (nj <= 0 || nj > w.max_jobs) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: job count");
@@ -537,6 +537,7 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
         if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, "exclusive_scan");
         hipLaunchKernelGGL(zkc_msm_seg2bucket, dim3((nb + 255) / 256), dim3(256), 0, st, w.segoff, nb, w.seg2bucket, (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_seg2bucket");
+        if (ev_sorted) ZKC_HIP_CHECK(ctx, hipEventRecord(ev_sorted, st));          // the short kernels of this pass are through: what follows is long-running
     }
     XYZZ<F>* partial = reinterpret_cast<XYZZ<F>*>(w.partial);
     XYZZ<F>* wres = reinterpret_cast<XYZZ<F>*>(w.wres);
@@ -585,7 +586,7 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     if (to_host) ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.h_results, results, (size_t)nj * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
     return ZKC_OK;
 }
-int msm_pass_g1(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st) { return msm_pass<Fq>(zk, w, zk->d_g1, jl, slot, to_host, st); }
-int msm_pass_g2(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st) { return msm_pass<Fq2>(zk, w, zk->d_g2, jl, slot, to_host, st); }
+int msm_pass_g1(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st, hipEvent_t ev_sorted) { return msm_pass<Fq>(zk, w, zk->d_g1, jl, slot, to_host, st, ev_sorted); }
+int msm_pass_g2(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st) { return msm_pass<Fq2>(zk, w, zk->d_g2, jl, slot, to_host, st, nullptr); }
 
 }  // namespace zkc

@@ -72,7 +72,7 @@ struct zkc_lane {
     hipStream_t st = nullptr, st2 = nullptr, fin = nullptr;               // buildABC/NTT/G1 MSM ; G2 MSM ; blinding + D2H
     zkc::Fr *d_abc = nullptr, *d_t = nullptr; uint32_t* d_p = nullptr;   // [inflight][3n] x2 (d_t = NTT scratch), [inflight][n x 8]
     zkc::MsmWork w1, w2;                                                  // G1 and G2 pipelines
-    hipEvent_t ev_msm = nullptr, ev_msm2 = nullptr, ev_fin[2] = {nullptr, nullptr}; int npass = 0;      // ev_fin[slot]: blinding of the pass that used result slot `slot`
+    hipEvent_t ev_msm = nullptr, ev_msm2 = nullptr, ev_sorted = nullptr, ev_fin[2] = {nullptr, nullptr}; int npass = 0;      // ev_fin[slot]: blinding of the pass that used result slot `slot`
 };
 
 struct zkc_zkey {
@@ -116,7 +116,8 @@ int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, size_t max_buck
 void msm_work_free(MsmWork& w);
 // runs all jobs of `jl` through one pipeline pass; results (XYZZ per job) go to device slot `slot` (0/1) of w.results and, when
 // to_host is set, to w.h_results (valid after the caller syncs the stream)
-int msm_pass_g1(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st);
+// ev_sorted (optional): recorded on st once the digit/sort/segment kernels are through, i.e. right before the long accumulation kernel
+int msm_pass_g1(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st, hipEvent_t ev_sorted = nullptr);
 int msm_pass_g2(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st);
 int finalize_launch(zkc_ctx* ctx, hipStream_t st, const FinalizeArgs& a, int nproofs);
 int msm_precompute_g1(zkc_ctx* ctx, uint32_t count, G1Affine* d_table, int c);   // d_table[0..count) = base on entry
