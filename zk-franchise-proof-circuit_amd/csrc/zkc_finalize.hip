@@ -36,7 +36,8 @@ zkc_finalize(FinalizeArgs a) {
     { const uint4* p = reinterpret_cast<const uint4*>(a.rs + 64 * (size_t)q); uint4 x = p[0], y = p[1], z = p[2], w = p[3];
       r[0] = x.x; r[1] = x.y; r[2] = x.z; r[3] = x.w; r[4] = y.x; r[5] = y.y; r[6] = y.z; r[7] = y.w;
       s[0] = z.x; s[1] = z.y; s[2] = z.z; s[3] = z.w; s[4] = w.x; s[5] = w.y; s[6] = w.z; s[7] = w.w; }
-    const G1XYZZ A = xyzz_add(a.r1[4 * q + 0], a.kA), B1 = xyzz_add(a.r1[4 * q + 1], a.kB1);
+    const int nq = gridDim.x;                         // results of a pass: H_0 .. H_{nq-1}, then A_q, B1_q, C_q per proof
+    const G1XYZZ A = xyzz_add(a.r1[nq + 3 * q + 0], a.kA), B1 = xyzz_add(a.r1[nq + 3 * q + 1], a.kB1);
     if (lane < 2) sh[lane] = xyzz_mul(lane == 0 ? A : B1, lane == 0 ? s : r);            // s A' , r B1'
     else if (lane < 7) {
         uint32_t k[8];
@@ -54,7 +55,7 @@ zkc_finalize(FinalizeArgs a) {
         G1Affine p = xyzz_to_affine(xyzz_add(xyzz_add_affine(A, a.alpha1), sh[2]));
         store_fq_std(out, p.x); store_fq_std(out + 32, p.y);
     } else if (lane == 1) {     // piC = C' + H + s A' + s alpha + r B1' + r beta1 + rs delta
-        G1XYZZ c = xyzz_add(xyzz_add(a.r1[4 * q + 2], a.kC), a.r1[4 * q + 3]);
+        G1XYZZ c = xyzz_add(xyzz_add(a.r1[nq + 3 * q + 2], a.kC), a.r1[q]);
         c = xyzz_add(c, sh[0]); c = xyzz_add(c, sh[5]); c = xyzz_add(c, sh[1]); c = xyzz_add(c, sh[6]); c = xyzz_add(c, sh[4]);
         G1Affine p = xyzz_to_affine(c);
         store_fq_std(out + 192, p.x); store_fq_std(out + 224, p.y);

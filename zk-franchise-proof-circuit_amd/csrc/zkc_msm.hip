@@ -50,7 +50,7 @@ template <class BB> struct PointIO<Fq2T<BB>> {
 
 // ---- K4 ----
 extern "C" __global__ void __launch_bounds__(256)
-zkc_msm_digits(const MsmJobList* __restrict__ jlp, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+zkc_msm_digits(const MsmJobList* __restrict__ jlp, uint16_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     const int j = blockIdx.y;
     const MsmJobList& jl = *jlp;
     const MsmJob job = jl.job[j];
@@ -59,8 +59,9 @@ zkc_msm_digits(const MsmJobList* __restrict__ jlp, uint32_t* __restrict__ keys, 
     const uint32_t wire = job.vmap ? job.vmap[i] : i;
     const uint4* sp = reinterpret_cast<const uint4*>(job.scalars + 8 * (size_t)wire); uint4 a = sp[0], b = sp[1];
     const uint32_t s[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    const uint32_t pt = job.tbl_off + (uint32_t)((int32_t)wire - job.pt_shift);
+    const uint32_t pt = (uint32_t)((int32_t)wire - job.pt_shift);
     const uint32_t c = job.c, half = 1u << (c - 1), mask = (1u << c) - 1;
+    const uint32_t rowmask = (1u << jl.row_bits) - 1, jtag = (uint32_t)j << jl.row_bits;
     uint32_t carry = 0;
     for (uint32_t w = 0; w < job.nw; w++) {
         const uint32_t bit = w * c, li = bit >> 5, sh = bit & 31;
@@ -72,18 +73,29 @@ zkc_msm_digits(const MsmJobList* __restrict__ jlp, uint32_t* __restrict__ keys, 
         uint32_t neg = 0;
         if (d > half) { d = (1u << c) - d; neg = 1; carry = 1; } else carry = 0;
         const size_t o = (size_t)job.ent_off + (size_t)w * job.count + i;
-        keys[o] = d ? job.boff + d - 1 : jl.total_buckets;     // pre-shifted bases: digit d of every window shares bucket d; zero digits sort to the end
-        vals[o] = (pt + w * job.tbl_count) | (neg << 31);
+        // pre-shifted bases: digit d of every window shares bucket d - 1; a zero digit becomes an entry that adds nothing (row field all ones)
+        const bool park = (uint32_t)j >= jl.gjob;            // this job's zero digits can go behind the real entries
+        keys[o] = (uint16_t)(d ? d - 1 : park ? jl.gkey : 0u);
+        vals[o] = d ? ((neg << 31) | jtag | (pt + w * job.tbl_count)) : (jtag | rowmask);
     }
 }
-// off[b] = first sorted position with key >= b
+// off[id] = first sorted position whose (bucket, job) is not below id's; the job of an entry is read from its value word
 extern "C" __global__ void __launch_bounds__(256)
-zkc_msm_offsets(const uint32_t* __restrict__ keys_sorted, uint32_t total, uint32_t nbuckets, uint32_t* __restrict__ off) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > nbuckets) return;
+zkc_msm_offsets(const MsmJobList* __restrict__ jlp, const uint16_t* __restrict__ keys_sorted, const uint32_t* __restrict__ vals_sorted, uint32_t total,
+                uint32_t* __restrict__ off) {
+    const MsmJobList& jl = *jlp;
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id > jl.total_buckets) return;
+    uint32_t d = jl.gkey, j = jl.gjob;                       // id == total_buckets: where the parked zero digits begin
+    if (id < jl.total_buckets) jl.decode(id, d, j);
+    const uint32_t want = (d << 16) | j, rb = jl.row_bits;
     uint32_t lo = 0, hi = total;
-    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (keys_sorted[mid] < b) lo = mid + 1; else hi = mid; }
-    off[b] = lo;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t have = ((uint32_t)keys_sorted[mid] << 16) | ((vals_sorted[mid] & 0x7fffffffu) >> rb);
+        if (have < want) lo = mid + 1; else hi = mid;
+    }
+    off[id] = lo;
 }
 // segcnt[b] = ceil(size_b / MSM_SEG); buckets cut into more than MSM_MERGE_T segments are listed for the wave-per-bucket merge
 extern "C" __global__ void __launch_bounds__(256)
@@ -102,36 +114,10 @@ zkc_msm_seg2bucket(const uint32_t* __restrict__ segoff, uint32_t nbuckets, uint3
     for (uint32_t s = segoff[b], e = segoff[b + 1]; s < e && s < max_segments; s++) seg2bucket[s] = b;
 }
 
-// ---- K5 ----
-template <class F, int MINW>
-__global__ void __launch_bounds__(128, MINW)
-zkc_msm_accumulate(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ off,
-                   const uint32_t* __restrict__ segoff, const uint32_t* __restrict__ seg2bucket, uint32_t nbuckets,
-                   XYZZ<F>* __restrict__ partial, uint32_t max_segments) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t nseg = segoff[nbuckets]; if (nseg > max_segments) nseg = max_segments;
-    if (s >= nseg) return;
-    const uint32_t b = seg2bucket[s];
-    const uint32_t start = off[b] + (s - segoff[b]) * MSM_SEG;
-    uint32_t end = start + MSM_SEG; const uint32_t bend = off[b + 1]; if (end > bend) end = bend;
-    XYZZ<F> acc = XYZZ<F>::inf();
-    uint32_t v = vals[start];
-    Affine<F> p = PointIO<F>::load(table + (v & 0x7fffffffu));
-    for (uint32_t j = start; j < end; j++) {
-        // issue the next 64-byte gather before the ~10 field products of this addition (the loads are independent of acc)
-        const uint32_t vn = (j + 1 < end) ? vals[j + 1] : v;
-        Affine<F> pn = PointIO<F>::load(table + (vn & 0x7fffffffu));
-        if (v >> 31) p.y = fp_neg(p.y);
-        acc = xyzz_add_affine(acc, p);
-        v = vn; p = pn;
-    }
-    partial[s] = acc;
-}
-
 // ---- K5, G1: the same segment walk with the accumulator kept in radix 2^29 (zkc_f29.h, zkc_f29_g1.h) ----
 template <int MINW>
 __global__ void __launch_bounds__(128, MINW)
-zkc_msm_accumulate29(const Affine<Fq>* __restrict__ table, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ off,
+zkc_msm_accumulate29(const Affine<Fq>* __restrict__ table_all, const MsmJobList* __restrict__ jlp, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ off,
                      const uint32_t* __restrict__ segoff, const uint32_t* __restrict__ seg2bucket, uint32_t nbuckets,
                      XYZZ<Fq>* __restrict__ partial, uint32_t max_segments) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -140,13 +126,16 @@ zkc_msm_accumulate29(const Affine<Fq>* __restrict__ table, const uint32_t* __res
     const uint32_t b = seg2bucket[s];
     const uint32_t start = off[b] + (s - segoff[b]) * MSM_SEG;
     uint32_t end = start + MSM_SEG; const uint32_t bend = off[b + 1]; if (end > bend) end = bend;
+    uint32_t bd, bj; jlp->decode(b, bd, bj);
+    const Affine<Fq>* __restrict__ table = table_all + jlp->job[bj].tbl_off;      // a segment belongs to one job
+    const uint32_t rowmask = (1u << jlp->row_bits) - 1;
     Acc29 acc; bool inf = true;
     uint32_t v = vals[start];
-    Affine<Fq> p = PointIO<Fq>::load(table + (v & 0x7fffffffu));
+    Affine<Fq> p = PointIO<Fq>::load(table + ((v & rowmask) == rowmask ? 0u : (v & rowmask)));
     for (uint32_t j = start; j < end; j++) {
         const uint32_t vn = (j + 1 < end) ? vals[j + 1] : v;
-        Affine<Fq> pn = PointIO<Fq>::load(table + (vn & 0x7fffffffu));      // next gather in flight during this addition
-        if (!p.is_inf()) {
+        Affine<Fq> pn = PointIO<Fq>::load(table + ((vn & rowmask) == rowmask ? 0u : (vn & rowmask)));      // next gather in flight during this addition
+        if ((v & rowmask) != rowmask && !p.is_inf()) {
             if (v >> 31) p.y = fp_neg(p.y);
             uint32_t x2[9], y2[9];
             f29_from_fp_shl5(x2, p.x.v); f29_from_fp_shl5(y2, p.y.v);
@@ -200,7 +189,7 @@ __device__ __forceinline__ G2Chunk g2_chunk_load(const uint32_t* p) {
 }
 template <int MINW>
 __global__ void __launch_bounds__(128, MINW)
-zkc_msm_accumulate29_g2(const uint32_t* __restrict__ table29, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ off,
+zkc_msm_accumulate29_g2(const uint32_t* __restrict__ table29_all, const MsmJobList* __restrict__ jlp, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ off,
                         const uint32_t* __restrict__ segoff, const uint32_t* __restrict__ seg2bucket, uint32_t nbuckets,
                         XYZZ<Fq2>* __restrict__ partial, uint32_t max_segments) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -209,15 +198,18 @@ zkc_msm_accumulate29_g2(const uint32_t* __restrict__ table29, const uint32_t* __
     const uint32_t b = seg2bucket[s];
     const uint32_t start = off[b] + (s - segoff[b]) * MSM_SEG;
     uint32_t end = start + MSM_SEG; const uint32_t bend = off[b + 1]; if (end > bend) end = bend;
+    uint32_t bd, bj; jlp->decode(b, bd, bj);
+    const uint32_t* __restrict__ table29 = table29_all + (size_t)jlp->job[bj].tbl_off * G2T29_WORDS;
+    const uint32_t rowmask = (1u << jlp->row_bits) - 1;
     Acc29G2 acc; bool inf = true;
     uint32_t v = vals[start];
-    const uint32_t* pp = table29 + (size_t)(v & 0x7fffffffu) * G2T29_WORDS;
+    const uint32_t* pp = table29 + (size_t)((v & rowmask) == rowmask ? 0u : (v & rowmask)) * G2T29_WORDS;
     G2Chunk cx = g2_chunk_load(pp), cy = g2_chunk_load(pp + ((v >> 31) ? 40 : 20));
     for (uint32_t j = start; j < end; j++) {
         const uint32_t vn = (j + 1 < end) ? vals[j + 1] : v;
-        const uint32_t* pn = table29 + (size_t)(vn & 0x7fffffffu) * G2T29_WORDS;
+        const uint32_t* pn = table29 + (size_t)((vn & rowmask) == rowmask ? 0u : (vn & rowmask)) * G2T29_WORDS;
         const G2Chunk nx = g2_chunk_load(pn), ny = g2_chunk_load(pn + ((vn >> 31) ? 40 : 20));      // next gather in flight during this addition
-        if (!cx.w[18]) {
+        if ((v & rowmask) != rowmask && !cx.w[18]) {
             F2x29 x2, y2;
 #pragma unroll
             for (int k = 0; k < 9; k++) { x2.c0[k] = cx.w[k]; x2.c1[k] = cx.w[9 + k]; y2.c0[k] = cy.w[k]; y2.c1[k] = cy.w[9 + k]; }
@@ -280,10 +272,10 @@ zkc_msm_window(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__
     XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds4);
     const MsmWindow win = windows[blockIdx.x];
     const int PER = (int)win.per;                                         // 16 (H) or 4 (witness sections)
-    const uint32_t first = win.bucket0 + threadIdx.x * PER;
+    const uint32_t first = win.bucket0 + threadIdx.x * PER * win.stride;
     XYZZ<F> run = XYZZ<F>::inf(), loc = XYZZ<F>::inf();                   // run = sum of the lane's buckets from the top; loc = sum_k k * B_k
     for (int k = PER - 1; k >= 0; k--) {
-        uint32_t s0 = segoff[first + k], s1 = s0 + segcnt[first + k];
+        uint32_t s0 = segoff[first + k * win.stride], s1 = s0 + segcnt[first + k * win.stride];
         if (s1 > max_segments) s1 = max_segments;
         for (uint32_t s = s0; s < s1; s++) run = xyzz_add(run, partial[s]);
         loc = xyzz_add(loc, run);
@@ -318,10 +310,10 @@ zkc_msm_window29(const XYZZ<Fq>* __restrict__ partial, const uint32_t* __restric
     __shared__ Acc29 sh[64];
     const MsmWindow win = windows[blockIdx.x];
     const int PER = (int)win.per;
-    const uint32_t first = win.bucket0 + threadIdx.x * PER;
+    const uint32_t first = win.bucket0 + threadIdx.x * PER * win.stride;
     Acc29 run, loc; f29_pt_set_inf(run); f29_pt_set_inf(loc);
     for (int k = PER - 1; k >= 0; k--) {
-        uint32_t s0 = segoff[first + k], s1 = s0 + segcnt[first + k];
+        uint32_t s0 = segoff[first + k * win.stride], s1 = s0 + segcnt[first + k * win.stride];
         if (s1 > max_segments) s1 = max_segments;
         for (uint32_t s = s0; s < s1; s++) { const Acc29 q = f29_pt_from_xyzz(partial[s]); f29_pt_add(run, run, q); }
         f29_pt_add(loc, loc, run);
@@ -460,8 +452,8 @@ int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, size_t max_buck
     w.max_entries = max_entries; w.max_jobs = max_jobs; w.max_buckets = max_buckets; w.xyzz_size = g2 ? sizeof(G2XYZZ) : sizeof(G1XYZZ);
     const size_t nb = max_buckets;
     w.max_segments = max_entries / MSM_SEG + nb;        // every non-empty bucket has at most one short segment
-    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.keys, max_entries * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.vals, max_entries * 4));
-    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.keys2, max_entries * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.vals2, max_entries * 4));
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.keys, max_entries * 2 + 16)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.vals, max_entries * 4));
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.keys2, max_entries * 2 + 16)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.vals2, max_entries * 4));
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.off, (nb + 2) * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.segcnt, (nb + 2) * 4));
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.segoff, (nb + 2) * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.seg2bucket, w.max_segments * 4));
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.heavy, (MSM_MAX_HEAVY + 1) * 4));
@@ -491,10 +483,13 @@ static const bool g_debug_sync = getenv("ZKC_DEBUG_SYNC") != nullptr;   // seria
                     hipGetErrorString(_e)); fflush(stderr); } } while (0)
 
 template <class F>
-static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJobList& jl, int slot, bool to_host, hipStream_t st, hipEvent_t ev_sorted) {
+static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJobList& jl_in, int slot, bool to_host, hipStream_t st, hipEvent_t ev_sorted) {
     zkc_ctx* ctx = zk->ctx;
-    const int nj = jl.njobs;
+    const int nj = jl_in.njobs;
     if (nj <= 0 || nj > w.max_jobs) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: job count");
+    static thread_local MsmJobList jl;                  // the caller's list plus the bucket-id layout of this pass
+    jl = jl_in;
+    if (!jl.finish()) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: jobs need at most two window sizes and tables below 2^row_bits rows");
     const size_t total = jl.total_entries;
     const uint32_t nb = jl.total_buckets;
     if (total > w.max_entries || nb > w.max_buckets) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: too many entries for the work space");
@@ -510,21 +505,23 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
         zkc_prof_scope _ps(ctx, ZKC_PROF_MSM_SORT, 0, st);
         static thread_local std::vector<MsmWindow> wins;
         wins.clear();
-        for (int j = 0; j < nj; j++) for (uint32_t k = 0; k < (uint32_t)msm_half((int)jl.job[j].c) / jl.job[j].vw; k++)
-            wins.push_back(MsmWindow{jl.job[j].boff + k * jl.job[j].vw, jl.job[j].win_off + k, jl.job[j].vw / 64});
+        for (int j = 0; j < nj; j++) for (uint32_t k = 0; k < (uint32_t)msm_half((int)jl.job[j].c) / jl.job[j].vw; k++) {
+            const uint32_t d0 = k * jl.job[j].vw;              // vw divides hs: a virtual window never straddles the two id regions
+            wins.push_back(MsmWindow{jl.id_of(d0, (uint32_t)j), jl.job[j].win_off + k, jl.job[j].vw / 64, d0 < jl.hs ? (uint32_t)nj : jl.nbig});
+        }
         ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.d_jobs, &jl, sizeof(MsmJobList), hipMemcpyHostToDevice, st));   // pageable source: staged before return
         ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.d_windows, wins.data(), wins.size() * sizeof(MsmWindow), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(zkc_msm_digits, dim3((maxcount + 255) / 256, nj), dim3(256), 0, st, (const MsmJobList*)w.d_jobs, w.keys, w.vals);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_digits");
-        int end_bit = 1; while ((1ull << end_bit) <= (uint64_t)nb) end_bit++;
+        int end_bit = 1; while ((1u << end_bit) <= jl.gkey) end_bit++;     // 16 bits with an H job in the pass, 13 without
         size_t need = 0;
         hipError_t e = rocprim::radix_sort_pairs(nullptr, need, w.keys, w.keys2, w.vals, w.vals2, total, 0, end_bit, st);
         if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, "radix_sort_pairs(size)");
         int rc = zkc_ensure(ctx, &w.sort_tmp, &w.sort_tmp_sz, need); if (rc) return rc;
-        e = rocprim::radix_sort_pairs(w.sort_tmp, need, w.keys, w.keys2, w.vals, w.vals2, total, 0, end_bit, st);
+        e = rocprim::radix_sort_pairs(w.sort_tmp, need, w.keys, w.keys2, w.vals, w.vals2, total, 0, end_bit, st);     // stable: equal buckets stay in job order
         if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, "radix_sort_pairs");
         ZKC_LAUNCH_CHECK(ctx, "radix_sort_pairs");
-        hipLaunchKernelGGL(zkc_msm_offsets, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, w.keys2, (uint32_t)total, nb, w.off);
+        hipLaunchKernelGGL(zkc_msm_offsets, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const MsmJobList*)w.d_jobs, w.keys2, w.vals2, (uint32_t)total, w.off);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_offsets");
         ZKC_HIP_CHECK(ctx, hipMemsetAsync(w.heavy + MSM_MAX_HEAVY, 0, 4, st));
         hipLaunchKernelGGL(zkc_msm_segcount, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, w.off, nb, w.segcnt, w.heavy, w.heavy + MSM_MAX_HEAVY);
@@ -548,10 +545,10 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
         if (!kG2 && ((ctx->prof.mask >> ZKC_PROF_MSM_ACC_G1) & 1)) ctx->prof.bytes[ZKC_PROF_MSM_G1_STREAMED] += streamed_bytes;
         if constexpr (kG2)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate29_g2<1>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
-                               zk->d_g2_29, w.vals2, w.off, w.segoff, w.seg2bucket, nb, reinterpret_cast<XYZZ<Fq2>*>(partial), (uint32_t)w.max_segments);
+                               zk->d_g2_29, (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.segoff, w.seg2bucket, nb, reinterpret_cast<XYZZ<Fq2>*>(partial), (uint32_t)w.max_segments);
         else      // G1: same layout, field type with the inlined product
             hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate29<2>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
-                               reinterpret_cast<const Affine<Fq>*>(table), w.vals2, w.off, w.segoff, w.seg2bucket, nb,
+                               reinterpret_cast<const Affine<Fq>*>(table), (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.segoff, w.seg2bucket, nb,
                                reinterpret_cast<XYZZ<Fq>*>(partial), (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_accumulate");
     }

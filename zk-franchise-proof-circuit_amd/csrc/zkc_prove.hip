@@ -426,6 +426,9 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
         if ((rc = h_evals_dev(zk, LN, w0, nb))) return rc;
         static thread_local MsmJobList j1, j2;     // 6 KB each: kept off the stack frame of a C-ABI entry point
         j1.clear(); j2.clear();
+        // job order of the G1 pass: the nb H jobs first (the 16-bit bucket sort wants the jobs with the larger bucket count in front), then
+        // A, B1, C per proof.  zkc_finalize reads results[q] = H_q and results[nb + 3 q + {0, 1, 2}] = A_q, B1_q, C_q.
+        for (int q = 0; q < nb; q++) j1.add(LN.d_p + 8 * (size_t)n * q, nullptr, n, zk->offH, n, 0, MSM_C_BIG);
         for (int q = 0; q < nb; q++) {
             const uint32_t* w = w0 + (size_t)q * nv * 8;
             if (fold) {
@@ -439,7 +442,6 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
                 j1.add(w + 8ull * (np + 1), nullptr, nc, zk->offC, nc, 0, MSM_C_SMALL);
                 j2.add(w, nullptr, nv, 0, nv, 0, MSM_C_SMALL);
             }
-            j1.add(LN.d_p + 8 * (size_t)n * q, nullptr, n, zk->offH, n, 0, MSM_C_BIG);
         }
         // The G2 MSM needs only the witness: by default it starts with the pass and runs beside buildABC/NTT/G1 sort.  ZKC_G2_LATE holds it back
         // until the G1 stream has finished its short kernels (they were seen to stall next to the G2 chain's low-occupancy kernels); the G2

@@ -29,30 +29,69 @@ struct MsmJob {
     uint32_t tbl_count;        // points per window in that table
     int32_t pt_shift;
     uint32_t c, nw, vw;        // window bits / windows of this job's table / buckets per virtual window
-    uint32_t boff, ent_off, win_off;   // first bucket / first (scalar, window) entry / first virtual window of this job inside the pass
+    uint32_t boff, ent_off, win_off;   // index among the jobs with the larger bucket count (finish()) / first (scalar, window) entry / first virtual window of this job inside the pass
 };
 // arguments of the blinding kernel (zkc_finalize.hip); everything except r1/r2/rs/out is constant per proving key
 struct FinalizeArgs {
-    const G1XYZZ* r1; const G2XYZZ* r2;                 // MSM results of this pass: r1[4q + {A,B1,C,H}], r2[q]
+    const G1XYZZ* r1; const G2XYZZ* r2;                 // MSM results of this pass: r1[q] = H_q, r1[n + 3q + {0,1,2}] = A_q, B1_q, C_q ; r2[q]
     G1XYZZ kA, kB1, kC; G2XYZZ kB2;                     // folded constants of this pass
     const G1Affine *tblDelta1, *tblAlpha1, *tblBeta1; const G2Affine* tblDelta2;   // 32 x 255 fixed-base tables
     G1Affine alpha1; G2Affine beta2;
     const uint8_t* rs; uint8_t* out;                    // device: nproofs x 64 (r || s) -> nproofs x 256 proof bytes
 };
+// The entries of a pass are sorted by their 16-bit bucket index alone (two radix passes over 6 bytes instead of three over 8); the sort is
+// stable and the entries are generated job by job, so inside one bucket index they come out grouped by job.  Bucket ids therefore run
+// bucket-major: id(d, j) = d * njobs + j for d < hs, and hs * njobs + (d - hs) * nbig + hidx(j) above (only the jobs with the larger bucket
+// count hb exist there).  A value word is  sign(1) | job(job bits) | row relative to the job's table(row_bits); all ones in the row field
+// marks a zero digit (nothing to add); zero digits carry the key `gkey` that sorts them behind every real entry (the rare zero digit of
+// a 65536-bucket job has no such key to go to and stays in its bucket 0 as an entry that adds nothing).
 struct MsmJobList {
     MsmJob job[MSM_MAX_JOBS]; int njobs; uint32_t total_buckets, total_entries, total_windows;
+    uint32_t hs, hb, nbig, row_bits, gkey, gjob;        // set by finish(); entries with (key, job) >= (gkey, gjob) are zero digits
+    uint16_t bigjob[MSM_MAX_JOBS];                      // hidx -> job
     void add(const uint32_t* scalars, const uint32_t* vmap, uint32_t count, uint32_t tbl_off, uint32_t tbl_count, int32_t pt_shift, int c) {
         MsmJob& j = job[njobs++];
-        j = MsmJob{scalars, vmap, count, tbl_off, tbl_count, pt_shift, (uint32_t)c, (uint32_t)msm_nw(c), (uint32_t)msm_vw(c), total_buckets, total_entries, total_windows};
-        total_buckets += (uint32_t)msm_half(c); total_entries += count * (uint32_t)msm_nw(c); total_windows += (uint32_t)(msm_half(c) / msm_vw(c));
+        j = MsmJob{scalars, vmap, count, tbl_off, tbl_count, pt_shift, (uint32_t)c, (uint32_t)msm_nw(c), (uint32_t)msm_vw(c), 0, total_entries, total_windows};
+        total_entries += count * (uint32_t)msm_nw(c); total_windows += (uint32_t)(msm_half(c) / msm_vw(c));
     }
-    void clear() { njobs = 0; total_buckets = total_entries = total_windows = 0; }
+    void clear() { njobs = 0; total_buckets = total_entries = total_windows = 0; hs = hb = nbig = row_bits = gkey = gjob = 0; }
+    // false: more than two distinct window sizes, or a table too large for the row field
+    bool finish() {
+        hs = 0xffffffffu; hb = 0;
+        for (int j = 0; j < njobs; j++) { const uint32_t h = 1u << (job[j].c - 1); hs = h < hs ? h : hs; hb = h > hb ? h : hb; }
+        nbig = 0; uint32_t maxrow = 0;
+        for (int j = 0; j < njobs; j++) {
+            const uint32_t h = 1u << (job[j].c - 1);
+            if (h != hs && h != hb) return false;
+            job[j].boff = 0xffffffffu;
+            if (h == hb) { job[j].boff = nbig; bigjob[nbig++] = (uint16_t)j; }          // boff doubles as hidx
+            const uint32_t rows = job[j].nw * job[j].tbl_count; maxrow = rows > maxrow ? rows : maxrow;
+        }
+        uint32_t jb = 0; while ((1u << jb) < (uint32_t)njobs) jb++;
+        row_bits = 31 - jb;
+        if ((uint64_t)maxrow + 1 >= (1ull << row_bits)) return false;
+        total_buckets = hs * (uint32_t)njobs + (hb - hs) * nbig;
+        // zero digits sort behind everything real: key `gkey`.  With 65536 buckets there is no spare 16-bit key, so the garbage shares key
+        // 0xFFFF with the last real bucket of the big jobs and must follow them in job order: big jobs first.
+        gkey = hb < 65536u ? hb : 0xffffu; gjob = 0;
+        if (hb == 65536u) {
+            gjob = nbig;
+            for (uint32_t k = 0; k < nbig; k++) if (bigjob[k] != k) return false;
+        }
+        return true;
+    }
+    ZKC_HD uint32_t id_of(uint32_t d, uint32_t j) const { return d < hs ? d * (uint32_t)njobs + j : hs * (uint32_t)njobs + (d - hs) * nbig + job[j].boff; }
+    ZKC_HD void decode(uint32_t id, uint32_t& d, uint32_t& j) const {
+        const uint32_t lim = hs * (uint32_t)njobs;
+        if (id < lim) { d = id / (uint32_t)njobs; j = id - d * (uint32_t)njobs; }
+        else { const uint32_t t = id - lim, q = t / nbig; d = hs + q; j = bigjob[t - q * nbig]; }
+    }
 };
-struct MsmWindow { uint32_t bucket0, out, per; };   // one wave of zkc_msm_window: buckets [bucket0, bucket0 + 64 per) -> wres[2*out] (weighted), wres[2*out+1] (plain sum)
+struct MsmWindow { uint32_t bucket0, out, per, stride; };   // one wave of zkc_msm_window: the 64 per buckets bucket0 + i stride -> wres[2*out] (weighted), wres[2*out+1] (plain sum)
 
 // Work space of one pipeline pass (sized for MSM_MAX_JOBS jobs and max_entries (scalar, window) pairs)
 struct MsmWork {
-    uint32_t *keys = nullptr, *vals = nullptr, *keys2 = nullptr, *vals2 = nullptr;   // max_entries each
+    uint16_t *keys = nullptr, *keys2 = nullptr; uint32_t *vals = nullptr, *vals2 = nullptr;   // max_entries each
     uint32_t *off = nullptr;        // bucket boundaries, njobs*NB + 1
     uint32_t *segcnt = nullptr, *segoff = nullptr, *seg2bucket = nullptr, *heavy = nullptr;
     void *partial = nullptr;        // XYZZ per segment
