@@ -50,7 +50,7 @@ template <class BB> struct PointIO<Fq2T<BB>> {
 
 // ---- K4 ----
 extern "C" __global__ void __launch_bounds__(256)
-zkc_msm_digits(const MsmJobList* __restrict__ jlp, uint16_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+zkc_msm_digits(const MsmJobList* __restrict__ jlp, msm_key_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     const int j = blockIdx.y;
     const MsmJobList& jl = *jlp;
     const MsmJob job = jl.job[j];
@@ -75,13 +75,13 @@ zkc_msm_digits(const MsmJobList* __restrict__ jlp, uint16_t* __restrict__ keys, 
         const size_t o = (size_t)job.ent_off + (size_t)w * job.count + i;
         // pre-shifted bases: digit d of every window shares bucket d - 1; a zero digit becomes an entry that adds nothing (row field all ones)
         const bool park = (uint32_t)j >= jl.gjob;            // this job's zero digits can go behind the real entries
-        keys[o] = (uint16_t)(d ? d - 1 : park ? jl.gkey : 0u);
+        keys[o] = (msm_key_t)(d ? d - 1 : park ? jl.gkey : 0u);
         vals[o] = d ? ((neg << 31) | jtag | (pt + w * job.tbl_count)) : (jtag | rowmask);
     }
 }
 // off[id] = first sorted position whose (bucket, job) is not below id's; the job of an entry is read from its value word
 extern "C" __global__ void __launch_bounds__(256)
-zkc_msm_offsets(const MsmJobList* __restrict__ jlp, const uint16_t* __restrict__ keys_sorted, const uint32_t* __restrict__ vals_sorted, uint32_t total,
+zkc_msm_offsets(const MsmJobList* __restrict__ jlp, const msm_key_t* __restrict__ keys_sorted, const uint32_t* __restrict__ vals_sorted, uint32_t total,
                 uint32_t* __restrict__ off) {
     const MsmJobList& jl = *jlp;
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -452,8 +452,8 @@ int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, size_t max_buck
     w.max_entries = max_entries; w.max_jobs = max_jobs; w.max_buckets = max_buckets; w.xyzz_size = g2 ? sizeof(G2XYZZ) : sizeof(G1XYZZ);
     const size_t nb = max_buckets;
     w.max_segments = max_entries / MSM_SEG + nb;        // every non-empty bucket has at most one short segment
-    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.keys, max_entries * 2 + 16)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.vals, max_entries * 4));
-    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.keys2, max_entries * 2 + 16)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.vals2, max_entries * 4));
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.keys, max_entries * sizeof(msm_key_t) + 16)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.vals, max_entries * 4));
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.keys2, max_entries * sizeof(msm_key_t) + 16)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.vals2, max_entries * 4));
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.off, (nb + 2) * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.segcnt, (nb + 2) * 4));
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.segoff, (nb + 2) * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.seg2bucket, w.max_segments * 4));
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.heavy, (MSM_MAX_HEAVY + 1) * 4));

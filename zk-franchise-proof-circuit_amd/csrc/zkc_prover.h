@@ -45,6 +45,8 @@ struct FinalizeArgs {
 // count hb exist there).  A value word is  sign(1) | job(job bits) | row relative to the job's table(row_bits); all ones in the row field
 // marks a zero digit (nothing to add); zero digits carry the key `gkey` that sorts them behind every real entry (the rare zero digit of
 // a 65536-bucket job has no such key to go to and stays in its bucket 0 as an entry that adds nothing).
+// storage type of the 16-bit sort key (u32 storage with end_bit = 16 measured the same as u16: 0.169 vs 0.165 ms per proof for digits + sort)
+typedef uint16_t msm_key_t;
 struct MsmJobList {
     MsmJob job[MSM_MAX_JOBS]; int njobs; uint32_t total_buckets, total_entries, total_windows;
     uint32_t hs, hb, nbig, row_bits, gkey, gjob;        // set by finish(); entries with (key, job) >= (gkey, gjob) are zero digits
@@ -91,7 +93,7 @@ struct MsmWindow { uint32_t bucket0, out, per, stride; };   // one wave of zkc_m
 
 // Work space of one pipeline pass (sized for MSM_MAX_JOBS jobs and max_entries (scalar, window) pairs)
 struct MsmWork {
-    uint16_t *keys = nullptr, *keys2 = nullptr; uint32_t *vals = nullptr, *vals2 = nullptr;   // max_entries each
+    msm_key_t *keys = nullptr, *keys2 = nullptr; uint32_t *vals = nullptr, *vals2 = nullptr;   // max_entries each
     uint32_t *off = nullptr;        // bucket boundaries, njobs*NB + 1
     uint32_t *segcnt = nullptr, *segoff = nullptr, *seg2bucket = nullptr, *heavy = nullptr;
     void *partial = nullptr;        // XYZZ per segment
