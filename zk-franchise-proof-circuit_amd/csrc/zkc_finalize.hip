@@ -1,11 +1,12 @@
-// zkc_finalize.hip -- K9: the constant-size blinding step of Groth16 on the device (stage a7), one wave per proof.
+// zkc_finalize.hip -- K9: the constant-size blinding step of Groth16 on the device (stage a7), one workgroup per proof.
 //
 //   piA = alpha + A + r delta ;  piB = beta2 + B2 + s delta2 ;  piC = C + H + s piA + r piB1 - r s delta
 // (snarkjs groth16_prove.js tail / rapidsnark; reached from ts_inputs/src/example.ts:358-362, zk_census_test.go:89).
 // Expanded so that nothing depends on piA / piB1:  s piA + r piB1 - rs delta = s A' + s alpha + r B1' + r beta1 + rs delta,
-// i.e. two variable-base products (lanes 0, 1) and six fixed-base ones read from 8-bit window tables (lanes 2..7).
+// i.e. two variable-base products and six fixed-base ones read from 8-bit window tables.
 // Runs on the context's second stream so that it overlaps the next pipeline pass.
 #include "zkc_prover.h"
+#include "zkc_f29_g1.h"
 
 namespace zkc {
 
@@ -27,46 +28,73 @@ __device__ void store_fq_std(uint8_t* out, const Fq& a) {
     d[0] = make_uint4(s[0], s[1], s[2], s[3]); d[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
 
-extern "C" __global__ void __launch_bounds__(64)
+// k * P for a 254-bit k: 4-bit fixed windows over radix-2^29 coordinates (zkc_f29_g1.h): 14 additions for the table, then 64 x
+// (4 doublings + 1 addition).  tab: 16 entries in LDS owned by the calling lane.
+__device__ G1XYZZ var_mul29(const G1XYZZ& P, const uint32_t k[8], Acc29* tab) {
+    if (P.is_inf()) return P;
+    f29_pt_set_inf(tab[0]); tab[1] = f29_pt_from_xyzz(P);
+    for (int i = 2; i < 16; i++) { Acc29 t = tab[i - 1]; f29_pt_add(t, t, tab[1]); tab[i] = t; }
+    Acc29 acc; f29_pt_set_inf(acc);
+    for (int w = 63; w >= 0; w--) {
+        if (!f29_pt_is_inf(acc)) for (int d = 0; d < 4; d++) f29_pt_dbl(acc, acc);
+        uint32_t limb = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) limb = (q == (w >> 3)) ? k[q] : limb;
+        const uint32_t dg = (limb >> (4 * (w & 7))) & 15u;
+        if (dg) f29_pt_add(acc, acc, tab[dg]);
+    }
+    return f29_pt_is_inf(acc) ? G1XYZZ::inf() : f29_pt_to_xyzz(acc);
+}
+
+// One workgroup of four waves per proof, one task per wave so that the three independent latency chains run side by side:
+//   wave 0: s A' and r B1' (lanes 0, 1; variable base), then piC once everything else has arrived
+//   wave 1: r delta, s delta, rs delta, s alpha, r beta1 from the 8-bit fixed-base tables (lanes 0..4), lane 0 goes on to piA
+//   wave 2: s delta2 in G2 and piB
+extern "C" __global__ void __launch_bounds__(256)
 zkc_finalize(FinalizeArgs a) {
     __shared__ G1XYZZ sh[8];
-    __shared__ G2XYZZ sh2;
-    const int q = blockIdx.x, lane = threadIdx.x;
+    __shared__ Acc29 tab[2][16];
+    const int q = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t r[8], s[8];
     { const uint4* p = reinterpret_cast<const uint4*>(a.rs + 64 * (size_t)q); uint4 x = p[0], y = p[1], z = p[2], w = p[3];
       r[0] = x.x; r[1] = x.y; r[2] = x.z; r[3] = x.w; r[4] = y.x; r[5] = y.y; r[6] = y.z; r[7] = y.w;
       s[0] = z.x; s[1] = z.y; s[2] = z.z; s[3] = z.w; s[4] = w.x; s[5] = w.y; s[6] = w.z; s[7] = w.w; }
     const int nq = gridDim.x;                         // results of a pass: H_0 .. H_{nq-1}, then A_q, B1_q, C_q per proof
-    const G1XYZZ A = xyzz_add(a.r1[nq + 3 * q + 0], a.kA), B1 = xyzz_add(a.r1[nq + 3 * q + 1], a.kB1);
-    if (lane < 2) sh[lane] = xyzz_mul(lane == 0 ? A : B1, lane == 0 ? s : r);            // s A' , r B1'
-    else if (lane < 7) {
+    uint8_t* out = a.out + 256 * (size_t)q;
+    if (wave == 0 && lane < 2) {
+        const G1XYZZ P = lane == 0 ? xyzz_add(a.r1[nq + 3 * q + 0], a.kA) : xyzz_add(a.r1[nq + 3 * q + 1], a.kB1);
+        sh[lane] = var_mul29(P, lane == 0 ? s : r, tab[lane]);                                 // s A' , r B1'
+    } else if (wave == 1 && lane < 5) {
         uint32_t k[8];
-        if (lane == 4) { Fr rs = fp_from_std<FrParams>(r) * fp_from_std<FrParams>(s); fp_to_std<FrParams>(k, rs); }
+        if (lane == 2) { Fr rs = fp_from_std<FrParams>(r) * fp_from_std<FrParams>(s); fp_to_std<FrParams>(k, rs); }
         else {
 #pragma unroll
-            for (int i = 0; i < 8; i++) k[i] = (lane == 2 || lane == 6) ? r[i] : s[i];
+            for (int i = 0; i < 8; i++) k[i] = (lane == 0 || lane == 4) ? r[i] : s[i];
         }
-        const G1Affine* tab = lane <= 4 ? a.tblDelta1 : lane == 5 ? a.tblAlpha1 : a.tblBeta1;   // r d, s d, rs d, s alpha, r beta1
-        sh[lane] = fb_mul<Fq>(tab, k);
-    } else if (lane == 7) sh2 = fb_mul<Fq2>(a.tblDelta2, s);                                  // s delta2
+        const G1Affine* tb = lane <= 2 ? a.tblDelta1 : lane == 3 ? a.tblAlpha1 : a.tblBeta1;       // r d, s d, rs d, s alpha, r beta1
+        const G1XYZZ v = fb_mul<Fq>(tb, k);
+        sh[2 + lane] = v;
+        if (lane == 0) {        // piA = A' + alpha + r delta
+            const G1XYZZ A = xyzz_add(a.r1[nq + 3 * q + 0], a.kA);
+            G1Affine p = xyzz_to_affine(xyzz_add(xyzz_add_affine(A, a.alpha1), v));
+            store_fq_std(out, p.x); store_fq_std(out + 32, p.y);
+        }
+    } else if (wave == 2 && lane == 0) {     // piB = B2' + beta2 + s delta2
+        const G2XYZZ sd = fb_mul<Fq2>(a.tblDelta2, s);
+        G2Affine p = xyzz_to_affine(xyzz_add(xyzz_add_affine(xyzz_add(a.r2[q], a.kB2), a.beta2), sd));
+        store_fq_std(out + 64, p.x.c0); store_fq_std(out + 96, p.x.c1); store_fq_std(out + 128, p.y.c0); store_fq_std(out + 160, p.y.c1);
+    }
     __syncthreads();
-    uint8_t* out = a.out + 256 * (size_t)q;
-    if (lane == 0) {            // piA = A' + alpha + r delta
-        G1Affine p = xyzz_to_affine(xyzz_add(xyzz_add_affine(A, a.alpha1), sh[2]));
-        store_fq_std(out, p.x); store_fq_std(out + 32, p.y);
-    } else if (lane == 1) {     // piC = C' + H + s A' + s alpha + r B1' + r beta1 + rs delta
+    if (threadIdx.x == 0) {     // piC = C' + H + s A' + s alpha + r B1' + r beta1 + rs delta
         G1XYZZ c = xyzz_add(xyzz_add(a.r1[nq + 3 * q + 2], a.kC), a.r1[q]);
         c = xyzz_add(c, sh[0]); c = xyzz_add(c, sh[5]); c = xyzz_add(c, sh[1]); c = xyzz_add(c, sh[6]); c = xyzz_add(c, sh[4]);
         G1Affine p = xyzz_to_affine(c);
         store_fq_std(out + 192, p.x); store_fq_std(out + 224, p.y);
-    } else if (lane == 7) {     // piB = B2' + beta2 + s delta2
-        G2Affine p = xyzz_to_affine(xyzz_add(xyzz_add_affine(xyzz_add(a.r2[q], a.kB2), a.beta2), sh2));
-        store_fq_std(out + 64, p.x.c0); store_fq_std(out + 96, p.x.c1); store_fq_std(out + 128, p.y.c0); store_fq_std(out + 160, p.y.c1);
     }
 }
 
 int finalize_launch(zkc_ctx* ctx, hipStream_t st, const FinalizeArgs& a, int nproofs) {
-    hipLaunchKernelGGL(zkc_finalize, dim3(nproofs), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(zkc_finalize, dim3(nproofs), dim3(256), 0, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, std::string("zkc_finalize: ") + hipGetErrorString(e));
     return ZKC_OK;
