@@ -4,16 +4,19 @@
 // ts_inputs/src/example.ts:358-362) and rapidsnark's multiexp (zk_census_test.go:89).
 //
 // The proving key is constant for the life of a context, so zkc_zkey_load pre-shifts every base once
-// (T[w][i] = 2^(13 w) P_i): all windows of a job then reduce with plain additions, no doublings.  A pipeline PASS
-// runs a list of jobs (sections x proofs in flight) through the same launches:
-//   K4  zkc_msm_digits      scalar -> 20 signed 13-bit digits; emits key = job*NB + w*4096 + |d|-1, val = point | sign
-//       rocPRIM radix sort of (key, val); zkc_msm_offsets = bucket boundaries; scan of ceil(size/16) -> segments
-//   K5  zkc_msm_accumulate  one lane per SEGMENT (<= 16 sorted entries of one bucket): XYZZ += affine (8M + 2S) with
-//       64-byte gathers from T.  Cutting buckets into segments keeps lanes balanced when many scalars repeat
-//       (witness bits; the circuit has only ~4.5k distinct values among 82k wires).
-//   K6  zkc_msm_window      one workgroup per (job, window): bucket = sum of its segments; per-lane running sums over
-//       16 buckets, a suffix scan across the 256 lanes in LDS, x16, tree sum  ->  sum_d d * B_d
-//       zkc_msm_final       sums the 20 window results of each job.
+// (T[w][i] = 2^(c w) P_i): windows combine with plain additions, no doublings, and a digit d of ANY window lands in
+// the same bucket d -- a job has 2^(c-1) signed-digit buckets in total (c = 17 for H, 13 for the witness sections).
+// A pipeline PASS runs a list of jobs (sections x proofs in flight) through the same launches:
+//   K4  zkc_msm_digits      scalar -> signed c-bit digits; emits key = |d| - 1 (16 bits), val = sign | job | table row
+//       rocPRIM radix sort on the 16-bit key alone (stable, so equal buckets stay in job order: bucket-major ids,
+//       MsmJobList); zkc_msm_offsets = (bucket, job) boundaries; scan of ceil(size/16) -> segments
+//   K5  zkc_msm_accumulate29[_g2]  one lane per SEGMENT (<= 16 sorted entries of one bucket): XYZZ += affine (8M + 2S)
+//       in radix-2^29 coordinates (zkc_f29*.h) with 64-byte gathers from T.  Cutting buckets into segments keeps lanes
+//       balanced when many scalars repeat (witness bits; the circuit has only ~4.5k distinct values among 82k wires).
+//   K6  zkc_msm_merge       buckets of more than 8 segments: a wave each, shuffle tree
+//       zkc_msm_window[29]  one wave per virtual window (1024 or 256 consecutive buckets of a job): per-lane running
+//       sums, a suffix scan across the 64 lanes in LDS, x per, tree sum  ->  W = sum_j j B_j and S = sum_j B_j
+//       zkc_msm_final       one workgroup per job: sum_k W_k + vw sum_k k S_k over its virtual windows.
 #include <cstdio>
 #include <ctime>
 #include <cstdlib>
@@ -238,7 +241,7 @@ zkc_msm_accumulate29_g2(const uint32_t* __restrict__ table29_all, const MsmJobLi
     partial[s] = out;
 }
 
-// buckets with many segments (the 7-bit top window holds n/97 entries per bucket; repeated witness values) are summed by
+// buckets with many segments (repeated witness values; every bucket of a 2^20-point job) are summed by
 // one wave each: lanes stride over the segments, then a shuffle tree; the result replaces the bucket's first segment.
 template <class F>
 __device__ __forceinline__ XYZZ<F> shfl_down_xyzz(const XYZZ<F>& p, int delta) {
