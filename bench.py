@@ -116,7 +116,7 @@ def main():
     # other full-rate VALU op) on this part; one mixed addition of the radix-2^29 kernel is 2700 instructions, 1566 of them v_mad_u64_u32.
     nproofs = args.steps * B
     pairs_per_proof = prof['msm_g1_streamed']['alg_bytes'] / 96.0 / nproofs             # (scalar, base) pairs entering the G1 MSMs of one proof
-    madds_per_proof = 15.0 * pk.domain_size + 20.0 * (pairs_per_proof - pk.domain_size)  # c = 17: 15 windows for H; c = 13: 20 windows for A, B1, C
+    madds_per_proof = 15.0 * pk.domain_size + 22.0 * (pairs_per_proof - pk.domain_size)  # c = 17: 15 windows for H; c = 12: 22 windows for A, B1, C
     madd_rate = madds_per_proof * nproofs / (d['ms'] * 1e-3) if d['ms'] > 0 else 0.0
     alu = {'unit': 'mixed additions/s', 'achieved': round(madd_rate / 1e9, 3), 'achieved_unit': 'G madd/s', 'instr_per_madd': 2700,
            'peak_lane_instr_per_s': 35.4e12, 'frac': round(madd_rate * 2700 / 35.4e12, 4),

@@ -7,9 +7,10 @@ namespace zkc {
 // Pippenger window bits per section (signed digits).  Because the bases are pre-shifted per window (T[w][i] = 2^(c w) P_i), a
 // digit d of ANY window lands in the same bucket d: a job has 2^(c-1) buckets in total, not per window, so large windows are cheap.
 // H (2^17 random scalars): c = 17 -> 15 additions per scalar into 65536 buckets (about 30 entries each); the witness sections A, B1,
-// C, B2 (8-11 k wires after constant folding): c = 13 -> 20 additions per scalar into 4096 buckets.
-constexpr int MSM_C_BIG = 17, MSM_C_SMALL = 13;
-constexpr int msm_nw(int c) { return (254 + c) / c; }          // 17 -> 15 windows (255 bits), 13 -> 20 windows (260 bits)
+// C, B2 (8-11 k wires after constant folding): c = 12 -> 22 additions per scalar into 2048 buckets (same box: c = 14 -> 1798, 13 -> 1919,
+// 12 -> 1958, 11 -> ~1856 proofs/s).
+constexpr int MSM_C_BIG = 17, MSM_C_SMALL = 12;
+constexpr int msm_nw(int c) { return (254 + c) / c; }          // 17 -> 15 windows (255 bits), 12 -> 22 windows (264 bits)
 constexpr int msm_half(int c) { return 1 << (c - 1); }         // buckets per job
 // buckets per workgroup of the reduction ("virtual window"): 1024 for H (64 waves per job; 512: 1496, 1024: 1548, 2048: 1505 proofs/s),
 // 256 for the witness sections (16 waves per job instead of 4: their reduction is a latency chain, not a throughput problem)
