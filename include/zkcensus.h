@@ -74,7 +74,7 @@ int zkc_prove_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, const uin
                   uint8_t proof[256], uint8_t* public_out);
 
 /* batch form: B witnesses resident in HBM (B x nWitness x 32 B), rs = B x 64 B (r || s per proof), outputs on the host:
- * proofs B x 256 B, publics B x nPublic x 32 B (may be NULL).  Up to ZKC_INFLIGHT (default 64) proofs share one MSM
+ * proofs B x 256 B, publics B x nPublic x 32 B (may be NULL).  Up to ZKC_INFLIGHT (default 96) proofs share one MSM
  * pipeline pass.  Mirrors what a rapidsnark / snarkjs caller would loop over (zk_census_test.go:89 per voter). */
 int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, int B, const uint8_t* rs, uint8_t* proofs, uint8_t* publics);
 

@@ -189,7 +189,7 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
     if ((rc = dmalloc(ctx, &zk->d_g2_29, 60 * (size_t)NWS * nv)) || (rc = msm_g2_table29(ctx, zk->d_g2, zk->d_g2_29, (size_t)NWS * nv))) return bail(rc);
     // ---- work buffers: `inflight` proofs share one MSM pipeline pass ----
     const char* e_inf = getenv("ZKC_INFLIGHT");
-    zk->max_inflight = e_inf ? std::max(1, std::min(atoi(e_inf), MSM_MAX_JOBS / 4)) : 64;      // measured: 16 -> 730, 32 -> 1365, 64 -> 1444, 96 -> 1435 proofs/s
+    zk->max_inflight = e_inf ? std::max(1, std::min(atoi(e_inf), MSM_MAX_JOBS / 4)) : 96;      // same box, batch 1024: 64 -> 1955, 80 -> 1985, 96 -> 2015, 112 -> 2000, 128 -> 2022 proofs/s
     const size_t per_proof_entries = (size_t)NWS * 3 * nv + (size_t)NWB * n;
     const size_t per_proof_buckets = 3 * (size_t)msm_half(MSM_C_SMALL) + msm_half(MSM_C_BIG);
     // ZKC_LANES=2 lets two lanes take alternate passes; measured no gain (the GPU is already saturated), so one lane is the default
