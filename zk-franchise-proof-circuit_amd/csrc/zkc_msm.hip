@@ -110,25 +110,37 @@ zkc_msm_segcount(const uint32_t* __restrict__ off, uint32_t nbuckets, uint32_t* 
     segcnt[b] = c;
     if (c > (uint32_t)MSM_MERGE_T) { uint32_t k = atomicAdd(heavy_count, 1u); if (k < (uint32_t)MSM_MAX_HEAVY) heavy[k] = b; }
 }
+// A bucket of L entries cut into k = ceil(L / MSM_SEG) segments is split EVENLY: segment i covers [floor(i L / k), floor((i + 1) L / k)).
+__device__ __forceinline__ void msm_seg_range(uint32_t L, uint32_t k, uint32_t i, uint32_t& lo, uint32_t& hi) {
+    lo = (uint32_t)(((uint64_t)i * L) / k); hi = (uint32_t)(((uint64_t)(i + 1) * L) / k);
+}
+// seg2bucket[s] = bucket of segment s; seglen[s] = its number of entries (the accumulation walks the segments longest first, in waves
+// of equal length: zkc_msm pass sorts (seglen, s) once per pass, a few million 6-bit keys)
 extern "C" __global__ void __launch_bounds__(256)
-zkc_msm_seg2bucket(const uint32_t* __restrict__ segoff, uint32_t nbuckets, uint32_t* __restrict__ seg2bucket, uint32_t max_segments) {
+zkc_msm_seg2bucket(const uint32_t* __restrict__ off, const uint32_t* __restrict__ segoff, uint32_t nbuckets, uint32_t* __restrict__ seg2bucket,
+                   uint32_t* __restrict__ seglen, uint32_t max_segments) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nbuckets) return;
-    for (uint32_t s = segoff[b], e = segoff[b + 1]; s < e && s < max_segments; s++) seg2bucket[s] = b;
+    const uint32_t s0 = segoff[b], k = segoff[b + 1] - s0, L = off[b + 1] - off[b];
+    for (uint32_t i = 0; i < k && s0 + i < max_segments; i++) {
+        uint32_t lo, hi; msm_seg_range(L, k, i, lo, hi);
+        seg2bucket[s0 + i] = b; seglen[s0 + i] = hi - lo;
+    }
 }
 
 // ---- K5, G1: the same segment walk with the accumulator kept in radix 2^29 (zkc_f29.h, zkc_f29_g1.h) ----
 template <int MINW>
 __global__ void __launch_bounds__(128, MINW)
 zkc_msm_accumulate29(const Affine<Fq>* __restrict__ table_all, const MsmJobList* __restrict__ jlp, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ off,
-                     const uint32_t* __restrict__ segoff, const uint32_t* __restrict__ seg2bucket, uint32_t nbuckets,
+                     const uint32_t* __restrict__ segoff, const uint32_t* __restrict__ seg2bucket, const uint32_t* __restrict__ perm, uint32_t nbuckets,
                      XYZZ<Fq>* __restrict__ partial, uint32_t max_segments) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t nseg = segoff[nbuckets]; if (nseg > max_segments) nseg = max_segments;
-    if (s >= nseg) return;
+    if (gid >= nseg) return;
+    const uint32_t s = perm[gid];                       // segments by decreasing length: the lanes of a wave finish together
     const uint32_t b = seg2bucket[s];
-    const uint32_t start = off[b] + (s - segoff[b]) * MSM_SEG;
-    uint32_t end = start + MSM_SEG; const uint32_t bend = off[b + 1]; if (end > bend) end = bend;
+    uint32_t lo, hi; msm_seg_range(off[b + 1] - off[b], segoff[b + 1] - segoff[b], s - segoff[b], lo, hi);
+    const uint32_t start = off[b] + lo, end = off[b] + hi;
     uint32_t bd, bj; jlp->decode(b, bd, bj);
     const Affine<Fq>* __restrict__ table = table_all + jlp->job[bj].tbl_off;      // a segment belongs to one job
     const uint32_t rowmask = (1u << jlp->row_bits) - 1;
@@ -193,14 +205,15 @@ __device__ __forceinline__ G2Chunk g2_chunk_load(const uint32_t* p) {
 template <int MINW>
 __global__ void __launch_bounds__(128, MINW)
 zkc_msm_accumulate29_g2(const uint32_t* __restrict__ table29_all, const MsmJobList* __restrict__ jlp, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ off,
-                        const uint32_t* __restrict__ segoff, const uint32_t* __restrict__ seg2bucket, uint32_t nbuckets,
+                        const uint32_t* __restrict__ segoff, const uint32_t* __restrict__ seg2bucket, const uint32_t* __restrict__ perm, uint32_t nbuckets,
                         XYZZ<Fq2>* __restrict__ partial, uint32_t max_segments) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t nseg = segoff[nbuckets]; if (nseg > max_segments) nseg = max_segments;
-    if (s >= nseg) return;
+    if (gid >= nseg) return;
+    const uint32_t s = perm[gid];                       // segments by decreasing length: the lanes of a wave finish together
     const uint32_t b = seg2bucket[s];
-    const uint32_t start = off[b] + (s - segoff[b]) * MSM_SEG;
-    uint32_t end = start + MSM_SEG; const uint32_t bend = off[b + 1]; if (end > bend) end = bend;
+    uint32_t lo, hi; msm_seg_range(off[b + 1] - off[b], segoff[b + 1] - segoff[b], s - segoff[b], lo, hi);
+    const uint32_t start = off[b] + lo, end = off[b] + hi;
     uint32_t bd, bj; jlp->decode(b, bd, bj);
     const uint32_t* __restrict__ table29 = table29_all + (size_t)jlp->job[bj].tbl_off * G2T29_WORDS;
     const uint32_t rowmask = (1u << jlp->row_bits) - 1;
@@ -459,6 +472,7 @@ int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, size_t max_buck
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.keys2, max_entries * sizeof(msm_key_t) + 16)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.vals2, max_entries * 4));
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.off, (nb + 2) * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.segcnt, (nb + 2) * 4));
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.segoff, (nb + 2) * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.seg2bucket, w.max_segments * 4));
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.seglen, w.max_segments * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.seglen2, w.max_segments * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.perm, w.max_segments * 4));
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.heavy, (MSM_MAX_HEAVY + 1) * 4));
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.d_jobs, sizeof(MsmJobList)));
     ZKC_HIP_CHECK(ctx, hipMalloc(&w.partial, w.max_segments * w.xyzz_size));
@@ -470,7 +484,7 @@ int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, size_t max_buck
     return ZKC_OK;
 }
 void msm_work_free(MsmWork& w) {
-    void* p[] = {w.keys, w.vals, w.keys2, w.vals2, w.off, w.segcnt, w.segoff, w.seg2bucket, w.heavy, w.d_jobs, w.d_windows, w.partial, w.wres, w.results, w.sort_tmp, w.scan_tmp};
+    void* p[] = {w.keys, w.vals, w.keys2, w.vals2, w.off, w.segcnt, w.segoff, w.seg2bucket, w.seglen, w.seglen2, w.perm, w.heavy, w.d_jobs, w.d_windows, w.partial, w.wres, w.results, w.sort_tmp, w.scan_tmp};
     for (void* q : p) if (q) (void)hipFree(q);
     if (w.h_results) (void)hipHostFree(w.h_results);
     w = MsmWork();
@@ -535,8 +549,18 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
         rc = zkc_ensure(ctx, &w.scan_tmp, &w.scan_tmp_sz, need); if (rc) return rc;
         e = rocprim::exclusive_scan(w.scan_tmp, need, w.segcnt, w.segoff, 0u, (size_t)nb + 1, rocprim::plus<uint32_t>(), st);
         if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, "exclusive_scan");
-        hipLaunchKernelGGL(zkc_msm_seg2bucket, dim3((nb + 255) / 256), dim3(256), 0, st, w.segoff, nb, w.seg2bucket, (uint32_t)w.max_segments);
+        const size_t seg_bound0 = std::min<size_t>(w.max_segments, total / MSM_SEG + nb);
+        ZKC_HIP_CHECK(ctx, hipMemsetAsync(w.seglen, 0, seg_bound0 * 4, st));          // slots past the real segment count sort to the end
+        hipLaunchKernelGGL(zkc_msm_seg2bucket, dim3((nb + 255) / 256), dim3(256), 0, st, w.off, w.segoff, nb, w.seg2bucket, w.seglen, (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_seg2bucket");
+        need = 0;
+        int len_bits = 1; while ((1 << len_bits) <= MSM_SEG) len_bits++;
+        e = rocprim::radix_sort_pairs_desc(nullptr, need, w.seglen, w.seglen2, rocprim::counting_iterator<uint32_t>(0), w.perm, seg_bound0, 0, len_bits, st);
+        if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, "radix_sort_pairs_desc(size)");
+        rc = zkc_ensure(ctx, &w.sort_tmp, &w.sort_tmp_sz, need); if (rc) return rc;
+        e = rocprim::radix_sort_pairs_desc(w.sort_tmp, need, w.seglen, w.seglen2, rocprim::counting_iterator<uint32_t>(0), w.perm, seg_bound0, 0, len_bits, st);
+        if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, "radix_sort_pairs_desc");
+        ZKC_LAUNCH_CHECK(ctx, "radix_sort_pairs_desc");
         if (ev_sorted) ZKC_HIP_CHECK(ctx, hipEventRecord(ev_sorted, st));          // the short kernels of this pass are through: what follows is long-running
     }
     XYZZ<F>* partial = reinterpret_cast<XYZZ<F>*>(w.partial);
@@ -548,10 +572,10 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
         if (!kG2 && ((ctx->prof.mask >> ZKC_PROF_MSM_ACC_G1) & 1)) ctx->prof.bytes[ZKC_PROF_MSM_G1_STREAMED] += streamed_bytes;
         if constexpr (kG2)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate29_g2<1>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
-                               zk->d_g2_29, (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.segoff, w.seg2bucket, nb, reinterpret_cast<XYZZ<Fq2>*>(partial), (uint32_t)w.max_segments);
+                               zk->d_g2_29, (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.segoff, w.seg2bucket, w.perm, nb, reinterpret_cast<XYZZ<Fq2>*>(partial), (uint32_t)w.max_segments);
         else      // G1: same layout, field type with the inlined product
             hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate29<2>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
-                               reinterpret_cast<const Affine<Fq>*>(table), (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.segoff, w.seg2bucket, nb,
+                               reinterpret_cast<const Affine<Fq>*>(table), (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.segoff, w.seg2bucket, w.perm, nb,
                                reinterpret_cast<XYZZ<Fq>*>(partial), (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_accumulate");
     }

@@ -97,6 +97,7 @@ struct MsmWork {
     msm_key_t *keys = nullptr, *keys2 = nullptr; uint32_t *vals = nullptr, *vals2 = nullptr;   // max_entries each
     uint32_t *off = nullptr;        // bucket boundaries, njobs*NB + 1
     uint32_t *segcnt = nullptr, *segoff = nullptr, *seg2bucket = nullptr, *heavy = nullptr;
+    uint32_t *seglen = nullptr, *seglen2 = nullptr, *perm = nullptr;     // per segment: entries; sorted lengths; segment ids by decreasing length
     void *partial = nullptr;        // XYZZ per segment
     void *wres = nullptr;           // XYZZ per (job, window)
     void *results = nullptr;        // XYZZ per job, two slots of max_jobs (device) ; h_results pinned host mirror of slot 0
