@@ -82,7 +82,7 @@ zkc_join_abc(const Fr* __restrict__ abc, uint32_t* __restrict__ p_std, int n) {
 //
 // Inside the tile every element is nine 29-bit limbs in R' = 2^261 form (zkc_f29.h): a loaded element enters as 32 x value (< 32 p); a
 // butterfly is t = v w (81 + 81 mads, < 1.7 p because the twiddle is < 1.2 p), u + t and u - t + D24, each carried -- no conditional
-// subtraction anywhere; magnitudes grow by at most 6.3 p per stage (< 90 p after nine, capacity 169 p) and are brought back below 3 p
+// subtraction anywhere; magnitudes grow by at most 6.3 p per stage (43 p in the product-free first stage; < 130 p after nine, capacity 169 p) and are brought back below 3 p
 // (or multiplied by the scale factor) before the exact division by 32 that returns the 8 x u32 form.  tw29[j] = w^j (or w^-j), j < n/2,
 // in that limb form, 12 words per entry (zkc_tw29).
 constexpr int NTT_TILE = 1024;        // elements per block tile = 36 KiB of LDS
@@ -95,7 +95,7 @@ extern "C" __global__ void __launch_bounds__(256) zkc_tw29(const Fr* __restrict_
     uint4* o = reinterpret_cast<uint4*>(out + (size_t)TW29_WORDS * i);
     o[0] = make_uint4(r[0], r[1], r[2], r[3]); o[1] = make_uint4(r[4], r[5], r[6], r[7]); o[2] = make_uint4(r[8], 0, 0, 0);
 }
-struct NttDom { static constexpr L9 D24 = f29_dominator<FrParams>(1u << 29, 1u << 24); };
+struct NttDom { static constexpr L9 D24 = f29_dominator<FrParams>(1u << 29, 1u << 24); static constexpr L9 D27 = f29_dominator<FrParams>(1u << 29, 1u << 27); };
 extern "C" __global__ void __launch_bounds__(256)
 zkc_ntt_pass(const Fr* __restrict__ src_all, Fr* __restrict__ dst_all, const uint32_t* __restrict__ tw29, const Fr* __restrict__ scale,
              int logn, int s0, int b, int first) {
@@ -135,9 +135,14 @@ zkc_ntt_pass(const Fr* __restrict__ src_all, Fr* __restrict__ dst_all, const uin
             uint32_t u[9], v[9], tt[9];
 #pragma unroll
             for (int i = 0; i < 9; i++) { u[i] = pu[i]; v[i] = pv[i]; }
-            f29_mul<FrParams>(tt, v, w);
+            if (s == 1) {                                         // first stage: every twiddle is w^0 = 1, no product (v < 32 p: dominator D27)
 #pragma unroll
-            for (int i = 0; i < 9; i++) { v[i] = u[i] + NttDom::D24.l[i] - tt[i]; u[i] += tt[i]; }
+                for (int i = 0; i < 9; i++) { const uint32_t vi = v[i]; v[i] = u[i] + NttDom::D27.l[i] - vi; u[i] += vi; }
+            } else {
+                f29_mul<FrParams>(tt, v, w);
+#pragma unroll
+                for (int i = 0; i < 9; i++) { v[i] = u[i] + NttDom::D24.l[i] - tt[i]; u[i] += tt[i]; }
+            }
             f29_carry(u); f29_carry(v);
 #pragma unroll
             for (int i = 0; i < 9; i++) { pu[i] = u[i]; pv[i] = v[i]; }
