@@ -146,6 +146,63 @@ ZKC_HD void f29_sqr(uint32_t r[9], const uint32_t a[9]) {
     r[8] = (uint32_t)(c[17] + carry);
 }
 
+// ---- fused forms: the Montgomery reduction maps T -> T / 2^261, so a term h 2^261 added to the column sums before the reduction comes
+// out as "+ h", and two products can share one reduction.  Each saves the separate add/subtract, its carry pass and (for the second
+// product) 81 of the 162 mads. ----
+template <class P>
+ZKC_HD void f29_reduce_cols(uint32_t r[9], uint64_t c[18]) {
+    constexpr L9 Pl = F29K<P>::p;
+    uint64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        c[i] += carry;
+        const uint32_t m = ((uint32_t)c[i] * F29K<P>::ninv) & F29_MASK;
+#pragma unroll
+        for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)m * Pl.l[j];
+        carry = c[i] >> 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) { c[k] += carry; r[k - 9] = (uint32_t)c[k] & F29_MASK; carry = c[k] >> 29; }
+    r[8] = (uint32_t)(c[17] + carry);
+}
+// a b / 2^261 + h  (h: any limbs below 2^32; same operand limits as f29_mul).  Output carried, below a b / 2^261 + h + p.
+template <class P>
+ZKC_HD void f29_mul_addhi(uint32_t r[9], const uint32_t a[9], const uint32_t b[9], const uint32_t h[9]) {
+    uint64_t c[18];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { c[k] = 0; c[9 + k] = h[k]; }
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+        for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)a[i] * b[j];
+    f29_reduce_cols<P>(r, c);
+}
+template <class P>
+ZKC_HD void f29_sqr_addhi(uint32_t r[9], const uint32_t a[9], const uint32_t h[9]) {
+    uint64_t c[18]; uint32_t a2[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { a2[k] = a[k] << 1; c[k] = 0; c[9 + k] = h[k]; }
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        c[2 * i] += (uint64_t)a[i] * a[i];
+#pragma unroll
+        for (int j = i + 1; j < 9; j++) c[i + j] += (uint64_t)a2[i] * a[j];
+    }
+    f29_reduce_cols<P>(r, c);
+}
+// (a1 b1 + a2 b2) / 2^261.  Requires max_limb(a1) max_limb(b1) + max_limb(a2) max_limb(b2) < 2^60.5.
+template <class P>
+ZKC_HD void f29_mul2sum(uint32_t r[9], const uint32_t a1[9], const uint32_t b1[9], const uint32_t a2[9], const uint32_t b2[9]) {
+    uint64_t c[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+        for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)a1[i] * b1[j] + (uint64_t)a2[i] * b2[j];
+    f29_reduce_cols<P>(r, c);
+}
+
 // is the CARRIED value a (limbs 0..7 < 2^29, value < 64 p) a multiple of p?  If a = k p then k = a[0] p^-1 mod 2^29, so everything
 // but one multiply, mask and compare runs with probability 2^-23.
 template <class P>

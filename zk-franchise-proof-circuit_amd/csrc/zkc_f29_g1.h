@@ -23,23 +23,24 @@ ZKC_HD void f29_enter_fq(uint32_t r[9], const uint32_t w[8]) {
 
 // ---- mixed addition acc += (x2, y2); x2, y2 = 32 x table coordinate (< 32 p).  Accumulator invariant: X, Y < 10.5 p carried, ZZ, ZZZ < 4 p.
 //   U2 = x2 ZZ, S2 = y2 ZZZ < 1.8 p ; P = U2 - X + D25, R = S2 - Y + D25 < 13.4 p ; PP, RR < 2.1 p ; PPP, Q < 1.2 p
-//   X3 = RR - PPP - 2Q + D24x3 < 8.4 p ; W = Q - X3 + D25 < 12.7 p ; Y3 = R W - Y PPP + D24 < 8.3 p ; ZZ PP, ZZZ PPP < 1.1 p
+//   X3 = RR - PPP - 2Q + D24x3 < 8.4 p ; W = Q - X3 + D25 < 12.7 p ; Y3 = (R W + (D25 - Y) PPP) / 2^261 + p < 2.2 p ; ZZ PP, ZZZ PPP < 1.1 p
 // Returns false and leaves acc alone when the two points share their x coordinate (same_y tells which case).
 ZKC_HD bool f29_madd(Acc29& acc, const uint32_t x2[9], const uint32_t y2[9], bool& same_y) {
     typedef FqParams P;
-    uint32_t U2[9], S2[9], Pn[9], Rn[9];
-    f29_mul<P>(U2, x2, acc.ZZ); f29_mul<P>(S2, y2, acc.ZZZ);
-    f29_sub(Pn, U2, acc.X, Dom29::D25); f29_carry(Pn);
-    f29_sub(Rn, S2, acc.Y, Dom29::D25); f29_carry(Rn);
-    if (f29_is_zero_mod_p<P>(Pn)) { same_y = f29_is_zero_mod_p<P>(Rn); return false; }
-    uint32_t PP[9], PPP[9], Q[9], RR[9], W[9], T[9], V[9];
-    f29_sqr<P>(PP, Pn); f29_mul<P>(PPP, Pn, PP); f29_mul<P>(Q, acc.X, PP); f29_sqr<P>(RR, Rn);
+    // every subtraction rides on a reduction: P = x2 ZZ / 2^261 + (D25 - X), likewise R, X3 = R^2 / 2^261 + (D24x3 - PPP - 2Q), and
+    // Y3 = (R W + (D25 - Y) PPP) / 2^261 with a single reduction for both products
+    uint32_t Pn[9], Rn[9], nX[9], nY[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) acc.X[k] = RR[k] + Dom29::D24x3.l[k] - PPP[k] - 2 * Q[k];
-    f29_carry(acc.X);
-    f29_sub(W, Q, acc.X, Dom29::D25);
-    f29_mul<P>(T, Rn, W); f29_mul<P>(V, acc.Y, PPP);
-    f29_sub(acc.Y, T, V, Dom29::D24); f29_carry(acc.Y);
+    for (int k = 0; k < 9; k++) { nX[k] = Dom29::D25.l[k] - acc.X[k]; nY[k] = Dom29::D25.l[k] - acc.Y[k]; }       // limbs <= 2^30, >= 0
+    f29_mul_addhi<P>(Pn, x2, acc.ZZ, nX); f29_mul_addhi<P>(Rn, y2, acc.ZZZ, nY);
+    if (f29_is_zero_mod_p<P>(Pn)) { same_y = f29_is_zero_mod_p<P>(Rn); return false; }
+    uint32_t PP[9], PPP[9], Q[9], W[9], T[9], V[9];
+    f29_sqr<P>(PP, Pn); f29_mul<P>(PPP, Pn, PP); f29_mul<P>(Q, acc.X, PP);
+#pragma unroll
+    for (int k = 0; k < 9; k++) T[k] = Dom29::D24x3.l[k] - PPP[k] - 2 * Q[k];
+    f29_sqr_addhi<P>(acc.X, Rn, T);
+    f29_sub(W, Q, acc.X, Dom29::D25);                              // limbs < 1.5 * 2^30: 13.5 + 9 + 2.25 (reduction) < 32 in units of 2^59 per column
+    f29_mul2sum<P>(acc.Y, Rn, W, nY, PPP);
     f29_mul<P>(T, acc.ZZ, PP); f29_mul<P>(V, acc.ZZZ, PPP);
 #pragma unroll
     for (int k = 0; k < 9; k++) { acc.ZZ[k] = T[k]; acc.ZZZ[k] = V[k]; }
