@@ -190,7 +190,18 @@ ZKC_HD void f29_sqr_addhi(uint32_t r[9], const uint32_t a[9], const uint32_t h[9
     }
     f29_reduce_cols<P>(r, c);
 }
-// (a1 b1 + a2 b2) / 2^261.  Requires max_limb(a1) max_limb(b1) + max_limb(a2) max_limb(b2) < 2^60.5.
+// (a1 b1 + a2 b2) / 2^261 [+ h].  Requires max_limb(a1) max_limb(b1) + max_limb(a2) max_limb(b2) < 2^60.5.
+template <class P>
+ZKC_HD void f29_mul2sum_addhi(uint32_t r[9], const uint32_t a1[9], const uint32_t b1[9], const uint32_t a2[9], const uint32_t b2[9], const uint32_t h[9]) {
+    uint64_t c[18];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { c[k] = 0; c[9 + k] = h[k]; }
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+        for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)a1[i] * b1[j] + (uint64_t)a2[i] * b2[j];
+    f29_reduce_cols<P>(r, c);
+}
 template <class P>
 ZKC_HD void f29_mul2sum(uint32_t r[9], const uint32_t a1[9], const uint32_t b1[9], const uint32_t a2[9], const uint32_t b2[9]) {
     uint64_t c[18];
