@@ -114,15 +114,15 @@ def main():
         pass
     # the bound that actually holds: VALU issue.  tools/probe/rate_probe.hip measures, in lane-instructions/s on this part: v_mad_u64_u32 34.8e12
     # (as v_mul_lo_u32, v_lshl_add_u64, v_fma_f64: one slot per 4.5 cycles per wave) and plain 32-bit ALU ops (v_add_u32, v_and_b32) 57.2e12.
-    # One mixed addition of the radix-2^29 kernel is 2650 instructions per loop iteration, 1566 of them v_mad_u64_u32 (ISA count).  Capacity
-    # = 1 / (1566 / 34.8e12 + 1084 / 57.2e12) = 15.6e9 mixed additions/s if every other instruction ran at the fast rate (some do not, so the
+    # One mixed addition of the radix-2^29 kernel is 2400 instructions per loop iteration, 1476 of them v_mad_u64_u32 (ISA count).  Capacity
+    # = 1 / (1476 / 34.8e12 + 924 / 57.2e12) = 17.1e9 mixed additions/s if every other instruction ran at the fast rate (some do not, so the
     # true ceiling is lower and frac is a lower bound on the issue utilisation).
     nproofs = args.steps * B
     pairs_per_proof = prof['msm_g1_streamed']['alg_bytes'] / 96.0 / nproofs             # (scalar, base) pairs entering the G1 MSMs of one proof
     madds_per_proof = 15.0 * pk.domain_size + 22.0 * (pairs_per_proof - pk.domain_size)  # c = 17: 15 windows for H; c = 12: 22 windows for A, B1, C
     madd_rate = madds_per_proof * nproofs / (d['ms'] * 1e-3) if d['ms'] > 0 else 0.0
-    capacity = 1.0 / (1566 / 34.8e12 + (2650 - 1566) / 57.2e12)
-    alu = {'unit': 'mixed additions/s', 'achieved': round(madd_rate / 1e9, 3), 'achieved_unit': 'G madd/s', 'instr_per_madd': 2650, 'mad_u64_u32_per_madd': 1566,
+    capacity = 1.0 / (1476 / 34.8e12 + (2400 - 1476) / 57.2e12)
+    alu = {'unit': 'mixed additions/s', 'achieved': round(madd_rate / 1e9, 3), 'achieved_unit': 'G madd/s', 'instr_per_madd': 2400, 'mad_u64_u32_per_madd': 1476,
            'peak': round(capacity / 1e9, 2), 'peak_unit': 'G madd/s', 'frac': round(madd_rate / capacity, 4),
            'note': 'VALU issue bound from measured instruction rates (tools/probe/rate_probe.hip: v_mad_u64_u32 34.8e12/s, 32-bit add/and 57.2e12/s); '
                    'this, not HBM, limits the kernel'}
@@ -131,7 +131,7 @@ def main():
                 'avg_launch_ms': round(d['ms'] / max(1, d['launches']), 4), 'alg_bytes_per_launch': d['alg_bytes'] // max(1, d['launches']),
                 'streamed_pair_bytes_per_launch': prof['msm_g1_streamed']['alg_bytes'] // max(1, d['launches']),
                 'note': 'achieved = algorithmic bytes (whole A,B1,C,H sections, SURVEY.md 8d) / kernel time; constant folding streams only streamed_pair_bytes. '
-                        'The kernel is bound by VALU issue (2650 instructions per mixed addition, see valu), not by HBM; traffic exceeds the algorithmic bytes because '
+                        'The kernel is bound by VALU issue (2400 instructions per mixed addition, see valu), not by HBM; traffic exceeds the algorithmic bytes because '
                         'every (scalar, window) digit gathers its own pre-shifted 64-byte base (15-20 table rows per base point) -- see DESIGN.md'}
 
     cpu = None

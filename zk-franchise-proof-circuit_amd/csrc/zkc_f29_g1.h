@@ -89,23 +89,27 @@ ZKC_HD void f29_pt_add(Acc29& r, const Acc29& a, const Acc29& b) {
     typedef FqParams P;
     if (f29_pt_is_inf(b)) { r = a; return; }
     if (f29_pt_is_inf(a)) { r = b; return; }
-    uint32_t U1[9], S1[9], Pn[9], Rn[9], T[9];
-    f29_mul<P>(U1, a.X, b.ZZ); f29_mul<P>(T, b.X, a.ZZ);
-    f29_sub(Pn, T, U1, Dom29::D25); f29_carry(Pn);
-    f29_mul<P>(S1, a.Y, b.ZZZ); f29_mul<P>(T, b.Y, a.ZZZ);
-    f29_sub(Rn, T, S1, Dom29::D25); f29_carry(Rn);
+    // as in f29_madd, the subtractions ride on reductions and Y3 needs one reduction for its two products
+    uint32_t U1[9], S1[9], Pn[9], Rn[9], T[9], nS1[9];
+    f29_mul<P>(U1, a.X, b.ZZ);
+#pragma unroll
+    for (int k = 0; k < 9; k++) T[k] = Dom29::D25.l[k] - U1[k];
+    f29_mul_addhi<P>(Pn, b.X, a.ZZ, T);
+    f29_mul<P>(S1, a.Y, b.ZZZ);
+#pragma unroll
+    for (int k = 0; k < 9; k++) nS1[k] = Dom29::D25.l[k] - S1[k];
+    f29_mul_addhi<P>(Rn, b.Y, a.ZZZ, nS1);
     if (f29_is_zero_mod_p<P>(Pn)) {
         if (f29_is_zero_mod_p<P>(Rn)) f29_pt_dbl(r, a); else f29_pt_set_inf(r);
         return;
     }
     uint32_t PP[9], PPP[9], Q[9], X3[9], Y3[9], V[9];
-    f29_sqr<P>(PP, Pn); f29_mul<P>(PPP, Pn, PP); f29_mul<P>(Q, U1, PP); f29_sqr<P>(T, Rn);
+    f29_sqr<P>(PP, Pn); f29_mul<P>(PPP, Pn, PP); f29_mul<P>(Q, U1, PP);
 #pragma unroll
-    for (int k = 0; k < 9; k++) X3[k] = T[k] + Dom29::D24x3.l[k] - PPP[k] - 2 * Q[k];
-    f29_carry(X3);
+    for (int k = 0; k < 9; k++) T[k] = Dom29::D24x3.l[k] - PPP[k] - 2 * Q[k];
+    f29_sqr_addhi<P>(X3, Rn, T);
     f29_sub(T, Q, X3, Dom29::D25);
-    f29_mul<P>(Y3, Rn, T); f29_mul<P>(V, S1, PPP);
-    f29_sub(Y3, Y3, V, Dom29::D24); f29_carry(Y3);
+    f29_mul2sum<P>(Y3, Rn, T, nS1, PPP);
     f29_mul<P>(T, a.ZZ, b.ZZ); f29_mul<P>(V, T, PP);
     f29_mul<P>(T, a.ZZZ, b.ZZZ); f29_mul<P>(Q, T, PPP);
 #pragma unroll
