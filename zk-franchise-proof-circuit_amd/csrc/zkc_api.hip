@@ -8,6 +8,7 @@ using namespace zkc;
 
 extern "C" __global__ void zkc_witness_chains(WitnessLayout L, PoseidonTable tab, const uint32_t* inputs, uint32_t* wtns, int32_t* status, int B, int tmpl_mode);
 extern "C" __global__ void zkc_witness_fill(const uint4* tmpl, uint4* wtns, int nWires, int B);
+extern "C" __global__ void zkc_witness_tostd(uint32_t* wtns, size_t nwires_total);
 
 static thread_local std::string g_create_err;
 
@@ -163,6 +164,7 @@ static int get_template(zkc_ctx* ctx, const WitnessLayout& L, uint32_t** out) {
     ZKC_HIP_CHECK(ctx, hipMemsetAsync(d_t, 0, (size_t)L.nWires * 32, ctx->stream));
     ZKC_HIP_CHECK(ctx, hipMemsetAsync(d_in, 0, (size_t)L.nInputs * 32, ctx->stream));
     hipLaunchKernelGGL(zkc_witness_chains, dim3(1), dim3(64), 0, ctx->stream, L, ctx->ptab, d_in, d_t, d_st, 1, 1);
+    hipLaunchKernelGGL(zkc_witness_tostd, dim3((L.nWires + 255) / 256), dim3(256), 0, ctx->stream, d_t, (size_t)L.nWires);
     ZKC_HIP_CHECK(ctx, hipGetLastError());
     ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ZKC_HIP_CHECK(ctx, hipFree(d_in)); ZKC_HIP_CHECK(ctx, hipFree(d_st));
@@ -185,6 +187,10 @@ static int witness_dev3(zkc_ctx* ctx, const WitnessLayout& L, const void* d_inpu
     // lanes of a wave share the chain kind; ceil so that kinds start on wave boundaries only when B % 64 == 0 (harmless otherwise)
     hipLaunchKernelGGL(zkc_witness_chains, dim3((3 * B + 63) / 64), dim3(64), 0, ctx->stream, L, ctx->ptab, (const uint32_t*)d_inputs,
                        (uint32_t*)d_wtns, d_status3, B, 0);
+    {   // the chains leave their wires in Montgomery form, marked: convert them (every lane busy, unlike the chains)
+        const size_t nw = (size_t)L.nWires * (size_t)B;
+        hipLaunchKernelGGL(zkc_witness_tostd, dim3((unsigned)std::min<size_t>((nw + 255) / 256, 256 * 64)), dim3(256), 0, ctx->stream, (uint32_t*)d_wtns, nw);
+    }
     ZKC_HIP_CHECK(ctx, hipGetLastError());
     return ZKC_OK;
 }

@@ -10,7 +10,8 @@
 //                        (empty-subtree Poseidon(0,0) level traces, oldKey=0 bit decomposition, ...)
 //   zkc_witness_chains   one lane per (voter, chain) with chain in {census tree, sik tree, misc}: walks the
 //                        Merkle path leaf->root (Poseidon is sequential along a path), and stores every surviving
-//                        signal of the non-empty levels straight into its wire slot (standard form).
+//                        signal of the non-empty levels straight into its wire slot (Montgomery form, marked).
+//   zkc_witness_tostd    wide: converts the marked wires to standard form
 // HBM layout: inputs  [B][nInputs][8 x u32]  standard form, census.circom declaration order
 //             witness [B][nWires ][8 x u32]  standard form (what .wtns section 2 holds and what MSM digits read)
 #include "zkc_field.h"
@@ -20,10 +21,12 @@ namespace zkc {
 
 struct Emit {                       // writes Montgomery values as standard-form wires
     uint32_t* base;                 // witness of this voter
+    // The conversion out of Montgomery form is a product that nothing downstream in the chain waits for: the chain kernel is one long
+    // dependency chain per lane, so it stores the Montgomery limbs with bit 255 set (values are below r < 2^254) and zkc_witness_tostd
+    // converts all marked wires afterwards, fully parallel.  (239 of the ~840 products of a Poseidon(2) level were these conversions.)
     __device__ __forceinline__ void put(int wire, const Fr& v) const {
-        uint32_t s[8]; fp_to_std<FrParams>(s, v);
         uint4* d = reinterpret_cast<uint4*>(base + 8 * (size_t)wire);
-        d[0] = make_uint4(s[0], s[1], s[2], s[3]); d[1] = make_uint4(s[4], s[5], s[6], s[7]);
+        d[0] = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]); d[1] = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7] | 0x80000000u);
     }
     __device__ __forceinline__ void put_std(int wire, const uint32_t s[8]) const {
         uint4* d = reinterpret_cast<uint4*>(base + 8 * (size_t)wire);
@@ -358,6 +361,17 @@ zkc_poseidon_batch_kernel(PoseidonTable tab, const uint32_t* __restrict__ in, ui
 }
 
 // coalesced broadcast of the template witness: one uint4 (half a wire) per lane
+extern "C" __global__ void __launch_bounds__(256)
+zkc_witness_tostd(uint32_t* __restrict__ wtns, size_t nwires_total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwires_total; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t* w = wtns + 8 * i;
+        if (!(w[7] & 0x80000000u)) continue;
+        uint4* d = reinterpret_cast<uint4*>(w); const uint4 a = d[0], b = d[1];
+        Fr v; v.v[0] = a.x; v.v[1] = a.y; v.v[2] = a.z; v.v[3] = a.w; v.v[4] = b.x; v.v[5] = b.y; v.v[6] = b.z; v.v[7] = b.w & 0x7fffffffu;
+        uint32_t s[8]; fp_to_std<FrParams>(s, v);
+        d[0] = make_uint4(s[0], s[1], s[2], s[3]); d[1] = make_uint4(s[4], s[5], s[6], s[7]);
+    }
+}
 extern "C" __global__ void __launch_bounds__(256)
 zkc_witness_fill(const uint4* __restrict__ tmpl, uint4* __restrict__ wtns, int nWires, int B) {
     const size_t per = (size_t)nWires * 2;
