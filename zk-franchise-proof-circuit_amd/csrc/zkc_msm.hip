@@ -103,10 +103,10 @@ zkc_msm_offsets(const MsmJobList* __restrict__ jlp, const msm_key_t* __restrict_
 // segcnt[b] = ceil(size_b / MSM_SEG); buckets cut into more than MSM_MERGE_T segments are listed for the wave-per-bucket merge
 extern "C" __global__ void __launch_bounds__(256)
 zkc_msm_segcount(const uint32_t* __restrict__ off, uint32_t nbuckets, uint32_t* __restrict__ segcnt, uint32_t* __restrict__ heavy,
-                 uint32_t* __restrict__ heavy_count) {
+                 uint32_t* __restrict__ heavy_count, uint32_t seg) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b > nbuckets) return;
-    const uint32_t c = b < nbuckets ? (off[b + 1] - off[b] + MSM_SEG - 1) / MSM_SEG : 0;
+    const uint32_t c = b < nbuckets ? (off[b + 1] - off[b] + seg - 1) / seg : 0;
     segcnt[b] = c;
     if (c > (uint32_t)MSM_MERGE_T) { uint32_t k = atomicAdd(heavy_count, 1u); if (k < (uint32_t)MSM_MAX_HEAVY) heavy[k] = b; }
 }
@@ -467,7 +467,7 @@ int fold_group_sums_g2(zkc_ctx* ctx, const G2Affine* tbl, const uint32_t* s, con
 int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, size_t max_buckets, int max_jobs, bool g2) {
     w.max_entries = max_entries; w.max_jobs = max_jobs; w.max_buckets = max_buckets; w.xyzz_size = g2 ? sizeof(G2XYZZ) : sizeof(G1XYZZ);
     const size_t nb = max_buckets;
-    w.max_segments = max_entries / MSM_SEG + nb;        // every non-empty bucket has at most one short segment
+    w.max_segments = max_entries / MSM_SEG_MIN + nb;    // every non-empty bucket has at most one short segment
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.keys, max_entries * sizeof(msm_key_t) + 16)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.vals, max_entries * 4));
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.keys2, max_entries * sizeof(msm_key_t) + 16)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.vals2, max_entries * 4));
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.off, (nb + 2) * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.segcnt, (nb + 2) * 4));
@@ -510,6 +510,9 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     const size_t total = jl.total_entries;
     const uint32_t nb = jl.total_buckets;
     if (total > w.max_entries || nb > w.max_buckets) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: too many entries for the work space");
+    // entries per accumulation lane: long segments mean fewer partial sums to reduce (best for a full pass), but a lane walks its segment
+    // serially, so a small pass (one proof) wants short ones: aim at ~2 waves per SIMD
+    const uint32_t seg = (uint32_t)std::min<size_t>(MSM_SEG, std::max<size_t>(MSM_SEG_MIN, total / 131072));
     constexpr bool kG2 = sizeof(F) == sizeof(Fq2);
     uint64_t alg_bytes = 0; uint32_t maxcount = 0;
     uint64_t streamed_bytes = 0;
@@ -541,7 +544,7 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
         hipLaunchKernelGGL(zkc_msm_offsets, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const MsmJobList*)w.d_jobs, w.keys2, w.vals2, (uint32_t)total, w.off);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_offsets");
         ZKC_HIP_CHECK(ctx, hipMemsetAsync(w.heavy + MSM_MAX_HEAVY, 0, 4, st));
-        hipLaunchKernelGGL(zkc_msm_segcount, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, w.off, nb, w.segcnt, w.heavy, w.heavy + MSM_MAX_HEAVY);
+        hipLaunchKernelGGL(zkc_msm_segcount, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, w.off, nb, w.segcnt, w.heavy, w.heavy + MSM_MAX_HEAVY, seg);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_segcount");
         need = 0;
         e = rocprim::exclusive_scan(nullptr, need, w.segcnt, w.segoff, 0u, (size_t)nb + 1, rocprim::plus<uint32_t>(), st);
@@ -549,12 +552,12 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
         rc = zkc_ensure(ctx, &w.scan_tmp, &w.scan_tmp_sz, need); if (rc) return rc;
         e = rocprim::exclusive_scan(w.scan_tmp, need, w.segcnt, w.segoff, 0u, (size_t)nb + 1, rocprim::plus<uint32_t>(), st);
         if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, "exclusive_scan");
-        const size_t seg_bound0 = std::min<size_t>(w.max_segments, total / MSM_SEG + nb);
+        const size_t seg_bound0 = std::min<size_t>(w.max_segments, total / seg + nb);
         ZKC_HIP_CHECK(ctx, hipMemsetAsync(w.seglen, 0, seg_bound0 * 4, st));          // slots past the real segment count sort to the end
         hipLaunchKernelGGL(zkc_msm_seg2bucket, dim3((nb + 255) / 256), dim3(256), 0, st, w.off, w.segoff, nb, w.seg2bucket, w.seglen, (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_seg2bucket");
         need = 0;
-        int len_bits = 1; while ((1 << len_bits) <= MSM_SEG) len_bits++;
+        int len_bits = 1; while ((1u << len_bits) <= seg) len_bits++;
         e = rocprim::radix_sort_pairs_desc(nullptr, need, w.seglen, w.seglen2, rocprim::counting_iterator<uint32_t>(0), w.perm, seg_bound0, 0, len_bits, st);
         if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, "radix_sort_pairs_desc(size)");
         rc = zkc_ensure(ctx, &w.sort_tmp, &w.sort_tmp_sz, need); if (rc) return rc;
@@ -566,7 +569,7 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     XYZZ<F>* partial = reinterpret_cast<XYZZ<F>*>(w.partial);
     XYZZ<F>* wres = reinterpret_cast<XYZZ<F>*>(w.wres);
     XYZZ<F>* results = reinterpret_cast<XYZZ<F>*>(w.results) + (size_t)slot * w.max_jobs;
-    const size_t seg_bound = std::min<size_t>(w.max_segments, total / MSM_SEG + nb);     // launch bound on the number of segments
+    const size_t seg_bound = std::min<size_t>(w.max_segments, total / seg + nb);     // launch bound on the number of segments
     {
         zkc_prof_scope _ps(ctx, kG2 ? ZKC_PROF_MSM_ACC_G2 : ZKC_PROF_MSM_ACC_G1, alg_bytes, st);
         if (!kG2 && ((ctx->prof.mask >> ZKC_PROF_MSM_ACC_G1) & 1)) ctx->prof.bytes[ZKC_PROF_MSM_G1_STREAMED] += streamed_bytes;

@@ -16,6 +16,7 @@ constexpr int msm_half(int c) { return 1 << (c - 1); }         // buckets per jo
 // 256 for the witness sections (16 waves per job instead of 4: their reduction is a latency chain, not a throughput problem)
 constexpr int msm_vw(int c) { return c >= 16 ? 1024 : 256; }
 constexpr int MSM_VW_MIN = 256, MSM_MAX_VW_PER_JOB = 64;
+constexpr int MSM_SEG_MIN = 16;                    // ... down to this for small passes (latency of a single proof)
 constexpr int MSM_SEG = 128;                       // sorted entries per accumulation lane; with length-sorted waves (same box): 32 -> 2200, 40 -> 2222, 64 -> 2270, 128 -> 2297, 256 -> 2274, 512 -> 2220 proofs/s
 constexpr int MSM_MERGE_T = 8;                     // buckets with more segments get a wave of their own before the window pass
 constexpr int MSM_MAX_HEAVY = 1 << 20;
