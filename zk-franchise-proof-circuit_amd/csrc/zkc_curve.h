@@ -36,7 +36,6 @@ template <class B> ZKC_HD Fq2T<B> fp_inv(const Fq2T<B>& a) {
     return {a.c0 * n, fp_neg(a.c1 * n)};
 }
 using Fq2 = Fq2T<Fq>;
-using Fq2I = Fq2T<FqI>;             // layout-identical; inlined base-field products (G2 bucket accumulation)
 
 template <class F>
 struct Affine {

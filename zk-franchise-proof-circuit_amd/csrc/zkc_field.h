@@ -18,17 +18,12 @@ struct FqParams {
     static constexpr uint32_t r1[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u, 0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
     static constexpr uint32_t r2[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u, 0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
     static constexpr uint32_t inv = 0xe4866389u;   // -p^-1 mod 2^32
-    static constexpr bool kInlineMul = false;      // device product is an out-of-line call (see fp_mul_dev)
 };
-// same field; the product is inlined.  Used only by the hottest loop (G1 bucket accumulation): ten products of 335
-// instructions fit the instruction cache and free the register allocator from the call ABI.
-struct FqParamsInl : FqParams { static constexpr bool kInlineMul = true; };
 struct FrParams {
     static constexpr uint32_t p[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
     static constexpr uint32_t r1[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
     static constexpr uint32_t r2[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
     static constexpr uint32_t inv = 0xefffffffu;
-    static constexpr bool kInlineMul = false;
 };
 
 template <class P>
@@ -187,7 +182,6 @@ __device__ __noinline__ zkc_u32x8 fp_mul_dev(zkc_u32x8 a, zkc_u32x8 b) {
 }
 template <class P>
 __device__ __forceinline__ Fp<P> operator*(const Fp<P>& a, const Fp<P>& b) {
-    if constexpr (P::kInlineMul) { Fp<P> r; fp_mul_r29<P>(r.v, a.v, b.v); return r; }
     zkc_u32x8 x, y;
 #pragma unroll
     for (int i = 0; i < 8; i++) { x[i] = a.v[i]; y[i] = b.v[i]; }
@@ -247,7 +241,6 @@ ZKC_HD bool fp_std_lt_p(const uint32_t s[8]) {       // s < p ?
 }
 
 using Fq = Fp<FqParams>;
-using FqI = Fp<FqParamsInl>;      // layout-identical to Fq
 using Fr = Fp<FrParams>;
 
 }  // namespace zkc

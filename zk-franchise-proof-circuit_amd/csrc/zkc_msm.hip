@@ -599,17 +599,6 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
                            (const MsmJobList*)w.d_jobs, results);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_final");
     }
-    if (g_debug_sync && getenv("ZKC_DEBUG_DUMP")) {
-        ZKC_HIP_CHECK(ctx, hipStreamSynchronize(st));
-        std::vector<uint32_t> hb(64 * 8); uint32_t seg[4] = {0, 0, 0, 0};
-        auto dump = [&](const char* name, const void* dptr) {
-            (void)hipMemcpy(hb.data(), dptr, sizeof(XYZZ<F>), hipMemcpyDeviceToHost);
-            fprintf(stderr, "[zkc] %-10s", name); for (unsigned i = 0; i < 8; i++) fprintf(stderr, " %08x", hb[i]); fprintf(stderr, "\n");
-        };
-        (void)hipMemcpy(seg, w.segoff, 16, hipMemcpyDeviceToHost); fprintf(stderr, "[zkc] segoff %u %u %u %u\n", seg[0], seg[1], seg[2], seg[3]);
-        (void)hipMemcpy(seg, w.segcnt, 16, hipMemcpyDeviceToHost); fprintf(stderr, "[zkc] segcnt %u %u %u %u\n", seg[0], seg[1], seg[2], seg[3]);
-        dump("table0", table); dump("partial0", partial); dump("wres0(W)", wres); dump("wres1(S)", wres + 1); dump("result0", results);
-    }
     if (to_host) ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.h_results, results, (size_t)nj * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
     return ZKC_OK;
 }

@@ -337,8 +337,6 @@ extern "C" int zkc_msm_debug(zkc_zkey* zk, int which, const void* d_scalars, uin
     jl.add((const uint32_t*)d_scalars, nullptr, count, offs[which], full, 0, which == 4 ? MSM_C_BIG : MSM_C_SMALL);
     int rc = which == 2 ? msm_pass_g2(zk, L0.w2, jl, 0, true, L0.st) : msm_pass_g1(zk, L0.w1, jl, 0, true, L0.st); if (rc) return rc;
     ZKC_HIP_CHECK(ctx, hipStreamSynchronize(L0.st));
-    if (getenv("ZKC_DEBUG_DUMP")) { const uint32_t* h = (const uint32_t*)(which == 2 ? L0.w2.h_results : L0.w1.h_results);
-        fprintf(stderr, "[zkc] h_results "); for (int i = 0; i < (which == 2 ? 64 : 32); i++) fprintf(stderr, "%s%08x", i % 8 ? "" : " ", h[i]); fprintf(stderr, "\n"); }
     if (which == 2) g2_to_std((uint8_t*)host_out, xyzz_to_affine(*(G2XYZZ*)L0.w2.h_results));
     else g1_to_std((uint8_t*)host_out, xyzz_to_affine(*(G1XYZZ*)L0.w1.h_results));
     return ZKC_OK;
