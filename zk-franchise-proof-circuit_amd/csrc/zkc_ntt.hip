@@ -63,16 +63,31 @@ zkc_pointwise_mul(Fr* __restrict__ abc, int n) {
     Fr* a = abc + (size_t)blockIdx.y * 3 * n;
     if (i < n) st_fr(a + 2 * (size_t)n + i, ld_fr(a + i) * ld_fr(a + n + i));
 }
-// joinABC: p = a*b - c, written in STANDARD form (the H-MSM reads scalar digits from it)
+// joinABC: p = a*b - c, written in STANDARD form (the H-MSM reads scalar digits from it).  In radix 2^29: the three operands enter as
+// 32 x value (their R' form), (a b + (D - c) 2^261) / 2^261 is one fused product (zkc_f29.h), and a second reduction of the nine limbs alone
+// divides by R' once more, which is the way out of Montgomery form; 243 mads per element instead of two out-of-line products.
+struct JoinDom { static constexpr L9 D27 = f29_dominator<FrParams>(1u << 29, 1u << 27); };
 extern "C" __global__ void __launch_bounds__(256)
 zkc_join_abc(const Fr* __restrict__ abc, uint32_t* __restrict__ p_std, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Fr* a = abc + (size_t)blockIdx.y * 3 * n;
-    Fr r = ld_fr(a + i) * ld_fr(a + n + i) - ld_fr(a + 2 * (size_t)n + i);
-    uint32_t s[8]; fp_to_std<FrParams>(s, r);
+    const Fr av = ld_fr(a + i), bv = ld_fr(a + n + i), cv = ld_fr(a + 2 * (size_t)n + i);
+    uint32_t A[9], B[9], C[9], T[9];
+    f29_from_fp_shl5(A, av.v); f29_from_fp_shl5(B, bv.v); f29_from_fp_shl5(C, cv.v);
+#pragma unroll
+    for (int k = 0; k < 9; k++) C[k] = JoinDom::D27.l[k] - C[k];                 // c < 32 p: dominated by D27 (< 43.3 p)
+    f29_mul_addhi<FrParams>(T, A, B, C);                                         // (x y - z) 2^261, below 32 * 32 / 169 + 43.3 + 1 < 51 p
+    uint64_t col[18];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { col[k] = T[k]; col[9 + k] = 0; }
+    f29_reduce_cols<FrParams>(T, col);                                           // / 2^261: the standard-form value, below 51 p / 2^261 + p < 2 p
+    Fr r;
+    r.v[0] = f29_word<0>(T); r.v[1] = f29_word<32>(T); r.v[2] = f29_word<64>(T); r.v[3] = f29_word<96>(T);
+    r.v[4] = f29_word<128>(T); r.v[5] = f29_word<160>(T); r.v[6] = f29_word<192>(T); r.v[7] = f29_word<224>(T);
+    fp_reduce_once<FrParams>(r.v);
     uint4* d = reinterpret_cast<uint4*>(p_std + 8 * ((size_t)blockIdx.y * n + i));
-    d[0] = make_uint4(s[0], s[1], s[2], s[3]); d[1] = make_uint4(s[4], s[5], s[6], s[7]);
+    d[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]); d[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
 }
 
 // ---- one NTT pass: stages s0+1 .. s0+b of a DIT transform of size 2^logn ----
