@@ -1,6 +1,7 @@
 // zkc_api.hip -- context + witness entry points of the C ABI (include/zkcensus.h).  Product code: there is no
 // CPU fallback here -- without a working HIP device every call fails with ZKC_ERR_HIP.
 #include "zkc_internal.h"
+#include "zkc_f29.h"
 #include <cstring>
 #include "../../include/zkc_poseidon_constants.inc"
 
@@ -123,6 +124,13 @@ extern "C" int zkc_ctx_create(int device, zkc_ctx** out) {
     if ((e = hipMalloc(&ctx->d_ptab_mem, all.size() * sizeof(Fr))) != hipSuccess) return fail(e, "hipMalloc(poseidon)");
     if ((e = hipMemcpy(ctx->d_ptab_mem, all.data(), all.size() * sizeof(Fr), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(poseidon)");
     const Fr* base = (const Fr*)ctx->d_ptab_mem;
+    {   // radix-2^29 copies for the witness chains (host arithmetic: zkc_f29.h is host + device)
+        std::vector<uint32_t> l29(all.size() * 12, 0);
+        for (size_t i = 0; i < all.size(); i++) { uint32_t t9[9]; f29_from_fp_shl5(t9, all[i].v); f29_mul<FrParams>(&l29[12 * i], t9, F29K<FrParams>::one.l); }
+        if ((e = hipMalloc(&ctx->d_ptab29_mem, l29.size() * 4)) != hipSuccess) return fail(e, "hipMalloc(poseidon29)");
+        if ((e = hipMemcpy(ctx->d_ptab29_mem, l29.data(), l29.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(poseidon29)");
+        ctx->ptab.base = base; ctx->ptab.base29 = (const uint32_t*)ctx->d_ptab29_mem;
+    }
     for (int t = 3; t <= 5; t++) {
         ctx->ptab.C[t] = base + off[(t - 3) * 4 + 0]; ctx->ptab.S[t] = base + off[(t - 3) * 4 + 1];
         ctx->ptab.M[t] = base + off[(t - 3) * 4 + 2]; ctx->ptab.P[t] = base + off[(t - 3) * 4 + 3];
@@ -138,6 +146,7 @@ extern "C" void zkc_ctx_destroy(zkc_ctx* ctx) {
     for (auto e : ctx->prof.free_events) (void)hipEventDestroy(e);
     for (auto& kv : ctx->tmpl) (void)hipFree(kv.second);
     if (ctx->d_ptab_mem) (void)hipFree(ctx->d_ptab_mem);
+    if (ctx->d_ptab29_mem) (void)hipFree(ctx->d_ptab29_mem);
     if (ctx->d_scratch_in) (void)hipFree(ctx->d_scratch_in);
     if (ctx->d_scratch_out) (void)hipFree(ctx->d_scratch_out);
     if (ctx->d_status3) (void)hipFree(ctx->d_status3);

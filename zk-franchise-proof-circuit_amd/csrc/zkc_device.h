@@ -7,6 +7,7 @@ namespace zkc {
 
 struct PoseidonTable {           // device pointers, Montgomery form; index = t (3,4,5)
     const Fr* C[6]; const Fr* S[6]; const Fr* M[6]; const Fr* P[6];
+    const Fr* base; const uint32_t* base29;      // the same constants as 12-word entries (nine 29-bit limbs, R' form, below 1.2 p): entry k <-> base[k]
 };
 
 // Wire layout of ZkFranchiseProofCircuit(nL) as circom 2.1.5 -O2 numbered it (DESIGN.md "witness layout").

@@ -28,6 +28,7 @@ struct zkc_ctx {
     std::string err;
     zkc::PoseidonTable ptab{};            // device pointers
     void* d_ptab_mem = nullptr;
+    void* d_ptab29_mem = nullptr;         // the Poseidon constants again as radix-2^29 limbs (witness chains)
     std::map<int, uint32_t*> tmpl;        // nLevels -> device template witness (nWires x 8 u32)
     // scratch reused by the host-buffer entry points
     void* d_scratch_in = nullptr; size_t scratch_in_sz = 0;

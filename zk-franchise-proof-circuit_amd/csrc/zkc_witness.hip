@@ -16,6 +16,7 @@
 //             witness [B][nWires ][8 x u32]  standard form (what .wtns section 2 holds and what MSM digits read)
 #include "zkc_field.h"
 #include "zkc_device.h"
+#include "zkc_f29.h"
 
 namespace zkc {
 
@@ -159,6 +160,135 @@ __device__ Fr poseidon_trace(const Fr* in, unsigned cmask, const PoseidonTable& 
     return out;
 }
 
+// ---- the same trace in radix 2^29 (zkc_f29.h): the chain kernel is one dependency chain per lane, so what counts is the latency of a
+// product (inline 29-bit-limb code exposes the independent mads of a product to the scheduler; the out-of-line 8 x u32 product does not)
+// and the number of reductions: a mix row is T products with ONE reduction, "state += in0 * S" is a product with the addend folded in.
+// Magnitudes (multiples of r): constants < 1.2 (table base29); S-box outputs < 3; the partial rounds let state[1..] grow by about one
+// per round (< 64 after 60 rounds, capacity 169), everything else passes through a product again and shrinks.
+struct W29 { uint32_t l[9]; };
+__device__ __forceinline__ W29 ld_c29(const PoseidonTable& tab, const Fr* c) {
+    const uint4* q = reinterpret_cast<const uint4*>(tab.base29 + 12 * (size_t)(c - tab.base)); const uint4 a = q[0], b = q[1], d = q[2];
+    return W29{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x}};
+}
+__device__ __forceinline__ void emit29(const Emit& e, int wire, const W29& v) {
+    uint32_t t[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) t[k] = v.l[k];
+    f29_reduce_small<FrParams>(t);
+    e.put(wire, f29_to_fp<FrParams>(t));
+}
+__device__ __forceinline__ W29 sbox29(const W29& x, W29& in2, W29& in4) {
+    W29 o; f29_sqr<FrParams>(in2.l, x.l); f29_sqr<FrParams>(in4.l, in2.l); f29_mul<FrParams>(o.l, in4.l, x.l); return o;
+}
+// sum_j a[j] * c_j / 2^261 with one reduction (T <= 5 carried operands: 5 * 9 * 2^58 + 9 * 2^58 < 2^64)
+template <int T, class GetC>
+__device__ __forceinline__ W29 dot29(const W29* a, GetC getc) {
+    uint64_t col[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) col[k] = 0;
+#pragma unroll
+    for (int j = 0; j < T; j++) {
+        const W29 c = getc(j);
+#pragma unroll
+        for (int x = 0; x < 9; x++)
+#pragma unroll
+            for (int y = 0; y < 9; y++) col[x + y] += (uint64_t)a[j].l[x] * c.l[y];
+    }
+    W29 r; f29_reduce_cols<FrParams>(r.l, col); return r;
+}
+__device__ __forceinline__ W29 add29(const W29& a, const W29& b) { W29 r; f29_add(r.l, a.l, b.l); f29_carry(r.l); return r; }
+
+template <int T, int LAYOUT>
+__device__ Fr poseidon_trace29(const Fr* in, unsigned cmask, const PoseidonTable& tab, const Emit& e, int blk) {
+    constexpr int RP = (T == 3) ? 57 : (T == 4) ? 56 : 60;
+    const Fr* __restrict__ C = tab.C[T]; const Fr* __restrict__ S = tab.S[T];
+    const Fr* __restrict__ M = tab.M[T]; const Fr* __restrict__ Pm = tab.P[T];
+    const bool on = e.base != nullptr;
+    int rank[T]; int nc1 = 0;
+#pragma unroll
+    for (int j = 0; j < T; j++) { rank[j] = nc1; nc1 += !((cmask >> j) & 1); }
+    const int nA = nc1 + 6 * T, oLast = nA, oMS = nA + T - 1, oF = oMS + RP, oP = oF + 2 * (nc1 + 7 * T);
+    auto ark_idx = [&](int r, int j) -> int {
+        if (LAYOUT == 0) return r == 1 ? (((cmask >> j) & 1) ? -1 : rank[j]) : nc1 + (r - 2) * T + j;
+        if (r == 1) return j == 0 ? -1 : j - 1;
+        if (r <= 3) return 4 + (r - 2) * 5 + j;
+        if (r == 4) return j == 0 ? 14 : -1;
+        return 15 + (r - 5) * 5 + j;
+    };
+    auto sF_idx = [&](int r, int j) -> int {
+        if (LAYOUT == 0) return oF + 2 * (r == 0 ? (((cmask >> j) & 1) ? -1000 : rank[j]) : nc1 + (r - 1) * T + j);
+        return 98 + 2 * (r == 0 ? (j == 0 ? -1000 : j - 1) : 4 + (r - 1) * 5 + j);
+    };
+    const int oPp = (LAYOUT == 0) ? oP : 176;
+
+    W29 st[T];
+#pragma unroll
+    for (int k = 0; k < 9; k++) st[0].l[k] = 0;
+#pragma unroll
+    for (int j = 1; j < T; j++) f29_from_fp_shl5(st[j].l, in[j - 1].v);          // 32 x value: below 32
+#pragma unroll
+    for (int j = 0; j < T; j++) st[j] = add29(st[j], ld_c29(tab, C + j));
+    for (int r = 0; r < 4; r++) {                                                  // first half of the full rounds
+        W29 ns[T];
+#pragma unroll
+        for (int j = 0; j < T; j++) {
+            W29 i2, i4; const W29 o = sbox29(st[j], i2, i4);
+            const int fi = sF_idx(r, j);
+            if (on && fi >= 0) { emit29(e, blk + fi, i2); emit29(e, blk + fi + 1, i4); }
+            ns[j] = add29(o, ld_c29(tab, C + (r + 1) * T + j));
+            const int ai = ark_idx(r + 1, j);
+            if (on && ai >= 0) emit29(e, blk + ai, ns[j]);
+        }
+        const Fr* __restrict__ MM = (r < 3) ? M : Pm;
+#pragma unroll
+        for (int i = 0; i < T; i++) st[i] = dot29<T>(ns, [&](int j) { return ld_c29(tab, MM + j * T + i); });
+    }
+    if constexpr (LAYOUT == 1) { if (on) emit29(e, blk + 30, st[4]); }                    // mix[3].out[4]
+    for (int r = 0; r < RP; r++) {                                                 // partial rounds
+        const Fr* __restrict__ Sr = S + (2 * T - 1) * r;
+        W29 i2, i4; const W29 o = sbox29(st[0], i2, i4);
+        if (on) { emit29(e, blk + oPp + 2 * r, i2); emit29(e, blk + oPp + 2 * r + 1, i4); }
+        st[0] = add29(o, ld_c29(tab, C + 5 * T + r));                              // in0
+        if (LAYOUT == 1 && on && r == 59) emit29(e, blk + 97, st[0]);             // mixS[59].in[0]
+        const W29 n0 = dot29<T>(st, [&](int j) { return ld_c29(tab, Sr + j); });
+#pragma unroll
+        for (int i = 1; i < T; i++) { const W29 c = ld_c29(tab, Sr + T + i - 1); W29 t; f29_mul_addhi<FrParams>(t.l, st[0].l, c.l, st[i].l); st[i] = t; }
+        st[0] = n0;
+        if (on) {
+            if constexpr (LAYOUT == 0) emit29(e, blk + oMS + r, st[0]);
+            else {
+                if (r <= 56) emit29(e, blk + 35 + r, st[4]);
+                else if (r == 57) { emit29(e, blk + 92, st[1]); emit29(e, blk + 93, st[2]); emit29(e, blk + 94, st[3]); emit29(e, blk + 95, st[4]); }
+                else if (r == 58) emit29(e, blk + 96, st[4]);
+            }
+        }
+    }
+    for (int r = 0; r < 3; r++) {                                                  // second half of the full rounds
+        W29 ns[T];
+#pragma unroll
+        for (int j = 0; j < T; j++) {
+            W29 i2, i4; const W29 o = sbox29(st[j], i2, i4);
+            const int fi = sF_idx(4 + r, j);
+            if (on) { emit29(e, blk + fi, i2); emit29(e, blk + fi + 1, i4); }
+            ns[j] = add29(o, ld_c29(tab, C + 5 * T + RP + r * T + j));
+            if (on) emit29(e, blk + ark_idx(5 + r, j), ns[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < T; i++) st[i] = dot29<T>(ns, [&](int j) { return ld_c29(tab, M + j * T + i); });
+    }
+    W29 os[T];                                                                     // sigmaF[7] and mixLast
+    const int oL = (LAYOUT == 0) ? oLast : 31;
+#pragma unroll
+    for (int j = 0; j < T; j++) {
+        W29 i2, i4; os[j] = sbox29(st[j], i2, i4);
+        const int fi = sF_idx(7, j);
+        if (on) { emit29(e, blk + fi, i2); emit29(e, blk + fi + 1, i4); if (j < T - 1) emit29(e, blk + oL + j, os[j]); }
+    }
+    W29 out = dot29<T>(os, [&](int j) { return ld_c29(tab, M + j * T); });
+    f29_reduce_small<FrParams>(out.l);
+    return f29_to_fp<FrParams>(out.l);
+}
+
 __device__ __forceinline__ Fr load_std(const uint32_t* p) {
     const uint4* d = reinterpret_cast<const uint4*>(p); uint4 a = d[0], b = d[1];
     uint32_t s[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -220,7 +350,7 @@ __device__ Fr smt_verifier_chain(const WitnessLayout& L, const PoseidonTable& ta
     e.put_small(blk + 0, key0 ? 1u : 0u);                               // areKeyEquals.out
     e.put_small(blk + 2, 0u);                                           // checkRoot.isz.inv
     Fr hin[3] = {key, value, Fr::one()};
-    Fr h1new = poseidon_trace<4, 0>(hin, 1u | 8u, tab, e, blk + 4);
+    Fr h1new = poseidon_trace29<4, 0>(hin, 1u | 8u, tab, e, blk + 4);
     e.put(blk + 3, h1new);
     // levels d-1 .. 0 hold real hashes; levels >= d keep the template's Poseidon(0,0) trace
     Fr child = h1new;
@@ -235,7 +365,7 @@ __device__ Fr smt_verifier_chain(const WitnessLayout& L, const PoseidonTable& ta
         Fr s = load_std(sib + 8 * i);
         Fr in2[2];
         if (bit) { in2[0] = s; in2[1] = child; } else { in2[0] = child; in2[1] = s; }   // Switcher
-        Fr h = poseidon_trace<3, 0>(in2, 1u, tab, e, lb + o + 3);
+        Fr h = poseidon_trace29<3, 0>(in2, 1u, tab, e, lb + o + 3);
         e.put(lb + o, h);                                               // aux[0] = h * st_top (st_top = 1)
         e.put(lb + o + 1, h);                                           // proofHash.out
         e.put(lb + o + 2, in2[0]);                                      // proofHash.L
@@ -250,7 +380,7 @@ __device__ Fr smt_verifier_chain(const WitnessLayout& L, const PoseidonTable& ta
         if (tmpl_mode) {                                                // template: the Poseidon(0,0) trace of an empty level
             Fr z2[2] = {Fr::zero(), Fr::zero()};
             e.put_small(lb + o, 0u); e.put_small(lb + o + 1, 0u);       // child, aux[0]
-            Fr h = poseidon_trace<3, 0>(z2, 1u, tab, e, lb + o + 4);
+            Fr h = poseidon_trace29<3, 0>(z2, 1u, tab, e, lb + o + 4);
             e.put(lb + o + 2, h); e.put_small(lb + o + 3, 0u);          // proofHash.out, proofHash.L
         }
     }
@@ -324,10 +454,10 @@ zkc_witness_chains(WitnessLayout L, PoseidonTable tab, const uint32_t* __restric
         for (int i = 0; i <= 250; i++) e.put_small(L.off_checkweight + i, (uint32_t)bit_of(xs, i));
         Fr sig = load_std(signature), pw = load_std(password);
         Fr nin[4] = {sig, pw, load_std(eid), load_std(eid + 8)};
-        Fr nul = poseidon_trace<5, 1>(nin, 1u, tab, e, L.off_nullifier);
+        Fr nul = poseidon_trace29<5, 1>(nin, 1u, tab, e, L.off_nullifier);
         if (nul != load_std(nullifier) && st == ZKC_W_OK) st = ZKC_W_ERR_NULLIFIER;
         Fr sin[3] = {load_std(address), pw, sig};
-        Fr sik = poseidon_trace<4, 0>(sin, 1u, tab, e, L.off_sik + 1);
+        Fr sik = poseidon_trace29<4, 0>(sin, 1u, tab, e, L.off_sik + 1);
         e.put(L.off_sik, sik);
     } else {
         Fr key = load_std(address), value; const uint32_t *sib, *root; int blk;
