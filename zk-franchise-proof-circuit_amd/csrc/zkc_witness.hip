@@ -47,120 +47,11 @@ struct Emit {                       // writes Montgomery values as standard-form
     }
 };
 
-__device__ __forceinline__ Fr sbox(const Fr& x, Fr& in2, Fr& in4) { in2 = x * x; in4 = in2 * in2; return in4 * x; }
-
 // Optimised Poseidon (circomlib 2.0.5 schedule) over t = T state words, storing the surviving trace signals.
 // LAYOUT 0: the survivor set of every t=3 / t=4 instance; LAYOUT 1: the single t=5 instance (computedNullifier).
 // cmask bit j = state word j is a compile-time constant at round 0 (bit 0 always: initialState = 0).
 // `blk` = wire index of the first internal signal of this Poseidon block; emit.base == nullptr -> hash only.
-template <int T, int LAYOUT>
-__device__ Fr poseidon_trace(const Fr* in, unsigned cmask, const PoseidonTable& tab, const Emit& e, int blk) {
-    constexpr int RP = (T == 3) ? 57 : (T == 4) ? 56 : 60;
-    const Fr* __restrict__ C = tab.C[T]; const Fr* __restrict__ S = tab.S[T];
-    const Fr* __restrict__ M = tab.M[T]; const Fr* __restrict__ Pm = tab.P[T];
-    const bool on = e.base != nullptr;
-    int rank[T]; int nc1 = 0;
-#pragma unroll
-    for (int j = 0; j < T; j++) { rank[j] = nc1; nc1 += !((cmask >> j) & 1); }
-    // block offsets (LAYOUT 0)
-    const int nA = nc1 + 6 * T, oLast = nA, oMS = nA + T - 1, oF = oMS + RP, oP = oF + 2 * (nc1 + 7 * T);
-    auto ark_idx = [&](int r, int j) -> int {
-        if (LAYOUT == 0) return r == 1 ? (((cmask >> j) & 1) ? -1 : rank[j]) : nc1 + (r - 2) * T + j;
-        // t=5: ark[1][1..4], ark[2][*], ark[3][*], ark[4][0], ark[5..7][*]
-        if (r == 1) return j == 0 ? -1 : j - 1;
-        if (r <= 3) return 4 + (r - 2) * 5 + j;
-        if (r == 4) return j == 0 ? 14 : -1;
-        return 15 + (r - 5) * 5 + j;
-    };
-    auto sF_idx = [&](int r, int j) -> int {
-        if (LAYOUT == 0) return oF + 2 * (r == 0 ? (((cmask >> j) & 1) ? -1000 : rank[j]) : nc1 + (r - 1) * T + j);
-        return 98 + 2 * (r == 0 ? (j == 0 ? -1000 : j - 1) : 4 + (r - 1) * 5 + j);
-    };
-    const int oPp = (LAYOUT == 0) ? oP : 176;
-
-    Fr st[T];
-    st[0] = Fr::zero();
-#pragma unroll
-    for (int j = 1; j < T; j++) st[j] = in[j - 1];
-#pragma unroll
-    for (int j = 0; j < T; j++) st[j] = st[j] + C[j];
-    // first half of the full rounds: sigmaF[0..3], ark[1..4], mix[0..2] (M) and mix[3] (P)
-    for (int r = 0; r < 4; r++) {
-        Fr ns[T];
-#pragma unroll
-        for (int j = 0; j < T; j++) {
-            Fr i2, i4; Fr o = sbox(st[j], i2, i4);
-            int fi = sF_idx(r, j);
-            if (on && fi >= 0) { e.put(blk + fi, i2); e.put(blk + fi + 1, i4); }
-            ns[j] = o + C[(r + 1) * T + j];
-            int ai = ark_idx(r + 1, j);
-            if (on && ai >= 0) e.put(blk + ai, ns[j]);
-        }
-        const Fr* __restrict__ MM = (r < 3) ? M : Pm;
-#pragma unroll
-        for (int i = 0; i < T; i++) {
-            Fr acc = MM[i] * ns[0];
-#pragma unroll
-            for (int j = 1; j < T; j++) acc = acc + MM[j * T + i] * ns[j];
-            st[i] = acc;
-        }
-    }
-    if constexpr (LAYOUT == 1) { if (on) e.put(blk + 30, st[4]); }                    // mix[3].out[4]
-    // partial rounds
-    for (int r = 0; r < RP; r++) {
-        const Fr* __restrict__ Sr = S + (2 * T - 1) * r;
-        Fr i2, i4; Fr o = sbox(st[0], i2, i4);
-        if (on) { e.put(blk + oPp + 2 * r, i2); e.put(blk + oPp + 2 * r + 1, i4); }
-        Fr in0 = o + C[5 * T + r];
-        if (LAYOUT == 1 && on && r == 59) e.put(blk + 97, in0);      // mixS[59].in[0]
-        Fr n0 = Sr[0] * in0;
-#pragma unroll
-        for (int i = 1; i < T; i++) n0 = n0 + Sr[i] * st[i];
-#pragma unroll
-        for (int i = 1; i < T; i++) st[i] = st[i] + in0 * Sr[T + i - 1];
-        st[0] = n0;
-        if (on) {
-            if constexpr (LAYOUT == 0) e.put(blk + oMS + r, st[0]);
-            else {
-                if (r <= 56) e.put(blk + 35 + r, st[4]);
-                else if (r == 57) { e.put(blk + 92, st[1]); e.put(blk + 93, st[2]); e.put(blk + 94, st[3]); e.put(blk + 95, st[4]); }
-                else if (r == 58) e.put(blk + 96, st[4]);
-            }
-        }
-    }
-    // second half of the full rounds: sigmaF[4..6], ark[5..7], mix[4..6]
-    for (int r = 0; r < 3; r++) {
-        Fr ns[T];
-#pragma unroll
-        for (int j = 0; j < T; j++) {
-            Fr i2, i4; Fr o = sbox(st[j], i2, i4);
-            int fi = sF_idx(4 + r, j);
-            if (on) { e.put(blk + fi, i2); e.put(blk + fi + 1, i4); }
-            ns[j] = o + C[5 * T + RP + r * T + j];
-            if (on) e.put(blk + ark_idx(5 + r, j), ns[j]);
-        }
-#pragma unroll
-        for (int i = 0; i < T; i++) {
-            Fr acc = M[i] * ns[0];
-#pragma unroll
-            for (int j = 1; j < T; j++) acc = acc + M[j * T + i] * ns[j];
-            st[i] = acc;
-        }
-    }
-    // sigmaF[7] and mixLast
-    Fr out = Fr::zero();
-    const int oL = (LAYOUT == 0) ? oLast : 31;
-#pragma unroll
-    for (int j = 0; j < T; j++) {
-        Fr i2, i4; Fr o = sbox(st[j], i2, i4);
-        int fi = sF_idx(7, j);
-        if (on) { e.put(blk + fi, i2); e.put(blk + fi + 1, i4); if (j < T - 1) e.put(blk + oL + j, o); }
-        out = out + M[j * T] * o;
-    }
-    return out;
-}
-
-// ---- the same trace in radix 2^29 (zkc_f29.h): the chain kernel is one dependency chain per lane, so what counts is the latency of a
+// Arithmetic in radix 2^29 (zkc_f29.h): the chain kernel is one dependency chain per lane, so what counts is the latency of a
 // product (inline 29-bit-limb code exposes the independent mads of a product to the scheduler; the out-of-line 8 x u32 product does not)
 // and the number of reductions: a mix row is T products with ONE reduction, "state += in0 * S" is a product with the addend folded in.
 // Magnitudes (multiples of r): constants < 1.2 (table base29); S-box outputs < 3; the partial rounds let state[1..] grow by about one
@@ -465,7 +356,7 @@ zkc_witness_chains(WitnessLayout L, PoseidonTable tab, const uint32_t* __restric
         else {
             Fr sin[3] = {key, load_std(password), load_std(signature)};
             Emit none{nullptr};
-            value = poseidon_trace<4, 0>(sin, 1u, tab, none, 0);
+            value = poseidon_trace29<4, 0>(sin, 1u, tab, none, 0);
             sib = ss; root = sikRoot; blk = L.off_sikver;
         }
         bool bad_last;
@@ -484,7 +375,7 @@ zkc_poseidon_batch_kernel(PoseidonTable tab, const uint32_t* __restrict__ in, ui
     Emit none{nullptr};
     Fr x[4];
     for (int k = 0; k < nin; k++) x[k] = load_std(in + 8 * (i * nin + k));
-    Fr h = nin == 2 ? poseidon_trace<3, 0>(x, 1u, tab, none, 0) : nin == 3 ? poseidon_trace<4, 0>(x, 1u, tab, none, 0) : poseidon_trace<5, 1>(x, 1u, tab, none, 0);
+    Fr h = nin == 2 ? poseidon_trace29<3, 0>(x, 1u, tab, none, 0) : nin == 3 ? poseidon_trace29<4, 0>(x, 1u, tab, none, 0) : poseidon_trace29<5, 1>(x, 1u, tab, none, 0);
     uint32_t s[8]; fp_to_std<FrParams>(s, h);
     uint4* d = reinterpret_cast<uint4*>(out + 8 * i);
     d[0] = make_uint4(s[0], s[1], s[2], s[3]); d[1] = make_uint4(s[4], s[5], s[6], s[7]);
