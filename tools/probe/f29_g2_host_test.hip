@@ -35,6 +35,28 @@ int main() {
             for (int q = 0; q < 8; q++) { if (maxlimb(all[q]) >= (1u << 29)) { printf("limb bound\n"); bad++; } if (all[q][8] > worst_top) worst_top = all[q][8]; }
         }
     }
+    // full addition / doubling chains (bucket reduction)
+    auto rndpt = [&]() { return XYZZ<Fq2>{rnd2(), rnd2(), rnd2(), rnd2()}; };
+    auto same = [&](const Acc29G2& a, const XYZZ<Fq2>& r) {
+        if (r.is_inf()) return f29g2_pt_is_inf(a);
+        const XYZZ<Fq2> g = f29g2_pt_to_xyzz(a);
+        return g.X == r.X && g.Y == r.Y && g.ZZ == r.ZZ && g.ZZZ == r.ZZZ;
+    };
+    for (int chain = 0; chain < 150; chain++) {
+        XYZZ<Fq2> ref = rndpt(); Acc29G2 acc = f29g2_pt_from_xyzz(ref);
+        for (int it = 0; it < 40; it++) {
+            const int op = (int)(rng() % 8);
+            if (op == 0) { ref = xyzz_dbl(ref); f29g2_pt_dbl(acc, acc); }
+            else if (op == 1) { XYZZ<Fq2> q = ref; ref = xyzz_add(ref, q); Acc29G2 b = acc; f29g2_pt_add(acc, acc, b); }
+            else if (op == 2 && it > 30) { XYZZ<Fq2> q = xyzz_neg(ref); ref = xyzz_add(ref, q); Acc29G2 b = f29g2_pt_from_xyzz(q); f29g2_pt_add(acc, acc, b); }
+            else if (op == 3) { Acc29G2 b; f29g2_pt_set_inf(b); f29g2_pt_add(acc, acc, b); }
+            else { XYZZ<Fq2> q = rndpt(); ref = xyzz_add(ref, q); Acc29G2 b = f29g2_pt_from_xyzz(q); f29g2_pt_add(acc, acc, b); }
+            if (!same(acc, ref)) { if (bad < 5) printf("G2 reduction mismatch chain %d it %d op %d\n", chain, it, op); bad++; break; }
+            const uint32_t* all[8] = {acc.X.c0, acc.X.c1, acc.Y.c0, acc.Y.c1, acc.ZZ.c0, acc.ZZ.c1, acc.ZZZ.c0, acc.ZZZ.c1};
+            for (int q = 0; q < 8; q++) { if (maxlimb(all[q]) >= (1u << 29)) { printf("limb bound\n"); bad++; } if (all[q][8] > worst_top) worst_top = all[q][8]; }
+            if (ref.is_inf()) { ref = rndpt(); acc = f29g2_pt_from_xyzz(ref); }
+        }
+    }
     printf("G2 radix-2^29 mixed addition: %d mismatches; largest top limb %08x (10 p = %08x)\n", bad, worst_top, (uint32_t)(10.0 * (FqParams::p[7] >> 8)));
     return bad != 0;
 }

@@ -98,4 +98,79 @@ ZKC_HD bool f29g2_madd(Acc29G2& acc, const F2x29& x2, const F2x29& y2, bool& sam
     return true;
 }
 
+// ---- bucket reduction in G2: points with all coordinates carried and below 10 p per component ("tame": what the operations below return;
+// a canonical 8 x u32 point enters by slicing 32 x value and one f29_reduce_small per component).  Infinity is ZZ with all limbs zero.
+// Product outputs are below (A + 22.2) B / 169 + 1 [+ addend] for operands below A p, B p, so with tame inputs:
+//   full addition: U1, S1 < 3 p ; P, R = ... + (D24 - U1) < 9.3 p ; PP < 4.5 p ; PPP, Q < 2 p ; X3 = RR + (D25x3 - PPP - 2Q) < 17 p -> < 3 p ;
+//                  W = Q - X3 + D24 < 8.3 p ; V = S1 PPP < 1.3 p ; Y3 = R W + (D24 - V) < 8.9 p -> < 3 p ; ZZ3, ZZZ3 < 2 p
+//   doubling:      U = 2 Y < 6 p ; V = U^2 < 3 p ; W = U V, S = X V < 1.5 p ; M = 3 X^2 < 5.7 p ; X3 = M^2 + (D24x2 - 2 S) < 9.3 p -> < 3 p ;
+//                  T = S - X3 + D24 < 7.8 p ; Y3 = M T + (D24 - W Y) < 8.7 p -> < 3 p ; ZZ3 = V ZZ, ZZZ3 = W ZZZ < 2.6 p
+struct Dom29G2x { typedef FqParams P;
+    static constexpr L9 D25x3 = f29_dominator<P>(3u << 29, 1u << 25);
+    static constexpr L9 D24x2b = f29_dominator<P>(2u << 29, 1u << 24);
+};
+ZKC_HD bool f29g2_pt_is_inf(const Acc29G2& a) { uint32_t o = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) o |= a.ZZ.c0[k] | a.ZZ.c1[k]; return o == 0; }
+ZKC_HD void f29g2_pt_set_inf(Acc29G2& a) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) a.X.c0[k] = a.X.c1[k] = a.Y.c0[k] = a.Y.c1[k] = a.ZZ.c0[k] = a.ZZ.c1[k] = a.ZZZ.c0[k] = a.ZZZ.c1[k] = 0; }
+ZKC_HD void f29g2_enter(F2x29& r, const Fq2& a) {
+    f29_from_fp_shl5(r.c0, a.c0.v); f29_reduce_small<FqParams>(r.c0); f29_from_fp_shl5(r.c1, a.c1.v); f29_reduce_small<FqParams>(r.c1); }
+ZKC_HD Acc29G2 f29g2_pt_from_xyzz(const XYZZ<Fq2>& p) { Acc29G2 a; f29g2_enter(a.X, p.X); f29g2_enter(a.Y, p.Y); f29g2_enter(a.ZZ, p.ZZ); f29g2_enter(a.ZZZ, p.ZZZ); return a; }
+ZKC_HD Fq2 f29g2_leave(const F2x29& a) { return {f29_to_fp<FqParams>(a.c0), f29_to_fp<FqParams>(a.c1)}; }
+ZKC_HD XYZZ<Fq2> f29g2_pt_to_xyzz(const Acc29G2& a) { return {f29g2_leave(a.X), f29g2_leave(a.Y), f29g2_leave(a.ZZ), f29g2_leave(a.ZZZ)}; }
+ZKC_HD void f29g2_neg_hi(F2x29& h, const F2x29& v, const L9& D) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) { h.c0[k] = D.l[k] - v.c0[k]; h.c1[k] = D.l[k] - v.c1[k]; } }
+ZKC_HD void f29g2_reduce(F2x29& a) { f29_reduce_small<FqParams>(a.c0); f29_reduce_small<FqParams>(a.c1); }
+
+ZKC_HD void f29g2_pt_dbl(Acc29G2& r, const Acc29G2& a) {          // a finite
+    F2x29 U, V, W, S, M, T, h, X3, Y3;
+#pragma unroll
+    for (int k = 0; k < 9; k++) { U.c0[k] = a.Y.c0[k] << 1; U.c1[k] = a.Y.c1[k] << 1; }
+    f29_carry(U.c0); f29_carry(U.c1);
+    f29g2_sqr(V, U); f29g2_mul(W, U, V); f29g2_mul(S, a.X, V);
+    f29g2_sqr(T, a.X);
+#pragma unroll
+    for (int k = 0; k < 9; k++) { M.c0[k] = 3 * T.c0[k]; M.c1[k] = 3 * T.c1[k]; }
+    f29_carry(M.c0); f29_carry(M.c1);
+#pragma unroll
+    for (int k = 0; k < 9; k++) { h.c0[k] = Dom29G2x::D24x2b.l[k] - 2 * S.c0[k]; h.c1[k] = Dom29G2x::D24x2b.l[k] - 2 * S.c1[k]; }
+    f29g2_sqr_addhi(X3, M, h.c0, h.c1); f29g2_reduce(X3);
+    f29_sub(T.c0, S.c0, X3.c0, Dom29G2::D24); f29_carry(T.c0); f29_sub(T.c1, S.c1, X3.c1, Dom29G2::D24); f29_carry(T.c1);
+    f29g2_mul(S, W, a.Y);                                           // W Y
+    f29g2_neg_hi(h, S, Dom29G2::D24);
+    f29g2_mul_addhi(Y3, M, T, h.c0, h.c1); f29g2_reduce(Y3);
+    f29g2_mul(T, V, a.ZZ); f29g2_mul(S, W, a.ZZZ);
+    r.X = X3; r.Y = Y3; r.ZZ = T; r.ZZZ = S;
+}
+ZKC_HD void f29g2_pt_add(Acc29G2& r, const Acc29G2& a, const Acc29G2& b) {
+    if (f29g2_pt_is_inf(b)) { r = a; return; }
+    if (f29g2_pt_is_inf(a)) { r = b; return; }
+    F2x29 U1, S1, Pn, Rn, h, nS1;
+    f29g2_mul(U1, a.X, b.ZZ); f29g2_neg_hi(h, U1, Dom29G2::D24);
+    f29g2_mul_addhi(Pn, b.X, a.ZZ, h.c0, h.c1);
+    f29g2_mul(S1, a.Y, b.ZZZ); f29g2_neg_hi(nS1, S1, Dom29G2::D24);
+    f29g2_mul_addhi(Rn, b.Y, a.ZZZ, nS1.c0, nS1.c1);
+    if (f29g2_is_zero(Pn)) {
+        if (f29g2_is_zero(Rn)) f29g2_pt_dbl(r, a); else f29g2_pt_set_inf(r);
+        return;
+    }
+    F2x29 PP, PPP, Q, X3, Y3, W, V;
+    f29g2_sqr(PP, Pn); f29g2_mul(PPP, Pn, PP); f29g2_mul(Q, U1, PP);
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        h.c0[k] = Dom29G2x::D25x3.l[k] - PPP.c0[k] - 2 * Q.c0[k];
+        h.c1[k] = Dom29G2x::D25x3.l[k] - PPP.c1[k] - 2 * Q.c1[k];
+    }
+    f29g2_sqr_addhi(X3, Rn, h.c0, h.c1); f29g2_reduce(X3);
+    f29_sub(W.c0, Q.c0, X3.c0, Dom29G2::D24); f29_carry(W.c0); f29_sub(W.c1, Q.c1, X3.c1, Dom29G2::D24); f29_carry(W.c1);
+    f29g2_mul(V, S1, PPP); f29g2_neg_hi(h, V, Dom29G2::D24);
+    f29g2_mul_addhi(Y3, Rn, W, h.c0, h.c1); f29g2_reduce(Y3);
+    f29g2_mul(V, a.ZZ, b.ZZ); f29g2_mul(W, V, PP);
+    f29g2_mul(V, a.ZZZ, b.ZZZ); f29g2_mul(Q, V, PPP);
+    r.X = X3; r.Y = Y3; r.ZZ = W; r.ZZZ = Q;
+}
+
 }  // namespace zkc

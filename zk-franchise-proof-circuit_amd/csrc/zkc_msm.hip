@@ -354,6 +354,42 @@ zkc_msm_window29(const XYZZ<Fq>* __restrict__ partial, const uint32_t* __restric
     }
     if (threadIdx.x == 0) wres[2 * win.out] = f29_pt_is_inf(sh[0]) ? XYZZ<Fq>::inf() : f29_pt_to_xyzz(sh[0]);
 }
+// K6 for G2 in radix 2^29 (zkc_f29_g2.h): the generic version needs 256 VGPRs plus 1.4 KB of scratch per lane and was the longest
+// link of a single proof's critical path.
+__global__ void __launch_bounds__(64)
+zkc_msm_window29_g2(const XYZZ<Fq2>* __restrict__ partial, const uint32_t* __restrict__ segoff, const uint32_t* __restrict__ segcnt,
+                    const MsmWindow* __restrict__ windows, XYZZ<Fq2>* __restrict__ wres, uint32_t max_segments) {
+    __shared__ Acc29G2 sh[64];
+    const MsmWindow win = windows[blockIdx.x];
+    const int PER = (int)win.per;
+    const uint32_t first = win.bucket0 + threadIdx.x * PER * win.stride;
+    Acc29G2 run, loc; f29g2_pt_set_inf(run); f29g2_pt_set_inf(loc);
+    for (int k = PER - 1; k >= 0; k--) {
+        uint32_t s0 = segoff[first + k * win.stride], s1 = s0 + segcnt[first + k * win.stride];
+        if (s1 > max_segments) s1 = max_segments;
+        for (uint32_t s = s0; s < s1; s++) { const XYZZ<Fq2> pq = partial[s]; if (!pq.is_inf()) { const Acc29G2 q = f29g2_pt_from_xyzz(pq); f29g2_pt_add(run, run, q); } }
+        f29g2_pt_add(loc, loc, run);
+    }
+    sh[threadIdx.x] = run; __syncthreads();
+    for (int o = 1; o < 64; o <<= 1) {
+        Acc29G2 v; f29g2_pt_set_inf(v);
+        if ((int)threadIdx.x + o < 64) v = sh[threadIdx.x + o];
+        __syncthreads();
+        if ((int)threadIdx.x + o < 64) { Acc29G2 t = sh[threadIdx.x]; f29g2_pt_add(t, t, v); sh[threadIdx.x] = t; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) wres[2 * win.out + 1] = f29g2_pt_is_inf(sh[0]) ? XYZZ<Fq2>::inf() : f29g2_pt_to_xyzz(sh[0]);
+    Acc29G2 y; f29g2_pt_set_inf(y);
+    if (threadIdx.x >= 1) { y = sh[threadIdx.x]; if (!f29g2_pt_is_inf(y)) for (int k = PER; k > 1; k >>= 1) f29g2_pt_dbl(y, y); }
+    f29g2_pt_add(y, y, loc);
+    __syncthreads();
+    sh[threadIdx.x] = y; __syncthreads();
+    for (int st = 32; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) { Acc29G2 t = sh[threadIdx.x]; f29g2_pt_add(t, t, sh[threadIdx.x + st]); sh[threadIdx.x] = t; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) wres[2 * win.out] = f29g2_pt_is_inf(sh[0]) ? XYZZ<Fq2>::inf() : f29g2_pt_to_xyzz(sh[0]);
+}
 // one workgroup per job: result = sum_k W_k + vw * sum_k k * S_k over the job's virtual windows k (digit = vw k + local index)
 template <class F, int NT>
 __global__ void __launch_bounds__(NT)
@@ -588,8 +624,8 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
                            (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_merge");
         if constexpr (kG2)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_window<F>), dim3(jl.total_windows), dim3(64), 64 * sizeof(XYZZ<F>), st, partial, w.segoff, w.segcnt,
-                               (const MsmWindow*)w.d_windows, wres, (uint32_t)w.max_segments);
+            hipLaunchKernelGGL(zkc_msm_window29_g2, dim3(jl.total_windows), dim3(64), 0, st, reinterpret_cast<const XYZZ<Fq2>*>(partial), w.segoff, w.segcnt,
+                               (const MsmWindow*)w.d_windows, reinterpret_cast<XYZZ<Fq2>*>(wres), (uint32_t)w.max_segments);
         else
             hipLaunchKernelGGL(zkc_msm_window29, dim3(jl.total_windows), dim3(64), 0, st, reinterpret_cast<const XYZZ<Fq>*>(partial), w.segoff, w.segcnt,
                                (const MsmWindow*)w.d_windows, reinterpret_cast<XYZZ<Fq>*>(wres), (uint32_t)w.max_segments);
