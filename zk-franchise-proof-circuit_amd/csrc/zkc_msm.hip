@@ -279,45 +279,7 @@ zkc_msm_merge(XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ segoff
 }
 
 // ---- K6 ---- one wave per virtual window of 64 x per consecutive buckets of a job; lane t owns buckets per t .. per t + per - 1.
-// Output per virtual window: W = sum_{j=1..512} j * B_{j} (local weights) and S = sum B_j; zkc_msm_final applies the window's offset.
-template <class F>
-__global__ void __launch_bounds__(64)
-zkc_msm_window(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ segoff, const uint32_t* __restrict__ segcnt,
-               const MsmWindow* __restrict__ windows, XYZZ<F>* __restrict__ wres, uint32_t max_segments) {
-    extern __shared__ uint4 lds4[];
-    XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds4);
-    const MsmWindow win = windows[blockIdx.x];
-    const int PER = (int)win.per;                                         // 16 (H) or 4 (witness sections)
-    const uint32_t first = win.bucket0 + threadIdx.x * PER * win.stride;
-    XYZZ<F> run = XYZZ<F>::inf(), loc = XYZZ<F>::inf();                   // run = sum of the lane's buckets from the top; loc = sum_k k * B_k
-    for (int k = PER - 1; k >= 0; k--) {
-        uint32_t s0 = segoff[first + k * win.stride], s1 = s0 + segcnt[first + k * win.stride];
-        if (s1 > max_segments) s1 = max_segments;
-        for (uint32_t s = s0; s < s1; s++) run = xyzz_add(run, partial[s]);
-        loc = xyzz_add(loc, run);
-    }
-    // suffix sums R_t = sum_{t' >= t} S_t' across the 64 lanes (Hillis-Steele in LDS)
-    sh[threadIdx.x] = run; __syncthreads();
-    for (int o = 1; o < 64; o <<= 1) {
-        XYZZ<F> v = XYZZ<F>::inf();
-        if ((int)threadIdx.x + o < 64) v = sh[threadIdx.x + o];
-        __syncthreads();
-        if ((int)threadIdx.x + o < 64) sh[threadIdx.x] = xyzz_add(sh[threadIdx.x], v);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) wres[2 * win.out + 1] = sh[0];                   // S = R_0
-    // W = sum_t loc_t + PER * sum_{t>=1} R_t
-    XYZZ<F> y = XYZZ<F>::inf();
-    if (threadIdx.x >= 1) { y = sh[threadIdx.x]; for (int k = PER; k > 1; k >>= 1) y = xyzz_dbl(y); }
-    y = xyzz_add(y, loc);
-    __syncthreads();
-    sh[threadIdx.x] = y; __syncthreads();
-    for (int st = 32; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) sh[threadIdx.x] = xyzz_add(sh[threadIdx.x], sh[threadIdx.x + st]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) wres[2 * win.out] = sh[0];
-}
+// Output per virtual window: W = sum_j j * B_j (local weights) and S = sum_j B_j; zkc_msm_final applies the window's offset.
 // K6 for G1 with radix-2^29 coordinates (zkc_f29_g1.h): same walk, 1.7x fewer instructions per group addition than the generic code
 // through the out-of-line product.  Partials are read as canonical 8 x u32 points and sliced; W and S leave in canonical form.
 __global__ void __launch_bounds__(64)
@@ -418,6 +380,39 @@ zkc_msm_final(const XYZZ<F>* __restrict__ wres, const MsmJobList* __restrict__ j
         __syncthreads();
     }
     if (threadIdx.x == 0) results[j] = sh[0];
+}
+
+// the per-job sum for G2 in radix 2^29 (same scheme as zkc_msm_final)
+__global__ void __launch_bounds__(MSM_MAX_VW_PER_JOB)
+zkc_msm_final29_g2(const XYZZ<Fq2>* __restrict__ wres, const MsmJobList* __restrict__ jl, XYZZ<Fq2>* __restrict__ results) {
+    __shared__ Acc29G2 sh[MSM_MAX_VW_PER_JOB];
+    constexpr int nt = MSM_MAX_VW_PER_JOB;
+    const int j = blockIdx.x;
+    const uint32_t vw = jl->job[j].vw, nvw = (1u << (jl->job[j].c - 1)) / vw, w0 = jl->job[j].win_off;
+    Acc29G2 Wk, Sk; f29g2_pt_set_inf(Wk); f29g2_pt_set_inf(Sk);
+    if (threadIdx.x < nvw) {
+        const XYZZ<Fq2> a = wres[2 * (w0 + threadIdx.x)], b = wres[2 * (w0 + threadIdx.x) + 1];
+        if (!a.is_inf()) Wk = f29g2_pt_from_xyzz(a);
+        if (!b.is_inf()) Sk = f29g2_pt_from_xyzz(b);
+    }
+    sh[threadIdx.x] = Sk; __syncthreads();
+    for (int o = 1; o < nt; o <<= 1) {
+        Acc29G2 v; f29g2_pt_set_inf(v);
+        if ((int)threadIdx.x + o < nt) v = sh[threadIdx.x + o];
+        __syncthreads();
+        if ((int)threadIdx.x + o < nt) { Acc29G2 t = sh[threadIdx.x]; f29g2_pt_add(t, t, v); sh[threadIdx.x] = t; }
+        __syncthreads();
+    }
+    Acc29G2 y; f29g2_pt_set_inf(y);
+    if (threadIdx.x >= 1) { y = sh[threadIdx.x]; if (!f29g2_pt_is_inf(y)) for (uint32_t k = vw; k > 1; k >>= 1) f29g2_pt_dbl(y, y); }
+    f29g2_pt_add(y, y, Wk);
+    __syncthreads();
+    sh[threadIdx.x] = y; __syncthreads();
+    for (int st = nt / 2; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) { Acc29G2 t = sh[threadIdx.x]; f29g2_pt_add(t, t, sh[threadIdx.x + st]); sh[threadIdx.x] = t; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) results[j] = f29g2_pt_is_inf(sh[0]) ? XYZZ<Fq2>::inf() : f29g2_pt_to_xyzz(sh[0]);
 }
 
 // ---- one-time base table: table[w][i] = 2^c * table[w-1][i] ----
@@ -631,8 +626,12 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
                                (const MsmWindow*)w.d_windows, reinterpret_cast<XYZZ<Fq>*>(wres), (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_window");
         static_assert(msm_half(MSM_C_BIG) / msm_vw(MSM_C_BIG) <= MSM_MAX_VW_PER_JOB && msm_half(MSM_C_SMALL) / msm_vw(MSM_C_SMALL) <= MSM_MAX_VW_PER_JOB, "final kernel: one lane per virtual window");
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_final<F, MSM_MAX_VW_PER_JOB>), dim3(nj), dim3(MSM_MAX_VW_PER_JOB), MSM_MAX_VW_PER_JOB * sizeof(XYZZ<F>), st, wres,
-                           (const MsmJobList*)w.d_jobs, results);
+        if constexpr (kG2)
+            hipLaunchKernelGGL(zkc_msm_final29_g2, dim3(nj), dim3(MSM_MAX_VW_PER_JOB), 0, st, reinterpret_cast<const XYZZ<Fq2>*>(wres), (const MsmJobList*)w.d_jobs,
+                               reinterpret_cast<XYZZ<Fq2>*>(results));
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_final<F, MSM_MAX_VW_PER_JOB>), dim3(nj), dim3(MSM_MAX_VW_PER_JOB), MSM_MAX_VW_PER_JOB * sizeof(XYZZ<F>), st, wres,
+                               (const MsmJobList*)w.d_jobs, results);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_final");
     }
     if (to_host) ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.h_results, results, (size_t)nj * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
