@@ -254,27 +254,44 @@ zkc_msm_accumulate29_g2(const uint32_t* __restrict__ table29_all, const MsmJobLi
     partial[s] = out;
 }
 
-// buckets with many segments (repeated witness values; every bucket of a 2^20-point job) are summed by
-// one wave each: lanes stride over the segments, then a shuffle tree; the result replaces the bucket's first segment.
-template <class F>
-__device__ __forceinline__ XYZZ<F> shfl_down_xyzz(const XYZZ<F>& p, int delta) {
-    XYZZ<F> r; const uint32_t* s = reinterpret_cast<const uint32_t*>(&p); uint32_t* d = reinterpret_cast<uint32_t*>(&r);
-#pragma unroll
-    for (unsigned i = 0; i < sizeof(XYZZ<F>) / 4; i++) d[i] = (uint32_t)__shfl_down((int)s[i], delta, 64);
-    return r;
-}
-template <class F>
+// buckets with many segments (repeated witness values; every bucket of a 2^20-point job) are summed by one wave each: lanes stride over
+// the segments, then a tree over the lanes in LDS; the result replaces the bucket's first segment.  Radix-2^29 coordinates, one traits
+// struct per group.
+struct Merge29G1 {
+    typedef Fq F; typedef Acc29 Acc;
+    static __device__ __forceinline__ void set_inf(Acc& a) { f29_pt_set_inf(a); }
+    static __device__ __forceinline__ bool is_inf(const Acc& a) { return f29_pt_is_inf(a); }
+    static __device__ __forceinline__ Acc from(const XYZZ<F>& p) { return f29_pt_from_xyzz(p); }
+    static __device__ __forceinline__ XYZZ<F> to(const Acc& a) { return f29_pt_to_xyzz(a); }
+    static __device__ __forceinline__ void add(Acc& r, const Acc& a, const Acc& b) { f29_pt_add(r, a, b); }
+};
+struct Merge29G2 {
+    typedef Fq2 F; typedef Acc29G2 Acc;
+    static __device__ __forceinline__ void set_inf(Acc& a) { f29g2_pt_set_inf(a); }
+    static __device__ __forceinline__ bool is_inf(const Acc& a) { return f29g2_pt_is_inf(a); }
+    static __device__ __forceinline__ Acc from(const XYZZ<F>& p) { return f29g2_pt_from_xyzz(p); }
+    static __device__ __forceinline__ XYZZ<F> to(const Acc& a) { return f29g2_pt_to_xyzz(a); }
+    static __device__ __forceinline__ void add(Acc& r, const Acc& a, const Acc& b) { f29g2_pt_add(r, a, b); }
+};
+template <class G>
 __global__ void __launch_bounds__(64)
-zkc_msm_merge(XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ segoff, uint32_t* __restrict__ segcnt,
-              const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ heavy_count, uint32_t max_segments) {
+zkc_msm_merge29(XYZZ<typename G::F>* __restrict__ partial, const uint32_t* __restrict__ segoff, uint32_t* __restrict__ segcnt,
+                const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ heavy_count, uint32_t max_segments) {
+    __shared__ typename G::Acc sh[64];
     uint32_t nh = *heavy_count; if (nh > (uint32_t)MSM_MAX_HEAVY) nh = MSM_MAX_HEAVY;
     for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
         const uint32_t b = heavy[h], s0 = segoff[b];
         uint32_t s1 = s0 + segcnt[b]; if (s1 > max_segments) s1 = max_segments;
-        XYZZ<F> acc = XYZZ<F>::inf();
-        for (uint32_t s = s0 + threadIdx.x; s < s1; s += 64) acc = xyzz_add(acc, partial[s]);
-        for (int d = 32; d > 0; d >>= 1) acc = xyzz_add(acc, shfl_down_xyzz(acc, d));
-        if (threadIdx.x == 0) { partial[s0] = acc; segcnt[b] = 1; }
+        typename G::Acc acc; G::set_inf(acc);
+        for (uint32_t s = s0 + threadIdx.x; s < s1; s += 64) { const XYZZ<typename G::F> p = partial[s]; if (!p.is_inf()) { const typename G::Acc q = G::from(p); G::add(acc, acc, q); } }
+        __syncthreads();
+        sh[threadIdx.x] = acc; __syncthreads();
+        for (int st = 32; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) { typename G::Acc t = sh[threadIdx.x]; G::add(t, t, sh[threadIdx.x + st]); sh[threadIdx.x] = t; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { partial[s0] = G::is_inf(sh[0]) ? XYZZ<typename G::F>::inf() : G::to(sh[0]); segcnt[b] = 1; }
+        __syncthreads();
     }
 }
 
@@ -615,8 +632,12 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     }
     {
         zkc_prof_scope _pr(ctx, ZKC_PROF_MSM_REDUCE, 0, st);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_merge<F>), dim3(1024), dim3(64), 0, st, partial, w.segoff, w.segcnt, w.heavy, w.heavy + MSM_MAX_HEAVY,
-                           (uint32_t)w.max_segments);
+        if constexpr (kG2)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_merge29<Merge29G2>), dim3(1024), dim3(64), 0, st, reinterpret_cast<XYZZ<Fq2>*>(partial), w.segoff, w.segcnt, w.heavy,
+                               w.heavy + MSM_MAX_HEAVY, (uint32_t)w.max_segments);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_merge29<Merge29G1>), dim3(1024), dim3(64), 0, st, reinterpret_cast<XYZZ<Fq>*>(partial), w.segoff, w.segcnt, w.heavy,
+                               w.heavy + MSM_MAX_HEAVY, (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_merge");
         if constexpr (kG2)
             hipLaunchKernelGGL(zkc_msm_window29_g2, dim3(jl.total_windows), dim3(64), 0, st, reinterpret_cast<const XYZZ<Fq2>*>(partial), w.segoff, w.segcnt,
