@@ -252,3 +252,33 @@ def test_fullprove_batch_equals_witness_then_prove(env):
         r_i = int.from_bytes(rs[64 * i:64 * i + 32], 'little'); s_i = int.from_bytes(rs[64 * i + 32:64 * i + 64], 'little')
         rc, op, opub = ol.prove(zk, ws[i], r_i, s_i)
         assert rc == 0 and op == p1[256 * i:256 * i + 256]
+
+
+def test_optional_pipeline_modes_give_identical_proofs(env):
+    """ZKC_LANES=2 (two pipeline lanes taking alternate passes) and a small ZKC_INFLIGHT (many short passes) are scheduling options only:
+    same bytes as the default configuration."""
+    ctx, get, torch = env
+    import zkcensus_amd
+    nl, B = 10, 70
+    zk, pk, vk = get(nl)
+    from census_gen import random_voter
+    rng = random.Random(99)
+    voters = [random_voter(rng, ol.poseidon, nLevels=nl, depth_c=rng.randint(1, nl), depth_s=rng.randint(1, nl)) for _ in range(B)]
+    ws, st = ctx.witness(voters, nLevels=nl)
+    assert st == [0] * B
+    d_w = dev_bytes(torch, b''.join(ws))
+    rs = b''.join(rng.randrange(1 << 248).to_bytes(32, 'little') for _ in range(2 * B))
+    ref = pk.prove_batch_dev(d_w.data_ptr(), B, rs)
+    old = {k: os.environ.get(k) for k in ('ZKC_LANES', 'ZKC_INFLIGHT')}
+    try:
+        for lanes, inflight in (('2', '8'), ('1', '3'), ('2', '32')):
+            os.environ['ZKC_LANES'] = lanes; os.environ['ZKC_INFLIGHT'] = inflight
+            pk2 = zkcensus_amd.ProvingKey(ctx, zk)
+            try:
+                assert pk2.prove_batch_dev(d_w.data_ptr(), B, rs) == ref, 'lanes=%s inflight=%s' % (lanes, inflight)
+            finally:
+                pk2.close()
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
