@@ -72,3 +72,28 @@ def test_msm_over_generated_bases(gpu, logn):
         if logn == 8:
             assert got == ol.msm_g1(bases, scb)
     tbl.close()
+
+
+def test_engine_entry_points_reject_bad_input(gpu):
+    """Error behaviour of the stand-alone entry points: a base off the curve or with a coordinate >= q is refused at load time
+    (ZKC_ERR_FORMAT), and malformed NTT calls return ZKC_ERR_BAD_ARG instead of launching anything."""
+    ctx, torch = gpu
+    import zkcensus_amd
+    from zkcensus_amd import engines
+    n = 256
+    good = b''.join(ol.g1_mul(engines.G1_GENERATOR, k + 1) for k in range(n))
+    for bad_point in ((1).to_bytes(32, 'little') + (3).to_bytes(32, 'little'),            # (1, 3) is not on y^2 = x^3 + 3
+                      b'\xff' * 32 + (2).to_bytes(32, 'little')):                          # x >= q
+        buf = bytearray(good); buf[64 * 7:64 * 8] = bad_point
+        with pytest.raises(zkcensus_amd.ZkcError) as ei:
+            engines.G1Bases(ctx, _dev(torch, buf).data_ptr(), n)
+        assert ei.value.code == 5                                                         # ZKC_ERR_FORMAT
+    tbl = engines.G1Bases(ctx, _dev(torch, good).data_ptr(), n)                           # the clean set loads, infinity (all zero) included
+    zero = bytearray(good); zero[0:64] = bytes(64)
+    engines.G1Bases(ctx, _dev(torch, zero).data_ptr(), n).close()
+    tbl.close()
+    d = torch.zeros(32 * 1024, dtype=torch.uint8, device='cuda'); d2 = torch.zeros_like(d)
+    for args in ((d.data_ptr(), d.data_ptr(), 10, 1), (d.data_ptr(), d2.data_ptr(), 2, 1), (d.data_ptr(), d2.data_ptr(), 10, 0)):
+        with pytest.raises(zkcensus_amd.ZkcError) as ei:
+            engines.fft(ctx, *args)
+        assert ei.value.code == 4                                                         # ZKC_ERR_BAD_ARG
