@@ -81,6 +81,7 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     delete zk;
 }
 
+static int fold_prepare(zkc_zkey* zk);
 extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, zkc_zkey** out) {
     if (!ctx || !zkey_bytes || !out) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_zkey_load: bad argument");
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -214,6 +215,8 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
     }
     ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&zk->ev_start, hipEventDisableTiming));
     ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    // the folding tables of the voter-independent witness part are part of the key's one-time cost, not of the first proof
+    if (zk->nLevels >= 0 && (rc = fold_prepare(zk))) return bail(rc);
     *out = zk;
     return ZKC_OK;
 }
