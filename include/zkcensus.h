@@ -8,6 +8,12 @@
  * little-endian integers in STANDARD (non-Montgomery) form unless a comment says otherwise; points are affine
  * (G1 = x||y, G2 = x.c0||x.c1||y.c0||y.c1; all-zero = infinity).  No exceptions cross the ABI; functions return 0 on
  * success and a ZKC_ERR_* code otherwise, with text available from zkc_last_error().
+ *
+ * Threads: every entry point may be called from any thread.  Calls that take the same zkc_ctx (directly or through a zkc_zkey /
+ * zkc_msm made on it) are serialised by a mutex inside the context -- one GPU pipeline per context; different contexts (one per
+ * GPU) run concurrently.  groth16_prover is re-entrant the way rapidsnark's is (callable from concurrent goroutines): it keeps one
+ * process-wide context and the last key behind its own lock.  zkc_last_error(ctx) is the last error of that context (read it before
+ * another thread's call on the same context fails); zkc_verify_last_error is per thread.
  */
 #ifndef ZKCENSUS_H
 #define ZKCENSUS_H
@@ -46,6 +52,12 @@ void* zkc_ctx_stream(zkc_ctx* ctx);                    /* the hipStream_t every 
 /* ---- circuit shape: ZkFranchiseProofCircuit(nLevels), circuit/census.circom:49 ---- */
 int zkc_circuit_n_inputs(int nLevels);                 /* 334 for nLevels = 160 */
 int zkc_circuit_n_wires(int nLevels);                  /* 82754 for nLevels = 160 */
+/* Circuit selection the way snarkjs callers name a circuit: by its witness-calculator wasm (groth16.fullProve(input, wasmFile, zkey),
+ * ts_inputs/src/example.ts:358-362).  Hashes the image and returns nLevels of the native circuit it stands for -- 160 for
+ * sha256 80a73567...c139 (artifacts/zkCensus/dev/circuits-info.md:7) -- or -1 for a wasm this build has no native witness generator for.
+ * sha256_hex (may be NULL) receives the 64-digit hash + NUL either way. */
+int zkc_circuit_nlevels_from_wasm(const void* wasm, size_t len, char sha256_hex[65]);
+void zkc_sha256(const void* data, size_t len, uint8_t out[32]);
 
 /* ---- a1: witness calculation (replaces wtns.calculate / CalculateWTNSBin) ----
  * inputs : B x n_inputs x 32 B, census.circom:51-67 declaration order:
@@ -62,12 +74,15 @@ int zkc_witness_dev(zkc_ctx* ctx, int nLevels, const void* d_inputs, int B, void
 int  zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, zkc_zkey** out);
 void zkc_zkey_free(zkc_zkey* zk);
 int  zkc_zkey_info(const zkc_zkey* zk, uint32_t* nVars, uint32_t* nPublic, uint32_t* domainSize);
+int  zkc_zkey_sha256(const zkc_zkey* zk, uint8_t out[32]);      /* of the .zkey image it was loaded from (circuits-info.md:5 publishes this hash) */
 
 /* ---- a2-a7: Groth16 prove (replaces snarkjs groth16.prove / rapidsnark groth16_prover internals).
  * wtns   : nWitness x 32 B standard form (the payload of .wtns section 2), host (zkc_prove) or device (zkc_prove_dev)
  * r, s   : the two blinding scalars, 32 B LE, < field order.  snarkjs/rapidsnark draw them at random; they are explicit
  *          here so that identical (zkey, wtns, r, s) gives identical bytes on every backend (SURVEY.md hard part 3).
+ *          zkc_random_scalars fills n x 32 B with scalars uniform in [0, r) from the OS generator (rejection sampling).
  * proof  : A (64) | B (128) | C (64), affine, standard form.   public_out : nPublic x 32 B (may be NULL). */
+void zkc_random_scalars(uint8_t* out, size_t n);
 int zkc_prove(zkc_zkey* zk, const void* wtns, uint32_t nWitness, const uint8_t r[32], const uint8_t s[32],
               uint8_t proof[256], uint8_t* public_out);
 int zkc_prove_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, const uint8_t r[32], const uint8_t s[32],
@@ -75,7 +90,8 @@ int zkc_prove_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, const uin
 
 /* batch form: B witnesses resident in HBM (B x nWitness x 32 B), rs = B x 64 B (r || s per proof), outputs on the host:
  * proofs B x 256 B, publics B x nPublic x 32 B (may be NULL).  Up to ZKC_INFLIGHT (default 96) proofs share one MSM
- * pipeline pass.  Mirrors what a rapidsnark / snarkjs caller would loop over (zk_census_test.go:89 per voter). */
+ * pipeline pass; the work space grows with the number of proofs a call puts in flight (a single-proof caller reserves that of one
+ * proof, not of 96).  Mirrors what a rapidsnark / snarkjs caller would loop over (zk_census_test.go:89 per voter). */
 int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, int B, const uint8_t* rs, uint8_t* proofs, uint8_t* publics);
 
 /* groth16.fullProve (ts_inputs/src/example.ts:358-362) for a batch, everything on the device: B input blocks (zkc_circuit_n_inputs x 32 B
@@ -86,16 +102,25 @@ int zkc_fullprove_batch_dev(zkc_zkey* zk, const void* d_inputs, int B, void* d_w
 
 /* ---- the rapidsnark entry point (go-rapidsnark prover.h `groth16_prover`, reached from prover.Prove at
  * zk_census_test.go:89): whole .zkey and .wtns file images in, NUL-terminated proof / public-signal JSON out.
- * Returns 0 OK, 1 ERROR, 2 SHORT_BUFFER (required sizes written back), 3 INVALID_WITNESS_LENGTH.  r, s are random. */
+ * Returns 0 OK, 1 ERROR, 2 SHORT_BUFFER (required sizes written back; nothing is proved, so a size query is cheap),
+ * 3 INVALID_WITNESS_LENGTH.  r, s are random, uniform in Fr.  Thread-safe / re-entrant; the last key stays resident, keyed by the
+ * SHA-256 of the .zkey image. */
 int groth16_prover(const void* zkey_buffer, unsigned long zkey_size, const void* wtns_buffer, unsigned long wtns_size,
                    char* proof_buffer, unsigned long* proof_size, char* public_buffer, unsigned long* public_size,
                    char* error_msg, unsigned long error_msg_maxsize);
 
 /* ---- a9: verification on the CPU (replaces proof.Verify(vkey) zk_census_test.go:122 / snarkjs groth16.verify).
  * zkc_verify takes the texts of verification_key.json, signals.json and proof.json: 1 valid, 0 invalid, <0 = -ZKC_ERR_*.
+ * Never a positive value other than 1.  Proof points must be on their curves and B in the order-r subgroup of the twist (both
+ * entry points, single and batch, apply the same membership checks); JSON points must have z = 1 (or 0 = infinity).
  * zkc_verify_bin takes vk = alpha1(64) beta2(128) gamma2(128) delta2(128) IC[nPublic+1](64 each), standard form. */
 int zkc_verify(const char* vkey_json, const char* public_json, const char* proof_json);
 int zkc_verify_bin(const uint8_t* vk, int nPublic, const uint8_t* pub, const uint8_t* proof);
+
+/* e(P, Q) as snarkjs / ffjavascript compute and print it (optimal ate, libff's final exponentiation): what verification_key.json carries
+ * as vk_alphabeta_12 (artifacts/zkCensus/dev/160/verification_key.json:52).  g1 64 B, g2 128 B standard form; out = 12 x 32 B standard form
+ * in the nesting order of that JSON member.  Host only. */
+int zkc_pairing_bin(const uint8_t g1[64], const uint8_t g2[128], uint8_t out[384]);
 
 /* ---- f4: batch verification of N proofs under one key (what a vote-counting node does after zk_census_test.go:103-124 per vote).
  * One random-linear-combination pairing check: N + 3 Miller loops and one final exponentiation; the G1 scalar multiplications run on

@@ -1,10 +1,16 @@
-// Type surface kept identical to what ts_inputs/src/example.ts uses from snarkjs.
+// Type surface kept identical to what ts_inputs/src/example.ts uses from snarkjs (groth16.fullProve / prove / verify, wtns.calculate).
 export interface Groth16Proof { pi_a: string[]; pi_b: string[][]; pi_c: string[]; protocol: "groth16"; curve: "bn128"; }
 export interface ProveOptions { nLevels?: number; r?: bigint | string; s?: bigint | string; }
+export type Artifact = string | Uint8Array | { type: "mem"; data?: Uint8Array };
+export type CircuitInput = Record<string, string | string[]>;
 export declare const groth16: {
-  fullProve(input: Record<string, string | string[]>, wasmFile: string | Uint8Array | { type: "mem"; data: Uint8Array } | null,
-            zkeyFile: string | Uint8Array | { type: "mem"; data: Uint8Array }, logger?: unknown, opts?: ProveOptions):
+  /** wasmFile names the circuit by its SHA-256 (dev/160 circuit.wasm -> native nLevels = 160); null + opts.nLevels for the build's test keys */
+  fullProve(input: CircuitInput, wasmFile: Artifact | null, zkeyFile: Artifact, logger?: unknown, opts?: ProveOptions):
     Promise<{ proof: Groth16Proof; publicSignals: string[] }>;
+  prove(zkeyFile: Artifact, wtnsFile: Artifact, logger?: unknown, opts?: ProveOptions): Promise<{ proof: Groth16Proof; publicSignals: string[] }>;
   verify(vk: object, publicSignals: string[], proof: Groth16Proof): Promise<boolean>;
 };
-export declare function flatten(input: Record<string, string | string[]>, nLevels: number): Buffer;
+export declare const wtns: {
+  calculate(input: CircuitInput, wasmFile: Artifact | null, wtnsFile?: Artifact | null, opts?: ProveOptions): Promise<Buffer>;
+};
+export declare function flatten(input: CircuitInput, nLevels: number): Buffer;

@@ -1,10 +1,14 @@
-// zkcensus (N-API): drop-in for the two snarkjs calls the reference makes (ts_inputs/src/example.ts:1,358-362):
+// zkcensus (N-API): drop-in for the snarkjs calls the reference makes (ts_inputs/src/example.ts:1,358-362):
 //     const { groth16 } = require("zkcensus");   await groth16.fullProve(inputs, wasmFile, zkeyFile)
+// plus groth16.prove(zkeyFile, wtnsFile), groth16.verify(vk, publicSignals, proof) and wtns.calculate(input, wasmFile, wtnsFile).
 // Host code stays JavaScript/TypeScript; the arithmetic runs in libzkcensus.so's HIP kernels.  CommonJS, Node >= 12.
+//
+// wasmFile names the circuit, as it does for snarkjs: its SHA-256 selects the native witness generator (80a73567...c139 = the reference's
+// dev/160 circuit.wasm, artifacts/zkCensus/dev/circuits-info.md:7).  A wasm this build has no native circuit for is rejected loudly --
+// nothing here executes wasm.  wasmFile null/undefined + opts.nLevels selects ZkFranchiseProofCircuit(nLevels) directly (test keys).
 "use strict";
 const fs = require("fs");
 const path = require("path");
-const crypto = require("crypto");
 const native = require("./zkcensus.node");
 
 const R = 21888242871839275222246405745257275088548364400416034343698204186575808495617n;
@@ -34,23 +38,47 @@ function readArtifact(f) {
   if (f && f.type === "mem") return Buffer.from(f.data);
   return Buffer.from(f);
 }
-function rand32() { const b = crypto.randomBytes(32); b[31] = 0; return b; }     // < 2^248 < field order
+function circuitNLevels(wasmFile, opts) {
+  const want = opts && opts.nLevels;
+  if (wasmFile === null || wasmFile === undefined) return want || 160;
+  const c = native.circuitFromWasm(readArtifact(wasmFile), LIB);
+  if (c.nLevels < 0) {
+    throw new Error(`unknown circuit wasm (sha256 ${c.sha256}): this build has a native witness generator for the zkCensus circuit only ` +
+      "(dev/160 circuit.wasm, sha256 80a73567...c139) and does not execute wasm");
+  }
+  if (want && want !== c.nLevels) throw new Error(`wasm file is the nLevels=${c.nLevels} circuit but nLevels=${want} was requested`);
+  return c.nLevels;
+}
+function toJson(out) {
+  const p = out.proof, d = (o) => fromLe(p, o).toString();
+  const proof = { pi_a: [d(0), d(32), "1"], pi_b: [[d(64), d(96)], [d(128), d(160)], ["1", "0"]], pi_c: [d(192), d(224), "1"],
+    protocol: "groth16", curve: "bn128" };
+  const publicSignals = [];
+  for (let i = 0; i < out.publicSignals.length / 32; i++) publicSignals.push(fromLe(out.publicSignals, 32 * i).toString());
+  return { proof, publicSignals };
+}
+const blind = (opts, k) => (opts && opts[k] !== undefined ? le32(opts[k]) : null);      // null: drawn uniformly in Fr by the library
 
+const wtns = {
+  // snarkjs wtns.calculate(input, wasmFile, wtnsFileName): writes the .wtns file (or fills {type: "mem"}.data); also returns the image
+  async calculate(input, wasmFile, wtnsFile, opts) {
+    const nLevels = circuitNLevels(wasmFile, opts);
+    const image = await native.witnessRaw(flatten(input, nLevels), nLevels, LIB);
+    if (typeof wtnsFile === "string") fs.writeFileSync(wtnsFile, image);
+    else if (wtnsFile && wtnsFile.type === "mem") wtnsFile.data = new Uint8Array(image);
+    return image;
+  },
+};
 const groth16 = {
-  // wasmFile is accepted for source compatibility; the witness is computed natively for the zkCensus circuit
   async fullProve(input, wasmFile, zkeyFile, logger, opts) {
-    const nLevels = (opts && opts.nLevels) || 160;
-    const r = opts && opts.r !== undefined ? le32(opts.r) : rand32(), s = opts && opts.s !== undefined ? le32(opts.s) : rand32();
-    const out = await native.fullProveRaw(flatten(input, nLevels), nLevels, readArtifact(zkeyFile), r, s, LIB);
-    const p = out.proof, d = (o) => fromLe(p, o).toString();
-    const proof = { pi_a: [d(0), d(32), "1"], pi_b: [[d(64), d(96)], [d(128), d(160)], ["1", "0"]], pi_c: [d(192), d(224), "1"],
-      protocol: "groth16", curve: "bn128" };
-    const publicSignals = [];
-    for (let i = 0; i < out.publicSignals.length / 32; i++) publicSignals.push(fromLe(out.publicSignals, 32 * i).toString());
-    return { proof, publicSignals };
+    const nLevels = circuitNLevels(wasmFile, opts);
+    return toJson(await native.fullProveRaw(flatten(input, nLevels), nLevels, readArtifact(zkeyFile), blind(opts, "r"), blind(opts, "s"), LIB));
+  },
+  async prove(zkeyFile, wtnsFile, logger, opts) {
+    return toJson(await native.proveRaw(readArtifact(zkeyFile), readArtifact(wtnsFile), blind(opts, "r"), blind(opts, "s"), LIB));
   },
   async verify(vk, publicSignals, proof) {
     return native.verifyJson(JSON.stringify(vk), JSON.stringify(publicSignals), JSON.stringify(proof), LIB);
   },
 };
-module.exports = { groth16, flatten };
+module.exports = { groth16, wtns, flatten };

@@ -1,15 +1,19 @@
 // zkcensus_napi.cc -- Node N-API shim over libzkcensus.so (the thin C ABI in include/zkcensus.h).
 //
-// Keeps the snarkjs surface the reference calls at ts_inputs/src/example.ts:358-362:
+// Keeps the snarkjs surface the reference imports at ts_inputs/src/example.ts:1 and calls at :358-362:
 //     groth16.fullProve(input, wasmFile, zkeyFile) -> Promise<{proof, publicSignals}>
-// The JS wrapper (index.js) flattens the input object and formats decimal strings; this file only moves buffers across the
-// ABI.  All GPU work runs in napi_create_async_work so the event loop is never blocked.  libzkcensus.so is dlopen'ed at
-// first use (path: $ZKCENSUS_LIB or next to the package), so the addon itself builds with plain g++ and N-API >= 4 headers:
+//     groth16.prove(zkeyFile, wtnsFile), groth16.verify(vk, publicSignals, proof), wtns.calculate(input, wasmFile, wtnsFile)
+// The JS wrapper (index.js) flattens the input object, reads artifact files and formats decimal strings; this file only moves buffers
+// across the ABI.  All GPU work runs in napi_create_async_work so the event loop is never blocked.  Those work items run on libuv pool
+// threads, several at a time (Promise.all([...fullProve])): the process-wide context and the resident key below are guarded by one mutex
+// held across witness + prove, on top of the per-context lock inside the library.  libzkcensus.so is dlopen'ed at first use
+// (path: $ZKCENSUS_LIB or next to the package), so the addon itself builds with plain g++ and N-API >= 4 headers:
 //     g++ -std=c++17 -shared -fPIC -I/usr/include/node napi/zkcensus_napi.cc -o napi/zkcensus.node -ldl
 #include <node_api.h>
 #include <dlfcn.h>
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -19,57 +23,110 @@ struct Api {
     int (*ctx_create)(int, void**) = nullptr; const char* (*last_error)(const void*) = nullptr;
     int (*n_wires)(int) = nullptr; int (*n_inputs)(int) = nullptr;
     int (*witness)(void*, int, const void*, int, void*, int32_t*) = nullptr;
-    int (*zkey_load)(void*, const void*, size_t, void**) = nullptr;
+    int (*zkey_load)(void*, const void*, size_t, void**) = nullptr; void (*zkey_free)(void*) = nullptr;
     int (*zkey_info)(const void*, uint32_t*, uint32_t*, uint32_t*) = nullptr;
     int (*prove)(void*, const void*, uint32_t, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*) = nullptr;
     int (*verify)(const char*, const char*, const char*) = nullptr; const char* (*verify_err)() = nullptr;
-    void* ctx = nullptr; std::string err;
+    int (*wtns_parse)(const void*, unsigned long, const uint8_t**, uint32_t*) = nullptr;
+    unsigned long (*wtns_write)(const void*, uint32_t, void*, unsigned long) = nullptr;
+    int (*from_wasm)(const void*, size_t, char*) = nullptr; void (*sha256)(const void*, size_t, uint8_t*) = nullptr;
+    void (*random_scalars)(uint8_t*, size_t) = nullptr;
+    std::string err;
 } g;
+std::mutex g_mu;                       // guards everything below and every use of the shared context / key
+void* g_ctx = nullptr; void* g_key = nullptr; uint8_t g_key_sha[32];
 
-bool load_api(const std::string& hint) {
+bool load_api(const std::string& hint) {               // caller holds g_mu
     if (g.h) return true;
     const char* env = getenv("ZKCENSUS_LIB");
     std::string path = env ? env : hint;
-    g.h = dlopen(path.c_str(), RTLD_NOW | RTLD_GLOBAL);
-    if (!g.h) { g.err = std::string("cannot load libzkcensus.so: ") + dlerror(); return false; }
-#define SYM(field, name) *(void**)(&g.field) = dlsym(g.h, name); if (!g.field) { g.err = "missing symbol " name; return false; }
+    void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { g.err = std::string("cannot load libzkcensus.so: ") + dlerror(); return false; }
+#define SYM(field, name) *(void**)(&g.field) = dlsym(h, name); if (!g.field) { g.err = "missing symbol " name; dlclose(h); return false; }
     SYM(ctx_create, "zkc_ctx_create") SYM(last_error, "zkc_last_error") SYM(n_wires, "zkc_circuit_n_wires") SYM(n_inputs, "zkc_circuit_n_inputs")
-    SYM(witness, "zkc_witness") SYM(zkey_load, "zkc_zkey_load") SYM(zkey_info, "zkc_zkey_info") SYM(prove, "zkc_prove")
-    SYM(verify, "zkc_verify") SYM(verify_err, "zkc_verify_last_error")
+    SYM(witness, "zkc_witness") SYM(zkey_load, "zkc_zkey_load") SYM(zkey_free, "zkc_zkey_free") SYM(zkey_info, "zkc_zkey_info") SYM(prove, "zkc_prove")
+    SYM(verify, "zkc_verify") SYM(verify_err, "zkc_verify_last_error") SYM(wtns_parse, "zkc_wtns_parse") SYM(wtns_write, "zkc_wtns_write")
+    SYM(from_wasm, "zkc_circuit_nlevels_from_wasm") SYM(sha256, "zkc_sha256") SYM(random_scalars, "zkc_random_scalars")
 #undef SYM
+    g.h = h;
     return true;
 }
+bool ensure_ctx(std::string& err) {                     // caller holds g_mu
+    if (g_ctx) return true;
+    const char* d = getenv("ZKC_DEVICE");
+    if (g.ctx_create(d ? atoi(d) : 0, &g_ctx)) { g_ctx = nullptr; err = g.last_error(nullptr); return false; }
+    return true;
+}
+bool ensure_key(const std::vector<uint8_t>& zkey, std::string& err) {      // caller holds g_mu; identity = sha256 of the .zkey image
+    uint8_t d[32]; g.sha256(zkey.data(), zkey.size(), d);
+    if (g_key && !memcmp(d, g_key_sha, 32)) return true;
+    if (g_key) { g.zkey_free(g_key); g_key = nullptr; }                     // one resident key: the old one's HBM is released first
+    if (g.zkey_load(g_ctx, zkey.data(), zkey.size(), &g_key)) { g_key = nullptr; err = g.last_error(g_ctx); return false; }
+    memcpy(g_key_sha, d, 32);
+    return true;
+}
+const char* assert_site(int status) {                   // census.circom line of each assert, as the wasm's "Assert Failed" message names it
+    switch (status) {
+        case 1: return "ZkFranchiseProofCircuit line: 72"; case 2: return "ZkFranchiseProofCircuit line: 90"; case 3: return "ZkFranchiseProofCircuit line: 103";
+        case 4: return "ZkFranchiseProofCircuit line: 114"; case 5: return "SMTLevIns line: 93"; case 6: return "input >= field order";
+    }
+    return "?";
+}
 
+enum Kind { FULLPROVE, PROVE, WITNESS };
 struct Work {
-    napi_async_work work = nullptr; napi_deferred deferred = nullptr;
-    std::vector<uint8_t> inputs, zkey, r, s, proof, pub; int nLevels = 160; int32_t status = 0; std::string err; std::string libhint;
-    void* key = nullptr;
+    napi_async_work work = nullptr; napi_deferred deferred = nullptr; Kind kind = FULLPROVE;
+    std::vector<uint8_t> inputs, zkey, wtns_file, r, s, proof, pub, out; int nLevels = 160; std::string err; std::string libhint;
 };
-void* g_key = nullptr; std::vector<uint8_t> g_key_bytes;       // the last key stays resident, like the Python surface
-
+// inputs -> witness payload (nw x 32 B); caller holds g_mu
+bool run_witness(Work* w, std::vector<uint8_t>& wtns) {
+    const int nw = g.n_wires(w->nLevels), ni = g.n_inputs(w->nLevels);
+    if (nw <= 0 || (int)w->inputs.size() != ni * 32) { w->err = "Not all inputs have been set"; return false; }
+    wtns.resize((size_t)nw * 32); int32_t status = 0;
+    const int rc = g.witness(g_ctx, w->nLevels, w->inputs.data(), 1, wtns.data(), &status);
+    if (rc) { w->err = status ? std::string("Error: Assert Failed. Error in template ") + assert_site(status) : std::string(g.last_error(g_ctx)); return false; }
+    return true;
+}
+bool run_prove(Work* w, const uint8_t* payload, uint32_t nw) {      // caller holds g_mu
+    if (!ensure_key(w->zkey, w->err)) return false;
+    uint32_t nv, np, dn; g.zkey_info(g_key, &nv, &np, &dn);
+    if (nw != nv) { w->err = "Invalid witness length. Circuit: " + std::to_string(nv) + ", witness: " + std::to_string(nw); return false; }
+    uint8_t rs[64];
+    if (w->r.size() == 32 && w->s.size() == 32) { memcpy(rs, w->r.data(), 32); memcpy(rs + 32, w->s.data(), 32); }
+    else g.random_scalars(rs, 2);                                    // uniform in Fr, like snarkjs' Fr.random()
+    w->proof.resize(256); w->pub.resize(32 * (size_t)np);
+    if (g.prove(g_key, payload, nw, rs, rs + 32, w->proof.data(), w->pub.data())) { w->err = g.last_error(g_ctx); return false; }
+    return true;
+}
 void execute(napi_env, void* data) {
     Work* w = (Work*)data;
+    std::lock_guard<std::mutex> guard(g_mu);
     if (!load_api(w->libhint)) { w->err = g.err; return; }
-    if (!g.ctx) { const char* d = getenv("ZKC_DEVICE"); if (g.ctx_create(d ? atoi(d) : 0, &g.ctx)) { g.ctx = nullptr; w->err = g.last_error(nullptr); return; } }
-    if (!g_key || g_key_bytes != w->zkey) {
-        if (g.zkey_load(g.ctx, w->zkey.data(), w->zkey.size(), &g_key)) { g_key = nullptr; w->err = g.last_error(g.ctx); return; }
-        g_key_bytes = w->zkey;
+    if (!ensure_ctx(w->err)) return;
+    if (w->kind == PROVE) {
+        const uint8_t* payload; uint32_t nw;
+        if (g.wtns_parse(w->wtns_file.data(), w->wtns_file.size(), &payload, &nw)) { w->err = "Invalid witness file"; return; }
+        run_prove(w, payload, nw);
+        return;
     }
-    const int nw = g.n_wires(w->nLevels), ni = g.n_inputs(w->nLevels);
-    if ((int)w->inputs.size() != ni * 32) { w->err = "Not all inputs have been set"; return; }
-    std::vector<uint8_t> wtns((size_t)nw * 32);
-    int rc = g.witness(g.ctx, w->nLevels, w->inputs.data(), 1, wtns.data(), &w->status);
-    if (rc) { w->err = w->status ? "Error: Assert Failed. circuit assert " + std::to_string(w->status) : std::string(g.last_error(g.ctx)); return; }
-    uint32_t nv, np, dn; g.zkey_info(g_key, &nv, &np, &dn);
-    w->proof.resize(256); w->pub.resize(32 * (size_t)np);
-    rc = g.prove(g_key, wtns.data(), (uint32_t)nw, w->r.data(), w->s.data(), w->proof.data(), w->pub.data());
-    if (rc) w->err = g.last_error(g.ctx);
+    std::vector<uint8_t> wtns;
+    if (!run_witness(w, wtns)) return;
+    if (w->kind == WITNESS) {
+        const uint32_t nw = (uint32_t)(wtns.size() / 32);
+        w->out.resize(g.wtns_write(wtns.data(), nw, nullptr, 0));
+        g.wtns_write(wtns.data(), nw, w->out.data(), w->out.size());
+        return;
+    }
+    run_prove(w, wtns.data(), (uint32_t)(wtns.size() / 32));
 }
 void complete(napi_env env, napi_status, void* data) {
     Work* w = (Work*)data;
     if (!w->err.empty()) {
         napi_value msg, e; napi_create_string_utf8(env, w->err.c_str(), NAPI_AUTO_LENGTH, &msg); napi_create_error(env, nullptr, msg, &e);
         napi_reject_deferred(env, w->deferred, e);
+    } else if (w->kind == WITNESS) {
+        napi_value b; void* dst; napi_create_buffer_copy(env, w->out.size(), w->out.data(), &dst, &b);
+        napi_resolve_deferred(env, w->deferred, b);
     } else {
         napi_value obj, p, q; void* dst;
         napi_create_object(env, &obj);
@@ -79,31 +136,63 @@ void complete(napi_env env, napi_status, void* data) {
     }
     napi_delete_async_work(env, w->work); delete w;
 }
-std::vector<uint8_t> buf_arg(napi_env env, napi_value v) { void* p; size_t n; napi_get_buffer_info(env, v, &p, &n); return std::vector<uint8_t>((uint8_t*)p, (uint8_t*)p + n); }
-std::string str_arg(napi_env env, napi_value v) { size_t n; napi_get_value_string_utf8(env, v, nullptr, 0, &n); std::string s(n, 0); napi_get_value_string_utf8(env, v, &s[0], n + 1, &n); return s; }
-
-// fullProveRaw(flatInputs: Buffer, nLevels: number, zkey: Buffer, r: Buffer(32), s: Buffer(32), libPath: string) -> Promise<{proof, publicSignals}>
-napi_value FullProveRaw(napi_env env, napi_callback_info info) {
-    size_t argc = 6; napi_value a[6]; napi_get_cb_info(env, info, &argc, a, nullptr, nullptr);
-    Work* w = new Work();
-    w->inputs = buf_arg(env, a[0]); napi_get_value_int32(env, a[1], &w->nLevels); w->zkey = buf_arg(env, a[2]); w->r = buf_arg(env, a[3]); w->s = buf_arg(env, a[4]);
-    w->libhint = str_arg(env, a[5]);
+std::vector<uint8_t> buf_arg(napi_env env, napi_value v) {
+    bool isb = false; napi_is_buffer(env, v, &isb); if (!isb) return {};
+    void* p; size_t n; napi_get_buffer_info(env, v, &p, &n); return std::vector<uint8_t>((uint8_t*)p, (uint8_t*)p + n);
+}
+std::string str_arg(napi_env env, napi_value v) { size_t n = 0; napi_get_value_string_utf8(env, v, nullptr, 0, &n); std::string s(n, 0); napi_get_value_string_utf8(env, v, &s[0], n + 1, &n); return s; }
+napi_value queue(napi_env env, Work* w, const char* what) {
     napi_value promise, name; napi_create_promise(env, &w->deferred, &promise);
-    napi_create_string_utf8(env, "zkcensus.fullProve", NAPI_AUTO_LENGTH, &name);
+    napi_create_string_utf8(env, what, NAPI_AUTO_LENGTH, &name);
     napi_create_async_work(env, nullptr, name, execute, complete, w, &w->work); napi_queue_async_work(env, w->work);
     return promise;
+}
+// fullProveRaw(flatInputs: Buffer, nLevels, zkey: Buffer, r: Buffer(32)|null, s: Buffer(32)|null, libPath) -> Promise<{proof, publicSignals}>
+napi_value FullProveRaw(napi_env env, napi_callback_info info) {
+    size_t argc = 6; napi_value a[6]; napi_get_cb_info(env, info, &argc, a, nullptr, nullptr);
+    Work* w = new Work(); w->kind = FULLPROVE;
+    w->inputs = buf_arg(env, a[0]); napi_get_value_int32(env, a[1], &w->nLevels); w->zkey = buf_arg(env, a[2]); w->r = buf_arg(env, a[3]); w->s = buf_arg(env, a[4]);
+    w->libhint = str_arg(env, a[5]);
+    return queue(env, w, "zkcensus.fullProve");
+}
+// proveRaw(zkey: Buffer, wtnsFileImage: Buffer, r|null, s|null, libPath) -> Promise<{proof, publicSignals}>          (snarkjs groth16.prove)
+napi_value ProveRaw(napi_env env, napi_callback_info info) {
+    size_t argc = 5; napi_value a[5]; napi_get_cb_info(env, info, &argc, a, nullptr, nullptr);
+    Work* w = new Work(); w->kind = PROVE;
+    w->zkey = buf_arg(env, a[0]); w->wtns_file = buf_arg(env, a[1]); w->r = buf_arg(env, a[2]); w->s = buf_arg(env, a[3]); w->libhint = str_arg(env, a[4]);
+    return queue(env, w, "zkcensus.prove");
+}
+// witnessRaw(flatInputs: Buffer, nLevels, libPath) -> Promise<Buffer>  (.wtns file image; snarkjs wtns.calculate)
+napi_value WitnessRaw(napi_env env, napi_callback_info info) {
+    size_t argc = 3; napi_value a[3]; napi_get_cb_info(env, info, &argc, a, nullptr, nullptr);
+    Work* w = new Work(); w->kind = WITNESS;
+    w->inputs = buf_arg(env, a[0]); napi_get_value_int32(env, a[1], &w->nLevels); w->libhint = str_arg(env, a[2]);
+    return queue(env, w, "zkcensus.wtns.calculate");
+}
+// circuitFromWasm(wasm: Buffer, libPath) -> {nLevels: number (-1 = unknown circuit), sha256: string}     (host only)
+napi_value CircuitFromWasm(napi_env env, napi_callback_info info) {
+    size_t argc = 2; napi_value a[2]; napi_get_cb_info(env, info, &argc, a, nullptr, nullptr);
+    std::lock_guard<std::mutex> guard(g_mu);
+    if (!load_api(str_arg(env, a[1]))) { napi_throw_error(env, nullptr, g.err.c_str()); return nullptr; }
+    void* p; size_t n; napi_get_buffer_info(env, a[0], &p, &n);
+    char hex[65] = {0}; const int nl = g.from_wasm(p, n, hex);
+    napi_value obj, v, s; napi_create_object(env, &obj); napi_create_int32(env, nl, &v); napi_create_string_utf8(env, hex, 64, &s);
+    napi_set_named_property(env, obj, "nLevels", v); napi_set_named_property(env, obj, "sha256", s);
+    return obj;
 }
 // verifyJson(vkeyJson, publicJson, proofJson, libPath) -> boolean   (CPU pairing check, milliseconds)
 napi_value VerifyJson(napi_env env, napi_callback_info info) {
     size_t argc = 4; napi_value a[4]; napi_get_cb_info(env, info, &argc, a, nullptr, nullptr);
-    if (!load_api(str_arg(env, a[3]))) { napi_throw_error(env, nullptr, g.err.c_str()); return nullptr; }
+    { std::lock_guard<std::mutex> guard(g_mu); if (!load_api(str_arg(env, a[3]))) { napi_throw_error(env, nullptr, g.err.c_str()); return nullptr; } }
     int rc = g.verify(str_arg(env, a[0]).c_str(), str_arg(env, a[1]).c_str(), str_arg(env, a[2]).c_str());
     if (rc < 0) { napi_throw_error(env, nullptr, g.verify_err()); return nullptr; }
     napi_value out; napi_get_boolean(env, rc == 1, &out); return out;
 }
 napi_value Init(napi_env env, napi_value exports) {
-    napi_value f; napi_create_function(env, "fullProveRaw", NAPI_AUTO_LENGTH, FullProveRaw, nullptr, &f); napi_set_named_property(env, exports, "fullProveRaw", f);
-    napi_create_function(env, "verifyJson", NAPI_AUTO_LENGTH, VerifyJson, nullptr, &f); napi_set_named_property(env, exports, "verifyJson", f);
+    napi_value f;
+#define EXPORT(name, fn) napi_create_function(env, name, NAPI_AUTO_LENGTH, fn, nullptr, &f); napi_set_named_property(env, exports, name, f);
+    EXPORT("fullProveRaw", FullProveRaw) EXPORT("proveRaw", ProveRaw) EXPORT("witnessRaw", WitnessRaw) EXPORT("circuitFromWasm", CircuitFromWasm) EXPORT("verifyJson", VerifyJson)
+#undef EXPORT
     return exports;
 }
 }  // namespace

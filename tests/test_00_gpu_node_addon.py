@@ -1,0 +1,28 @@
+"""GPU, Node: the reference's host language.  `node napi/example.js <zkey> <vkey>` is the ts_inputs/src/example.ts:358-362 call through the N-API
+addon.  This file sorts first on purpose: node is started as a child process BEFORE this pytest process has initialised the GPU (the GPU
+boxes refuse an exec from a process that already has)."""
+import json
+import pytest
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def test_node_addon_full_surface_on_gpu():
+    """The reference's host language: node napi/example.js <zkey> <vkey> = the ts_inputs/src/example.ts:358-362 call through the N-API addon on the
+    GPU -- fullProve, wtns.calculate + prove with injected (r, s), four concurrent fullProve calls, a failing assert, an unknown wasm."""
+    import os, shutil, subprocess
+    from zkcensus_amd import setup
+    node = shutil.which('node')
+    addon = os.path.join(ol.ROOT, 'napi', 'zkcensus.node')
+    if not node or not os.path.exists(addon):
+        pytest.skip('node or the built addon is not available on this box')
+    _, zkey_path, vkey_path = setup.ensure_test_artifacts(160)
+    try:
+        r = subprocess.run([node, os.path.join(ol.ROOT, 'napi', 'example.js'), zkey_path, vkey_path], cwd=ol.ROOT, capture_output=True, text=True, timeout=900)
+    except OSError as e:                                   # the box refused to start a child program from this process
+        pytest.skip('cannot start node from this process: %s' % e)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j['verified'] is True and j['publicSignals'] == ol.load_json('ref/signals.json')
+    assert j['twoStepEqual'] and j['concurrentOk'] and j['badInputRejected'] and j['unknownWasmRejected']

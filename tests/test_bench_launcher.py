@@ -1,0 +1,31 @@
+"""bench.py --gpus N must launch its own ranks when it was not started by torch.distributed.run (the driver calls it both ways).
+CPU rehearsal: --dry-run-cpu runs the same launcher, rendezvous, record gather and max-over-ranks reduction over gloo with
+fabricated records; the real N > 1 run differs only in the backend (RCCL) and in where the records come from (the prover)."""
+import json, os, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(cmd):
+    env = dict(os.environ); env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_self_launch_two_ranks():
+    j = _line([sys.executable, 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--dry-run-cpu'])
+    assert j['n_gpus'] == 2 and j['dry_run'] and j['gathered_records_equal_per_rank_records'] and j['valid'] is False
+
+
+def test_under_torch_distributed_run():
+    j = _line([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+               '--master-port', str(29700 + os.getpid() % 200), 'bench.py', '--gpus', '2', '--dry-run-cpu'])
+    assert j['n_gpus'] == 2 and j['gathered_records_equal_per_rank_records']
+
+
+def test_single_rank_dry_run():
+    j = _line([sys.executable, 'bench.py', '--dry-run-cpu'])
+    assert j['n_gpus'] == 1 and j['gathered_records_equal_per_rank_records']

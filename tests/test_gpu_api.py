@@ -15,7 +15,9 @@ def test_snarkjs_surface_and_rapidsnark_entry():
     vk = json.load(open(vkey_path))
     ex = ol.load_json('ref/inputs_example.json')
     # groth16.fullProve(inputs, wasmFile, zkeyFile) -> {proof, publicSignals}
-    out = groth16.fullProve(ex, '../artifacts/zkCensus/dev/160/circuit.wasm', zkey_path)
+    out = groth16.fullProve(ex, None, zkey_path)             # wasm None = the native nLevels = 160 circuit (a wasm would be matched by sha256)
+    with pytest.raises(ValueError, match='unknown circuit wasm'):
+        groth16.fullProve(ex, b'\0asm not the census circuit', zkey_path)
     assert out['publicSignals'] == ol.load_json('ref/signals.json')
     assert set(out['proof']) == {'pi_a', 'pi_b', 'pi_c', 'protocol', 'curve'} and out['proof']['pi_a'][2] == '1'
     assert groth16.verify(vk, out['publicSignals'], out['proof']) is True
@@ -47,3 +49,46 @@ def test_snarkjs_surface_and_rapidsnark_entry():
     short = wt[:-32 * 5]                                                     # truncated witness -> invalid file
     rc = lib.groth16_prover(zk, len(zk), short, len(short), pb, ctypes.byref(ps), ub, ctypes.byref(us), err, 256)
     assert rc == 1
+    # re-entrant like rapidsnark's (goroutines call it concurrently): four threads, each proof verifies; then another key through the same
+    # entry point (the resident key is identified by the sha256 of the file image, so it is replaced, not aliased) and back again
+    import threading
+    _, zkey10, vkey10 = setup.ensure_test_artifacts(10)
+    zk10 = open(zkey10, 'rb').read(); vk10 = json.load(open(vkey10))
+    import random, sys, os
+    sys.path.insert(0, os.path.join(ol.ROOT, 'tools'))
+    from census_gen import random_voter
+    v10 = random_voter(random.Random(3), ol.poseidon, nLevels=10, depth_c=5, depth_s=4)
+    wt10 = groth16.wtns.calculate(v10, None, 10)
+    results = []
+
+    def call(zkb, wtb, key):
+        p_s, u_s = ctypes.c_ulong(2048), ctypes.c_ulong(2048)
+        p_b, u_b = ctypes.create_string_buffer(2048), ctypes.create_string_buffer(2048); e_b = ctypes.create_string_buffer(256)
+        r = lib.groth16_prover(zkb, len(zkb), wtb, len(wtb), p_b, ctypes.byref(p_s), u_b, ctypes.byref(u_s), e_b, 256)
+        results.append((r, key, p_b.value, u_b.value, e_b.value))
+    th = [threading.Thread(target=call, args=(zk, wt, 160)) for _ in range(4)]
+    for t in th: t.start()
+    for t in th: t.join()
+    call(zk10, wt10, 10); call(zk, wt, 160); call(zk10, wt10, 10)
+    assert len(results) == 7
+    for r, key, pjs, ujs, e in results:
+        assert r == 0, e
+        assert groth16.verify(vk if key == 160 else vk10, json.loads(ujs), json.loads(pjs))
+    assert len({pjs for _, _, pjs, _, _ in results}) == 7                    # fresh (r, s) every time
+
+
+def test_key_cache_is_keyed_by_content(tmp_path):
+    """groth16._key: a second, different key object (or a rewritten file at the same path) must never be served the first key's handle."""
+    import torch  # noqa: F401
+    from zkcensus_amd import groth16, setup
+    _, z10, v10 = setup.ensure_test_artifacts(10)
+    _, z10b, v10b = setup.ensure_test_artifacts(10, seed=99, directory=str(tmp_path))
+    a, b = open(z10, 'rb').read(), open(z10b, 'rb').read()
+    ka = groth16._key(a); kb = groth16._key(b)
+    assert ka is not kb and groth16._key(bytes(a)) is ka and groth16._key(z10) is ka
+    path = str(tmp_path / 'k.zkey')
+    open(path, 'wb').write(a); k1 = groth16._key(path)
+    open(path, 'wb').write(b); os_utime = __import__('os').utime; os_utime(path, None)
+    k2 = groth16._key(path)
+    assert k1 is ka and k2 is kb
+    assert len(groth16._keys) <= groth16.MAX_RESIDENT_KEYS

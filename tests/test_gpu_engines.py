@@ -46,7 +46,7 @@ def test_ntt_matches_oracle(gpu, logn):
     assert back.cpu().numpy().tobytes() == mont                   # inverse(forward(x)) == x, every byte
 
 
-@pytest.mark.parametrize('logn', [8, 15, 17])
+@pytest.mark.parametrize('logn', [8, 15, 17, 20])          # 2^20 = BASELINE configs[4] (ii), the synthetic large-census G1 MSM
 def test_msm_over_generated_bases(gpu, logn):
     ctx, torch = gpu
     from zkcensus_amd import engines

@@ -282,3 +282,38 @@ def test_optional_pipeline_modes_give_identical_proofs(env):
         for k, v in old.items():
             if v is None: os.environ.pop(k, None)
             else: os.environ[k] = v
+
+
+def test_fullprove_batch_nl160_three_passes_config3(env):
+    """BASELINE configs[2] regime at a size the oracle can follow: zkc_fullprove_batch_dev at nLevels = 160 over B = 200 voters of the
+    8 192-voter synthetic census (three pipeline passes of 96: 65 536-bucket H jobs, the pass boundaries 95/96 and 191/192 inside the
+    batch).  Every proof goes through the product's batch verifier, the pass-boundary proofs through the oracle's pairing verifier,
+    and two of them (first of pass 2, last of the batch) are re-proved by the CPU oracle from the device witness: identical bytes."""
+    ctx, get, torch = env
+    import zkcensus_amd
+    from zkcensus_amd import census, groth16
+    nl, B = 160, 200
+    zk, pk, vk = get(nl)
+    voters = census.synthetic_census(ctx, 8192, nl)[4000:4000 + B]
+    flat = b''.join(zkcensus_amd.flatten_inputs(v, nl) for v in voters)
+    d_in = dev_bytes(torch, flat)
+    nW = ctx.n_wires(nl)
+    d_w = torch.zeros(B * nW * 32, dtype=torch.uint8, device='cuda'); d_st = torch.zeros(B, dtype=torch.int32, device='cuda')
+    rng = random.Random(1600)
+    rs = b''.join(rng.randrange(R).to_bytes(32, 'little') for _ in range(2 * B))
+    proofs, pubs = pk.fullprove_batch_dev(d_in.data_ptr(), B, d_w.data_ptr(), d_st.data_ptr(), rs)
+    assert d_st.cpu().tolist() == [0] * B
+    assert groth16.verify_batch(ctx, vk, pubs, proofs)
+    for i in (0, 95, 96, 191, 192, B - 1):
+        assert ol.verify(vk, pubs[256 * i:256 * i + 256], proofs[256 * i:256 * i + 256]), i
+    wt = d_w.view(B, nW * 32)
+    for i in (96, B - 1):
+        w = wt[i].cpu().numpy().tobytes()
+        rc, ow = ol.witness(voters[i], nLevels=nl)
+        assert rc == 0 and ow == w
+        r_i = int.from_bytes(rs[64 * i:64 * i + 32], 'little'); s_i = int.from_bytes(rs[64 * i + 32:64 * i + 64], 'little')
+        rc, op, opub = ol.prove(zk, w, r_i, s_i)
+        assert rc == 0 and op == proofs[256 * i:256 * i + 256] and opub == pubs[256 * i:256 * i + 256], i
+    # a tampered proof in the middle of the batch is caught by the batch verifier
+    bad = bytearray(proofs); bad[256 * 100 + 5] ^= 1
+    assert not groth16.verify_batch(ctx, vk, pubs, bytes(bad))

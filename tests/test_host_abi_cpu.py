@@ -1,0 +1,140 @@
+"""Host-only entry points of the C ABI that need no GPU: the snarkjs-compatible pairing value (pinned to the reference's own
+verification_key.json), circuit selection by wasm hash (circuits-info.md:7), verifier strictness, blinding-scalar sampling, and the
+rapidsnark-shaped entry point's argument checks that come before any GPU work."""
+import ctypes, hashlib, json, os
+import pytest
+import oracle_lib as ol
+import zkcensus_amd
+from zkcensus_amd import _native, groth16
+
+
+def test_pairing_matches_reference_vk_alphabeta_12():
+    """verification_key.json of the reference carries e(alpha1, beta2) as snarkjs computed it (vk_alphabeta_12, :52): a known-answer
+    test for the product's optimal-ate pairing + libff final exponentiation, and the value zkc_setup_from_r1cs now writes."""
+    lib = _native.load()
+    vk = ol.load_json('ref/verification_key.json')
+    out = ctypes.create_string_buffer(384)
+    assert lib.zkc_pairing_bin(ol.g1_json(vk['vk_alpha_1']), ol.g2_json(vk['vk_beta_2']), out) == 0
+    got = [str(int.from_bytes(out.raw[32 * i:32 * i + 32], 'little')) for i in range(12)]
+    assert got == [x for h in vk['vk_alphabeta_12'] for c in h for x in c]
+    # bilinearity through the same function: e(2 alpha, beta) == e(alpha, beta)^2 is not expressible here without GT arithmetic, but
+    # e(alpha, beta) must differ from e(IC0, beta), and a point off the curve is refused
+    out2 = ctypes.create_string_buffer(384)
+    assert lib.zkc_pairing_bin(ol.g1_json(vk['IC'][0]), ol.g2_json(vk['vk_beta_2']), out2) == 0 and out2.raw != out.raw
+    bad = bytearray(ol.g1_json(vk['vk_alpha_1'])); bad[0] ^= 1
+    assert lib.zkc_pairing_bin(bytes(bad), ol.g2_json(vk['vk_beta_2']), out2) != 0
+
+
+def test_generated_verification_key_has_reference_schema(tmp_path):
+    from zkcensus_amd import setup
+    _, _, vp = setup.ensure_test_artifacts(10, directory=str(tmp_path))
+    mine = json.load(open(vp)); ref = ol.load_json('ref/verification_key.json')
+    assert list(mine.keys()) == list(ref.keys())
+    ab = mine['vk_alphabeta_12']
+    assert len(ab) == 2 and all(len(h) == 3 and all(len(c) == 2 for c in h) for h in ab)
+    out = ctypes.create_string_buffer(384)
+    assert _native.load().zkc_pairing_bin(ol.g1_json(mine['vk_alpha_1']), ol.g2_json(mine['vk_beta_2']), out) == 0
+    assert [str(int.from_bytes(out.raw[32 * i:32 * i + 32], 'little')) for i in range(12)] == [x for h in ab for c in h for x in c]
+
+
+def test_circuit_selection_by_wasm_hash():
+    lib = _native.load()
+    hexbuf = ctypes.create_string_buffer(65)
+    junk = b'\0asm\x01\0\0\0' + bytes(100)
+    assert lib.zkc_circuit_nlevels_from_wasm(junk, len(junk), hexbuf) == -1
+    assert hexbuf.value.decode() == hashlib.sha256(junk).hexdigest()
+    with pytest.raises(ValueError, match='unknown circuit wasm'):
+        groth16.circuit_nlevels(junk)
+    assert groth16.circuit_nlevels(None) == 160 and groth16.circuit_nlevels(None, 10) == 10
+    d = ctypes.create_string_buffer(32); lib.zkc_sha256(b'abc', 3, d)
+    assert d.raw == hashlib.sha256(b'abc').digest()
+    # the hash table entry is the one the reference publishes for dev/160 (tests/golden/ref/circuits-info.md = circuits-info.md:7)
+    info = open(ol.golden('ref/circuits-info.md')).read()
+    sha = [l.split()[0] for l in info.splitlines() if l.strip().endswith('circuit.wasm')][0]
+    assert sha == '80a73567f6a4655d4332301efcff4bc5711bb48176d1c71fdb1e48df222ac139'
+    wasm = '/root/reference/artifacts/zkCensus/dev/160/circuit.wasm'
+    if os.path.exists(wasm):                                      # only where the reference tree is present (not on the GPU box)
+        raw = open(wasm, 'rb').read()
+        assert lib.zkc_circuit_nlevels_from_wasm(raw, len(raw), hexbuf) == 160 and hexbuf.value.decode() == sha
+        assert groth16.circuit_nlevels(wasm) == 160
+        with pytest.raises(ValueError):
+            groth16.circuit_nlevels(wasm, 10)
+
+
+def test_verifier_strictness_and_return_codes():
+    """Every return of the verifiers is 1, 0 or negative (a caller that tests rc > 0 must never accept on an error); JSON points need z in
+    {0, 1}; B must be in the order-r subgroup; the verification key's points are checked too."""
+    lib = _native.load()
+    vk = ol.load_json('ref/verification_key.json'); pr = ol.load_json('ref/proof.json'); sig = ol.load_json('ref/signals.json')
+    t = lambda x: json.dumps(x).encode()
+    assert lib.zkc_verify(t(vk), t(sig), t(pr)) == 1
+    bad = json.loads(json.dumps(pr)); bad['pi_a'][2] = '2'
+    assert lib.zkc_verify(t(vk), t(sig), t(bad)) == 0
+    bad = json.loads(json.dumps(pr)); bad['pi_b'][2] = ['1', '1']
+    assert lib.zkc_verify(t(vk), t(sig), t(bad)) == 0
+    badvk = json.loads(json.dumps(vk)); badvk['vk_alpha_1'][0] = str(int(badvk['vk_alpha_1'][0]) + 1)
+    assert lib.zkc_verify(t(badvk), t(sig), t(pr)) < 0                                        # alpha not on the curve
+    assert lib.zkc_verify(b'{}', t(sig), t(pr)) < 0 and lib.zkc_verify(None, t(sig), t(pr)) < 0
+    # a twist point outside the order-r subgroup: x = 1 + u ... search a small x with a square right-hand side, in Python (Fq2 arithmetic)
+    q = ol.Q
+    def f2mul(a, b): return ((a[0] * b[0] - a[1] * b[1]) % q, (a[0] * b[1] + a[1] * b[0]) % q)
+    def f2pow(a, e):
+        r = (1, 0)
+        while e:
+            if e & 1: r = f2mul(r, a)
+            a = f2mul(a, a); e >>= 1
+        return r
+    def f2inv(a):
+        n = pow(a[0] * a[0] + a[1] * a[1], -1, q); return (a[0] * n % q, -a[1] * n % q)
+    def f2sqrt(a):                                         # q = 3 mod 4: complex method
+        if a == (0, 0): return a
+        a1 = f2pow(a, (q - 3) // 4); alpha = f2mul(f2mul(a1, a1), a); x0 = f2mul(a1, a)
+        if alpha == (q - 1, 0): return f2mul((0, 1), x0)
+        b = f2pow(((1 + alpha[0]) % q, alpha[1]), (q - 1) // 2); return f2mul(b, x0)
+    Btw = f2mul((3, 0), f2inv((9, 1)))
+    pt = None
+    for x0 in range(1, 50):
+        x = (x0, 1); rhs = f2mul(f2mul(x, x), x); rhs = ((rhs[0] + Btw[0]) % q, (rhs[1] + Btw[1]) % q)
+        y = f2sqrt(rhs)
+        if f2mul(y, y) == rhs:
+            pt = (x, y); break
+    assert pt is not None
+    prb = bytearray(ol.proof_bytes(pr))
+    prb[64:192] = b''.join(ol.le32(v) for v in (pt[0][0], pt[0][1], pt[1][0], pt[1][1]))     # on the twist, (almost surely) not in the subgroup
+    assert lib.zkc_verify_bin(ol.vk_bytes(vk), 8, b''.join(ol.le32(x) for x in sig), bytes(prb)) == 0
+    # batch verifier without a usable context: negative, never positive
+    rc = lib.zkc_verify_batch(None, ol.vk_bytes(vk), 8, b''.join(ol.le32(x) for x in sig), ol.proof_bytes(pr), 1, None)
+    assert rc < 0
+
+
+def test_random_scalars_are_field_elements():
+    lib = _native.load()
+    buf = ctypes.create_string_buffer(32 * 4000)
+    lib.zkc_random_scalars(buf, 4000)
+    v = [int.from_bytes(buf.raw[32 * i:32 * i + 32], 'little') for i in range(4000)]
+    assert max(v) < ol.R and len(set(v)) == 4000
+    assert max(v) > ol.R * 0.99 and sum(1 for x in v if x >> 248) > 3000        # uniform in Fr, not capped at 2^248 as in round 1
+
+
+def test_groth16_prover_argument_checks_before_any_gpu_work(tmp_path):
+    """rapidsnark's entry point: malformed files, witness-length mismatch and the SHORT_BUFFER size query are answered from the file headers alone
+    (no context, no key load, no proof)."""
+    from zkcensus_amd import setup
+    lib = _native.load()
+    _, zp, _ = setup.ensure_test_artifacts(10, directory=str(tmp_path))
+    zk = open(zp, 'rb').read()
+    nv = ol.lib().zko_n_wires(10)
+    payload = bytes(32 * nv)
+    need = lib.zkc_wtns_write(payload, nv, None, 0); w = ctypes.create_string_buffer(need); lib.zkc_wtns_write(payload, nv, w, need)
+    err = ctypes.create_string_buffer(256)
+    ps, us = ctypes.c_ulong(0), ctypes.c_ulong(0)
+    rc = lib.groth16_prover(zk, len(zk), w.raw, need, None, ctypes.byref(ps), None, ctypes.byref(us), err, 256)
+    assert rc == 2 and ps.value >= 768 and us.value >= 8 * 78 and b'too short' in err.value          # size query: no GPU needed here
+    pb, ub = ctypes.create_string_buffer(ps.value), ctypes.create_string_buffer(us.value)
+    short = ctypes.create_string_buffer(need - 32); lib.zkc_wtns_write(payload[32:], nv - 1, short, need - 32)
+    rc = lib.groth16_prover(zk, len(zk), short.raw, need - 32, pb, ctypes.byref(ps), ub, ctypes.byref(us), err, 256)
+    assert rc == 3 and b'Invalid witness length' in err.value
+    rc = lib.groth16_prover(zk[:1000], 1000, w.raw, need, pb, ctypes.byref(ps), ub, ctypes.byref(us), err, 256)
+    assert rc == 1
+    rc = lib.groth16_prover(zk, len(zk), b'wtnsXXXX' + bytes(40), 48, pb, ctypes.byref(ps), ub, ctypes.byref(us), err, 256)
+    assert rc == 1 and b'Invalid witness file' in err.value

@@ -153,3 +153,14 @@ def test_napi_shim_loads_and_verifies_reference_triple():
           "const b=await z.groth16.verify(vk,sg,pr);console.log(JSON.stringify([a,b,z.flatten(require('./tests/golden/ref/inputs_example.json'),160).length]))})()")
     out = subprocess.check_output([node, '-e', js], cwd=ol.ROOT, timeout=120).decode()
     assert json.loads(out.strip().splitlines()[-1]) == [True, False, 334 * 32]
+    # the snarkjs surface is complete (groth16.fullProve / prove / verify, wtns.calculate) and a wasm names the circuit by its sha256:
+    # an unknown wasm is refused before any GPU work; the reference's dev/160 circuit.wasm (when the tree is here) selects nLevels = 160
+    wasm = '/root/reference/artifacts/zkCensus/dev/160/circuit.wasm'
+    js = ("const z=require('./napi');const inp=require('./tests/golden/ref/inputs_example.json');(async()=>{"
+          "const api=[typeof z.groth16.fullProve,typeof z.groth16.prove,typeof z.groth16.verify,typeof z.wtns.calculate];"
+          "let unknown=null;try{await z.groth16.fullProve(inp,Buffer.from('not a circuit'),'nokey.zkey')}catch(e){unknown=String(e)}"
+          "let mism=null;try{await z.wtns.calculate(inp,%s,null,{nLevels:10})}catch(e){mism=String(e)}"
+          "console.log(JSON.stringify({api,unknown,mism}))})()" % (json.dumps(wasm) if os.path.exists(wasm) else 'Buffer.from("x")'))
+    r = json.loads(subprocess.check_output([node, '-e', js], cwd=ol.ROOT, timeout=120).decode().strip().splitlines()[-1])
+    assert r['api'] == ['function'] * 4 and 'unknown circuit wasm' in r['unknown']
+    assert ('nLevels=160 circuit but nLevels=10' in r['mism']) if os.path.exists(wasm) else ('unknown circuit wasm' in r['mism'])

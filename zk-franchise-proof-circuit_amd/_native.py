@@ -64,6 +64,11 @@ def load():
     L.zkc_msm_g1_free.argtypes = [vp]; L.zkc_msm_g1_free.restype = None
     L.zkc_profile_read.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     L.zkc_setup_from_r1cs.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+    L.zkc_circuit_nlevels_from_wasm.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+    L.zkc_sha256.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]; L.zkc_sha256.restype = None
+    L.zkc_zkey_sha256.argtypes = [vp, ctypes.c_char_p]
+    L.zkc_random_scalars.argtypes = [ctypes.c_char_p, ctypes.c_size_t]; L.zkc_random_scalars.restype = None
+    L.zkc_pairing_bin.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
     _lib = L
     return L
 

@@ -45,6 +45,7 @@ zkc_prof_scope::~zkc_prof_scope() {
 }
 extern "C" int zkc_profile_enable(zkc_ctx* ctx, uint32_t mask) {
     if (!ctx) return ZKC_ERR_BAD_ARG;
+    ZKC_LOCK(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& r : ctx->prof.pending) { ctx->prof.free_events.push_back(r.a); ctx->prof.free_events.push_back(r.b); }
     ctx->prof.pending.clear();
@@ -54,6 +55,7 @@ extern "C" int zkc_profile_enable(zkc_ctx* ctx, uint32_t mask) {
 }
 extern "C" int zkc_profile_read(zkc_ctx* ctx, int cat, double* total_ms, uint64_t* launches, uint64_t* alg_bytes) {
     if (!ctx || cat < 0 || cat >= ZKC_PROF_NCAT) return ZKC_ERR_BAD_ARG;
+    ZKC_LOCK(ctx);
     ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream2));
     for (auto& r : ctx->prof.pending) {
         float ms = 0; (void)hipEventElapsedTime(&ms, r.a, r.b); ctx->prof.ms[r.cat] += ms;
@@ -66,6 +68,7 @@ extern "C" int zkc_profile_read(zkc_ctx* ctx, int cat, double* total_ms, uint64_
 
 extern "C" int zkc_poseidon_batch(zkc_ctx* ctx, int n_inputs, const void* inputs, size_t B, void* out) {
     if (!ctx || !inputs || !out || n_inputs < 2 || n_inputs > 4 || B == 0) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_poseidon_batch: bad argument");
+    ZKC_LOCK(ctx);
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     int rc;
     if ((rc = zkc_ensure(ctx, &ctx->d_scratch_in, &ctx->scratch_in_sz, B * n_inputs * 32))) return rc;
@@ -215,6 +218,7 @@ int zkc_witness_chunk_async(zkc_ctx* ctx, int nLevels, const void* d_inputs, int
 
 extern "C" int zkc_witness_dev(zkc_ctx* ctx, int nLevels, const void* d_inputs, int B, void* d_wtns, int32_t* d_status) {
     if (!ctx || !d_inputs || !d_wtns || !d_status || B <= 0 || nLevels < 3 || nLevels > 252) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_witness_dev: bad argument");
+    ZKC_LOCK(ctx);
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     WitnessLayout L = WitnessLayout::make(nLevels);
     int rc = zkc_ensure(ctx, (void**)&ctx->d_status3, &ctx->status3_n, (size_t)B * 3 * sizeof(int32_t)); if (rc) return rc;
@@ -226,6 +230,7 @@ extern "C" int zkc_witness_dev(zkc_ctx* ctx, int nLevels, const void* d_inputs, 
 
 extern "C" int zkc_witness(zkc_ctx* ctx, int nLevels, const void* inputs, int B, void* wtns, int32_t* status) {
     if (!ctx || !inputs || !wtns || !status || B <= 0 || nLevels < 3 || nLevels > 252) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_witness: bad argument");
+    ZKC_LOCK(ctx);
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     WitnessLayout L = WitnessLayout::make(nLevels);
     const size_t in_sz = (size_t)B * L.nInputs * 32, out_sz = (size_t)B * L.nWires * 32;

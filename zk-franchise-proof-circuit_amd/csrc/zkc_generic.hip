@@ -63,9 +63,12 @@ struct zkc_msm {
 // and out; inverse != 0 computes the inverse transform including the 1/n factor.  d_src != d_dst.  3 <= logn <= 27.
 extern "C" int zkc_ntt_dev(zkc_ctx* ctx, const void* d_src, void* d_dst, int logn, int nvec, int inverse) {
     if (!ctx || !d_src || !d_dst || d_src == d_dst || logn < 3 || logn > 27 || nvec <= 0) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_ntt_dev: bad argument");
+    ZKC_LOCK(ctx);
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const uint32_t n = 1u << logn;
-    TwiddleSet& t = g_tw[{ctx, logn}];
+    static std::mutex g_tw_mu;                      // the map is shared by all contexts
+    TwiddleSet* tp; { std::lock_guard<std::mutex> g(g_tw_mu); tp = &g_tw[{ctx, logn}]; }      // std::map nodes are stable
+    TwiddleSet& t = *tp;
     if (!t.fwd) {
         const Fr w = root_of_unity(logn), wi = fp_inv<FrParams>(w);
         std::vector<Fr> f(n / 2), b(n / 2);
@@ -88,6 +91,7 @@ extern "C" int zkc_ntt_dev(zkc_ctx* ctx, const void* d_src, void* d_dst, int log
 // d_out[i] = k_i * base for n scalars (device, standard form 32 B each); base and outputs are affine points in standard form (64 B).
 extern "C" int zkc_g1_mul_batch_dev(zkc_ctx* ctx, const uint8_t base_std[64], const void* d_scalars, uint32_t n, void* d_out) {
     if (!ctx || !base_std || !d_scalars || !d_out || n == 0) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_g1_mul_batch_dev: bad argument");
+    ZKC_LOCK(ctx);
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     uint32_t x[8], y[8]; memcpy(x, base_std, 32); memcpy(y, base_std + 32, 32);
     if (!fp_std_lt_p<FqParams>(x) || !fp_std_lt_p<FqParams>(y)) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_g1_mul_batch_dev: base coordinate >= q");
@@ -106,6 +110,7 @@ extern "C" int zkc_g1_mul_batch_dev(zkc_ctx* ctx, const uint8_t base_std[64], co
 // A fixed set of n G1 bases (device, affine standard form, 64 B each) made resident as pre-shifted window tables.
 extern "C" int zkc_msm_g1_load_dev(zkc_ctx* ctx, const void* d_bases_std, uint32_t n, zkc_msm** out) {
     if (!ctx || !d_bases_std || !out || n == 0 || n > (1u << 24)) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_msm_g1_load_dev: bad argument");
+    ZKC_LOCK(ctx);
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     zkc_msm* m = new zkc_msm(); m->zk.ctx = ctx; m->n = n; m->c = n >= (1u << 15) ? MSM_C_BIG : MSM_C_SMALL;
     const int nw = msm_nw(m->c);
@@ -128,6 +133,7 @@ extern "C" int zkc_msm_g1_load_dev(zkc_ctx* ctx, const void* d_bases_std, uint32
 extern "C" int zkc_msm_g1_dev(zkc_msm* m, const void* d_scalars, uint8_t out[64]) {
     if (!m || !d_scalars || !out) return ZKC_ERR_BAD_ARG;
     zkc_ctx* ctx = m->zk.ctx;
+    ZKC_LOCK(ctx);
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     m->jl.clear(); m->jl.add((const uint32_t*)d_scalars, nullptr, m->n, 0, m->n, 0, m->c);
     int rc = msm_pass_g1(&m->zk, m->w, m->jl, 0, true, ctx->stream); if (rc) return rc;
@@ -138,6 +144,7 @@ extern "C" int zkc_msm_g1_dev(zkc_msm* m, const void* d_scalars, uint8_t out[64]
 }
 extern "C" void zkc_msm_g1_free(zkc_msm* m) {
     if (!m) return;
+    ZKC_LOCK(m->zk.ctx);
     (void)hipSetDevice(m->zk.ctx->device); (void)hipStreamSynchronize(m->zk.ctx->stream);
     if (m->zk.d_g1) (void)hipFree(m->zk.d_g1);
     m->zk.d_g1 = nullptr; msm_work_free(m->w);

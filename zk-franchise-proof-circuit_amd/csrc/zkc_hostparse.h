@@ -1,0 +1,193 @@
+// zkc_hostparse.h -- the host-only parsers of libzkcensus (product code): iden3 binfile section tables, the Groth16 .zkey header
+// checks, .wtns, the decimal-string JSON shapes of proof.json / signals.json / verification_key.json, and SHA-256 (key-cache
+// identity, circuit selection by wasm hash: artifacts/zkCensus/dev/circuits-info.md:5-7).
+//
+// Plain C++17, no HIP: the same header is compiled into libzkcensus.so by hipcc and, with -fsanitize=address,undefined, into
+// tests/host/parse_asan.cc, which feeds it truncated / oversized / mutated files (tests/test_host_parsers_asan.py).  Every read
+// below is preceded by a bounds check that cannot wrap; nothing here allocates in proportion to an untrusted length field.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+namespace zkc { namespace parse {
+
+static constexpr uint32_t kFqP[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+static constexpr uint32_t kFrP[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+
+inline uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+inline uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+
+// ---- iden3 binfile: magic(4) version(u32) nSections(u32) then per section id(u32) size(u64) payload ----
+struct BinSections { const uint8_t* sec[16]; uint64_t ssz[16]; };
+inline bool binfile_sections(const uint8_t* buf, size_t len, const char magic[4], uint32_t version, BinSections& out, std::string& err) {
+    for (int i = 0; i < 16; i++) { out.sec[i] = nullptr; out.ssz[i] = 0; }
+    if (!buf || len < 12 || memcmp(buf, magic, 4) != 0 || rd32(buf + 4) != version) { err = std::string("not a ") + std::string(magic, 4) + " v" + std::to_string(version) + " file"; return false; }
+    size_t p = 12;
+    for (uint32_t i = 0, ns = rd32(buf + 8); i < ns; i++) {
+        if (len - p < 12) { err = "truncated section table"; return false; }
+        const uint32_t id = rd32(buf + p); const uint64_t sz = rd64(buf + p + 4); p += 12;
+        if (sz > len - p) { err = "truncated section " + std::to_string(id); return false; }        // no wrap: p <= len
+        if (id < 16) { out.sec[id] = buf + p; out.ssz[id] = sz; }
+        p += (size_t)sz;
+    }
+    return true;
+}
+
+// ---- Groth16 .zkey (snarkjs zkey format v1; circuit/circuit-compiler.sh:112-131 writes it) ----
+struct ZkeyHeader { uint32_t nVars, nPub, n, logn, nCoeffs; };
+inline bool zkey_check(const BinSections& s, ZkeyHeader& h, std::string& err) {
+    for (int i = 1; i <= 9; i++) if (!s.sec[i]) { err = "zkey: missing section " + std::to_string(i); return false; }
+    if (s.ssz[1] < 4 || rd32(s.sec[1]) != 1) { err = "zkey: protocol is not groth16"; return false; }
+    // section 2: n8q(4) q(32) n8r(4) r(32) nVars nPub domainSize(4 each) alpha1 beta1(64 each) beta2 gamma2(128 each) delta1(64) delta2(128) = 660 bytes
+    if (s.ssz[2] < 660) { err = "zkey: header section too short"; return false; }
+    const uint8_t* b = s.sec[2];
+    if (rd32(b) != 32 || memcmp(b + 4, kFqP, 32) != 0 || rd32(b + 36) != 32 || memcmp(b + 40, kFrP, 32) != 0) { err = "zkey: curve is not bn128"; return false; }
+    h.nVars = rd32(b + 72); h.nPub = rd32(b + 76); h.n = rd32(b + 80); h.logn = 0;
+    while (h.logn < 31 && (1u << h.logn) < h.n) h.logn++;
+    if (h.n < 4 || (1u << h.logn) != h.n || h.logn > 28) { err = "zkey: domain size must be a power of two in [4, 2^28]"; return false; }
+    if (h.nVars == 0 || h.nPub >= h.nVars) { err = "zkey: nVars / nPublic out of range"; return false; }
+    const uint64_t nv = h.nVars, np = h.nPub, nc = nv - np - 1, n = h.n;
+    if (s.ssz[3] != 64 * (np + 1) || s.ssz[5] != 64 * nv || s.ssz[6] != 64 * nv || s.ssz[7] != 128 * nv || s.ssz[8] != 64 * nc || s.ssz[9] != 64 * n) {
+        err = "zkey: section sizes do not match the header"; return false;
+    }
+    if (s.ssz[4] < 4) { err = "zkey: coefficient section too short"; return false; }
+    h.nCoeffs = rd32(s.sec[4]);
+    if (s.ssz[4] != 4 + 44ull * h.nCoeffs) { err = "zkey: coefficient section size"; return false; }
+    const uint8_t* c = s.sec[4] + 4;
+    for (uint32_t i = 0; i < h.nCoeffs; i++) {
+        const uint32_t m = rd32(c + 44ull * i), cc = rd32(c + 44ull * i + 4), w = rd32(c + 44ull * i + 8);
+        if (m > 1 || cc >= h.n || w >= h.nVars) { err = "zkey: coefficient out of range"; return false; }
+    }
+    return true;
+}
+
+// ---- .wtns (iden3 binfile "wtns" v2): section 1 = n8(4) prime(32) nWitness(4); section 2 = nWitness x 32 B ----
+inline bool wtns_view(const uint8_t* buf, size_t len, const uint8_t** payload, uint32_t* nWitness) {
+    BinSections s; std::string err;
+    if (!binfile_sections(buf, len, "wtns", 2, s, err)) return false;
+    if (!s.sec[1] || !s.sec[2] || s.ssz[1] < 40) return false;
+    if (rd32(s.sec[1]) != 32 || memcmp(s.sec[1] + 4, kFrP, 32) != 0) return false;
+    const uint32_t nw = rd32(s.sec[1] + 36);
+    if (s.ssz[2] != 32ull * nw) return false;
+    if (payload) *payload = s.sec[2];
+    if (nWitness) *nWitness = nw;
+    return true;
+}
+
+// ---- decimal strings <-> 32-byte little-endian integers ----
+inline bool dec_to_std(const std::string& d, uint32_t out[8]) {          // false: not a decimal number, or >= 2^256
+    uint32_t t[8] = {0}; if (d.empty() || d.size() > 80) return false;
+    for (char ch : d) {
+        if (ch < '0' || ch > '9') return false;
+        uint64_t c = (uint64_t)(ch - '0');
+        for (int j = 0; j < 8; j++) { c += (uint64_t)t[j] * 10; t[j] = (uint32_t)c; c >>= 32; }
+        if (c) return false;
+    }
+    memcpy(out, t, 32); return true;
+}
+inline std::string dec_of(const uint8_t* p) {
+    uint32_t s[8]; memcpy(s, p, 32); std::string out; bool nz = true;
+    while (nz) { uint64_t rem = 0; nz = false; for (int i = 7; i >= 0; i--) { uint64_t cur = (rem << 32) | s[i]; s[i] = (uint32_t)(cur / 10); rem = cur % 10; if (s[i]) nz = true; } out.push_back((char)('0' + rem)); }
+    return std::string(out.rbegin(), out.rend());
+}
+// collects every string found under key `key` (nullptr: the document itself), flattened in document order
+inline bool json_strings_under(const std::string& js, const char* key, std::vector<std::string>& out) {
+    size_t k = key ? js.find(std::string("\"") + key + "\"") : 0;
+    if (k == std::string::npos) return false;
+    size_t p = key ? js.find(':', k) : 0; if (p == std::string::npos) return false;
+    if (key) p++;
+    while (p < js.size() && (js[p] == ' ' || js[p] == '\n' || js[p] == '\t' || js[p] == '\r')) p++;
+    if (p >= js.size()) return false;
+    if (js[p] == '"') { size_t e = js.find('"', p + 1); if (e == std::string::npos) return false; out.push_back(js.substr(p + 1, e - p - 1)); return true; }
+    if (js[p] != '[') return false;
+    int depth = 0;
+    for (; p < js.size(); p++) {
+        if (js[p] == '[') depth++;
+        else if (js[p] == ']') { if (--depth == 0) return true; }
+        else if (js[p] == '"') { size_t e = js.find('"', p + 1); if (e == std::string::npos) return false; out.push_back(js.substr(p + 1, e - p - 1)); p = e; }
+    }
+    return false;
+}
+// JSON projective points as snarkjs writes them: G1 [x, y, z], G2 [[x0,x1],[y0,y1],[z0,z1]] with z = 1 (affine) or 0 (infinity).
+// Any other z is rejected: the artifacts never carry one, and silently treating it as affine would accept a different point.
+inline bool put_g1_json(const std::vector<std::string>& v, size_t at, uint8_t* out) {
+    uint32_t z[8]; if (at + 3 > v.size() || !dec_to_std(v[at + 2], z)) return false;
+    uint32_t hi = 0; for (int i = 1; i < 8; i++) hi |= z[i];
+    if (hi || z[0] > 1) return false;
+    if (z[0] == 0) { memset(out, 0, 64); return true; }
+    uint32_t s[8]; if (!dec_to_std(v[at], s)) return false; memcpy(out, s, 32);
+    if (!dec_to_std(v[at + 1], s)) return false; memcpy(out + 32, s, 32); return true;
+}
+inline bool put_g2_json(const std::vector<std::string>& v, size_t at, uint8_t* out) {
+    uint32_t z0[8], z1[8]; if (at + 6 > v.size() || !dec_to_std(v[at + 4], z0) || !dec_to_std(v[at + 5], z1)) return false;
+    uint32_t hi = 0; for (int i = 1; i < 8; i++) hi |= z0[i]; for (int i = 0; i < 8; i++) hi |= z1[i];
+    if (hi || z0[0] > 1) return false;
+    if (z0[0] == 0) { memset(out, 0, 128); return true; }
+    for (int k = 0; k < 4; k++) { uint32_t s[8]; if (!dec_to_std(v[at + k], s)) return false; memcpy(out + 32 * k, s, 32); }
+    return true;
+}
+// verification_key.json + signals.json + proof.json texts -> the binary layouts of zkc_verify_bin.
+// returns 1 ok, 0 = proof / signals malformed (an invalid proof), -1 = verification key malformed (err set)
+inline int verify_inputs_from_json(const std::string& vk, const std::string& pj, const std::string& pr, std::vector<uint8_t>& vkb, std::vector<uint8_t>& pubb,
+                                   std::vector<uint8_t>& prb, int& nPublic, std::string& err) {
+    std::vector<std::string> a1, b2, g2, d2, ic, pub, pa, pb, pc;
+    if (!json_strings_under(vk, "vk_alpha_1", a1) || !json_strings_under(vk, "vk_beta_2", b2) || !json_strings_under(vk, "vk_gamma_2", g2) ||
+        !json_strings_under(vk, "vk_delta_2", d2) || !json_strings_under(vk, "IC", ic)) { err = "verification key JSON: missing member"; return -1; }
+    if (!json_strings_under(pj, nullptr, pub)) { err = "public signals JSON: expected an array of decimal strings"; return -1; }
+    if (!json_strings_under(pr, "pi_a", pa) || !json_strings_under(pr, "pi_b", pb) || !json_strings_under(pr, "pi_c", pc)) { err = "proof JSON: missing member"; return -1; }
+    const size_t np = pub.size();
+    if (np > 4096 || ic.size() != 3 * (np + 1)) { err = "verification key: IC length does not match the public signals"; return -1; }
+    vkb.assign(448 + 64 * (np + 1), 0); pubb.assign(32 * np + 1, 0); prb.assign(256, 0);
+    if (!put_g1_json(a1, 0, vkb.data()) || !put_g2_json(b2, 0, vkb.data() + 64) || !put_g2_json(g2, 0, vkb.data() + 192) || !put_g2_json(d2, 0, vkb.data() + 320)) {
+        err = "verification key JSON: bad point"; return -1;
+    }
+    for (size_t i = 0; i <= np; i++) if (!put_g1_json(ic, 3 * i, vkb.data() + 448 + 64 * i)) { err = "verification key JSON: bad IC point"; return -1; }
+    nPublic = (int)np;
+    for (size_t i = 0; i < np; i++) { uint32_t s[8]; if (!dec_to_std(pub[i], s)) return 0; memcpy(pubb.data() + 32 * i, s, 32); }
+    if (!put_g1_json(pa, 0, prb.data()) || !put_g2_json(pb, 0, prb.data() + 64) || !put_g1_json(pc, 0, prb.data() + 192)) return 0;
+    return 1;
+}
+
+// ---- SHA-256 (FIPS 180-4) ----
+struct Sha256 {
+    uint32_t h[8]; uint8_t buf[64]; uint64_t total = 0; size_t fill = 0;
+    Sha256() { static const uint32_t iv[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u}; memcpy(h, iv, 32); }
+    static uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+    void block(const uint8_t* p) {
+        static const uint32_t K[64] = {
+            0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u, 0xd807aa98u, 0x12835b01u, 0x243185beu, 0x550c7dc3u,
+            0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u, 0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu, 0x2de92c6fu, 0x4a7484aau, 0x5cb0a9dcu, 0x76f988dau,
+            0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u, 0x06ca6351u, 0x14292967u, 0x27b70a85u, 0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u,
+            0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u, 0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u, 0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u,
+            0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u, 0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u,
+            0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
+        uint32_t w[64];
+        for (int i = 0; i < 16; i++) w[i] = ((uint32_t)p[4 * i] << 24) | ((uint32_t)p[4 * i + 1] << 16) | ((uint32_t)p[4 * i + 2] << 8) | p[4 * i + 3];
+        for (int i = 16; i < 64; i++) { const uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10); w[i] = w[i - 16] + s0 + w[i - 7] + s1; }
+        uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+        for (int i = 0; i < 64; i++) {
+            const uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+            const uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+            hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
+    void update(const void* data, size_t n) {
+        const uint8_t* p = (const uint8_t*)data; total += n;
+        if (fill) { const size_t k = n < 64 - fill ? n : 64 - fill; memcpy(buf + fill, p, k); fill += k; p += k; n -= k; if (fill == 64) { block(buf); fill = 0; } }
+        for (; n >= 64; p += 64, n -= 64) block(p);
+        if (n) { memcpy(buf, p, n); fill = n; }
+    }
+    void final(uint8_t out[32]) {
+        const uint64_t bits = total * 8; uint8_t pad[72] = {0x80}; const size_t padlen = (fill < 56 ? 56 : 120) - fill;
+        uint8_t lenb[8]; for (int i = 0; i < 8; i++) lenb[i] = (uint8_t)(bits >> (56 - 8 * i));
+        update(pad, padlen); update(lenb, 8);
+        for (int i = 0; i < 8; i++) { out[4 * i] = (uint8_t)(h[i] >> 24); out[4 * i + 1] = (uint8_t)(h[i] >> 16); out[4 * i + 2] = (uint8_t)(h[i] >> 8); out[4 * i + 3] = (uint8_t)h[i]; }
+    }
+};
+inline void sha256(const void* data, size_t n, uint8_t out[32]) { Sha256 s; s.update(data, n); s.final(out); }
+inline std::string hex_of(const uint8_t* p, size_t n) { static const char* d = "0123456789abcdef"; std::string s; for (size_t i = 0; i < n; i++) { s.push_back(d[p[i] >> 4]); s.push_back(d[p[i] & 15]); } return s; }
+
+}}  // namespace zkc::parse

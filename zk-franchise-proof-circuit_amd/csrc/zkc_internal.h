@@ -4,9 +4,11 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <mutex>
 #include "../../include/zkcensus.h"
 #include "zkc_device.h"
 
+#define ZKC_LOCK(ctx) std::lock_guard<std::recursive_mutex> _zkc_guard((ctx)->mu)
 #define ZKC_HIP_CHECK(ctx, call)                                                                            \
     do { hipError_t _e = (call); if (_e != hipSuccess) {                                                     \
         return zkc_fail((ctx), ZKC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); } } while (0)
@@ -20,7 +22,10 @@ struct zkc_prof {
     std::vector<Rec> pending; std::vector<hipEvent_t> free_events;
     double ms[ZKC_PROF_NCAT] = {0}; uint64_t launches[ZKC_PROF_NCAT] = {0}; uint64_t bytes[ZKC_PROF_NCAT] = {0};
 };
+// Thread-safety contract (include/zkcensus.h): every entry point that takes a zkc_ctx* or a zkc_zkey* locks the context's mutex for its whole
+// duration, so calls on one context from several threads are serialised (one GPU pipeline per context); different contexts run concurrently.
 struct zkc_ctx {
+    std::recursive_mutex mu;
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;        // G2 MSM pipeline (independent of buildABC/NTT): overlaps the G1 pipeline

@@ -8,6 +8,7 @@
 // (zk_census_test.go:89).
 #include "zkc_prover.h"
 #include "zkc_fixedbase.h"
+#include "zkc_hostparse.h"
 #include <cstring>
 #include <algorithm>
 
@@ -62,6 +63,7 @@ zkc_fold_check(WitnessLayout L, const uint32_t* __restrict__ wtns, const uint32_
 
 extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     if (!zk) return;
+    ZKC_LOCK(zk->ctx);
     (void)hipSetDevice(zk->ctx->device);
     (void)hipStreamSynchronize(zk->ctx->stream);
     void* ptrs[] = {zk->d_perm, zk->d_rowlen, zk->d_jdptr, zk->d_col, zk->d_val, zk->d_tw_fwd, zk->d_tw_inv, zk->d_tw_fwd29, zk->d_tw_inv29, zk->d_coset, zk->d_g1, zk->d_g2, zk->d_g2_29, zk->d_flags,
@@ -82,55 +84,65 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
 }
 
 static int fold_prepare(zkc_zkey* zk);
+// (Re)allocates the per-pass work space of every lane for `inflight` proofs per pass (grow only).  The caller holds the context lock and no
+// pass is in flight.  Footprint per proof in flight at nLevels = 160: abc + NTT scratch 2 x 12 MiB, p 4 MiB, MSM entries ~25 MB, partial sums.
+static int lanes_ensure(zkc_zkey* zk, int inflight) {
+    inflight = std::max(1, std::min(inflight, zk->max_inflight));
+    if (inflight <= zk->cur_inflight) return ZKC_OK;
+    inflight = std::max(inflight, std::min(2 * zk->cur_inflight, zk->max_inflight));          // grow geometrically: no reallocation per call for B = 2, 3, 4 ...
+    zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n, nv = zk->nVars; int rc;
+    constexpr int NWS = msm_nw(MSM_C_SMALL), NWB = msm_nw(MSM_C_BIG);
+    const size_t per_proof_entries = (size_t)NWS * 3 * nv + (size_t)NWB * n;
+    const size_t per_proof_buckets = 3 * (size_t)msm_half(MSM_C_SMALL) + msm_half(MSM_C_BIG);
+    for (int l = 0; l < zk->nlanes; l++) {
+        zkc_lane& L = zk->lane[l];
+        for (hipStream_t q : {L.st, L.st2, L.fin}) ZKC_HIP_CHECK(ctx, hipStreamSynchronize(q));
+        for (void** q : {(void**)&L.d_abc, (void**)&L.d_t, (void**)&L.d_p}) if (*q) { ZKC_HIP_CHECK(ctx, hipFree(*q)); *q = nullptr; }
+        msm_work_free(L.w1); msm_work_free(L.w2);
+        if ((rc = dmalloc(ctx, &L.d_abc, 3 * (size_t)n * inflight)) || (rc = dmalloc(ctx, &L.d_t, 3 * (size_t)n * inflight)) ||
+            (rc = dmalloc(ctx, &L.d_p, 8 * (size_t)n * inflight))) return rc;
+        if ((rc = msm_work_alloc(ctx, L.w1, per_proof_entries * inflight, per_proof_buckets * inflight, 4 * inflight, false))) return rc;
+        if ((rc = msm_work_alloc(ctx, L.w2, (size_t)NWS * nv * inflight, (size_t)msm_half(MSM_C_SMALL) * inflight, inflight, true))) return rc;
+    }
+    zk->cur_inflight = inflight;
+    return ZKC_OK;
+}
 extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, zkc_zkey** out) {
     if (!ctx || !zkey_bytes || !out) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_zkey_load: bad argument");
+    ZKC_LOCK(ctx);
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const uint8_t* buf = (const uint8_t*)zkey_bytes;
-    if (len < 12 || memcmp(buf, "zkey", 4) || rd32(buf + 4) != 1) return zkc_fail(ctx, ZKC_ERR_FORMAT, "not a zkey v1 file");
-    const uint8_t* sec[16] = {nullptr}; uint64_t ssz[16] = {0};
-    size_t p = 12;
-    for (uint32_t i = 0, ns = rd32(buf + 8); i < ns; i++) {
-        if (p + 12 > len) return zkc_fail(ctx, ZKC_ERR_FORMAT, "zkey: truncated section table");
-        uint32_t id = rd32(buf + p); uint64_t sz = rd64(buf + p + 4); p += 12;
-        if (p + sz > len) return zkc_fail(ctx, ZKC_ERR_FORMAT, "zkey: truncated section");
-        if (id < 16) { sec[id] = buf + p; ssz[id] = sz; }
-        p += sz;
-    }
-    for (int i = 1; i <= 9; i++) if (!sec[i]) return zkc_fail(ctx, ZKC_ERR_FORMAT, "zkey: missing section " + std::to_string(i));
-    if (rd32(sec[1]) != 1) return zkc_fail(ctx, ZKC_ERR_FORMAT, "zkey: protocol is not groth16");
+    // every length and index of the file is validated by the host-only parser (zkc_hostparse.h, also built under ASan/UBSan by the tests)
+    parse::BinSections bs; parse::ZkeyHeader zh; std::string perr;
+    if (!parse::binfile_sections(buf, len, "zkey", 1, bs, perr) || !parse::zkey_check(bs, zh, perr)) return zkc_fail(ctx, ZKC_ERR_FORMAT, perr);
+    const uint8_t* const* sec = bs.sec;
     const uint8_t* h = sec[2];
-    if (rd32(h) != 32 || memcmp(h + 4, FqParams::p, 32) || rd32(h + 36) != 32 || memcmp(h + 40, FrParams::p, 32))
-        return zkc_fail(ctx, ZKC_ERR_FORMAT, "zkey: curve is not bn128");
     zkc_zkey* zk = new zkc_zkey(); zk->ctx = ctx;
-    zk->nVars = rd32(h + 72); zk->nPub = rd32(h + 76); zk->n = rd32(h + 80);
-    while ((1u << zk->logn) < zk->n) zk->logn++;
+    zk->nVars = zh.nVars; zk->nPub = zh.nPub; zk->n = zh.n; zk->logn = zh.logn; zk->nCoeffs = zh.nCoeffs;
+    parse::sha256(buf, len, zk->sha256);
     const uint32_t n = zk->n, nv = zk->nVars, np = zk->nPub, nc = nv - np - 1;
-    if ((1u << zk->logn) != n || ssz[3] != 64ull * (np + 1) || ssz[5] != 64ull * nv || ssz[6] != 64ull * nv || ssz[7] != 128ull * nv ||
-        ssz[8] != 64ull * nc || ssz[9] != 64ull * n) { delete zk; return zkc_fail(ctx, ZKC_ERR_FORMAT, "zkey: section sizes do not match the header"); }
     zk->alpha1 = rd_g1(h + 84); zk->beta1 = rd_g1(h + 148); zk->beta2 = rd_g2(h + 212); zk->gamma2 = rd_g2(h + 340);
     zk->delta1 = rd_g1(h + 468); zk->delta2 = rd_g2(h + 532);
     for (uint32_t i = 0; i <= np; i++) zk->ic.push_back(rd_g1(sec[3] + 64ull * i));
-    zk->nCoeffs = rd32(sec[4]);
     {   // wires whose A / B / C polynomial is zero have the point at infinity as base: they never enter an MSM
         auto zero64 = [](const uint8_t* q) { for (int i = 0; i < 64; i++) if (q[i]) return false; return true; };
         zk->fold.infA.resize(nv); zk->fold.infB.resize(nv); zk->fold.infC.assign(nv, 0);
         for (uint32_t i = 0; i < nv; i++) { zk->fold.infA[i] = zero64(sec[5] + 64ull * i); zk->fold.infB[i] = zero64(sec[6] + 64ull * i); if (i > np) zk->fold.infC[i] = zero64(sec[8] + 64ull * (i - np - 1)); }
     }
-    if (ssz[4] != 4 + 44ull * zk->nCoeffs) { delete zk; return zkc_fail(ctx, ZKC_ERR_FORMAT, "zkey: coefficient section size"); }
     // a key whose shape is ZkFranchiseProofCircuit(nLevels) can use the voter-independent witness template
     if (np == 8 && !getenv("ZKC_NO_FOLD")) for (int nl = 3; nl <= 252; nl++) if ((uint32_t)WitnessLayout::make(nl).nWires == nv) { zk->nLevels = nl; break; }
     int rc = ZKC_OK;
     auto bail = [&](int code) { zkc_zkey_free(zk); return code; };
-#define ZKC_UP(dst, src, bytes)                                                                          \
-    do { hipError_t _e = hipMemcpy((dst), (src), (bytes), hipMemcpyHostToDevice);                        \
-        if (_e != hipSuccess) return bail(zkc_fail(ctx, ZKC_ERR_HIP, std::string("hipMemcpy H2D: ") + hipGetErrorString(_e))); } while (0)
+    // from here on every failure releases the half-built key: no early return without bail()
+#define ZKC_HIP_BAIL(call)                                                                                      \
+    do { hipError_t _e = (call); if (_e != hipSuccess) return bail(zkc_fail(ctx, ZKC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e))); } while (0)
+#define ZKC_UP(dst, src, bytes) ZKC_HIP_BAIL(hipMemcpy((dst), (src), (bytes), hipMemcpyHostToDevice))
     // ---- section 4 -> CSR (row = matrix * n + constraint) ----
     {
         std::vector<uint32_t> rowptr(2 * (size_t)n + 1, 0), col(zk->nCoeffs); std::vector<Fr> val(zk->nCoeffs);
         const uint8_t* c = sec[4] + 4;
         for (uint32_t i = 0; i < zk->nCoeffs; i++) {
             uint32_t m = rd32(c + 44ull * i), cc = rd32(c + 44ull * i + 4), s = rd32(c + 44ull * i + 8);
-            if (m > 1 || cc >= n || s >= nv) return bail(zkc_fail(ctx, ZKC_ERR_FORMAT, "zkey: coefficient out of range"));
             rowptr[(size_t)m * n + cc + 1]++;
         }
         for (size_t r = 0; r < 2 * (size_t)n; r++) rowptr[r + 1] += rowptr[r];
@@ -188,24 +200,20 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
         (rc = msm_precompute_g1(ctx, nc, zk->d_g1 + zk->offC, MSM_C_SMALL)) || (rc = msm_precompute_g1(ctx, n, zk->d_g1 + zk->offH, MSM_C_BIG)) ||
         (rc = msm_precompute_g2(ctx, nv, zk->d_g2, MSM_C_SMALL))) return bail(rc);
     if ((rc = dmalloc(ctx, &zk->d_g2_29, 60 * (size_t)NWS * nv)) || (rc = msm_g2_table29(ctx, zk->d_g2, zk->d_g2_29, (size_t)NWS * nv))) return bail(rc);
-    // ---- work buffers: `inflight` proofs share one MSM pipeline pass ----
+    // ---- work buffers: up to `max_inflight` proofs share one MSM pipeline pass; the buffers themselves are sized by lanes_ensure() for
+    //      the number of proofs a call actually puts in flight (a single-proof caller does not reserve the work space of 96) ----
     const char* e_inf = getenv("ZKC_INFLIGHT");
     zk->max_inflight = e_inf ? std::max(1, std::min(atoi(e_inf), MSM_MAX_JOBS / 4)) : 96;      // same box, batch 1024: 64 -> 1955, 80 -> 1985, 96 -> 2015, 112 -> 2000, 128 -> 2022 proofs/s
-    const size_t per_proof_entries = (size_t)NWS * 3 * nv + (size_t)NWB * n;
-    const size_t per_proof_buckets = 3 * (size_t)msm_half(MSM_C_SMALL) + msm_half(MSM_C_BIG);
     // ZKC_LANES=2 lets two lanes take alternate passes; measured no gain (the GPU is already saturated), so one lane is the default
     { const char* e_l = getenv("ZKC_LANES"); zk->nlanes = e_l ? std::max(1, std::min(atoi(e_l), 2)) : 1; }
     for (int l = 0; l < zk->nlanes; l++) {
         zkc_lane& L = zk->lane[l];
-        ZKC_HIP_CHECK(ctx, hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking)); ZKC_HIP_CHECK(ctx, hipStreamCreateWithFlags(&L.st2, hipStreamNonBlocking));
-        ZKC_HIP_CHECK(ctx, hipStreamCreateWithFlags(&L.fin, hipStreamNonBlocking));
-        ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&L.ev_msm, hipEventDisableTiming)); ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&L.ev_msm2, hipEventDisableTiming)); ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&L.ev_sorted, hipEventDisableTiming));
-        ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&L.ev_fin[0], hipEventDisableTiming)); ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&L.ev_fin[1], hipEventDisableTiming));
-        if ((rc = dmalloc(ctx, &L.d_abc, 3 * (size_t)n * zk->max_inflight)) || (rc = dmalloc(ctx, &L.d_t, 3 * (size_t)n * zk->max_inflight)) ||
-            (rc = dmalloc(ctx, &L.d_p, 8 * (size_t)n * zk->max_inflight))) return bail(rc);
-        if ((rc = msm_work_alloc(ctx, L.w1, per_proof_entries * zk->max_inflight, per_proof_buckets * zk->max_inflight, 4 * zk->max_inflight, false))) return bail(rc);
-        if ((rc = msm_work_alloc(ctx, L.w2, (size_t)NWS * nv * zk->max_inflight, (size_t)msm_half(MSM_C_SMALL) * zk->max_inflight, zk->max_inflight, true))) return bail(rc);
+        ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking)); ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.st2, hipStreamNonBlocking));
+        ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.fin, hipStreamNonBlocking));
+        ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_msm, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_msm2, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_sorted, hipEventDisableTiming));
+        ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_fin[0], hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_fin[1], hipEventDisableTiming));
     }
+    if ((rc = lanes_ensure(zk, 1))) return bail(rc);
     {   // fixed-base tables for the blinding step (delta1, alpha1, beta1 in G1; delta2 in G2)
         FixedBase<Fq> td(zk->delta1), ta(zk->alpha1), tb(zk->beta1); FixedBase<Fq2> t2(zk->delta2);
         if ((rc = dmalloc(ctx, &zk->d_tblDelta1, td.tab.size())) || (rc = dmalloc(ctx, &zk->d_tblAlpha1, ta.tab.size())) ||
@@ -213,12 +221,14 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
         ZKC_UP(zk->d_tblDelta1, td.tab.data(), td.tab.size() * sizeof(G1Affine)); ZKC_UP(zk->d_tblAlpha1, ta.tab.data(), ta.tab.size() * sizeof(G1Affine));
         ZKC_UP(zk->d_tblBeta1, tb.tab.data(), tb.tab.size() * sizeof(G1Affine)); ZKC_UP(zk->d_tblDelta2, t2.tab.data(), t2.tab.size() * sizeof(G2Affine));
     }
-    ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&zk->ev_start, hipEventDisableTiming));
-    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ZKC_HIP_BAIL(hipEventCreateWithFlags(&zk->ev_start, hipEventDisableTiming));
+    ZKC_HIP_BAIL(hipStreamSynchronize(ctx->stream));
     // the folding tables of the voter-independent witness part are part of the key's one-time cost, not of the first proof
     if (zk->nLevels >= 0 && (rc = fold_prepare(zk))) return bail(rc);
     *out = zk;
     return ZKC_OK;
+#undef ZKC_UP
+#undef ZKC_HIP_BAIL
 }
 
 extern "C" int zkc_zkey_info(const zkc_zkey* zk, uint32_t* nVars, uint32_t* nPublic, uint32_t* domainSize) {
@@ -314,6 +324,7 @@ static int h_evals_dev(zkc_zkey* zk, zkc_lane& L, const uint32_t* d_wtns0, int n
 extern "C" int zkc_debug_stage(zkc_zkey* zk, const void* d_wtns, int stage, void* host_out) {
     if (!zk || !d_wtns || !host_out) return ZKC_ERR_BAD_ARG;
     zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n; zkc_lane& L0 = zk->lane[0];
+    ZKC_LOCK(ctx);
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device)); ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (stage == 0) {
         hipLaunchKernelGGL(zkc_matvec_jds, dim3((2 * n + 63 * zk->nlong + 255) / 256, 1), dim3(256), 0, L0.st, zk->d_perm, zk->d_rowlen, zk->d_jdptr, zk->d_col, zk->d_val,
@@ -332,6 +343,7 @@ extern "C" int zkc_debug_stage(zkc_zkey* zk, const void* d_wtns, int stage, void
 extern "C" int zkc_msm_debug(zkc_zkey* zk, int which, const void* d_scalars, uint32_t count, void* host_out) {
     if (!zk || !d_scalars || !host_out || which < 0 || which > 4) return ZKC_ERR_BAD_ARG;
     zkc_ctx* ctx = zk->ctx; zkc_lane& L0 = zk->lane[0];
+    ZKC_LOCK(ctx);
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device)); ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t full = which == 3 ? zk->nVars - zk->nPub - 1 : which == 4 ? zk->n : zk->nVars;
     if (count != full) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_msm_debug: count must equal the section size");
@@ -352,6 +364,7 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
                             const void* d_inputs, int32_t* d_status) {
     if (!zk || !d_wtns || !rs || !proofs || B <= 0) return zkc_fail(zk ? zk->ctx : nullptr, ZKC_ERR_BAD_ARG, "zkc_prove_batch_dev: bad argument");
     zkc_ctx* ctx = zk->ctx;
+    ZKC_LOCK(ctx);
     if (nWitness != zk->nVars) return zkc_fail(ctx, ZKC_ERR_INVALID_WITNESS_LENGTH, "Invalid witness length. Circuit: " + std::to_string(zk->nVars) + ", witness: " + std::to_string(nWitness));
     for (int b = 0; b < 2 * B; b++) { uint32_t t[8]; memcpy(t, rs + 32 * (size_t)b, 32); if (!fp_std_lt_p<FrParams>(t)) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "r or s >= field order"); }
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -359,6 +372,7 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
     const bool can_fold = zk->nLevels >= 0;
     hipStream_t st0 = ctx->stream;
     WitnessLayout L{}; int rc;
+    if ((rc = lanes_ensure(zk, B))) return rc;
     if (zk->rs_cap < (size_t)B) {
         if (zk->d_rs) { ZKC_HIP_CHECK(ctx, hipFree(zk->d_rs)); ZKC_HIP_CHECK(ctx, hipFree(zk->d_proofs)); ZKC_HIP_CHECK(ctx, hipHostFree(zk->h_out)); zk->d_rs = zk->d_proofs = zk->h_out = nullptr; }
         ZKC_HIP_CHECK(ctx, hipMalloc((void**)&zk->d_rs, 64 * (size_t)B)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&zk->d_proofs, 256 * (size_t)B));
@@ -504,6 +518,7 @@ extern "C" int zkc_prove(zkc_zkey* zk, const void* wtns, uint32_t nWitness, cons
                          uint8_t proof[256], uint8_t* public_out) {
     if (!zk || !wtns) return zkc_fail(zk ? zk->ctx : nullptr, ZKC_ERR_BAD_ARG, "zkc_prove: bad argument");
     zkc_ctx* ctx = zk->ctx;
+    ZKC_LOCK(ctx);
     if (nWitness != zk->nVars) return zkc_fail(ctx, ZKC_ERR_INVALID_WITNESS_LENGTH, "Invalid witness length. Circuit: " + std::to_string(zk->nVars) + ", witness: " + std::to_string(nWitness));
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     int rc = zkc_ensure(ctx, &ctx->d_scratch_out, &ctx->scratch_out_sz, 32ull * nWitness); if (rc) return rc;

@@ -137,7 +137,9 @@ struct zkc_zkey {
     uint32_t* d_g2_29 = nullptr;                                            // the G2 table again in radix 2^29 (60 words per point: x, y, -y), read by the accumulation
     uint32_t offA = 0, offB1 = 0, offC = 0, offH = 0;                       // table offsets inside d_g1 (points)
     // per-proof work buffers
-    int max_inflight = 0;                                                   // proofs per pipeline pass
+    int max_inflight = 0;                                                   // proofs per pipeline pass (upper limit)
+    int cur_inflight = 0;                                                   // what the lanes' work space is currently sized for (lanes_ensure)
+    uint8_t sha256[32] = {0};                                               // of the .zkey image: key-cache identity (groth16_prover)
     zkc_lane lane[2]; int nlanes = 2;
     uint32_t *d_flags = nullptr, *h_flags = nullptr; size_t flags_cap = 0;  // fold check: [B][2][n]
     zkc::G1Affine *d_tblDelta1 = nullptr, *d_tblAlpha1 = nullptr, *d_tblBeta1 = nullptr; zkc::G2Affine* d_tblDelta2 = nullptr;

@@ -15,6 +15,8 @@
 #include "zkc_fixedbase.h"
 #include "../../include/zkcensus.h"
 
+#include "zkc_hostparse.h"
+extern "C" int zkc_pairing_bin(const uint8_t g1[64], const uint8_t g2[128], uint8_t out[384]);
 using namespace zkc;
 
 namespace {
@@ -172,10 +174,26 @@ extern "C" int zkc_setup_from_r1cs(const char* r1cs_path, uint64_t seed, const c
     fwrite("zkey", 1, 4, o); uint32_t ver = 1, ns = 10; fwrite(&ver, 4, 1, o); fwrite(&ns, 4, 1, o);
     for (uint32_t id = 1; id <= 10; id++) { uint64_t len = sec[id].size(); fwrite(&id, 4, 1, o); fwrite(&len, 8, 1, o); fwrite(sec[id].data(), 1, len, o); }
     fclose(o);
-    // ---- verification_key.json (layout of artifacts/zkCensus/dev/160/verification_key.json; vk_alphabeta_12 omitted) ----
+    // ---- verification_key.json (members and order of artifacts/zkCensus/dev/160/verification_key.json, vk_alphabeta_12 = e(alpha1, beta2)
+    //      as snarkjs' `zkey export verificationkey` prints it, circuit/circuit-compiler.sh:133-134) ----
     if (vkey_json_path) {
         std::string j = "{\n \"protocol\": \"groth16\",\n \"curve\": \"bn128\",\n \"nPublic\": " + std::to_string(nPub) + ",\n";
-        j += " \"vk_alpha_1\": " + json_g1(alpha1) + ",\n \"vk_beta_2\": " + json_g2(beta2) + ",\n \"vk_gamma_2\": " + json_g2(gamma2) + ",\n \"vk_delta_2\": " + json_g2(delta2) + ",\n \"IC\": [\n";
+        j += " \"vk_alpha_1\": " + json_g1(alpha1) + ",\n \"vk_beta_2\": " + json_g2(beta2) + ",\n \"vk_gamma_2\": " + json_g2(gamma2) + ",\n \"vk_delta_2\": " + json_g2(delta2) + ",\n";
+        {
+            uint8_t a[64], b[128], e[384]; uint32_t t[8];
+            fp_to_std<FqParams>(t, alpha1.x); memcpy(a, t, 32); fp_to_std<FqParams>(t, alpha1.y); memcpy(a + 32, t, 32);
+            const Fq* bc[4] = {&beta2.x.c0, &beta2.x.c1, &beta2.y.c0, &beta2.y.c1};
+            for (int i = 0; i < 4; i++) { fp_to_std<FqParams>(t, *bc[i]); memcpy(b + 32 * i, t, 32); }
+            if (zkc_pairing_bin(a, b, e) != ZKC_OK) return fail(err, errlen, "pairing e(alpha, beta) failed");
+            j += " \"vk_alphabeta_12\": [\n";
+            for (int h = 0; h < 2; h++) {
+                j += "  [\n";
+                for (int k = 0; k < 3; k++) j += "   [\"" + zkc::parse::dec_of(e + 64 * (3 * h + k)) + "\", \"" + zkc::parse::dec_of(e + 64 * (3 * h + k) + 32) + "\"]" + (k < 2 ? ",\n" : "\n");
+                j += h == 0 ? "  ],\n" : "  ]\n";
+            }
+            j += " ],\n";
+        }
+        j += " \"IC\": [\n";
         for (uint32_t i = 0; i <= nPub; i++) j += "  " + json_g1(pC[i]) + (i < nPub ? ",\n" : "\n");
         j += " ]\n}\n";
         FILE* v = fopen(vkey_json_path, "wb"); if (!v) return fail(err, errlen, std::string("cannot write ") + vkey_json_path);

@@ -13,6 +13,8 @@
 #include <thread>
 #include <algorithm>
 #include "zkc_prover.h"
+#include "zkc_hostparse.h"
+#include <mutex>
 
 using namespace zkc;
 
@@ -65,7 +67,15 @@ Fq12 miller(const G1Affine& P, const G2Affine& Q) {
         if ((T[i >> 6] >> (i & 63)) & 1) {
             if (rinf) { xR = Q.x; yR = Q.y; rinf = false; continue; }
             Fq2 dx = Q.x - xR;
-            if (dx.is_zero()) { rinf = true; continue; }              // vertical line: killed by the final exponentiation
+            if (dx.is_zero()) {
+                if ((Q.y - yR).is_zero()) {                              // R == Q: the chord is the tangent (only small-order points get here)
+                    Fq2 x2 = fp_sqr(xR), lam = (fp_dbl(x2) + x2) * fp_inv(fp_dbl(yR));
+                    f = f * line_eval(lam, xR, yR, P);
+                    Fq2 x3 = fp_sqr(lam) - fp_dbl(xR), y3 = lam * (xR - x3) - yR;
+                    xR = x3; yR = y3;
+                } else rinf = true;                                      // R == -Q: vertical line, killed by the final exponentiation
+                continue;
+            }
             Fq2 lam = (Q.y - yR) * fp_inv(dx);
             f = f * line_eval(lam, xR, yR, P);
             Fq2 x3 = fp_sqr(lam) - xR - Q.x, y3 = lam * (xR - x3) - yR;
@@ -84,66 +94,59 @@ Fq12 final_exp(const Fq12& f) {          // (q^12 - 1)/r = (q^6 - 1) * ((q^6 + 1
     for (int k = 1267; k >= 0; k--) { r = r * r; if ((E[k >> 6] >> (k & 63)) & 1) r = r * b; }
     return r;
 }
+// ---- the pairing value snarkjs stores in verification_key.json as vk_alphabeta_12 (artifacts/zkCensus/dev/160/verification_key.json:52) ----
+// ffjavascript/wasmcurves follow libff's alt_bn128: optimal ate Miller loop over 6x + 2 with the two Frobenius line steps, then a final
+// exponentiation whose last chunk (Fuentes-Castaneda et al.) yields the reduced pairing raised to 2x(6x^2 + 3x + 1).  Pinned by
+// tests/test_oracle_pinning.py against the reference's own verification key (alpha, beta -> vk_alphabeta_12).
+Fq2 fq2_pow(const Fq2& a, const uint32_t* e, int nbits) { Fq2 r = Fq2::one(); for (int i = nbits - 1; i >= 0; i--) { r = fp_sqr(r); if ((e[i >> 5] >> (i & 31)) & 1) r = r * a; } return r; }
+Fq2 fq2_conj(const Fq2& a) { return {a.c0, fp_neg(a.c1)}; }
+Fq12 miller_optimal_ate(const G1Affine& P, const G2Affine& Q) {
+    Fq12 f = one12();
+    if (P.is_inf() || Q.is_inf()) return f;
+    static const uint64_t S[2] = {0x9d797039be763ba8ull, 0x1ull};             // 6x + 2 = 29793968203157093288
+    Fq2 xR = Q.x, yR = Q.y;
+    auto dbl = [&]() { Fq2 x2 = fp_sqr(xR), lam = (fp_dbl(x2) + x2) * fp_inv(fp_dbl(yR)); f = f * line_eval(lam, xR, yR, P);
+                       Fq2 x3 = fp_sqr(lam) - fp_dbl(xR), y3 = lam * (xR - x3) - yR; xR = x3; yR = y3; };
+    auto add = [&](const Fq2& xq, const Fq2& yq) { Fq2 lam = (yq - yR) * fp_inv(xq - xR); f = f * line_eval(lam, xR, yR, P);
+                                                   Fq2 x3 = fp_sqr(lam) - xR - xq, y3 = lam * (xR - x3) - yR; xR = x3; yR = y3; };
+    for (int i = 63; i >= 0; i--) { f = f * f; dbl(); if ((S[i >> 6] >> (i & 63)) & 1) add(Q.x, Q.y); }
+    // pi(Q) = (conj(x) xi^((q-1)/3), conj(y) xi^((q-1)/2)); pi^2(Q) = (x N(g12), y N(g13)) with the norms of those constants
+    uint32_t e3[8], e2[8];
+    { uint32_t qm1[8]; for (int i = 0; i < 8; i++) qm1[i] = FqParams::p[i]; qm1[0] -= 1;
+      uint64_t rem = 0; for (int i = 7; i >= 0; i--) { uint64_t cur = (rem << 32) | qm1[i]; e3[i] = (uint32_t)(cur / 3); rem = cur % 3; }
+      for (int i = 0; i < 8; i++) e2[i] = (qm1[i] >> 1) | (i < 7 ? qm1[i + 1] << 31 : 0); }
+    const Fq2 xi{fp_from_u32<FqParams>(9), Fq::one()};
+    const Fq2 g12 = fq2_pow(xi, e3, 254), g13 = fq2_pow(xi, e2, 254);
+    const Fq2 x1 = fq2_conj(Q.x) * g12, y1 = fq2_conj(Q.y) * g13;
+    const Fq2 x2 = Q.x * (g12 * fq2_conj(g12)), y2 = fp_neg(Q.y * (g13 * fq2_conj(g13)));
+    add(x1, y1); add(x2, y2);
+    return f;
+}
+Fq12 pairing_snarkjs(const G1Affine& P, const G2Affine& Q) {
+    const Fq12 e = final_exp(miller_optimal_ate(P, Q));
+    // m = 2x(6x^2 + 3x + 1), x = 4965661367192848881
+    static const uint64_t M[3] = {0x2e5d4e223ddedaf4ull, 0x1ea96b02d9d9e38dull, 0x3bec47df15e307c8ull};      // 190 bits
+    Fq12 r = one12();
+    for (int k = 189; k >= 0; k--) { r = r * r; if ((M[k >> 6] >> (k & 63)) & 1) r = r * e; }
+    return r;
+}
 bool g1_on_curve(const G1Affine& a) { return a.is_inf() || fp_sqr(a.y) == fp_sqr(a.x) * a.x + fp_from_u32<FqParams>(3); }
 bool g2_on_curve(const G2Affine& a) {
     if (a.is_inf()) return true;
     static const Fq2 B = Fq2{fp_from_u32<FqParams>(3), Fq::zero()} * fp_inv(Fq2{fp_from_u32<FqParams>(9), Fq::one()});
     return fp_sqr(a.y) == fp_sqr(a.x) * a.x + B;
 }
+bool g2_in_subgroup(const G2Affine& a) {            // on the twist and [r]a = infinity
+    if (!g2_on_curve(a)) return false;
+    if (a.is_inf()) return true;
+    uint32_t rord[8]; for (int q = 0; q < 8; q++) rord[q] = FrParams::p[q];
+    return xyzz_mul(G2XYZZ::from_affine(a), rord).is_inf();
+}
 bool rd_fq_std(Fq& o, const uint8_t* p) { uint32_t s[8]; memcpy(s, p, 32); if (!fp_std_lt_p<FqParams>(s)) return false; o = fp_from_std<FqParams>(s); return true; }
 bool rd_g1_std(G1Affine& o, const uint8_t* p) { return rd_fq_std(o.x, p) && rd_fq_std(o.y, p + 32); }
 bool rd_g2_std(G2Affine& o, const uint8_t* p) { return rd_fq_std(o.x.c0, p) && rd_fq_std(o.x.c1, p + 32) && rd_fq_std(o.y.c0, p + 64) && rd_fq_std(o.y.c1, p + 96); }
 
-// ---------------- minimal JSON reader for the three artifact shapes (arrays of decimal strings) ----------------
-struct JTok { const char* p; const char* e; };
-void skip_ws(JTok& t) { while (t.p < t.e && (*t.p == ' ' || *t.p == '\n' || *t.p == '\r' || *t.p == '\t' || *t.p == ',')) t.p++; }
-bool dec_to_std(const std::string& d, uint32_t out[8], bool reduce_mod_r) {
-    uint32_t t[8] = {0}; if (d.empty()) return false;
-    for (char ch : d) {
-        if (ch < '0' || ch > '9') return false;
-        uint64_t c = (uint64_t)(ch - '0');
-        for (int j = 0; j < 8; j++) { c += (uint64_t)t[j] * 10; t[j] = (uint32_t)c; c >>= 32; }
-        if (c) { if (!reduce_mod_r) return false; return false; }
-    }
-    memcpy(out, t, 32); return true;
-}
-// collects every decimal string found under key `key` (flattened, document order)
-bool json_strings_under(const std::string& js, const char* key, std::vector<std::string>& out) {
-    size_t k = key ? js.find(std::string("\"") + key + "\"") : 0;
-    if (k == std::string::npos) return false;
-    size_t p = key ? js.find(':', k) : 0; if (p == std::string::npos) return false;
-    if (key) p++;
-    while (p < js.size() && (js[p] == ' ' || js[p] == '\n' || js[p] == '\t' || js[p] == '\r')) p++;
-    if (p >= js.size()) return false;
-    if (js[p] == '"') { size_t e = js.find('"', p + 1); if (e == std::string::npos) return false; out.push_back(js.substr(p + 1, e - p - 1)); return true; }
-    if (js[p] != '[') return false;
-    int depth = 0;
-    for (; p < js.size(); p++) {
-        if (js[p] == '[') depth++;
-        else if (js[p] == ']') { if (--depth == 0) return true; }
-        else if (js[p] == '"') { size_t e = js.find('"', p + 1); if (e == std::string::npos) return false; out.push_back(js.substr(p + 1, e - p - 1)); p = e; }
-    }
-    return false;
-}
-std::string dec_of(const uint8_t* p) {
-    uint32_t s[8]; memcpy(s, p, 32); std::string out; bool nz = true;
-    while (nz) { uint64_t rem = 0; nz = false; for (int i = 7; i >= 0; i--) { uint64_t cur = (rem << 32) | s[i]; s[i] = (uint32_t)(cur / 10); rem = cur % 10; if (s[i]) nz = true; } out.push_back((char)('0' + rem)); }
-    return std::string(out.rbegin(), out.rend());
-}
-bool put_g1_json(const std::vector<std::string>& v, size_t at, uint8_t* out) {   // [x, y, z]
-    uint32_t z[8]; if (at + 3 > v.size() || !dec_to_std(v[at + 2], z, false)) return false;
-    bool inf = true; for (int i = 0; i < 8; i++) inf &= z[i] == 0;
-    if (inf) { memset(out, 0, 64); return true; }
-    uint32_t s[8]; if (!dec_to_std(v[at], s, false)) return false; memcpy(out, s, 32);
-    if (!dec_to_std(v[at + 1], s, false)) return false; memcpy(out + 32, s, 32); return true;
-}
-bool put_g2_json(const std::vector<std::string>& v, size_t at, uint8_t* out) {   // [[x0,x1],[y0,y1],[z0,z1]]
-    uint32_t z0[8], z1[8]; if (at + 6 > v.size() || !dec_to_std(v[at + 4], z0, false) || !dec_to_std(v[at + 5], z1, false)) return false;
-    bool inf = true; for (int i = 0; i < 8; i++) inf &= (z0[i] | z1[i]) == 0;
-    if (inf) { memset(out, 0, 128); return true; }
-    for (int k = 0; k < 4; k++) { uint32_t s[8]; if (!dec_to_std(v[at + k], s, false)) return false; memcpy(out + 32 * k, s, 32); }
-    return true;
-}
+using parse::dec_of;
 
 thread_local std::string g_err;
 int vfail(int code, const std::string& m) { g_err = m; return code; }
@@ -151,20 +154,46 @@ int vfail(int code, const std::string& m) { g_err = m; return code; }
 }  // namespace
 
 extern "C" const char* zkc_verify_last_error(void) { return g_err.c_str(); }
+// e(P, Q) as snarkjs / ffjavascript compute and print it: 12 x 32 B standard form, order c0.a0.(c0,c1) c0.a1 c0.a2 c1.a0 c1.a1 c1.a2
+// (the nesting of vk_alphabeta_12 in verification_key.json).  Host only.
+extern "C" int zkc_pairing_bin(const uint8_t g1[64], const uint8_t g2[128], uint8_t out[384]) {
+    G1Affine P; G2Affine Q;
+    if (!g1 || !g2 || !out || !rd_g1_std(P, g1) || !rd_g2_std(Q, g2) || !g1_on_curve(P) || !g2_on_curve(Q)) return ZKC_ERR_BAD_ARG;
+    const Fq12 e = pairing_snarkjs(P, Q);
+    const Fq2* c[6] = {&e.a.a0, &e.a.a1, &e.a.a2, &e.b.a0, &e.b.a1, &e.b.a2};
+    for (int i = 0; i < 6; i++) { uint32_t t[8]; fp_to_std<FqParams>(t, c[i]->c0); memcpy(out + 64 * i, t, 32); fp_to_std<FqParams>(t, c[i]->c1); memcpy(out + 64 * i + 32, t, 32); }
+    return ZKC_OK;
+}
+extern "C" void zkc_sha256(const void* data, size_t len, uint8_t out[32]) { parse::sha256(data, len, out); }
+extern "C" int zkc_zkey_sha256(const zkc_zkey* zk, uint8_t out[32]) { if (!zk || !out) return ZKC_ERR_BAD_ARG; memcpy(out, zk->sha256, 32); return ZKC_OK; }
+// circuits this build has a native witness generator for, by the sha256 of their circom witness-calculator wasm
+extern "C" int zkc_circuit_nlevels_from_wasm(const void* wasm, size_t len, char sha256_hex[65]) {
+    static const struct { const char* sha; int nLevels; } known[] = {
+        {"80a73567f6a4655d4332301efcff4bc5711bb48176d1c71fdb1e48df222ac139", 160},      // artifacts/zkCensus/dev/circuits-info.md:7
+    };
+    if (!wasm) return -1;
+    uint8_t d[32]; parse::sha256(wasm, len, d); const std::string hex = parse::hex_of(d, 32);
+    if (sha256_hex) memcpy(sha256_hex, hex.c_str(), 65);
+    for (const auto& k : known) if (hex == k.sha) return k.nLevels;
+    return -1;
+}
 
 // vk: alpha1(64) beta2(128) gamma2(128) delta2(128) IC[nPublic+1](64 each); pub: nPublic x 32; proof: A(64) B(128) C(64); standard form
 extern "C" int zkc_verify_bin(const uint8_t* vk, int nPublic, const uint8_t* pub, const uint8_t* proof) {
     if (!vk || !pub || !proof || nPublic < 0) return vfail(-ZKC_ERR_BAD_ARG, "zkc_verify_bin: bad argument");
     G1Affine alpha, A, C; G2Affine beta, gamma, delta, B;
     if (!rd_g1_std(alpha, vk) || !rd_g2_std(beta, vk + 64) || !rd_g2_std(gamma, vk + 192) || !rd_g2_std(delta, vk + 320)) return vfail(-ZKC_ERR_FORMAT, "verification key coordinate >= q");
+    if (!g1_on_curve(alpha) || !g2_in_subgroup(beta) || !g2_in_subgroup(gamma) || !g2_in_subgroup(delta)) return vfail(-ZKC_ERR_FORMAT, "verification key point not on the curve / not in the order-r subgroup");
     if (!rd_g1_std(A, proof) || !rd_g2_std(B, proof + 64) || !rd_g1_std(C, proof + 192)) return 0;
-    if (!g1_on_curve(A) || !g1_on_curve(C) || !g2_on_curve(B)) return 0;
-    G1Affine ic; if (!rd_g1_std(ic, vk + 448)) return vfail(-ZKC_ERR_FORMAT, "IC coordinate >= q");
+    // B must lie in the order-r subgroup of the twist (G2 has a cofactor): go-rapidsnark's bn256 unmarshalling and this library's batch verifier
+    // reject such points too, so the two entry points agree on crafted proofs
+    if (!g1_on_curve(A) || !g1_on_curve(C) || !g2_in_subgroup(B)) return 0;
+    G1Affine ic; if (!rd_g1_std(ic, vk + 448) || !g1_on_curve(ic)) return vfail(-ZKC_ERR_FORMAT, "IC point invalid");
     G1XYZZ acc = G1XYZZ::from_affine(ic);
     for (int i = 0; i < nPublic; i++) {
         uint32_t k[8]; memcpy(k, pub + 32 * i, 32);
         if (!fp_std_lt_p<FrParams>(k)) return 0;                                   // snarkjs: public input not in field -> invalid
-        if (!rd_g1_std(ic, vk + 448 + 64 * (i + 1))) return vfail(-ZKC_ERR_FORMAT, "IC coordinate >= q");
+        if (!rd_g1_std(ic, vk + 448 + 64 * (i + 1)) || !g1_on_curve(ic)) return vfail(-ZKC_ERR_FORMAT, "IC point invalid");
         acc = xyzz_add(acc, xyzz_mul(G1XYZZ::from_affine(ic), k));
     }
     const G1Affine vkx = xyzz_to_affine(acc);
@@ -178,8 +207,8 @@ extern "C" int zkc_verify_bin(const uint8_t* vk, int nPublic, const uint8_t* pub
 // i.e. N + 3 Miller loops and ONE final exponentiation instead of 4 N and N.  The G1 work (rho_i A_i for every proof and the MSM
 // sum rho_i C_i) runs on the GPU with the prover's double-and-add / group-sum kernels; Miller loops run on host threads.
 // A cheating prover passes with probability about 2^-128 provided the weights are unpredictable to it: `seed32` must be fresh
-// randomness (NULL: std::random_device).  Each B_i is checked to lie in the order-r subgroup of the twist (G2 has a cofactor; the
-// single-proof check, like snarkjs, does not need that).  Returns 1 all valid / 0 at least one invalid / <0 = -ZKC_ERR_*.
+// randomness (NULL: std::random_device).  Each B_i is checked to lie in the order-r subgroup of the twist (G2 has a cofactor), as
+// zkc_verify_bin does.  Returns 1 all valid / 0 at least one invalid / <0 = -ZKC_ERR_*.
 namespace {
 struct Xoshiro { uint64_t s[4]; uint64_t next() { auto rotl = [](uint64_t x, int k) { return (x << k) | (x >> (64 - k)); };
     const uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17; s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45); return r; } };
@@ -188,7 +217,8 @@ extern "C" int zkc_verify_batch(zkc_ctx* ctx, const uint8_t* vk, int nPublic, co
     if (!ctx || !vk || !pubs || !proofs || nPublic < 0 || N <= 0) return vfail(-ZKC_ERR_BAD_ARG, "zkc_verify_batch: bad argument");
     G1Affine alpha; G2Affine beta, gamma, delta; std::vector<G1Affine> ic(nPublic + 1);
     if (!rd_g1_std(alpha, vk) || !rd_g2_std(beta, vk + 64) || !rd_g2_std(gamma, vk + 192) || !rd_g2_std(delta, vk + 320)) return vfail(-ZKC_ERR_FORMAT, "verification key coordinate >= q");
-    for (int j = 0; j <= nPublic; j++) if (!rd_g1_std(ic[j], vk + 448 + 64 * (size_t)j)) return vfail(-ZKC_ERR_FORMAT, "IC coordinate >= q");
+    for (int j = 0; j <= nPublic; j++) if (!rd_g1_std(ic[j], vk + 448 + 64 * (size_t)j) || !g1_on_curve(ic[j])) return vfail(-ZKC_ERR_FORMAT, "IC point invalid");
+    if (!g1_on_curve(alpha) || !g2_in_subgroup(beta) || !g2_in_subgroup(gamma) || !g2_in_subgroup(delta)) return vfail(-ZKC_ERR_FORMAT, "verification key point not on the curve / not in the order-r subgroup");
     Xoshiro rng;
     if (seed32) memcpy(rng.s, seed32, 32); else { std::random_device rd; for (auto& x : rng.s) x = ((uint64_t)rd() << 32) | rd(); }
     if (!(rng.s[0] | rng.s[1] | rng.s[2] | rng.s[3])) rng.s[0] = 1;
@@ -212,7 +242,8 @@ extern "C" int zkc_verify_batch(zkc_ctx* ctx, const uint8_t* vk, int nPublic, co
     // ---- G1 side on the GPU: rho_i A_i (N single-element groups) and sum rho_i C_i (one group) ----
     std::vector<G1XYZZ> gout(N + 1);
     {
-        ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+        ZKC_LOCK(ctx);
+        if (hipSetDevice(ctx->device) != hipSuccess) return vfail(-ZKC_ERR_HIP, "zkc_verify_batch: hipSetDevice failed");     // never a positive code: 1 means "all valid"
         G1Affine* d_pts = nullptr; uint32_t *d_rho = nullptr, *d_idx = nullptr, *d_gs = nullptr;
         std::vector<uint32_t> idx(2 * (size_t)N), gs(N + 2);
         for (size_t i = 0; i < idx.size(); i++) idx[i] = (uint32_t)i;
@@ -225,7 +256,7 @@ extern "C" int zkc_verify_batch(zkc_ctx* ctx, const uint8_t* vk, int nPublic, co
             hipMemcpy(d_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_gs, gs.data(), gs.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return vfail(-ZKC_ERR_HIP, "zkc_verify_batch: hipMemcpy failed"); }
         rc = fold_group_sums_g1(ctx, d_pts, d_rho, d_idx, 2 * (uint32_t)N, 0, d_gs, (uint32_t)N + 1, gout.data());
         cleanup();
-        if (rc) return vfail(-rc, std::string("zkc_verify_batch: ") + zkc_last_error(ctx));
+        if (rc) return vfail(rc > 0 ? -rc : -ZKC_ERR_GENERIC, std::string("zkc_verify_batch: ") + zkc_last_error(ctx));
     }
     // ---- vk_x side: (sum rho) IC0 + sum_j (sum_i rho_i x_ij) IC_j ----
     uint32_t k[8]; fp_to_std<FrParams>(k, rsum);
@@ -239,7 +270,7 @@ extern "C" int zkc_verify_batch(zkc_ctx* ctx, const uint8_t* vk, int nPublic, co
         uint32_t rord[8]; for (int q = 0; q < 8; q++) rord[q] = FrParams::p[q];
         Fq12 f = one12();
         for (int i = (int)t; i < N; i += (int)nthr) {
-            if (!xyzz_mul(G2XYZZ::from_affine(Bs[i]), rord).is_inf()) { bad[t] = 1; return; }
+            if (!Bs[i].is_inf() && !xyzz_mul(G2XYZZ::from_affine(Bs[i]), rord).is_inf()) { bad[t] = 1; return; }
             f = f * miller(affine_neg(xyzz_to_affine(gout[i])), Bs[i]);
         }
         part[t] = f;
@@ -255,20 +286,10 @@ extern "C" int zkc_verify_batch(zkc_ctx* ctx, const uint8_t* vk, int nPublic, co
 // JSON surface: the three artifact files of the reference (verification_key.json, signals.json, proof.json). 1 valid / 0 invalid / <0 error
 extern "C" int zkc_verify(const char* vkey_json, const char* public_json, const char* proof_json) {
     if (!vkey_json || !public_json || !proof_json) return vfail(-ZKC_ERR_BAD_ARG, "zkc_verify: bad argument");
-    const std::string vk(vkey_json), pj(public_json), pr(proof_json);
-    std::vector<std::string> a1, b2, g2, d2, ic, pub, pa, pb, pc;
-    if (!json_strings_under(vk, "vk_alpha_1", a1) || !json_strings_under(vk, "vk_beta_2", b2) || !json_strings_under(vk, "vk_gamma_2", g2) ||
-        !json_strings_under(vk, "vk_delta_2", d2) || !json_strings_under(vk, "IC", ic)) return vfail(-ZKC_ERR_FORMAT, "verification key JSON: missing member");
-    if (!json_strings_under(pj, nullptr, pub)) return vfail(-ZKC_ERR_FORMAT, "public signals JSON: expected an array of decimal strings");
-    if (!json_strings_under(pr, "pi_a", pa) || !json_strings_under(pr, "pi_b", pb) || !json_strings_under(pr, "pi_c", pc)) return vfail(-ZKC_ERR_FORMAT, "proof JSON: missing member");
-    const int np = (int)pub.size();
-    if (ic.size() != 3 * (size_t)(np + 1)) return vfail(-ZKC_ERR_FORMAT, "verification key: IC length does not match the public signals");
-    std::vector<uint8_t> vkb(448 + 64 * (size_t)(np + 1)), pubb(32 * (size_t)np + 1), prb(256);
-    if (!put_g1_json(a1, 0, vkb.data()) || !put_g2_json(b2, 0, vkb.data() + 64) || !put_g2_json(g2, 0, vkb.data() + 192) || !put_g2_json(d2, 0, vkb.data() + 320))
-        return vfail(-ZKC_ERR_FORMAT, "verification key JSON: bad point");
-    for (int i = 0; i <= np; i++) if (!put_g1_json(ic, 3 * (size_t)i, vkb.data() + 448 + 64 * i)) return vfail(-ZKC_ERR_FORMAT, "verification key JSON: bad IC point");
-    for (int i = 0; i < np; i++) { uint32_t s[8]; if (!dec_to_std(pub[i], s, false)) return 0; memcpy(pubb.data() + 32 * i, s, 32); }
-    if (!put_g1_json(pa, 0, prb.data()) || !put_g2_json(pb, 0, prb.data() + 64) || !put_g1_json(pc, 0, prb.data() + 192)) return 0;
+    std::vector<uint8_t> vkb, pubb, prb; int np = 0; std::string perr;
+    const int rc = parse::verify_inputs_from_json(vkey_json, public_json, proof_json, vkb, pubb, prb, np, perr);
+    if (rc < 0) return vfail(-ZKC_ERR_FORMAT, perr);
+    if (rc == 0) return 0;
     return zkc_verify_bin(vkb.data(), np, pubb.data(), prb.data());
 }
 
@@ -294,22 +315,7 @@ extern "C" int zkc_proof_to_json(const uint8_t proof[256], const uint8_t* pub, i
 
 // .wtns (iden3 binfile) -> pointer to the nWitness x 32 B payload inside the buffer
 extern "C" int zkc_wtns_parse(const void* wtns_bytes, unsigned long size, const uint8_t** payload, uint32_t* nWitness) {
-    const uint8_t* b = (const uint8_t*)wtns_bytes;
-    if (!b || size < 12 || memcmp(b, "wtns", 4)) return ZKC_ERR_FORMAT;
-    uint32_t ver, nsec; memcpy(&ver, b + 4, 4); memcpy(&nsec, b + 8, 4); if (ver != 2) return ZKC_ERR_FORMAT;
-    size_t p = 12; const uint8_t *s1 = nullptr, *s2 = nullptr; uint64_t z2 = 0;
-    for (uint32_t i = 0; i < nsec; i++) {
-        if (p + 12 > size) return ZKC_ERR_FORMAT;
-        uint32_t id; uint64_t sz; memcpy(&id, b + p, 4); memcpy(&sz, b + p + 4, 8); p += 12;
-        if (p + sz > size) return ZKC_ERR_FORMAT;
-        if (id == 1) s1 = b + p; if (id == 2) { s2 = b + p; z2 = sz; }
-        p += sz;
-    }
-    if (!s1 || !s2) return ZKC_ERR_FORMAT;
-    uint32_t n8, nw; memcpy(&n8, s1, 4); if (n8 != 32 || memcmp(s1 + 4, FrParams::p, 32)) return ZKC_ERR_FORMAT;
-    memcpy(&nw, s1 + 36, 4); if (z2 != 32ull * nw) return ZKC_ERR_FORMAT;
-    if (payload) *payload = s2; if (nWitness) *nWitness = nw;
-    return ZKC_OK;
+    return parse::wtns_view((const uint8_t*)wtns_bytes, size, payload, nWitness) ? ZKC_OK : ZKC_ERR_FORMAT;
 }
 extern "C" unsigned long zkc_wtns_write(const void* payload, uint32_t nWitness, void* out, unsigned long out_size) {
     const unsigned long need = 12 + 12 + 40 + 12 + 32ul * nWitness;
@@ -322,31 +328,50 @@ extern "C" unsigned long zkc_wtns_write(const void* payload, uint32_t nWitness, 
     return need;
 }
 
+// n scalars uniform in [0, r): 254 random bits from the OS generator, rejected when >= r (what snarkjs' Fr.random and rapidsnark do)
+extern "C" void zkc_random_scalars(uint8_t* out, size_t n) {
+    std::random_device rd;
+    for (size_t i = 0; i < n; i++) {
+        uint32_t t[8];
+        do { for (int k = 0; k < 8; k++) t[k] = (uint32_t)rd(); t[7] &= 0x3fffffffu; } while (!fp_std_lt_p<FrParams>(t));
+        memcpy(out + 32 * i, t, 32);
+    }
+}
+
 // rapidsnark's entry point (prover.h), byte for byte: whole .zkey and .wtns buffers in, NUL-terminated JSON out.
-// r and s are drawn from the OS generator like the reference provers do.  One process-wide context on device
-// $ZKC_DEVICE (default 0); the last key stays resident so that repeated calls with the same buffer skip the load.
+// r and s are drawn from the OS generator like the reference provers do.  Re-entrant: one process-wide context on device $ZKC_DEVICE
+// (default 0) behind a mutex; the last key stays resident and is identified by the SHA-256 of the .zkey image (the identity the reference
+// publishes for its keys, artifacts/zkCensus/dev/circuits-info.md:5), so repeated calls with the same key skip the load and a different key
+// can never alias.  When a buffer is too short the required sizes are written back WITHOUT proving (they depend only on nPublic).
 extern "C" int groth16_prover(const void* zkey_buffer, unsigned long zkey_size, const void* wtns_buffer, unsigned long wtns_size,
                               char* proof_buffer, unsigned long* proof_size, char* public_buffer, unsigned long* public_size,
                               char* error_msg, unsigned long error_msg_maxsize) {
     auto err = [&](int code, const std::string& m) { if (error_msg && error_msg_maxsize) snprintf(error_msg, error_msg_maxsize, "%s", m.c_str()); return code; };
     if (!zkey_buffer || !wtns_buffer || !proof_size || !public_size) return err(ZKC_ERR_GENERIC, "groth16_prover: null argument");
-    static zkc_ctx* ctx = nullptr; static zkc_zkey* zk = nullptr; static const void* zk_ptr = nullptr; static unsigned long zk_len = 0; static uint64_t zk_sum = 0;
-    if (!ctx) { const char* d = getenv("ZKC_DEVICE"); int rc = zkc_ctx_create(d ? atoi(d) : 0, &ctx); if (rc) { ctx = nullptr; return err(ZKC_ERR_GENERIC, zkc_last_error(nullptr)); } }
-    uint64_t sum = 1469598103934665603ull; { const uint8_t* b = (const uint8_t*)zkey_buffer; for (unsigned long i = 0; i < zkey_size; i += 4099) sum = (sum ^ b[i]) * 1099511628211ull; }
-    if (!zk || zk_ptr != zkey_buffer || zk_len != zkey_size || zk_sum != sum) {
-        if (zk) { zkc_zkey_free(zk); zk = nullptr; }
-        int rc = zkc_zkey_load(ctx, zkey_buffer, zkey_size, &zk); if (rc) { zk = nullptr; return err(ZKC_ERR_GENERIC, zkc_last_error(ctx)); }
-        zk_ptr = zkey_buffer; zk_len = zkey_size; zk_sum = sum;
-    }
+    static std::mutex mu; static zkc_ctx* ctx = nullptr; static zkc_zkey* zk = nullptr;
+    // everything that does not need the GPU first: file shapes and buffer sizes
+    parse::BinSections bs; parse::ZkeyHeader zh; std::string perr;
+    if (!parse::binfile_sections((const uint8_t*)zkey_buffer, zkey_size, "zkey", 1, bs, perr) || !parse::zkey_check(bs, zh, perr)) return err(ZKC_ERR_GENERIC, perr);
     const uint8_t* payload; uint32_t nw;
     if (zkc_wtns_parse(wtns_buffer, wtns_size, &payload, &nw)) return err(ZKC_ERR_GENERIC, "Invalid witness file");
-    uint32_t nv, np, dn; zkc_zkey_info(zk, &nv, &np, &dn);
-    if (nw != nv) return err(ZKC_ERR_INVALID_WITNESS_LENGTH, "Invalid witness length. Circuit: " + std::to_string(nv) + ", witness: " + std::to_string(nw));
-    uint8_t r[32], s[32], proof[256]; std::vector<uint8_t> pub(32 * (size_t)np + 1);
-    { std::random_device rd; for (int i = 0; i < 31; i++) { r[i] = (uint8_t)rd(); s[i] = (uint8_t)rd(); } r[31] = s[31] = 0; }    // < 2^248 < field order
-    int rc = zkc_prove(zk, payload, nw, r, s, proof, pub.data());
+    if (nw != zh.nVars) return err(ZKC_ERR_INVALID_WITNESS_LENGTH, "Invalid witness length. Circuit: " + std::to_string(zh.nVars) + ", witness: " + std::to_string(nw));
+    const unsigned long need_proof = 8 * 80 + 128, need_public = (unsigned long)zh.nPub * 80 + 8;      // hold ANY proof of this shape (77 decimal digits per coordinate)
+    if (!proof_buffer || !public_buffer || *proof_size < need_proof || *public_size < need_public) {
+        *proof_size = need_proof; *public_size = need_public;
+        return err(ZKC_ERR_SHORT_BUFFER, "Proof or public signals buffer is too short");
+    }
+    uint8_t digest[32]; parse::sha256(zkey_buffer, zkey_size, digest);
+    std::lock_guard<std::mutex> guard(mu);
+    if (!ctx) { const char* d = getenv("ZKC_DEVICE"); int rc = zkc_ctx_create(d ? atoi(d) : 0, &ctx); if (rc) { ctx = nullptr; return err(ZKC_ERR_GENERIC, zkc_last_error(nullptr)); } }
+    if (!zk || memcmp(zk->sha256, digest, 32) != 0) {
+        if (zk) { zkc_zkey_free(zk); zk = nullptr; }
+        int rc = zkc_zkey_load(ctx, zkey_buffer, zkey_size, &zk); if (rc) { zk = nullptr; return err(ZKC_ERR_GENERIC, zkc_last_error(ctx)); }
+    }
+    uint8_t rs[64], proof[256]; std::vector<uint8_t> pub(32 * (size_t)zh.nPub + 1);
+    zkc_random_scalars(rs, 2);
+    int rc = zkc_prove(zk, payload, nw, rs, rs + 32, proof, pub.data());
     if (rc) return err(rc == ZKC_ERR_INVALID_WITNESS_LENGTH ? rc : ZKC_ERR_GENERIC, zkc_last_error(ctx));
-    rc = zkc_proof_to_json(proof, pub.data(), (int)np, proof_buffer, proof_size, public_buffer, public_size);
+    rc = zkc_proof_to_json(proof, pub.data(), (int)zh.nPub, proof_buffer, proof_size, public_buffer, public_size);
     if (rc == ZKC_ERR_SHORT_BUFFER) return err(ZKC_ERR_SHORT_BUFFER, "Proof or public signals buffer is too short");
     return rc;
 }

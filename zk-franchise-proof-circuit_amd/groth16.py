@@ -2,10 +2,14 @@
 (ts_inputs/src/example.ts:1,358-362 imports `groth16` from snarkjs and calls `groth16.fullProve(inputs, wasm, zkey)`).
 
 Same argument meaning and result shapes as snarkjs 0.7.0: proof = {pi_a, pi_b, pi_c, protocol, curve} of decimal strings,
-publicSignals = list of decimal strings.  The `wasm_file` argument is accepted for drop-in compatibility and only used to
-select the circuit shape (its witness calculator is replaced by the HIP kernels); an optional `rs=(r, s)` makes the proof
-deterministic for parity tests (snarkjs draws them at random)."""
+publicSignals = list of decimal strings.  The `wasm_file` argument names the circuit the way it does for snarkjs: its SHA-256 selects
+the native witness generator (80a73567...c139 = the reference's dev/160 circuit.wasm, artifacts/zkCensus/dev/circuits-info.md:7); a
+wasm this build has no native circuit for is refused loudly -- nothing here executes wasm.  `wasm_file=None` with an explicit
+`nLevels` selects the native ZkFranchiseProofCircuit(nLevels) directly (the build's own test keys have no wasm).  An optional
+`rs=(r, s)` makes the proof deterministic for parity tests (snarkjs draws them at random)."""
+import collections
 import ctypes
+import hashlib
 import json
 import os
 import secrets
@@ -14,7 +18,9 @@ from . import _native
 from .inputs import R_MOD
 
 _ctx = None
-_keys = {}
+_keys = collections.OrderedDict()      # sha256 of the .zkey image -> ProvingKey; at most MAX_RESIDENT_KEYS stay in HBM
+_path_digest = {}                       # (path, mtime_ns, size) -> sha256, so that an unchanged file is not re-read per proof
+MAX_RESIDENT_KEYS = 2
 
 
 def _context(device=None):
@@ -35,11 +41,41 @@ def _read(f):
 
 
 def _key(zkey_file):
+    """Resident proving key for a .zkey given as path / bytes / {type: 'mem'}.  Identity = SHA-256 of the file image (what
+    circuits-info.md publishes for the reference's key): a rewritten file or a second bytes object can never get a stale key."""
     from . import ProvingKey
-    ident = zkey_file if isinstance(zkey_file, str) else id(zkey_file)
-    if ident not in _keys:
-        _keys[ident] = ProvingKey(_context(), _read(zkey_file))
-    return _keys[ident]
+    raw = None
+    if isinstance(zkey_file, str):
+        st = os.stat(zkey_file); ident = (os.path.abspath(zkey_file), st.st_mtime_ns, st.st_size)
+        digest = _path_digest.get(ident)
+        if digest is None:
+            raw = _read(zkey_file); digest = hashlib.sha256(raw).digest()
+            _path_digest.clear(); _path_digest[ident] = digest
+    else:
+        raw = _read(zkey_file); digest = hashlib.sha256(raw).digest()
+    if digest in _keys:
+        _keys.move_to_end(digest)
+        return _keys[digest]
+    while len(_keys) >= MAX_RESIDENT_KEYS:
+        _, old = _keys.popitem(last=False)
+        old.close()
+    _keys[digest] = ProvingKey(_context(), raw if raw is not None else _read(zkey_file))
+    return _keys[digest]
+
+
+def circuit_nlevels(wasm_file, nLevels=None):
+    """nLevels of the native circuit a snarkjs-style call names.  wasm_file None: the explicit nLevels (default 160)."""
+    if wasm_file is None:
+        return 160 if nLevels is None else int(nLevels)
+    raw = _read(wasm_file)
+    hexbuf = ctypes.create_string_buffer(65)
+    nl = _native.load().zkc_circuit_nlevels_from_wasm(raw, len(raw), hexbuf)
+    if nl < 0:
+        raise ValueError('unknown circuit wasm (sha256 %s): this build has a native witness generator for the zkCensus circuit only '
+                         '(dev/160 circuit.wasm, sha256 80a73567...c139) and does not execute wasm' % hexbuf.value.decode())
+    if nLevels is not None and int(nLevels) != nl:
+        raise ValueError('wasm file is the nLevels=%d circuit but nLevels=%s was requested' % (nl, nLevels))
+    return nl
 
 
 def proof_to_json(proof, pub):
@@ -55,8 +91,9 @@ def proof_to_json(proof, pub):
 
 class wtns:
     @staticmethod
-    def calculate(inputs, wasm_file=None, nLevels=160):
+    def calculate(inputs, wasm_file=None, nLevels=None):
         """Returns the .wtns file image (bytes).  Raises like snarkjs when a circuit assert fails."""
+        nLevels = circuit_nlevels(wasm_file, nLevels)
         ctx = _context()
         ws, st = ctx.witness([inputs], nLevels)
         if st[0] != 0:
@@ -89,7 +126,7 @@ def prove(zkey_file, wtns_file, rs=None):
     return {'proof': pj, 'publicSignals': sj}
 
 
-def fullProve(inputs, wasm_file, zkey_file, rs=None, nLevels=160):
+def fullProve(inputs, wasm_file, zkey_file, rs=None, nLevels=None):
     return prove(zkey_file, wtns.calculate(inputs, wasm_file, nLevels), rs)
 
 
