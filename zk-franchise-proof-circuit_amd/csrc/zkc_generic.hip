@@ -109,7 +109,7 @@ extern "C" int zkc_g1_mul_batch_dev(zkc_ctx* ctx, const uint8_t base_std[64], co
 
 // A fixed set of n G1 bases (device, affine standard form, 64 B each) made resident as pre-shifted window tables.
 extern "C" int zkc_msm_g1_load_dev(zkc_ctx* ctx, const void* d_bases_std, uint32_t n, zkc_msm** out) {
-    if (!ctx || !d_bases_std || !out || n == 0 || n > (1u << 24)) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_msm_g1_load_dev: bad argument");
+    if (!ctx || !d_bases_std || !out || n == 0 || n > (1u << 21)) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_msm_g1_load_dev: bad argument (1 <= n <= 2^21)");
     ZKC_LOCK(ctx);
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     zkc_msm* m = new zkc_msm(); m->zk.ctx = ctx; m->n = n; m->c = n >= (1u << 15) ? MSM_C_BIG : MSM_C_SMALL;

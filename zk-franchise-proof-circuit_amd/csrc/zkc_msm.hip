@@ -5,12 +5,12 @@
 //
 // The proving key is constant for the life of a context, so zkc_zkey_load pre-shifts every base once
 // (T[w][i] = 2^(c w) P_i): windows combine with plain additions, no doublings, and a digit d of ANY window lands in
-// the same bucket d -- a job has 2^(c-1) signed-digit buckets in total (c = 17 for H, 13 for the witness sections).
+// the same bucket d -- a job has 2^(c-1) signed-digit buckets in total (c = 17 for H, 12 for the witness sections).
 // A pipeline PASS runs a list of jobs (sections x proofs in flight) through the same launches:
-//   K4  zkc_msm_digits      scalar -> signed c-bit digits; emits key = |d| - 1 (16 bits), val = sign | job | table row
-//       rocPRIM radix sort on the 16-bit key alone (stable, so equal buckets stay in job order: bucket-major ids,
-//       MsmJobList); zkc_msm_offsets = (bucket, job) boundaries; scan of ceil(size/16) -> segments
-//   K5  zkc_msm_accumulate29[_g2]  one lane per SEGMENT (<= 16 sorted entries of one bucket): XYZZ += affine (8M + 2S)
+//   K4  zkc_msm_sort.hip    scalar -> signed c-bit digits -> entries (sign | table row) grouped by bucket inside each job's own region
+//       (two counting passes per job, hand-written: no key array, no device-wide sort), bucket boundaries, segments of <= 128 entries
+//       and their order by decreasing length
+//   K5  zkc_msm_accumulate29[_g2]  one lane per SEGMENT (<= 128 entries of one bucket): XYZZ += affine (8M + 2S)
 //       in radix-2^29 coordinates (zkc_f29*.h) with 64-byte gathers from T.  Cutting buckets into segments keeps lanes
 //       balanced when many scalars repeat (witness bits; the circuit has only ~4.5k distinct values among 82k wires).
 //   K6  zkc_msm_merge       buckets of more than 8 segments: a wave each, shuffle tree
@@ -18,6 +18,7 @@
 //       sums, a suffix scan across the 64 lanes in LDS, x per, tree sum  ->  W = sum_j j B_j and S = sum_j B_j
 //       zkc_msm_final       one workgroup per job: sum_k W_k + vw sum_k k S_k over its virtual windows.
 #include <cstdio>
+#include <cstddef>
 #include <ctime>
 #include <cstdlib>
 #include <cstring>
@@ -27,7 +28,6 @@
 #include "zkc_f29.h"
 #include "zkc_f29_g1.h"
 #include "zkc_f29_g2.h"
-#include <rocprim/rocprim.hpp>
 
 namespace zkc {
 
@@ -51,106 +51,34 @@ template <class BB> struct PointIO<Fq2T<BB>> {
     }
 };
 
-// ---- K4 ----
-extern "C" __global__ void __launch_bounds__(256)
-zkc_msm_digits(const MsmJobList* __restrict__ jlp, msm_key_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-    const int j = blockIdx.y;
-    const MsmJobList& jl = *jlp;
-    const MsmJob job = jl.job[j];
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= job.count) return;
-    const uint32_t wire = job.vmap ? job.vmap[i] : i;
-    const uint4* sp = reinterpret_cast<const uint4*>(job.scalars + 8 * (size_t)wire); uint4 a = sp[0], b = sp[1];
-    const uint32_t s[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    const uint32_t pt = (uint32_t)((int32_t)wire - job.pt_shift);
-    const uint32_t c = job.c, half = 1u << (c - 1), mask = (1u << c) - 1;
-    const uint32_t rowmask = (1u << jl.row_bits) - 1, jtag = (uint32_t)j << jl.row_bits;
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < job.nw; w++) {
-        const uint32_t bit = w * c, li = bit >> 5, sh = bit & 31;
-        uint32_t lo = 0, hi = 0;
-#pragma unroll
-        for (int q = 0; q < 8; q++) { lo = ((uint32_t)q == li) ? s[q] : lo; hi = ((uint32_t)q == li + 1) ? s[q] : hi; }
-        const uint64_t two = (uint64_t)lo | ((uint64_t)hi << 32);
-        uint32_t d = (uint32_t)((two >> sh) & mask) + carry;
-        uint32_t neg = 0;
-        if (d > half) { d = (1u << c) - d; neg = 1; carry = 1; } else carry = 0;
-        const size_t o = (size_t)job.ent_off + (size_t)w * job.count + i;
-        // pre-shifted bases: digit d of every window shares bucket d - 1; a zero digit becomes an entry that adds nothing (row field all ones)
-        const bool park = (uint32_t)j >= jl.gjob;            // this job's zero digits can go behind the real entries
-        keys[o] = (msm_key_t)(d ? d - 1 : park ? jl.gkey : 0u);
-        vals[o] = d ? ((neg << 31) | jtag | (pt + w * job.tbl_count)) : (jtag | rowmask);
-    }
-}
-// off[id] = first sorted position whose (bucket, job) is not below id's; the job of an entry is read from its value word
-extern "C" __global__ void __launch_bounds__(256)
-zkc_msm_offsets(const MsmJobList* __restrict__ jlp, const msm_key_t* __restrict__ keys_sorted, const uint32_t* __restrict__ vals_sorted, uint32_t total,
-                uint32_t* __restrict__ off) {
-    const MsmJobList& jl = *jlp;
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id > jl.total_buckets) return;
-    uint32_t d = jl.gkey, j = jl.gjob;                       // id == total_buckets: where the parked zero digits begin
-    if (id < jl.total_buckets) jl.decode(id, d, j);
-    const uint32_t want = (d << 16) | j, rb = jl.row_bits;
-    uint32_t lo = 0, hi = total;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        const uint32_t have = ((uint32_t)keys_sorted[mid] << 16) | ((vals_sorted[mid] & 0x7fffffffu) >> rb);
-        if (have < want) lo = mid + 1; else hi = mid;
-    }
-    off[id] = lo;
-}
-// segcnt[b] = ceil(size_b / MSM_SEG); buckets cut into more than MSM_MERGE_T segments are listed for the wave-per-bucket merge
-extern "C" __global__ void __launch_bounds__(256)
-zkc_msm_segcount(const uint32_t* __restrict__ off, uint32_t nbuckets, uint32_t* __restrict__ segcnt, uint32_t* __restrict__ heavy,
-                 uint32_t* __restrict__ heavy_count, uint32_t seg) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > nbuckets) return;
-    const uint32_t c = b < nbuckets ? (off[b + 1] - off[b] + seg - 1) / seg : 0;
-    segcnt[b] = c;
-    if (c > (uint32_t)MSM_MERGE_T) { uint32_t k = atomicAdd(heavy_count, 1u); if (k < (uint32_t)MSM_MAX_HEAVY) heavy[k] = b; }
-}
-// A bucket of L entries cut into k = ceil(L / MSM_SEG) segments is split EVENLY: segment i covers [floor(i L / k), floor((i + 1) L / k)).
+// A bucket of L entries cut into k = ceil(L / seg) segments is split EVENLY: segment i covers [floor(i L / k), floor((i + 1) L / k)).
 __device__ __forceinline__ void msm_seg_range(uint32_t L, uint32_t k, uint32_t i, uint32_t& lo, uint32_t& hi) {
     lo = (uint32_t)(((uint64_t)i * L) / k); hi = (uint32_t)(((uint64_t)(i + 1) * L) / k);
-}
-// seg2bucket[s] = bucket of segment s; seglen[s] = its number of entries (the accumulation walks the segments longest first, in waves
-// of equal length: zkc_msm pass sorts (seglen, s) once per pass, a few million 6-bit keys)
-extern "C" __global__ void __launch_bounds__(256)
-zkc_msm_seg2bucket(const uint32_t* __restrict__ off, const uint32_t* __restrict__ segoff, uint32_t nbuckets, uint32_t* __restrict__ seg2bucket,
-                   uint32_t* __restrict__ seglen, uint32_t max_segments) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nbuckets) return;
-    const uint32_t s0 = segoff[b], k = segoff[b + 1] - s0, L = off[b + 1] - off[b];
-    for (uint32_t i = 0; i < k && s0 + i < max_segments; i++) {
-        uint32_t lo, hi; msm_seg_range(L, k, i, lo, hi);
-        seg2bucket[s0 + i] = b; seglen[s0 + i] = hi - lo;
-    }
 }
 
 // ---- K5, G1: the same segment walk with the accumulator kept in radix 2^29 (zkc_f29.h, zkc_f29_g1.h) ----
 template <int MINW>
 __global__ void __launch_bounds__(128, MINW)
 zkc_msm_accumulate29(const Affine<Fq>* __restrict__ table_all, const MsmJobList* __restrict__ jlp, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ off,
-                     const uint32_t* __restrict__ segoff, const uint32_t* __restrict__ seg2bucket, const uint32_t* __restrict__ perm, uint32_t nbuckets,
+                     const uint32_t* __restrict__ bcnt, const uint32_t* __restrict__ segoff, const uint32_t* __restrict__ seg2bucket, const uint32_t* __restrict__ perm, uint32_t nbuckets,
                      XYZZ<Fq>* __restrict__ partial, uint32_t max_segments) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t nseg = segoff[nbuckets]; if (nseg > max_segments) nseg = max_segments;
     if (gid >= nseg) return;
     const uint32_t s = perm[gid];                       // segments by decreasing length: the lanes of a wave finish together
     const uint32_t b = seg2bucket[s];
-    uint32_t lo, hi; msm_seg_range(off[b + 1] - off[b], segoff[b + 1] - segoff[b], s - segoff[b], lo, hi);
+    uint32_t lo, hi; msm_seg_range(bcnt[b], segoff[b + 1] - segoff[b], s - segoff[b], lo, hi);
     const uint32_t start = off[b] + lo, end = off[b] + hi;
     uint32_t bd, bj; jlp->decode(b, bd, bj);
     const Affine<Fq>* __restrict__ table = table_all + jlp->job[bj].tbl_off;      // a segment belongs to one job
-    const uint32_t rowmask = (1u << jlp->row_bits) - 1;
+    constexpr uint32_t rowmask = 0x7fffffffu;                                     // entry word: sign | table row
     Acc29 acc; bool inf = true;
     uint32_t v = vals[start];
-    Affine<Fq> p = PointIO<Fq>::load(table + ((v & rowmask) == rowmask ? 0u : (v & rowmask)));
+    Affine<Fq> p = PointIO<Fq>::load(table + (v & rowmask));
     for (uint32_t j = start; j < end; j++) {
         const uint32_t vn = (j + 1 < end) ? vals[j + 1] : v;
-        Affine<Fq> pn = PointIO<Fq>::load(table + ((vn & rowmask) == rowmask ? 0u : (vn & rowmask)));      // next gather in flight during this addition
-        if ((v & rowmask) != rowmask && !p.is_inf()) {
+        Affine<Fq> pn = PointIO<Fq>::load(table + (vn & rowmask));      // next gather in flight during this addition
+        if (!p.is_inf()) {
             if (v >> 31) p.y = fp_neg(p.y);
             uint32_t x2[9], y2[9];
             f29_from_fp_shl5(x2, p.x.v); f29_from_fp_shl5(y2, p.y.v);
@@ -205,27 +133,27 @@ __device__ __forceinline__ G2Chunk g2_chunk_load(const uint32_t* p) {
 template <int MINW>
 __global__ void __launch_bounds__(128, MINW)
 zkc_msm_accumulate29_g2(const uint32_t* __restrict__ table29_all, const MsmJobList* __restrict__ jlp, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ off,
-                        const uint32_t* __restrict__ segoff, const uint32_t* __restrict__ seg2bucket, const uint32_t* __restrict__ perm, uint32_t nbuckets,
+                        const uint32_t* __restrict__ bcnt, const uint32_t* __restrict__ segoff, const uint32_t* __restrict__ seg2bucket, const uint32_t* __restrict__ perm, uint32_t nbuckets,
                         XYZZ<Fq2>* __restrict__ partial, uint32_t max_segments) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t nseg = segoff[nbuckets]; if (nseg > max_segments) nseg = max_segments;
     if (gid >= nseg) return;
     const uint32_t s = perm[gid];                       // segments by decreasing length: the lanes of a wave finish together
     const uint32_t b = seg2bucket[s];
-    uint32_t lo, hi; msm_seg_range(off[b + 1] - off[b], segoff[b + 1] - segoff[b], s - segoff[b], lo, hi);
+    uint32_t lo, hi; msm_seg_range(bcnt[b], segoff[b + 1] - segoff[b], s - segoff[b], lo, hi);
     const uint32_t start = off[b] + lo, end = off[b] + hi;
     uint32_t bd, bj; jlp->decode(b, bd, bj);
     const uint32_t* __restrict__ table29 = table29_all + (size_t)jlp->job[bj].tbl_off * G2T29_WORDS;
-    const uint32_t rowmask = (1u << jlp->row_bits) - 1;
+    constexpr uint32_t rowmask = 0x7fffffffu;
     Acc29G2 acc; bool inf = true;
     uint32_t v = vals[start];
-    const uint32_t* pp = table29 + (size_t)((v & rowmask) == rowmask ? 0u : (v & rowmask)) * G2T29_WORDS;
+    const uint32_t* pp = table29 + (size_t)(v & rowmask) * G2T29_WORDS;
     G2Chunk cx = g2_chunk_load(pp), cy = g2_chunk_load(pp + ((v >> 31) ? 40 : 20));
     for (uint32_t j = start; j < end; j++) {
         const uint32_t vn = (j + 1 < end) ? vals[j + 1] : v;
-        const uint32_t* pn = table29 + (size_t)((vn & rowmask) == rowmask ? 0u : (vn & rowmask)) * G2T29_WORDS;
+        const uint32_t* pn = table29 + (size_t)(vn & rowmask) * G2T29_WORDS;
         const G2Chunk nx = g2_chunk_load(pn), ny = g2_chunk_load(pn + ((vn >> 31) ? 40 : 20));      // next gather in flight during this addition
-        if ((v & rowmask) != rowmask && !cx.w[18]) {
+        if (!cx.w[18]) {
             F2x29 x2, y2;
 #pragma unroll
             for (int k = 0; k < 9; k++) { x2.c0[k] = cx.w[k]; x2.c1[k] = cx.w[9 + k]; y2.c0[k] = cy.w[k]; y2.c1[k] = cy.w[9 + k]; }
@@ -305,10 +233,10 @@ zkc_msm_window29(const XYZZ<Fq>* __restrict__ partial, const uint32_t* __restric
     __shared__ Acc29 sh[64];
     const MsmWindow win = windows[blockIdx.x];
     const int PER = (int)win.per;
-    const uint32_t first = win.bucket0 + threadIdx.x * PER * win.stride;
+    const uint32_t first = win.bucket0 + threadIdx.x * PER;
     Acc29 run, loc; f29_pt_set_inf(run); f29_pt_set_inf(loc);
     for (int k = PER - 1; k >= 0; k--) {
-        uint32_t s0 = segoff[first + k * win.stride], s1 = s0 + segcnt[first + k * win.stride];
+        uint32_t s0 = segoff[first + k], s1 = s0 + segcnt[first + k];
         if (s1 > max_segments) s1 = max_segments;
         for (uint32_t s = s0; s < s1; s++) { const Acc29 q = f29_pt_from_xyzz(partial[s]); f29_pt_add(run, run, q); }
         f29_pt_add(loc, loc, run);
@@ -341,10 +269,10 @@ zkc_msm_window29_g2(const XYZZ<Fq2>* __restrict__ partial, const uint32_t* __res
     __shared__ Acc29G2 sh[64];
     const MsmWindow win = windows[blockIdx.x];
     const int PER = (int)win.per;
-    const uint32_t first = win.bucket0 + threadIdx.x * PER * win.stride;
+    const uint32_t first = win.bucket0 + threadIdx.x * PER;
     Acc29G2 run, loc; f29g2_pt_set_inf(run); f29g2_pt_set_inf(loc);
     for (int k = PER - 1; k >= 0; k--) {
-        uint32_t s0 = segoff[first + k * win.stride], s1 = s0 + segcnt[first + k * win.stride];
+        uint32_t s0 = segoff[first + k], s1 = s0 + segcnt[first + k];
         if (s1 > max_segments) s1 = max_segments;
         for (uint32_t s = s0; s < s1; s++) { const XYZZ<Fq2> pq = partial[s]; if (!pq.is_inf()) { const Acc29G2 q = f29g2_pt_from_xyzz(pq); f29g2_pt_add(run, run, q); } }
         f29g2_pt_add(loc, loc, run);
@@ -516,25 +444,37 @@ int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, size_t max_buck
     w.max_entries = max_entries; w.max_jobs = max_jobs; w.max_buckets = max_buckets; w.xyzz_size = g2 ? sizeof(G2XYZZ) : sizeof(G1XYZZ);
     const size_t nb = max_buckets;
     w.max_segments = max_entries / MSM_SEG_MIN + nb;    // every non-empty bucket has at most one short segment
-    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.keys, max_entries * sizeof(msm_key_t) + 16)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.vals, max_entries * 4));
-    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.keys2, max_entries * sizeof(msm_key_t) + 16)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.vals2, max_entries * 4));
-    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.off, (nb + 2) * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.segcnt, (nb + 2) * 4));
+    w.max_bins = (size_t)max_jobs << MSM_MAX_HBITS;
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.vals, max_entries * 4 + 16)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.vals2, max_entries * 4 + 16));
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.hist, w.max_bins * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.bin_start, w.max_bins * 4));
+    w.max_tilecnt = max_entries / 8 + ((size_t)max_jobs << MSM_MAX_HBITS);       // sum over jobs of 2^hbits x ceil(count / 1024): count <= entries / nw, nw >= 8
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.tilecnt, w.max_tilecnt * 4));
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.off, (nb + 2) * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.bcnt, (nb + 2) * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.segcnt, (nb + 2) * 4));
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.segoff, (nb + 2) * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.seg2bucket, w.max_segments * 4));
-    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.seglen, w.max_segments * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.seglen2, w.max_segments * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.perm, w.max_segments * 4));
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.seglen, w.max_segments * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.perm, w.max_segments * 4));
+    w.max_lencnt = (size_t)(MSM_SEG + 1) * (w.max_segments / 256 + 2);
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.lencnt, w.max_lencnt * 4));
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.scan_blk, (std::max(nb + 2, w.max_lencnt) / 1024 + 2) * 4));
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.heavy, (MSM_MAX_HEAVY + 1) * 4));
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.d_jobs, sizeof(MsmJobList)));
     ZKC_HIP_CHECK(ctx, hipMalloc(&w.partial, w.max_segments * w.xyzz_size));
     const size_t max_vw = max_buckets / MSM_VW_MIN + (size_t)max_jobs;
     ZKC_HIP_CHECK(ctx, hipMalloc(&w.wres, 2 * max_vw * w.xyzz_size));
-    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.d_windows, max_vw * sizeof(MsmWindow)));
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.d_windows, max_vw * sizeof(MsmWindow))); w.max_windows = max_vw;
+    for (int s = 0; s < 2; s++) {
+        ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&w.h_jobs[s], sizeof(MsmJobList))); ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&w.h_windows[s], max_vw * sizeof(MsmWindow)));
+        ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&w.h_ev[s], hipEventDisableTiming));
+    }
     ZKC_HIP_CHECK(ctx, hipMalloc(&w.results, 2 * (size_t)max_jobs * w.xyzz_size));
     ZKC_HIP_CHECK(ctx, hipHostMalloc(&w.h_results, (size_t)max_jobs * w.xyzz_size));
     return ZKC_OK;
 }
 void msm_work_free(MsmWork& w) {
-    void* p[] = {w.keys, w.vals, w.keys2, w.vals2, w.off, w.segcnt, w.segoff, w.seg2bucket, w.seglen, w.seglen2, w.perm, w.heavy, w.d_jobs, w.d_windows, w.partial, w.wres, w.results, w.sort_tmp, w.scan_tmp};
+    void* p[] = {w.vals, w.vals2, w.hist, w.bin_start, w.tilecnt, w.off, w.bcnt, w.segcnt, w.segoff, w.seg2bucket, w.seglen, w.perm, w.scan_blk, w.lencnt, w.heavy, w.d_jobs, w.d_windows,
+                 w.partial, w.wres, w.results};
     for (void* q : p) if (q) (void)hipFree(q);
     if (w.h_results) (void)hipHostFree(w.h_results);
+    for (int s = 0; s < 2; s++) { if (w.h_jobs[s]) (void)hipHostFree(w.h_jobs[s]); if (w.h_windows[s]) (void)hipHostFree(w.h_windows[s]); if (w.h_ev[s]) (void)hipEventDestroy(w.h_ev[s]); }
     w = MsmWork();
 }
 
@@ -554,7 +494,7 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     if (nj <= 0 || nj > w.max_jobs) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: job count");
     static thread_local MsmJobList jl;                  // the caller's list plus the bucket-id layout of this pass
     jl = jl_in;
-    if (!jl.finish()) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: jobs need at most two window sizes and tables below 2^row_bits rows");
+    if (!jl.finish()) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: jobs need at most two window sizes (the larger first) and tables that fit the entry word");
     const size_t total = jl.total_entries;
     const uint32_t nb = jl.total_buckets;
     if (total > w.max_entries || nb > w.max_buckets) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: too many entries for the work space");
@@ -569,64 +509,38 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
         streamed_bytes += (uint64_t)jl.job[j].count * (sizeof(Affine<F>) + 32);     // (scalar, base) pairs that actually enter the MSM
         maxcount = std::max(maxcount, jl.job[j].count);
     }
+    const size_t seg_bound = std::min<size_t>(w.max_segments, total / seg + nb);     // launch bound on the number of segments
     {
         zkc_prof_scope _ps(ctx, ZKC_PROF_MSM_SORT, 0, st);
-        static thread_local std::vector<MsmWindow> wins;
-        wins.clear();
-        for (int j = 0; j < nj; j++) for (uint32_t k = 0; k < (uint32_t)msm_half((int)jl.job[j].c) / jl.job[j].vw; k++) {
-            const uint32_t d0 = k * jl.job[j].vw;              // vw divides hs: a virtual window never straddles the two id regions
-            wins.push_back(MsmWindow{jl.id_of(d0, (uint32_t)j), jl.job[j].win_off + k, jl.job[j].vw / 64, d0 < jl.hs ? (uint32_t)nj : jl.nbig});
-        }
-        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.d_jobs, &jl, sizeof(MsmJobList), hipMemcpyHostToDevice, st));   // pageable source: staged before return
-        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.d_windows, wins.data(), wins.size() * sizeof(MsmWindow), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(zkc_msm_digits, dim3((maxcount + 255) / 256, nj), dim3(256), 0, st, (const MsmJobList*)w.d_jobs, w.keys, w.vals);
-        ZKC_LAUNCH_CHECK(ctx, "zkc_msm_digits");
-        int end_bit = 1; while ((1u << end_bit) <= jl.gkey) end_bit++;     // 16 bits with an H job in the pass, 13 without
-        size_t need = 0;
-        hipError_t e = rocprim::radix_sort_pairs(nullptr, need, w.keys, w.keys2, w.vals, w.vals2, total, 0, end_bit, st);
-        if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, "radix_sort_pairs(size)");
-        int rc = zkc_ensure(ctx, &w.sort_tmp, &w.sort_tmp_sz, need); if (rc) return rc;
-        e = rocprim::radix_sort_pairs(w.sort_tmp, need, w.keys, w.keys2, w.vals, w.vals2, total, 0, end_bit, st);     // stable: equal buckets stay in job order
-        if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, "radix_sort_pairs");
-        ZKC_LAUNCH_CHECK(ctx, "radix_sort_pairs");
-        hipLaunchKernelGGL(zkc_msm_offsets, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const MsmJobList*)w.d_jobs, w.keys2, w.vals2, (uint32_t)total, w.off);
-        ZKC_LAUNCH_CHECK(ctx, "zkc_msm_offsets");
-        ZKC_HIP_CHECK(ctx, hipMemsetAsync(w.heavy + MSM_MAX_HEAVY, 0, 4, st));
-        hipLaunchKernelGGL(zkc_msm_segcount, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, w.off, nb, w.segcnt, w.heavy, w.heavy + MSM_MAX_HEAVY, seg);
-        ZKC_LAUNCH_CHECK(ctx, "zkc_msm_segcount");
-        need = 0;
-        e = rocprim::exclusive_scan(nullptr, need, w.segcnt, w.segoff, 0u, (size_t)nb + 1, rocprim::plus<uint32_t>(), st);
-        if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, "exclusive_scan(size)");
-        rc = zkc_ensure(ctx, &w.scan_tmp, &w.scan_tmp_sz, need); if (rc) return rc;
-        e = rocprim::exclusive_scan(w.scan_tmp, need, w.segcnt, w.segoff, 0u, (size_t)nb + 1, rocprim::plus<uint32_t>(), st);
-        if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, "exclusive_scan");
-        const size_t seg_bound0 = std::min<size_t>(w.max_segments, total / seg + nb);
-        ZKC_HIP_CHECK(ctx, hipMemsetAsync(w.seglen, 0, seg_bound0 * 4, st));          // slots past the real segment count sort to the end
-        hipLaunchKernelGGL(zkc_msm_seg2bucket, dim3((nb + 255) / 256), dim3(256), 0, st, w.off, w.segoff, nb, w.seg2bucket, w.seglen, (uint32_t)w.max_segments);
-        ZKC_LAUNCH_CHECK(ctx, "zkc_msm_seg2bucket");
-        need = 0;
-        int len_bits = 1; while ((1u << len_bits) <= seg) len_bits++;
-        e = rocprim::radix_sort_pairs_desc(nullptr, need, w.seglen, w.seglen2, rocprim::counting_iterator<uint32_t>(0), w.perm, seg_bound0, 0, len_bits, st);
-        if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, "radix_sort_pairs_desc(size)");
-        rc = zkc_ensure(ctx, &w.sort_tmp, &w.sort_tmp_sz, need); if (rc) return rc;
-        e = rocprim::radix_sort_pairs_desc(w.sort_tmp, need, w.seglen, w.seglen2, rocprim::counting_iterator<uint32_t>(0), w.perm, seg_bound0, 0, len_bits, st);
-        if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, "radix_sort_pairs_desc");
-        ZKC_LAUNCH_CHECK(ctx, "radix_sort_pairs_desc");
+        if (jl.total_windows > w.max_windows) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: too many virtual windows for the work space");
+        const int hs = w.h_next; w.h_next ^= 1;
+        ZKC_HIP_CHECK(ctx, hipEventSynchronize(w.h_ev[hs]));                            // the copy that last used this staging slot has executed (two passes back)
+        MsmWindow* wins = w.h_windows[hs]; uint32_t nwin = 0;
+        for (int j = 0; j < nj; j++) for (uint32_t k = 0; k < (uint32_t)msm_half((int)jl.job[j].c) / jl.job[j].vw; k++)
+            wins[nwin++] = MsmWindow{jl.id_of(k * jl.job[j].vw, (uint32_t)j), jl.job[j].win_off + k, jl.job[j].vw / 64};
+        memcpy(w.h_jobs[hs], &jl, offsetof(MsmJobList, job) + (size_t)nj * sizeof(MsmJob)); w.h_jobs[hs]->njobs = jl.njobs;
+        memcpy(&w.h_jobs[hs]->njobs, &jl.njobs, sizeof(MsmJobList) - offsetof(MsmJobList, njobs));
+        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.d_jobs, w.h_jobs[hs], sizeof(MsmJobList), hipMemcpyHostToDevice, st));
+        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.d_windows, wins, (size_t)nwin * sizeof(MsmWindow), hipMemcpyHostToDevice, st));
+        ZKC_HIP_CHECK(ctx, hipEventRecord(w.h_ev[hs], st));
+        int rc = msm_bucket_entries(ctx, w, jl, st); if (rc) return rc;                  // K4: digits -> entries grouped by bucket (vals2, off, bcnt)
+        if (g_debug_sync) { hipError_t _e = hipStreamSynchronize(st); fprintf(stderr, "[zkc] bucket entries: %s\n", hipGetErrorString(_e)); }
+        rc = msm_build_segments(ctx, w, jl, seg, seg_bound, st); if (rc) return rc;      // segments of <= seg entries, longest first
+        if (g_debug_sync) { hipError_t _e = hipStreamSynchronize(st); fprintf(stderr, "[zkc] segments: %s\n", hipGetErrorString(_e)); }
         if (ev_sorted) ZKC_HIP_CHECK(ctx, hipEventRecord(ev_sorted, st));          // the short kernels of this pass are through: what follows is long-running
     }
     XYZZ<F>* partial = reinterpret_cast<XYZZ<F>*>(w.partial);
     XYZZ<F>* wres = reinterpret_cast<XYZZ<F>*>(w.wres);
     XYZZ<F>* results = reinterpret_cast<XYZZ<F>*>(w.results) + (size_t)slot * w.max_jobs;
-    const size_t seg_bound = std::min<size_t>(w.max_segments, total / seg + nb);     // launch bound on the number of segments
     {
         zkc_prof_scope _ps(ctx, kG2 ? ZKC_PROF_MSM_ACC_G2 : ZKC_PROF_MSM_ACC_G1, alg_bytes, st);
         if (!kG2 && ((ctx->prof.mask >> ZKC_PROF_MSM_ACC_G1) & 1)) ctx->prof.bytes[ZKC_PROF_MSM_G1_STREAMED] += streamed_bytes;
         if constexpr (kG2)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate29_g2<1>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
-                               zk->d_g2_29, (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.segoff, w.seg2bucket, w.perm, nb, reinterpret_cast<XYZZ<Fq2>*>(partial), (uint32_t)w.max_segments);
+                               zk->d_g2_29, (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.bcnt, w.segoff, w.seg2bucket, w.perm, nb, reinterpret_cast<XYZZ<Fq2>*>(partial), (uint32_t)w.max_segments);
         else      // G1: same layout, field type with the inlined product
             hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate29<2>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
-                               reinterpret_cast<const Affine<Fq>*>(table), (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.segoff, w.seg2bucket, w.perm, nb,
+                               reinterpret_cast<const Affine<Fq>*>(table), (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.bcnt, w.segoff, w.seg2bucket, w.perm, nb,
                                reinterpret_cast<XYZZ<Fq>*>(partial), (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_accumulate");
     }

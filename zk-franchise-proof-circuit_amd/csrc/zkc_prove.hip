@@ -10,6 +10,8 @@
 #include "zkc_fixedbase.h"
 #include "zkc_hostparse.h"
 #include <cstring>
+#include <ctime>
+#include <cstdio>
 #include <algorithm>
 
 using namespace zkc;
@@ -419,11 +421,17 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
         ZKC_HIP_CHECK(ctx, hipEventRecord(zk->ev_chunk[c], st0));                // wtns of this chunk (and rs) ready, flags on the host
     }
     for (int l = 0; l < zk->nlanes; l++) zk->lane[l].npass = 0;
+    // ZKC_TRACE_HOST=1: where the enqueueing thread spends its time, per pass (diagnostics: a blocking call here idles a stream)
+    static const bool trace_host = getenv("ZKC_TRACE_HOST") != nullptr;
+    auto now_ms = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; };
+    const double t_begin = now_ms(); double tr[6] = {0};
     int pass = 0;
     for (int p0 = 0; p0 < B; p0 += zk->max_inflight, pass++) {
         const int nb = std::min(zk->max_inflight, B - p0);
         zkc_lane& LN = zk->lane[pass % zk->nlanes]; const int slot = LN.npass & 1;       // MSM results are double-buffered: the blinding of pass k overlaps pass k+1
+        tr[0] = now_ms();
         ZKC_HIP_CHECK(ctx, hipEventSynchronize(zk->ev_chunk[pass]));              // host: this chunk's fold flags have arrived
+        tr[1] = now_ms();
         ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(LN.st, zk->ev_chunk[pass], 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(LN.st2, zk->ev_chunk[pass], 0));
         hipStream_t st = LN.st, st2 = LN.st2, fin = LN.fin;
         const uint32_t* w0 = (const uint32_t*)d_wtns + (size_t)p0 * nv * 8;
@@ -439,6 +447,7 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
         if (LN.npass >= 2) { ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, LN.ev_fin[slot], 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st2, LN.ev_fin[slot], 0)); }   // slot still read by the blinding two passes back?
         LN.npass++;
         if ((rc = h_evals_dev(zk, LN, w0, nb))) return rc;
+        tr[2] = now_ms();
         static thread_local MsmJobList j1, j2;     // 6 KB each: kept off the stack frame of a C-ABI entry point
         const uint32_t vws = nb <= 4 ? 64u : 256u;          // few proofs in the pass: favour latency in the bucket reduction
         j1.clear(vws); j2.clear(vws);
@@ -464,7 +473,9 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
         // kernels then starve behind the 13 ms G1 accumulation instead and spill into the next pass -- measured equal within noise.
         static const bool g2_early = getenv("ZKC_G2_LATE") == nullptr;
         if (g2_early) { if ((rc = msm_pass_g2(zk, LN.w2, j2, slot, false, st2))) return rc; ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_msm2, st2)); }
+        tr[3] = now_ms();
         if ((rc = msm_pass_g1(zk, LN.w1, j1, slot, false, st, LN.ev_sorted))) return rc;
+        tr[4] = now_ms();
         if (!g2_early) {
             ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st2, LN.ev_sorted, 0));
             if ((rc = msm_pass_g2(zk, LN.w2, j2, slot, false, st2))) return rc;
@@ -488,6 +499,9 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
         if ((rc = finalize_launch(ctx, fin, fa, nb))) return rc;
         ZKC_HIP_CHECK(ctx, hipMemcpyAsync(zk->h_out + 256ull * p0, zk->d_proofs + 256 * (size_t)p0, 256ull * nb, hipMemcpyDeviceToHost, fin));
         ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_fin[slot], fin));
+        tr[5] = now_ms();
+        if (trace_host) fprintf(stderr, "[zkc host] pass %2d: start %8.2f | chunk wait %6.2f | h_evals %6.2f | g2 pass %6.2f | g1 pass %6.2f | blinding %6.2f ms\n", pass, tr[0] - t_begin,
+                                tr[1] - tr[0], tr[2] - tr[1], tr[3] - tr[2], tr[4] - tr[3], tr[5] - tr[4]);
     }
     for (int l = 0; l < zk->nlanes; l++) { ZKC_HIP_CHECK(ctx, hipStreamSynchronize(zk->lane[l].st)); ZKC_HIP_CHECK(ctx, hipStreamSynchronize(zk->lane[l].st2)); ZKC_HIP_CHECK(ctx, hipStreamSynchronize(zk->lane[l].fin)); }
     memcpy(proofs, zk->h_out, 256ull * B);

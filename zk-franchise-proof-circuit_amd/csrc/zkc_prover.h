@@ -31,7 +31,10 @@ struct MsmJob {
     uint32_t tbl_count;        // points per window in that table
     int32_t pt_shift;
     uint32_t c, nw, vw;        // window bits / windows of this job's table / buckets per virtual window
-    uint32_t boff, ent_off, win_off;   // index among the jobs with the larger bucket count (finish()) / first (scalar, window) entry / first virtual window of this job inside the pass
+    uint32_t ent_off, win_off; // first (scalar, window) entry / first virtual window of this job inside the pass
+    // bucketing (zkc_msm_sort.hip): the job's 2^(c-1) buckets are ids [bucket0, bucket0 + 2^(c-1)) (job-major); its entries are first split into
+    // 2^hbits level-1 bins by the high bits of the bucket index (bins [bin0, bin0 + 2^hbits) of the pass), then each bin into 2^lbits buckets
+    uint32_t bucket0, bin0, hbits, lbits, tile0, cnt0;   // tile0: first 1024-scalar tile of this job in the flattened tile list of the pass; cnt0: its (bin, tile) counters
 };
 // arguments of the blinding kernel (zkc_finalize.hip); everything except r1/r2/rs/out is constant per proving key
 struct FinalizeArgs {
@@ -41,73 +44,72 @@ struct FinalizeArgs {
     G1Affine alpha1; G2Affine beta2;
     const uint8_t* rs; uint8_t* out;                    // device: nproofs x 64 (r || s) -> nproofs x 256 proof bytes
 };
-// The entries of a pass are sorted by their 16-bit bucket index alone (two radix passes over 6 bytes instead of three over 8); the sort is
-// stable and the entries are generated job by job, so inside one bucket index they come out grouped by job.  Bucket ids therefore run
-// bucket-major: id(d, j) = d * njobs + j for d < hs, and hs * njobs + (d - hs) * nbig + hidx(j) above (only the jobs with the larger bucket
-// count hb exist there).  A value word is  sign(1) | job(job bits) | row relative to the job's table(row_bits); all ones in the row field
-// marks a zero digit (nothing to add); zero digits carry the key `gkey` that sorts them behind every real entry (the rare zero digit of
-// a 65536-bucket job has no such key to go to and stays in its bucket 0 as an entry that adds nothing).
-// storage type of the 16-bit sort key (u32 storage with end_bit = 16 measured the same as u16: 0.169 vs 0.165 ms per proof for digits + sort)
-typedef uint16_t msm_key_t;
+// The (digit, point) entries of a pass are bucketed JOB BY JOB (an entry never leaves its job's region [ent_off, ent_off + count nw) of the
+// value arrays), in two counting passes instead of a device-wide key sort: the job is implicit in the position, the key is never stored.
+//   entry word after level 1 :  sign(1) | low bucket bits (lbits) | table row relative to the job's table (31 - lbits bits)
+//   entry word after level 2 :  sign(1) | table row (31 bits)          -- what the accumulation reads; zero digits are never emitted
+// Bucket ids are job-major; a pass may hold jobs of at most two window sizes, the larger ones first (decode() is then closed-form).
+constexpr int MSM_TILE = 256, MSM_TILE_SCALARS = 1024;  // threads / scalars per workgroup of the counting and level-1 kernels
+constexpr uint32_t MSM_MAX_HBITS = 10;                 // level-1 bins per job <= 1024 (LDS histogram)
 struct MsmJobList {
-    MsmJob job[MSM_MAX_JOBS]; int njobs; uint32_t total_buckets, total_entries, total_windows;
-    uint32_t hs, hb, nbig, row_bits, gkey, gjob;        // set by finish(); entries with (key, job) >= (gkey, gjob) are zero digits
-    uint16_t bigjob[MSM_MAX_JOBS];                      // hidx -> job
+    MsmJob job[MSM_MAX_JOBS]; int njobs; uint32_t total_buckets, total_entries, total_windows, total_bins, total_tiles, total_tilecnt;
+    uint32_t hs, hb, nbig;                              // set by finish(): bucket counts of the small / big jobs, number of big jobs (they come first)
     uint32_t vw_small = 256;                            // virtual window of the c < 16 jobs: 256 for throughput, 64 for the latency of a small pass (same box: 256 -> 2431 proofs/s, 4.9 ms ; 128 -> 2375, 4.0 ms ; 64 -> 2304, 3.9 ms single prove)
     void add(const uint32_t* scalars, const uint32_t* vmap, uint32_t count, uint32_t tbl_off, uint32_t tbl_count, int32_t pt_shift, int c) {
         MsmJob& j = job[njobs++];
         const uint32_t vw = c >= 16 ? (uint32_t)msm_vw(c) : vw_small;
-        j = MsmJob{scalars, vmap, count, tbl_off, tbl_count, pt_shift, (uint32_t)c, (uint32_t)msm_nw(c), vw, 0, total_entries, total_windows};
+        j = MsmJob{scalars, vmap, count, tbl_off, tbl_count, pt_shift, (uint32_t)c, (uint32_t)msm_nw(c), vw, total_entries, total_windows, 0, 0, 0, 0, 0, 0};
         total_entries += count * (uint32_t)msm_nw(c); total_windows += (uint32_t)msm_half(c) / vw;
     }
-    void clear(uint32_t vw_small_jobs = 256) { vw_small = vw_small_jobs; njobs = 0; total_buckets = total_entries = total_windows = 0; hs = hb = nbig = row_bits = gkey = gjob = 0; }
-    // false: more than two distinct window sizes, or a table too large for the row field
+    void clear(uint32_t vw_small_jobs = 256) { vw_small = vw_small_jobs; njobs = 0; total_buckets = total_entries = total_windows = total_bins = total_tiles = total_tilecnt = 0; hs = hb = nbig = 0; }
+    // false: more than two distinct window sizes, big jobs not in front, or a table too large for the row field of the level-1 entry word
     bool finish() {
         hs = 0xffffffffu; hb = 0;
         for (int j = 0; j < njobs; j++) { const uint32_t h = 1u << (job[j].c - 1); hs = h < hs ? h : hs; hb = h > hb ? h : hb; }
-        nbig = 0; uint32_t maxrow = 0;
+        nbig = 0; total_buckets = total_bins = total_tiles = total_tilecnt = 0;
         for (int j = 0; j < njobs; j++) {
-            const uint32_t h = 1u << (job[j].c - 1);
+            MsmJob& q = job[j]; const uint32_t h = 1u << (q.c - 1);
             if (h != hs && h != hb) return false;
-            job[j].boff = 0xffffffffu;
-            if (h == hb) { job[j].boff = nbig; bigjob[nbig++] = (uint16_t)j; }          // boff doubles as hidx
-            const uint32_t rows = job[j].nw * job[j].tbl_count; maxrow = rows > maxrow ? rows : maxrow;
-        }
-        uint32_t jb = 0; while ((1u << jb) < (uint32_t)njobs) jb++;
-        row_bits = 31 - jb;
-        if ((uint64_t)maxrow + 1 >= (1ull << row_bits)) return false;
-        total_buckets = hs * (uint32_t)njobs + (hb - hs) * nbig;
-        // zero digits sort behind everything real: key `gkey`.  With 65536 buckets there is no spare 16-bit key, so the garbage shares key
-        // 0xFFFF with the last real bucket of the big jobs and must follow them in job order: big jobs first.
-        gkey = hb < 65536u ? hb : 0xffffu; gjob = 0;
-        if (hb == 65536u) {
-            gjob = nbig;
-            for (uint32_t k = 0; k < nbig; k++) if (bigjob[k] != k) return false;
+            if (h == hb) { if ((uint32_t)j != nbig) return false; nbig++; }
+            uint32_t hbits = q.c - 1 < 8 ? q.c - 1 : 8, lbits = q.c - 1 - hbits;
+            const uint64_t rows = (uint64_t)q.nw * q.tbl_count;
+            while (lbits > 8 || (lbits > 0 && rows >= (1ull << (31 - lbits)))) { lbits--; hbits++; }      // level 2 handles <= 256 buckets per bin
+            if (hbits > MSM_MAX_HBITS || rows >= (1ull << (31 - lbits))) return false;
+            q.hbits = hbits; q.lbits = lbits;
+            q.bucket0 = total_buckets; total_buckets += h;
+            q.bin0 = total_bins; total_bins += 1u << hbits;
+            const uint32_t nt = (q.count + MSM_TILE_SCALARS - 1) / MSM_TILE_SCALARS;
+            q.tile0 = total_tiles; total_tiles += nt; q.cnt0 = total_tilecnt; total_tilecnt += nt << hbits;
         }
         return true;
     }
-    ZKC_HD uint32_t id_of(uint32_t d, uint32_t j) const { return d < hs ? d * (uint32_t)njobs + j : hs * (uint32_t)njobs + (d - hs) * nbig + job[j].boff; }
+    ZKC_HD uint32_t id_of(uint32_t d, uint32_t j) const { return job[j].bucket0 + d; }
     ZKC_HD void decode(uint32_t id, uint32_t& d, uint32_t& j) const {
-        const uint32_t lim = hs * (uint32_t)njobs;
-        if (id < lim) { d = id / (uint32_t)njobs; j = id - d * (uint32_t)njobs; }
-        else { const uint32_t t = id - lim, q = t / nbig; d = hs + q; j = bigjob[t - q * nbig]; }
+        const uint32_t lim = hb * nbig;
+        if (id < lim) { j = id / hb; d = id - j * hb; }
+        else { const uint32_t t = id - lim, q = t / hs; j = nbig + q; d = t - q * hs; }
     }
 };
-struct MsmWindow { uint32_t bucket0, out, per, stride; };   // one wave of zkc_msm_window: the 64 per buckets bucket0 + i stride -> wres[2*out] (weighted), wres[2*out+1] (plain sum)
+struct MsmWindow { uint32_t bucket0, out, per; };   // one wave of zkc_msm_window: the 64 per consecutive buckets from bucket0 -> wres[2*out] (weighted), wres[2*out+1] (plain sum)
 
-// Work space of one pipeline pass (sized for MSM_MAX_JOBS jobs and max_entries (scalar, window) pairs)
+// Work space of one pipeline pass (sized for max_jobs jobs and max_entries (scalar, window) pairs)
 struct MsmWork {
-    msm_key_t *keys = nullptr, *keys2 = nullptr; uint32_t *vals = nullptr, *vals2 = nullptr;   // max_entries each
-    uint32_t *off = nullptr;        // bucket boundaries, njobs*NB + 1
+    uint32_t *vals = nullptr, *vals2 = nullptr;       // max_entries each: level-1 output / bucketed entries
+    uint32_t *hist = nullptr, *bin_start = nullptr;      // per level-1 bin of the pass (max_bins): entries, first position
+    uint32_t *tilecnt = nullptr; size_t max_tilecnt = 0; // per (job, bin, tile): entries, then (scanned) the start of the tile's run inside the bin
+    uint32_t *off = nullptr, *bcnt = nullptr;          // per bucket: first entry in vals2, number of entries
     uint32_t *segcnt = nullptr, *segoff = nullptr, *seg2bucket = nullptr, *heavy = nullptr;
-    uint32_t *seglen = nullptr, *seglen2 = nullptr, *perm = nullptr;     // per segment: entries; sorted lengths; segment ids by decreasing length
+    uint32_t *seglen = nullptr, *perm = nullptr;       // per segment: entries; segment ids by decreasing length
+    uint32_t *scan_blk = nullptr, *lencnt = nullptr; size_t max_lencnt = 0;  // block sums of the device-wide scan; per (length key, workgroup) segment counts
     void *partial = nullptr;        // XYZZ per segment
     void *wres = nullptr;           // XYZZ per (job, window)
     void *results = nullptr;        // XYZZ per job, two slots of max_jobs (device) ; h_results pinned host mirror of slot 0
     void *h_results = nullptr;
     MsmJobList* d_jobs = nullptr;   // device copy of the pass' job list (too large for kernel arguments)
-    MsmWindow* d_windows = nullptr; size_t max_buckets = 0;
-    void *sort_tmp = nullptr; size_t sort_tmp_sz = 0; void* scan_tmp = nullptr; size_t scan_tmp_sz = 0;
+    MsmWindow* d_windows = nullptr; size_t max_buckets = 0, max_bins = 0, max_windows = 0;
+    // pinned host staging of (job list, window list), two slots: a pageable source made hipMemcpyAsync hold the enqueueing thread until
+    // the stream had drained, which kept the G2 stream idle for 8 ms of every pass.  h_ev[s] = the copy out of slot s has executed.
+    MsmJobList* h_jobs[2] = {nullptr, nullptr}; MsmWindow* h_windows[2] = {nullptr, nullptr}; hipEvent_t h_ev[2] = {nullptr, nullptr}; int h_next = 0;
     size_t max_entries = 0, max_segments = 0; int max_jobs = 0; size_t xyzz_size = 0;
 };
 }  // namespace zkc
@@ -167,6 +169,10 @@ void msm_work_free(MsmWork& w);
 // ev_sorted (optional): recorded on st once the digit/sort/segment kernels are through, i.e. right before the long accumulation kernel
 int msm_pass_g1(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st, hipEvent_t ev_sorted = nullptr);
 int msm_pass_g2(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st);
+// zkc_msm_sort.hip -- K4: scalars -> signed digits -> entries bucketed per job (vals2, off, bcnt), then the segment lists of the accumulation
+// (segcnt, segoff, seg2bucket, seglen, perm, heavy).  `jl` is the finished host copy of what w.d_jobs already holds on the device.
+int msm_bucket_entries(zkc_ctx* ctx, MsmWork& w, const MsmJobList& jl, hipStream_t st);
+int msm_build_segments(zkc_ctx* ctx, MsmWork& w, const MsmJobList& jl, uint32_t seg, size_t seg_bound, hipStream_t st);
 int finalize_launch(zkc_ctx* ctx, hipStream_t st, const FinalizeArgs& a, int nproofs);
 int msm_precompute_g1(zkc_ctx* ctx, uint32_t count, G1Affine* d_table, int c);   // d_table[0..count) = base on entry
 int msm_precompute_g2(zkc_ctx* ctx, uint32_t count, G2Affine* d_table, int c);
