@@ -46,6 +46,12 @@ __device__ G1XYZZ var_mul29(const G1XYZZ& P, const uint32_t k[8], Acc29* tab) {
     return f29_pt_is_inf(acc) ? G1XYZZ::inf() : f29_pt_to_xyzz(acc);
 }
 
+// the voter-independent part of a section's MSM for proof q (constant folding, zkc_prove.hip): base + sum over the folded levels of both trees
+template <class P>
+__device__ P fold_const(const P* __restrict__ tab, const FinalizeArgs& a, int q) {
+    if (a.dc[q] == 255) return P::inf();
+    return xyzz_add(tab[0], xyzz_add(tab[1 + a.dc[q]], tab[1 + a.fold_n + a.ds[q]]));
+}
 // One workgroup of four waves per proof, one task per wave so that the three independent latency chains run side by side:
 //   wave 0: s A' and r B1' (lanes 0, 1; variable base), then piC once everything else has arrived
 //   wave 1: r delta, s delta, rs delta, s alpha, r beta1 from the 8-bit fixed-base tables (lanes 0..4), lane 0 goes on to piA
@@ -62,7 +68,7 @@ zkc_finalize(FinalizeArgs a) {
     const int nq = gridDim.x;                         // results of a pass: H_0 .. H_{nq-1}, then A_q, B1_q, C_q per proof
     uint8_t* out = a.out + 256 * (size_t)q;
     if (wave == 0 && lane < 2) {
-        const G1XYZZ P = lane == 0 ? xyzz_add(a.r1[nq + 3 * q + 0], a.kA) : xyzz_add(a.r1[nq + 3 * q + 1], a.kB1);
+        const G1XYZZ P = lane == 0 ? xyzz_add(a.r1[nq + 3 * q + 0], fold_const(a.foldA, a, q)) : xyzz_add(a.r1[nq + 3 * q + 1], fold_const(a.foldB1, a, q));
         sh[lane] = var_mul29(P, lane == 0 ? s : r, tab[lane]);                                 // s A' , r B1'
     } else if (wave == 1 && lane < 5) {
         uint32_t k[8];
@@ -75,18 +81,18 @@ zkc_finalize(FinalizeArgs a) {
         const G1XYZZ v = fb_mul<Fq>(tb, k);
         sh[2 + lane] = v;
         if (lane == 0) {        // piA = A' + alpha + r delta
-            const G1XYZZ A = xyzz_add(a.r1[nq + 3 * q + 0], a.kA);
+            const G1XYZZ A = xyzz_add(a.r1[nq + 3 * q + 0], fold_const(a.foldA, a, q));
             G1Affine p = xyzz_to_affine(xyzz_add(xyzz_add_affine(A, a.alpha1), v));
             store_fq_std(out, p.x); store_fq_std(out + 32, p.y);
         }
     } else if (wave == 2 && lane == 0) {     // piB = B2' + beta2 + s delta2
         const G2XYZZ sd = fb_mul<Fq2>(a.tblDelta2, s);
-        G2Affine p = xyzz_to_affine(xyzz_add(xyzz_add_affine(xyzz_add(a.r2[q], a.kB2), a.beta2), sd));
+        G2Affine p = xyzz_to_affine(xyzz_add(xyzz_add_affine(xyzz_add(a.r2[q], fold_const(a.foldB2, a, q)), a.beta2), sd));
         store_fq_std(out + 64, p.x.c0); store_fq_std(out + 96, p.x.c1); store_fq_std(out + 128, p.y.c0); store_fq_std(out + 160, p.y.c1);
     }
     __syncthreads();
     if (threadIdx.x == 0) {     // piC = C' + H + s A' + s alpha + r B1' + r beta1 + rs delta
-        G1XYZZ c = xyzz_add(xyzz_add(a.r1[nq + 3 * q + 2], a.kC), a.r1[q]);
+        G1XYZZ c = xyzz_add(xyzz_add(a.r1[nq + 3 * q + 2], fold_const(a.foldC, a, q)), a.r1[q]);
         c = xyzz_add(c, sh[0]); c = xyzz_add(c, sh[5]); c = xyzz_add(c, sh[1]); c = xyzz_add(c, sh[6]); c = xyzz_add(c, sh[4]);
         G1Affine p = xyzz_to_affine(c);
         store_fq_std(out + 192, p.x); store_fq_std(out + 224, p.y);

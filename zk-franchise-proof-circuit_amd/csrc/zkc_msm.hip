@@ -461,7 +461,10 @@ int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, size_t max_buck
     const size_t max_vw = max_buckets / MSM_VW_MIN + (size_t)max_jobs;
     ZKC_HIP_CHECK(ctx, hipMalloc(&w.wres, 2 * max_vw * w.xyzz_size));
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.d_windows, max_vw * sizeof(MsmWindow))); w.max_windows = max_vw;
+    w.max_tiles = max_entries / (8 * MSM_TILE_SCALARS) + (size_t)max_jobs + 1;
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.d_tilejob, w.max_tiles * 2));
     for (int s = 0; s < 2; s++) {
+        ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&w.h_tilejob[s], w.max_tiles * 2));
         ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&w.h_jobs[s], sizeof(MsmJobList))); ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&w.h_windows[s], max_vw * sizeof(MsmWindow)));
         ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&w.h_ev[s], hipEventDisableTiming));
     }
@@ -474,7 +477,8 @@ void msm_work_free(MsmWork& w) {
                  w.partial, w.wres, w.results};
     for (void* q : p) if (q) (void)hipFree(q);
     if (w.h_results) (void)hipHostFree(w.h_results);
-    for (int s = 0; s < 2; s++) { if (w.h_jobs[s]) (void)hipHostFree(w.h_jobs[s]); if (w.h_windows[s]) (void)hipHostFree(w.h_windows[s]); if (w.h_ev[s]) (void)hipEventDestroy(w.h_ev[s]); }
+    if (w.d_tilejob) (void)hipFree(w.d_tilejob);
+    for (int s = 0; s < 2; s++) { if (w.h_tilejob[s]) (void)hipHostFree(w.h_tilejob[s]); if (w.h_jobs[s]) (void)hipHostFree(w.h_jobs[s]); if (w.h_windows[s]) (void)hipHostFree(w.h_windows[s]); if (w.h_ev[s]) (void)hipEventDestroy(w.h_ev[s]); }
     w = MsmWork();
 }
 
@@ -522,6 +526,9 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
         memcpy(&w.h_jobs[hs]->njobs, &jl.njobs, sizeof(MsmJobList) - offsetof(MsmJobList, njobs));
         ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.d_jobs, w.h_jobs[hs], sizeof(MsmJobList), hipMemcpyHostToDevice, st));
         ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.d_windows, wins, (size_t)nwin * sizeof(MsmWindow), hipMemcpyHostToDevice, st));
+        if (jl.total_tiles > w.max_tiles) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: too many tiles for the work space");
+        { uint16_t* tj = w.h_tilejob[hs]; uint32_t k = 0; for (int j = 0; j < nj; j++) { const uint32_t nt = (jl.job[j].count + MSM_TILE_SCALARS - 1) / MSM_TILE_SCALARS; for (uint32_t i = 0; i < nt; i++) tj[k++] = (uint16_t)j; } }
+        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.d_tilejob, w.h_tilejob[hs], (size_t)jl.total_tiles * 2, hipMemcpyHostToDevice, st));
         ZKC_HIP_CHECK(ctx, hipEventRecord(w.h_ev[hs], st));
         int rc = msm_bucket_entries(ctx, w, jl, st); if (rc) return rc;                  // K4: digits -> entries grouped by bucket (vals2, off, bcnt)
         if (g_debug_sync) { hipError_t _e = hipStreamSynchronize(st); fprintf(stderr, "[zkc] bucket entries: %s\n", hipGetErrorString(_e)); }

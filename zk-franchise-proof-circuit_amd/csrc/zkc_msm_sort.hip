@@ -20,16 +20,6 @@
 
 namespace zkc {
 
-__device__ __forceinline__ uint32_t job_of_tile(const MsmJobList& jl, uint32_t tile) {      // last job with tile0 <= tile
-    uint32_t lo = 0, hi = (uint32_t)jl.njobs - 1;
-    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (jl.job[mid].tile0 <= tile) lo = mid; else hi = mid - 1; }
-    return lo;
-}
-__device__ __forceinline__ uint32_t job_of_bin(const MsmJobList& jl, uint32_t bin) {
-    uint32_t lo = 0, hi = (uint32_t)jl.njobs - 1;
-    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (jl.job[mid].bin0 <= bin) lo = mid; else hi = mid - 1; }
-    return lo;
-}
 // The tile of a workgroup: 1024 consecutive scalars of one job, four per thread, walked WINDOW BY WINDOW with a barrier in between, so that the
 // entries a tile contributes to a bin are ordered by window (then arbitrarily inside the 1024 scalars): together with the tile-ordered
 // placement below, the entries of a bucket end up ordered by (tile, window) -- the accumulation then streams through compact regions of the
@@ -67,10 +57,10 @@ __device__ __forceinline__ uint32_t msm_tile_digit(TileState& t, int k, uint32_t
 
 // tilecnt[job.cnt0 + bin * ntiles + tile] = entries the tile has for the bin (no atomics on global memory: placement is deterministic)
 __global__ void __launch_bounds__(MSM_TILE)
-zkc_msm_count(const MsmJobList* __restrict__ jlp, uint32_t* __restrict__ tilecnt) {
+zkc_msm_count(const MsmJobList* __restrict__ jlp, const uint16_t* __restrict__ tilejob, uint32_t* __restrict__ tilecnt) {
     __shared__ uint32_t cnt[1u << MSM_MAX_HBITS];
     const MsmJobList& jl = *jlp;
-    const uint32_t j = job_of_tile(jl, blockIdx.x);
+    const uint32_t j = tilejob[blockIdx.x];
     const MsmJob job = jl.job[j];
     const uint32_t nbins = 1u << job.hbits, tile = blockIdx.x - job.tile0, ntiles = (job.count + MSM_TILE_SCALARS - 1) / MSM_TILE_SCALARS;
     for (uint32_t b = threadIdx.x; b < nbins; b += MSM_TILE) cnt[b] = 0;
@@ -115,10 +105,10 @@ zkc_msm_binscan(const MsmJobList* __restrict__ jlp, uint32_t* __restrict__ tilec
     }
 }
 __global__ void __launch_bounds__(MSM_TILE)
-zkc_msm_split(const MsmJobList* __restrict__ jlp, const uint32_t* __restrict__ tilecnt, uint32_t* __restrict__ vals) {
+zkc_msm_split(const MsmJobList* __restrict__ jlp, const uint16_t* __restrict__ tilejob, const uint32_t* __restrict__ tilecnt, uint32_t* __restrict__ vals) {
     __shared__ uint32_t cur[1u << MSM_MAX_HBITS];      // next free position of this tile's run inside each bin
     const MsmJobList& jl = *jlp;
-    const uint32_t j = job_of_tile(jl, blockIdx.x);
+    const uint32_t j = tilejob[blockIdx.x];
     const MsmJob job = jl.job[j];
     const uint32_t nbins = 1u << job.hbits, tile = blockIdx.x - job.tile0, ntiles = (job.count + MSM_TILE_SCALARS - 1) / MSM_TILE_SCALARS;
     for (uint32_t b = threadIdx.x; b < nbins; b += MSM_TILE) cur[b] = tilecnt[job.cnt0 + b * ntiles + tile];
@@ -143,8 +133,9 @@ __global__ void __launch_bounds__(256)
 zkc_msm_bucket(const MsmJobList* __restrict__ jlp, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ bin_start, const uint32_t* __restrict__ vals,
                uint32_t* __restrict__ vals2, uint32_t* __restrict__ off, uint32_t* __restrict__ bcnt) {
     __shared__ uint32_t cnt[256], pos[256];
+    __shared__ uint32_t stage[256 * 32];              // the bin, grouped by bucket, before it leaves in whole cache lines (register path)
     const MsmJobList& jl = *jlp;
-    const uint32_t bin = blockIdx.x, j = job_of_bin(jl, bin);
+    const uint32_t bin = blockIdx.x, j = jl.job_of_bin(bin);
     const MsmJob& job = jl.job[j];
     const uint32_t lbits = job.lbits, nb2 = 1u << lbits, lowshift = 31 - lbits, lowmask = nb2 - 1, rowmask = (1u << lowshift) - 1;
     const uint32_t start = bin_start[bin], n = hist[bin];
@@ -175,15 +166,18 @@ zkc_msm_bucket(const MsmJobList* __restrict__ jlp, const uint32_t* __restrict__ 
     __syncthreads();
     if (threadIdx.x < nb2) { off[bucket_first + threadIdx.x] = start + excl; bcnt[bucket_first + threadIdx.x] = mine; }
     pos[threadIdx.x] = excl; __syncthreads();
+    constexpr uint32_t excl_base = 0;
     // scatter, 256 entries at a time with a barrier in between, so that a bucket keeps the (tile, window) order of the bin
     if (in_regs) {
 #pragma unroll
         for (int k = 0; k < BIG; k++) {
             if ((uint32_t)k * 256 < n) {                     // uniform
-                if ((uint32_t)k * 256 + threadIdx.x < n) { const uint32_t p = atomicAdd(&pos[(e[k] >> lowshift) & lowmask], 1u); vals2[start + p] = (e[k] & 0x80000000u) | (e[k] & rowmask); }
+                if ((uint32_t)k * 256 + threadIdx.x < n) { const uint32_t p = atomicAdd(&pos[(e[k] >> lowshift) & lowmask], 1u) - excl_base; stage[p] = (e[k] & 0x80000000u) | (e[k] & rowmask); }
                 __syncthreads();
             }
         }
+        // scattered 4-byte stores into a 31 KB window left the L2 as partial lines (2.4 ms per pass); from LDS the bin goes out coalesced
+        for (uint32_t i = threadIdx.x; i < n; i += 256) vals2[start + i] = stage[i];
     } else {
         for (uint32_t i0 = 0; i0 < n; i0 += 256 * SMALL) {
             uint32_t v[SMALL];
@@ -314,11 +308,11 @@ int msm_bucket_entries(zkc_ctx* ctx, MsmWork& w, const MsmJobList& jl, hipStream
     if (jl.total_bins > w.max_bins) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_bucket_entries: too many level-1 bins for the work space");
     const MsmJobList* dj = (const MsmJobList*)w.d_jobs;
     if (jl.total_tilecnt > w.max_tilecnt) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_bucket_entries: too many (bin, tile) counters for the work space");
-    hipLaunchKernelGGL(zkc_msm_count, dim3(jl.total_tiles), dim3(MSM_TILE), 0, st, dj, w.tilecnt);
+    hipLaunchKernelGGL(zkc_msm_count, dim3(jl.total_tiles), dim3(MSM_TILE), 0, st, dj, (const uint16_t*)w.d_tilejob, w.tilecnt);
     ZKC_SORT_LAUNCH_CHECK("zkc_msm_count");
     hipLaunchKernelGGL(zkc_msm_binscan, dim3(jl.njobs), dim3(256), 0, st, dj, w.tilecnt, w.hist, w.bin_start);
     ZKC_SORT_LAUNCH_CHECK("zkc_msm_binscan");
-    hipLaunchKernelGGL(zkc_msm_split, dim3(jl.total_tiles), dim3(MSM_TILE), 0, st, dj, w.tilecnt, w.vals);
+    hipLaunchKernelGGL(zkc_msm_split, dim3(jl.total_tiles), dim3(MSM_TILE), 0, st, dj, (const uint16_t*)w.d_tilejob, w.tilecnt, w.vals);
     ZKC_SORT_LAUNCH_CHECK("zkc_msm_split");
     hipLaunchKernelGGL(zkc_msm_bucket, dim3(jl.total_bins), dim3(256), 0, st, dj, w.hist, w.bin_start, w.vals, w.vals2, w.off, w.bcnt);
     ZKC_SORT_LAUNCH_CHECK("zkc_msm_bucket");

@@ -72,6 +72,7 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
                     zk->d_tblDelta1, zk->d_tblAlpha1, zk->d_tblBeta1, zk->d_tblDelta2, zk->d_rs, zk->d_proofs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : zk->fold.vmaps) if (kv.second.d) (void)hipFree(kv.second.d);
+    for (void* q : {(void*)zk->fold.d_foldA, (void*)zk->fold.d_foldB1, (void*)zk->fold.d_foldC, (void*)zk->fold.d_foldB2}) if (q) (void)hipFree(q);
     if (zk->h_flags) (void)hipHostFree(zk->h_flags);
     if (zk->h_out) (void)hipHostFree(zk->h_out);
     if (zk->ev_start) (void)hipEventDestroy(zk->ev_start);
@@ -253,6 +254,12 @@ template <class X> static void suffix_sums(std::vector<X>& suf, const X* g, int 
     suf.assign(n, X::inf());
     for (int D = n - 2; D >= 0; D--) suf[D] = xyzz_add(suf[D + 1], g[D]);
 }
+template <class PT> static int fold_upload(zkc_ctx* ctx, PT** d, const std::vector<PT>& b, const std::vector<PT>* suf) {
+    std::vector<PT> t; t.push_back(b[0]); t.insert(t.end(), suf[0].begin(), suf[0].end()); t.insert(t.end(), suf[1].begin(), suf[1].end());
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)d, t.size() * sizeof(PT)));
+    ZKC_HIP_CHECK(ctx, hipMemcpy(*d, t.data(), t.size() * sizeof(PT), hipMemcpyHostToDevice));
+    return ZKC_OK;
+}
 static int fold_prepare(zkc_zkey* zk) {
     if (zk->fold.ready) return ZKC_OK;
     zkc_ctx* ctx = zk->ctx; const WitnessLayout L = WitnessLayout::make(zk->nLevels); const int n = L.n;
@@ -279,6 +286,9 @@ static int fold_prepare(zkc_zkey* zk) {
     }
     f.baseA = {xyzz_add(gA[n - 1], gA[2 * n - 1])}; f.baseB1 = {xyzz_add(gB1[n - 1], gB1[2 * n - 1])};
     f.baseC = {xyzz_add(gC[n - 1], gC[2 * n - 1])}; f.baseB2 = {xyzz_add(gB2[n - 1], gB2[2 * n - 1])};
+    // device tables for the blinding kernel: [base | suf[0][0..n) | suf[1][0..n)]
+    if ((rc = fold_upload(ctx, &f.d_foldA, f.baseA, f.sufA)) || (rc = fold_upload(ctx, &f.d_foldB1, f.baseB1, f.sufB1)) || (rc = fold_upload(ctx, &f.d_foldC, f.baseC, f.sufC)) ||
+        (rc = fold_upload(ctx, &f.d_foldB2, f.baseB2, f.sufB2))) return rc;
     f.ready = true;
     return ZKC_OK;
 }
@@ -435,15 +445,17 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
         ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(LN.st, zk->ev_chunk[pass], 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(LN.st2, zk->ev_chunk[pass], 0));
         hipStream_t st = LN.st, st2 = LN.st2, fin = LN.fin;
         const uint32_t* w0 = (const uint32_t*)d_wtns + (size_t)p0 * nv * 8;
-        int Dc = 0, Ds = 0; bool fold = can_fold;
+        // constant folding is per proof: voter q keeps the census levels below its own leaf depth dcq[q] (sik: dsq[q]) in its MSMs; the levels
+        // above are the template's and come back as a constant in the blinding kernel.  One foreign witness (n2bOld block differs) unfolds the pass.
+        uint8_t dcq[MSM_MAX_JOBS / 4], dsq[MSM_MAX_JOBS / 4]; bool fold = can_fold;
         for (int q = 0; q < nb && fold; q++) for (int t = 0; t < 2; t++) {
             const uint32_t* f = zk->h_flags + ((size_t)(p0 + q) * 2 + t) * L.n;
             if (f[L.n - 1]) { fold = false; break; }                              // n2bOld block differs: not one of our witnesses
             int D = 0; for (int g = 0; g < L.n - 1; g++) if (f[g]) D = g + 1;
-            if (t == 0) Dc = std::max(Dc, D); else Ds = std::max(Ds, D);
+            (t == 0 ? dcq : dsq)[q] = (uint8_t)D;
         }
-        zkc_zkey::Fold::VMap vm;
-        if (fold && (rc = fold_vmap(zk, Dc, Ds, &vm))) return rc;
+        static thread_local zkc_zkey::Fold::VMap vms[MSM_MAX_JOBS / 4];
+        if (fold) for (int q = 0; q < nb; q++) if ((rc = fold_vmap(zk, dcq[q], dsq[q], &vms[q]))) return rc;
         if (LN.npass >= 2) { ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, LN.ev_fin[slot], 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st2, LN.ev_fin[slot], 0)); }   // slot still read by the blinding two passes back?
         LN.npass++;
         if ((rc = h_evals_dev(zk, LN, w0, nb))) return rc;
@@ -457,6 +469,7 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
         for (int q = 0; q < nb; q++) {
             const uint32_t* w = w0 + (size_t)q * nv * 8;
             if (fold) {
+                const zkc_zkey::Fold::VMap& vm = vms[q];
                 j1.add(w, vm.d + vm.offA, vm.nA, zk->offA, nv, 0, MSM_C_SMALL);
                 j1.add(w, vm.d + vm.offB, vm.nB, zk->offB1, nv, 0, MSM_C_SMALL);
                 j1.add(w, vm.d + vm.offC, vm.nC, zk->offC, nc, (int32_t)np + 1, MSM_C_SMALL);
@@ -487,12 +500,8 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
         // a7 on the second stream: overlaps the next pass
         FinalizeArgs fa{};
         fa.r1 = (const G1XYZZ*)LN.w1.results + (size_t)slot * LN.w1.max_jobs; fa.r2 = (const G2XYZZ*)LN.w2.results + (size_t)slot * LN.w2.max_jobs;
-        fa.kA = fa.kB1 = fa.kC = G1XYZZ::inf(); fa.kB2 = G2XYZZ::inf();
-        if (fold) {
-            const auto& f = zk->fold;
-            fa.kA = xyzz_add(f.baseA[0], xyzz_add(f.sufA[0][Dc], f.sufA[1][Ds])); fa.kB1 = xyzz_add(f.baseB1[0], xyzz_add(f.sufB1[0][Dc], f.sufB1[1][Ds]));
-            fa.kC = xyzz_add(f.baseC[0], xyzz_add(f.sufC[0][Dc], f.sufC[1][Ds])); fa.kB2 = xyzz_add(f.baseB2[0], xyzz_add(f.sufB2[0][Dc], f.sufB2[1][Ds]));
-        }
+        fa.foldA = zk->fold.d_foldA; fa.foldB1 = zk->fold.d_foldB1; fa.foldC = zk->fold.d_foldC; fa.foldB2 = zk->fold.d_foldB2; fa.fold_n = can_fold ? L.n : 0;
+        for (int q = 0; q < nb; q++) { fa.dc[q] = fold ? dcq[q] : (uint8_t)255; fa.ds[q] = fold ? dsq[q] : (uint8_t)255; }
         fa.tblDelta1 = zk->d_tblDelta1; fa.tblAlpha1 = zk->d_tblAlpha1; fa.tblBeta1 = zk->d_tblBeta1; fa.tblDelta2 = zk->d_tblDelta2;
         fa.alpha1 = zk->alpha1; fa.beta2 = zk->beta2; fa.rs = zk->d_rs + 64 * (size_t)p0; fa.out = zk->d_proofs + 256 * (size_t)p0;
         ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm, 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm2, 0));

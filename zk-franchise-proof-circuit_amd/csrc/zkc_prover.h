@@ -39,7 +39,10 @@ struct MsmJob {
 // arguments of the blinding kernel (zkc_finalize.hip); everything except r1/r2/rs/out is constant per proving key
 struct FinalizeArgs {
     const G1XYZZ* r1; const G2XYZZ* r2;                 // MSM results of this pass: r1[q] = H_q, r1[n + 3q + {0,1,2}] = A_q, B1_q, C_q ; r2[q]
-    G1XYZZ kA, kB1, kC; G2XYZZ kB2;                     // folded constants of this pass
+    // constant folding, per proof: proof q folds census levels >= dc[q] and sik levels >= ds[q] (255: this pass is not folded); its constant for
+    // a section is tab[0] + tab[1 + dc] + tab[1 + fold_n + ds] with tab = [base | suffix sums census tree | suffix sums sik tree] (device)
+    const G1XYZZ *foldA, *foldB1, *foldC; const G2XYZZ* foldB2; int fold_n;
+    uint8_t dc[MSM_MAX_JOBS / 4], ds[MSM_MAX_JOBS / 4];
     const G1Affine *tblDelta1, *tblAlpha1, *tblBeta1; const G2Affine* tblDelta2;   // 32 x 255 fixed-base tables
     G1Affine alpha1; G2Affine beta2;
     const uint8_t* rs; uint8_t* out;                    // device: nproofs x 64 (r || s) -> nproofs x 256 proof bytes
@@ -54,6 +57,7 @@ constexpr uint32_t MSM_MAX_HBITS = 10;                 // level-1 bins per job <
 struct MsmJobList {
     MsmJob job[MSM_MAX_JOBS]; int njobs; uint32_t total_buckets, total_entries, total_windows, total_bins, total_tiles, total_tilecnt;
     uint32_t hs, hb, nbig;                              // set by finish(): bucket counts of the small / big jobs, number of big jobs (they come first)
+    uint32_t hbits_big, hbits_small;                    // level-1 bin bits of the two job classes when uniform inside each class (else 0xff: search)
     uint32_t vw_small = 256;                            // virtual window of the c < 16 jobs: 256 for throughput, 64 for the latency of a small pass (same box: 256 -> 2431 proofs/s, 4.9 ms ; 128 -> 2375, 4.0 ms ; 64 -> 2304, 3.9 ms single prove)
     void add(const uint32_t* scalars, const uint32_t* vmap, uint32_t count, uint32_t tbl_off, uint32_t tbl_count, int32_t pt_shift, int c) {
         MsmJob& j = job[njobs++];
@@ -66,7 +70,7 @@ struct MsmJobList {
     bool finish() {
         hs = 0xffffffffu; hb = 0;
         for (int j = 0; j < njobs; j++) { const uint32_t h = 1u << (job[j].c - 1); hs = h < hs ? h : hs; hb = h > hb ? h : hb; }
-        nbig = 0; total_buckets = total_bins = total_tiles = total_tilecnt = 0;
+        nbig = 0; total_buckets = total_bins = total_tiles = total_tilecnt = 0; hbits_big = hbits_small = 0;
         for (int j = 0; j < njobs; j++) {
             MsmJob& q = job[j]; const uint32_t h = 1u << (q.c - 1);
             if (h != hs && h != hb) return false;
@@ -76,6 +80,7 @@ struct MsmJobList {
             while (lbits > 8 || (lbits > 0 && rows >= (1ull << (31 - lbits)))) { lbits--; hbits++; }      // level 2 handles <= 256 buckets per bin
             if (hbits > MSM_MAX_HBITS || rows >= (1ull << (31 - lbits))) return false;
             q.hbits = hbits; q.lbits = lbits;
+            { uint32_t& cls = h == hb ? hbits_big : hbits_small; cls = (cls == 0 || cls == hbits) ? hbits : 0xffu; }
             q.bucket0 = total_buckets; total_buckets += h;
             q.bin0 = total_bins; total_bins += 1u << hbits;
             const uint32_t nt = (q.count + MSM_TILE_SCALARS - 1) / MSM_TILE_SCALARS;
@@ -84,6 +89,16 @@ struct MsmJobList {
         return true;
     }
     ZKC_HD uint32_t id_of(uint32_t d, uint32_t j) const { return job[j].bucket0 + d; }
+    // job owning level-1 bin `bin` of the pass: closed form when the two job classes have uniform bin counts (the prover's passes), else a search
+    ZKC_HD uint32_t job_of_bin(uint32_t bin) const {
+        if (hbits_big != 0xffu && hbits_small != 0xffu) {
+            const uint32_t lim = nbig << hbits_big;
+            return bin < lim ? bin >> hbits_big : nbig + ((bin - lim) >> hbits_small);
+        }
+        uint32_t lo = 0, hi = (uint32_t)njobs - 1;
+        while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (job[mid].bin0 <= bin) lo = mid; else hi = mid - 1; }
+        return lo;
+    }
     ZKC_HD void decode(uint32_t id, uint32_t& d, uint32_t& j) const {
         const uint32_t lim = hb * nbig;
         if (id < lim) { j = id / hb; d = id - j * hb; }
@@ -109,6 +124,7 @@ struct MsmWork {
     MsmWindow* d_windows = nullptr; size_t max_buckets = 0, max_bins = 0, max_windows = 0;
     // pinned host staging of (job list, window list), two slots: a pageable source made hipMemcpyAsync hold the enqueueing thread until
     // the stream had drained, which kept the G2 stream idle for 8 ms of every pass.  h_ev[s] = the copy out of slot s has executed.
+    uint16_t* d_tilejob = nullptr; uint16_t* h_tilejob[2] = {nullptr, nullptr}; size_t max_tiles = 0;      // tile of the pass -> job
     MsmJobList* h_jobs[2] = {nullptr, nullptr}; MsmWindow* h_windows[2] = {nullptr, nullptr}; hipEvent_t h_ev[2] = {nullptr, nullptr}; int h_next = 0;
     size_t max_entries = 0, max_segments = 0; int max_jobs = 0; size_t xyzz_size = 0;
 };
@@ -155,6 +171,7 @@ struct zkc_zkey {
         struct VMap { uint32_t* d = nullptr; uint32_t offA = 0, nA = 0, offB = 0, nB = 0, offC = 0, nC = 0; };   // three lists in one allocation
         std::map<std::pair<int, int>, VMap> vmaps;                                              // (Dc, Ds) -> surviving wires per section
         std::vector<uint8_t> infA, infB, infC;                                                  // base point is the point at infinity (zero polynomial)
+        zkc::G1XYZZ *d_foldA = nullptr, *d_foldB1 = nullptr, *d_foldC = nullptr; zkc::G2XYZZ* d_foldB2 = nullptr;    // [1 + 2 n] each: base, suf[0][], suf[1][]
         bool ready = false;
     } fold;
 };
