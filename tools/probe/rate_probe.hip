@@ -15,7 +15,7 @@ template <int OP> __global__ void __launch_bounds__(256) probe(uint64_t* out, ui
     for (int i = 0; i < 8; i++) { a[i] = ((uint64_t)(seed + i) << 33) + i + threadIdx.x; d[i] = (double)(seed + i) + threadIdx.x; }
     double m = 1.0000001, c = 0.5;
     const uint64_t t0 = __builtin_amdgcn_s_memtime();
-    for (int it = 0; it < ITER; it++) {
+    for (int it = 0; it < (OP == 17 ? 0 : ITER); it++) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             uint32_t lo = (uint32_t)a[i];
@@ -40,6 +40,20 @@ template <int OP> __global__ void __launch_bounds__(256) probe(uint64_t* out, ui
             if (OP == 16) asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_and_b32 %1, %2, %1" : "+v"(a[i]), "+v"(z) : "v"(x), "v"(y) : "vcc");   // 1 mad : 1 full-rate op, interleaved
         }
     }
+    if (OP == 17) {     // the accumulation kernel's mix: 10 v_mad_u64_u32, 3 half-rate 64-bit / 3-operand ops, 3 plain 32-bit ops per 16 instructions, no two
+                        // neighbours on the same register (profiles/r02_accumulate_isa_histogram.txt: 63.5 % / 19 % / 17.5 % of one mixed addition)
+        uint64_t b0 = a[0] ^ 5, b1 = a[1] ^ 9; uint32_t z0 = x ^ 1, z1 = y ^ 2, z2 = z ^ 3, z3 = x + y;
+        for (int it = 0; it < ITER * 4; it++) {
+            asm volatile(
+                "v_mad_u64_u32 %0, vcc, %14, %15, %0\n\tv_mad_u64_u32 %1, vcc, %14, %15, %1\n\tv_and_b32 %10, %14, %10\n\tv_mad_u64_u32 %2, vcc, %14, %15, %2\n\t"
+                "v_lshrrev_b64 %8, 1, %8\n\tv_mad_u64_u32 %3, vcc, %14, %15, %3\n\tv_mad_u64_u32 %4, vcc, %14, %15, %4\n\tv_add_u32 %11, %15, %11\n\t"
+                "v_mad_u64_u32 %5, vcc, %14, %15, %5\n\tv_lshl_add_u64 %9, %8, 0, %9\n\tv_mad_u64_u32 %6, vcc, %14, %15, %6\n\tv_mad_u64_u32 %7, vcc, %14, %15, %7\n\t"
+                "v_and_b32 %12, %15, %12\n\tv_mad_u64_u32 %0, vcc, %15, %14, %0\n\tv_alignbit_b32 %13, %14, %13, 29\n\tv_mad_u64_u32 %1, vcc, %15, %14, %1"
+                : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(b0), "+v"(b1), "+v"(z0), "+v"(z1), "+v"(z2), "+v"(z3)
+                : "v"(x), "v"(y) : "vcc");
+        }
+        a[2] += b0 + b1 + z0 + z1 + z2 + z3;
+    }
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
     uint64_t s = x + z + y; for (int i = 0; i < 8; i++) s += a[i] + (uint64_t)d[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
@@ -63,6 +77,7 @@ int main() {
     uint64_t *d, *dt; hipMalloc(&d, 256 * 8 * 256 * 8); hipMalloc(&dt, 256 * 8 * 4 * 8);
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
     printf("# %s, %d CUs, clockRate %d kHz; 8 chains per lane, %d iterations; W = waves per SIMD\n", p.gcnArchName, p.multiProcessorCount, p.clockRate, ITER);
+    for (int w : {1, 2, 3, 4, 8}) run<17>("accumulation mix 10 mad : 3 half : 3 full", w, 8, d, dt);     // 16 instructions per 8-instruction slot of the generic loop, x 4 iterations: see ops below
     for (int w : {2, 3, 8}) {
         run<6>("v_add_u32", w, 1, d, dt); run<7>("v_and_b32", w, 1, d, dt); run<0>("v_mad_u64_u32", w, 1, d, dt);
         run<16>("v_mad_u64_u32 + v_and_b32 (1:1)", w, 2, d, dt);
