@@ -225,12 +225,13 @@ def main():
     pairs_per_proof = prof['msm_g1_streamed']['alg_bytes'] / 96.0 / nproofs             # (scalar, base) pairs entering the G1 MSMs of one proof
     madds_per_proof = 15.0 * pk.domain_size + 22.0 * (pairs_per_proof - pk.domain_size)  # c = 17: 15 windows for H; c = 12: 22 windows for A, B1, C
     madd_rate = madds_per_proof * nproofs / (d['ms'] * 1e-3) if d['ms'] > 0 else 0.0
-    capacity = 1.0 / (vm['mad_u64_u32_per_madd'] / vm['rate_mad_u64_u32'] + (vm['instr_per_madd'] - vm['mad_u64_u32_per_madd']) / vm['rate_valu32'])
+    capacity = vm.get('capacity_madd_per_s') or 1.0 / (vm['mad_u64_u32_per_madd'] / vm['rate_mad_u64_u32'] + (vm['instr_per_madd'] - vm['mad_u64_u32_per_madd']) / vm['rate_valu32'])
     alu = {'unit': 'mixed additions/s', 'achieved': round(madd_rate / 1e9, 3), 'achieved_unit': 'G madd/s', 'instr_per_madd': vm['instr_per_madd'],
            'mad_u64_u32_per_madd': vm['mad_u64_u32_per_madd'], 'peak': round(capacity / 1e9, 2), 'peak_unit': 'G madd/s', 'frac': round(madd_rate / capacity, 4),
            'model_source': vm.get('source'),
-           'note': 'VALU issue bound: instruction mix of one mixed addition (ISA count) priced at the measured lane-instruction rates of this part; '
-                   'this, not HBM, limits the kernel'}
+           'note': 'VALU issue bound: capacity = lane-operations/s a dependency-free loop with the kernel\'s own instruction mix sustains on this part '
+                   '(tools/probe/rate_probe.hip, profiles/r02_rate_probe.txt) / VALU instructions of one mixed addition (profiles/r02_accumulate_isa_histogram.txt); '
+                   'rocprofv3 SQ counters of the kernel are in profiles/r02_pmc_sq_accumulate.json.  This, not HBM, limits the kernel; box-to-box clock differences move frac by a few percent'}
     roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'valu': alu,
                 'frac': round(achieved / HBM_PEAK_GBPS, 6), 'traffic': traffic, 'traffic_source': traffic_src,
                 'avg_launch_ms': round(d['ms'] / max(1, d['launches']), 4), 'alg_bytes_per_launch': d['alg_bytes'] // max(1, d['launches']),
