@@ -222,11 +222,10 @@ def main():
     except Exception:
         pass
     nproofs = args.steps * B
-    pairs_per_proof = prof['msm_g1_streamed']['alg_bytes'] / 96.0 / nproofs             # (scalar, base) pairs entering the G1 MSMs of one proof
-    madds_per_proof = 15.0 * pk.domain_size + 22.0 * (pairs_per_proof - pk.domain_size)  # c = 17: 15 windows for H; c = 12: 22 windows for A, B1, C
-    madd_rate = madds_per_proof * nproofs / (d['ms'] * 1e-3) if d['ms'] > 0 else 0.0
+    madds = prof['msm_g1_streamed']['launches']                                          # counted on the device: non-zero signed digits = mixed additions performed
+    madd_rate = madds / (d['ms'] * 1e-3) if d['ms'] > 0 else 0.0
     capacity = vm.get('capacity_madd_per_s') or 1.0 / (vm['mad_u64_u32_per_madd'] / vm['rate_mad_u64_u32'] + (vm['instr_per_madd'] - vm['mad_u64_u32_per_madd']) / vm['rate_valu32'])
-    alu = {'unit': 'mixed additions/s', 'achieved': round(madd_rate / 1e9, 3), 'achieved_unit': 'G madd/s', 'instr_per_madd': vm['instr_per_madd'],
+    alu = {'unit': 'mixed additions/s', 'achieved': round(madd_rate / 1e9, 3), 'achieved_unit': 'G madd/s', 'madds_per_proof': round(madds / max(1, nproofs)), 'instr_per_madd': vm['instr_per_madd'],
            'mad_u64_u32_per_madd': vm['mad_u64_u32_per_madd'], 'peak': round(capacity / 1e9, 2), 'peak_unit': 'G madd/s', 'frac': round(madd_rate / capacity, 4),
            'model_source': vm.get('source'),
            'note': 'VALU issue bound: capacity = lane-operations/s a dependency-free loop with the kernel\'s own instruction mix sustains on this part '

@@ -165,7 +165,8 @@ int zkc_poseidon_batch(zkc_ctx* ctx, int n_inputs, const void* inputs, size_t B,
 
 /* ---- measurement: HIP-event timing per kernel category on zkc_ctx_stream (bit i of mask enables category i) ----
  * 0 witness, 1 buildABC mat-vec, 2 NTT+joinABC, 3 MSM digits+sort+offsets, 4 MSM bucket accumulation G1, 5 same G2,
- * 6 MSM heavy+reduce+final.  zkc_profile_read returns the summed duration, the number of bracketed launches and the
+ * 6 MSM heavy+reduce+final, 7 (no timing) bytes = (scalar, base) pairs x 96 B that entered the G1 MSMs after constant folding and
+ * launches = group additions the G1 bucket accumulation actually performed (non-zero digits).  zkc_profile_read returns the summed duration, the number of bracketed launches and the
  * ALGORITHMIC bytes those launches processed. */
 int zkc_profile_enable(zkc_ctx* ctx, uint32_t mask);
 int zkc_profile_read(zkc_ctx* ctx, int category, double* total_ms, uint64_t* launches, uint64_t* alg_bytes);

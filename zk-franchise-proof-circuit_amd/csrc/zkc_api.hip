@@ -50,6 +50,8 @@ extern "C" int zkc_profile_enable(zkc_ctx* ctx, uint32_t mask) {
     for (auto& r : ctx->prof.pending) { ctx->prof.free_events.push_back(r.a); ctx->prof.free_events.push_back(r.b); }
     ctx->prof.pending.clear();
     for (int i = 0; i < ZKC_PROF_NCAT; i++) { ctx->prof.ms[i] = 0; ctx->prof.launches[i] = 0; ctx->prof.bytes[i] = 0; }
+    if (!ctx->d_prof_entries && hipMalloc((void**)&ctx->d_prof_entries, 8) != hipSuccess) ctx->d_prof_entries = nullptr;
+    if (ctx->d_prof_entries) (void)hipMemset(ctx->d_prof_entries, 0, 8);
     ctx->prof.mask = mask;
     return ZKC_OK;
 }
@@ -62,6 +64,9 @@ extern "C" int zkc_profile_read(zkc_ctx* ctx, int cat, double* total_ms, uint64_
         ctx->prof.free_events.push_back(r.a); ctx->prof.free_events.push_back(r.b);
     }
     ctx->prof.pending.clear();
+    if (cat == ZKC_PROF_MSM_G1_STREAMED && ctx->d_prof_entries) {      // launches of this bytes-only category = mixed additions the G1 accumulation really performed
+        unsigned long long v = 0; (void)hipDeviceSynchronize(); (void)hipMemcpy(&v, ctx->d_prof_entries, 8, hipMemcpyDeviceToHost); ctx->prof.launches[cat] = v;
+    }
     if (total_ms) *total_ms = ctx->prof.ms[cat]; if (launches) *launches = ctx->prof.launches[cat]; if (alg_bytes) *alg_bytes = ctx->prof.bytes[cat];
     return ZKC_OK;
 }
@@ -154,6 +159,7 @@ extern "C" void zkc_ctx_destroy(zkc_ctx* ctx) {
     if (ctx->d_scratch_out) (void)hipFree(ctx->d_scratch_out);
     if (ctx->d_status3) (void)hipFree(ctx->d_status3);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->d_prof_entries) (void)hipFree(ctx->d_prof_entries);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->fin_stream) (void)hipStreamDestroy(ctx->fin_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -41,6 +41,7 @@ struct zkc_ctx {
     int32_t* d_status3 = nullptr; size_t status3_n = 0;
     int32_t* d_status = nullptr; size_t status_n = 0;
     zkc_prof prof;
+    unsigned long long* d_prof_entries = nullptr;      // device counter: (digit, point) entries = group additions of the G1 passes while profiling is on
 };
 
 int zkc_fail(zkc_ctx* ctx, int code, const std::string& msg);

@@ -530,7 +530,8 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
         { uint16_t* tj = w.h_tilejob[hs]; uint32_t k = 0; for (int j = 0; j < nj; j++) { const uint32_t nt = (jl.job[j].count + MSM_TILE_SCALARS - 1) / MSM_TILE_SCALARS; for (uint32_t i = 0; i < nt; i++) tj[k++] = (uint16_t)j; } }
         ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.d_tilejob, w.h_tilejob[hs], (size_t)jl.total_tiles * 2, hipMemcpyHostToDevice, st));
         ZKC_HIP_CHECK(ctx, hipEventRecord(w.h_ev[hs], st));
-        int rc = msm_bucket_entries(ctx, w, jl, st); if (rc) return rc;                  // K4: digits -> entries grouped by bucket (vals2, off, bcnt)
+        unsigned long long* ectr = (!kG2 && ((ctx->prof.mask >> ZKC_PROF_MSM_ACC_G1) & 1)) ? ctx->d_prof_entries : nullptr;      // profiling: real G1 additions of the pass
+        int rc = msm_bucket_entries(ctx, w, jl, st, ectr); if (rc) return rc;                  // K4: digits -> entries grouped by bucket (vals2, off, bcnt)
         if (g_debug_sync) { hipError_t _e = hipStreamSynchronize(st); fprintf(stderr, "[zkc] bucket entries: %s\n", hipGetErrorString(_e)); }
         rc = msm_build_segments(ctx, w, jl, seg, seg_bound, st); if (rc) return rc;      // segments of <= seg entries, longest first
         if (g_debug_sync) { hipError_t _e = hipStreamSynchronize(st); fprintf(stderr, "[zkc] segments: %s\n", hipGetErrorString(_e)); }

@@ -76,7 +76,8 @@ zkc_msm_count(const MsmJobList* __restrict__ jlp, const uint16_t* __restrict__ t
 // one workgroup per job: exclusive scan (in place) of its nbins x ntiles tile counts in (bin, tile) order, offset by ent_off -> where each tile's
 // run inside each bin starts; hist[bin] = entries of the bin, bin_start[bin] = its first position
 __global__ void __launch_bounds__(256)
-zkc_msm_binscan(const MsmJobList* __restrict__ jlp, uint32_t* __restrict__ tilecnt, uint32_t* __restrict__ hist, uint32_t* __restrict__ bin_start) {
+zkc_msm_binscan(const MsmJobList* __restrict__ jlp, uint32_t* __restrict__ tilecnt, uint32_t* __restrict__ hist, uint32_t* __restrict__ bin_start,
+                unsigned long long* __restrict__ entry_counter) {
     __shared__ uint32_t part[256];
     __shared__ uint32_t carry_sh;
     const MsmJob& job = jlp->job[blockIdx.x];
@@ -99,6 +100,7 @@ zkc_msm_binscan(const MsmJobList* __restrict__ jlp, uint32_t* __restrict__ tilec
     }
     // bin boundaries from the scanned counts: bin b starts where its tile 0 starts
     const uint32_t end = carry_sh;
+    if (entry_counter && threadIdx.x == 0) atomicAdd(entry_counter, (unsigned long long)(end - job.ent_off));      // non-zero digits = group additions this job needs (measurement only)
     for (uint32_t b = threadIdx.x; b < nbins; b += 256) {
         const uint32_t st = c[b * ntiles], en = b + 1 < nbins ? c[(b + 1) * ntiles] : end;
         bin_start[job.bin0 + b] = st; hist[job.bin0 + b] = en - st;
@@ -304,13 +306,13 @@ zkc_msm_lenscatter(const uint32_t* __restrict__ seglen, const uint32_t* __restri
 
 #define ZKC_SORT_LAUNCH_CHECK(name) do { hipError_t _e = hipGetLastError(); if (_e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, std::string(name ": ") + hipGetErrorString(_e)); } while (0)
 
-int msm_bucket_entries(zkc_ctx* ctx, MsmWork& w, const MsmJobList& jl, hipStream_t st) {
+int msm_bucket_entries(zkc_ctx* ctx, MsmWork& w, const MsmJobList& jl, hipStream_t st, unsigned long long* d_entry_counter) {
     if (jl.total_bins > w.max_bins) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_bucket_entries: too many level-1 bins for the work space");
     const MsmJobList* dj = (const MsmJobList*)w.d_jobs;
     if (jl.total_tilecnt > w.max_tilecnt) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_bucket_entries: too many (bin, tile) counters for the work space");
     hipLaunchKernelGGL(zkc_msm_count, dim3(jl.total_tiles), dim3(MSM_TILE), 0, st, dj, (const uint16_t*)w.d_tilejob, w.tilecnt);
     ZKC_SORT_LAUNCH_CHECK("zkc_msm_count");
-    hipLaunchKernelGGL(zkc_msm_binscan, dim3(jl.njobs), dim3(256), 0, st, dj, w.tilecnt, w.hist, w.bin_start);
+    hipLaunchKernelGGL(zkc_msm_binscan, dim3(jl.njobs), dim3(256), 0, st, dj, w.tilecnt, w.hist, w.bin_start, d_entry_counter);
     ZKC_SORT_LAUNCH_CHECK("zkc_msm_binscan");
     hipLaunchKernelGGL(zkc_msm_split, dim3(jl.total_tiles), dim3(MSM_TILE), 0, st, dj, (const uint16_t*)w.d_tilejob, w.tilecnt, w.vals);
     ZKC_SORT_LAUNCH_CHECK("zkc_msm_split");

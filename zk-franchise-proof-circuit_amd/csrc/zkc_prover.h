@@ -188,7 +188,7 @@ int msm_pass_g1(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool t
 int msm_pass_g2(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st);
 // zkc_msm_sort.hip -- K4: scalars -> signed digits -> entries bucketed per job (vals2, off, bcnt), then the segment lists of the accumulation
 // (segcnt, segoff, seg2bucket, seglen, perm, heavy).  `jl` is the finished host copy of what w.d_jobs already holds on the device.
-int msm_bucket_entries(zkc_ctx* ctx, MsmWork& w, const MsmJobList& jl, hipStream_t st);
+int msm_bucket_entries(zkc_ctx* ctx, MsmWork& w, const MsmJobList& jl, hipStream_t st, unsigned long long* d_entry_counter = nullptr);
 int msm_build_segments(zkc_ctx* ctx, MsmWork& w, const MsmJobList& jl, uint32_t seg, size_t seg_bound, hipStream_t st);
 int finalize_launch(zkc_ctx* ctx, hipStream_t st, const FinalizeArgs& a, int nproofs);
 int msm_precompute_g1(zkc_ctx* ctx, uint32_t count, G1Affine* d_table, int c);   // d_table[0..count) = base on entry
