@@ -179,6 +179,157 @@ zkc_ntt_pass(const Fr* __restrict__ src_all, Fr* __restrict__ dst_all, const uin
     }
 }
 
+// ================= [round 2] the transform PAIR of the prover without bit reversal and with three HBM round trips =================
+// h_evals needs, per vector, iNTT -> multiply by g^i / n -> NTT.  Both transforms use multiply-then-add (Cooley-Tukey) butterflies:
+//   inverse : natural input -> BIT-REVERSED output ("NR": spans n/2 ... 1; every butterfly of block i of a stage with 2^q blocks uses the one
+//             twiddle w^-(brev_q(i) n / 2^(q+1)))
+//   forward : bit-reversed input -> natural output ("RN": spans 1 ... n/2, the stages zkc_ntt_pass runs)
+// so position p simply holds X[brev(p)] in between, the scale table is stored bit-reversed once per key, and no load or store of any pass is a
+// permutation (round 1 gathered 32-byte elements by bit-reversed index in the first pass of both transforms).  The last nine NR stages, the
+// scaling and the first nine RN stages all live on the same 512 consecutive positions, so they share one LDS residency:
+//   zkc_ntt_nr_head   NR stages 0 .. logn-10 : tile = (top bits) x 4 neighbouring positions           (HBM round trip 1)
+//   zkc_ntt_mid       NR stages logn-9 .. logn-1, x scale_br, RN stages 1 .. 9 on 2 x 512 positions    (HBM round trip 2)
+//   zkc_ntt_pass      RN stages 10 .. logn (the existing kernel, first = 0)                            (HBM round trip 3)
+// Element format between kernels stays 8 x u32 Montgomery (R = 2^256); inside a tile nine 29-bit limbs (R' = 2^261) as in zkc_ntt_pass.
+__device__ __forceinline__ void ntt_ld_w(uint32_t w[9], const uint32_t* __restrict__ tw29, size_t e) {
+    const uint4* wp = reinterpret_cast<const uint4*>(tw29 + (size_t)TW29_WORDS * e);
+    const uint4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+    w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w; w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w; w[8] = w2.x;
+}
+// one multiply-then-add butterfly on two LDS slots; `plain`: twiddle is 1 and v may be as large as 32 p (freshly loaded)
+__device__ __forceinline__ void ntt_bfly(uint32_t* pu, uint32_t* pv, const uint32_t w[9], bool plain, bool carry) {
+    uint32_t u[9], v[9], tt[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { u[i] = pu[i]; v[i] = pv[i]; }
+    if (plain) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) { const uint32_t vi = v[i]; v[i] = u[i] + NttDom::D27.l[i] - vi; u[i] += vi; }
+    } else {
+        f29_mul<FrParams>(tt, v, w);
+#pragma unroll
+        for (int i = 0; i < 9; i++) { v[i] = u[i] + NttDom::D24.l[i] - tt[i]; u[i] += tt[i]; }
+    }
+    if (carry) { f29_carry(u); f29_carry(v); }
+#pragma unroll
+    for (int i = 0; i < 9; i++) { pu[i] = u[i]; pv[i] = v[i]; }
+}
+// NR stages q0 .. q0+b-1 over a tile whose `mid` index (b bits) is the position bits those stages pair up; slot(mid, l) gives the LDS slot.
+// prefix = the position bits above mid (q0 of them): block index of stage q0 + r is (prefix << r) | (mid >> (b - r)).
+template <class Slot>
+__device__ __forceinline__ void ntt_nr_stages(uint32_t* tile, Slot slot, int b, int lo_t, int q0, uint32_t prefix_of_l0, int prefix_per_l, const uint32_t* __restrict__ tw29, int logn, bool fresh) {
+    const int mid_n = 1 << b, pairs = (mid_n >> 1) * lo_t;
+    for (int r = 0; r < b; r++) {
+        const int q = q0 + r, span = mid_n >> (r + 1);
+        for (int x = threadIdx.x; x < pairs; x += blockDim.x) {
+            const int l = x % lo_t, pr = x / lo_t;
+            const int blk = pr / span, j = pr - blk * span;
+            const int m0 = blk * 2 * span + j, m1 = m0 + span;
+            const uint32_t i = ((prefix_of_l0 + (uint32_t)(prefix_per_l * l)) << r) | (uint32_t)blk;          // block of stage q (q bits)
+            const uint32_t e = q ? (__brev(i) >> (32 - q)) << (logn - q - 1) : 0u;
+            uint32_t w[9]; ntt_ld_w(w, tw29, e);
+            ntt_bfly(tile + 9 * slot(m0, l), tile + 9 * slot(m1, l), w, fresh && r == 0 && q == 0, ((r & 1) == 1) || r == b - 1);
+        }
+        __syncthreads();
+    }
+}
+extern "C" __global__ void __launch_bounds__(256)
+zkc_ntt_nr_head(const Fr* src_all, Fr* dst_all, const uint32_t* __restrict__ tw29, int logn, int b) {      // src_all == dst_all: in place
+    // tile: mid = top b position bits (stride 2^(logn-b)), lo_t = NTT_TILE >> b neighbouring positions starting at lo0
+    const Fr* src = src_all + ((size_t)blockIdx.y << logn);
+    Fr* dst = dst_all + ((size_t)blockIdx.y << logn);
+    extern __shared__ uint32_t tile[];
+    const int mid_n = 1 << b, sh = logn - b, lo_t = NTT_TILE >> b, elems = mid_n * lo_t;
+    const int lo0 = blockIdx.x * lo_t;
+    for (int e = threadIdx.x; e < elems; e += blockDim.x) {
+        const int mid = e / lo_t, l = e - mid * lo_t;
+        const Fr x = ld_fr(src + (((size_t)mid << sh) + lo0 + l));
+        uint32_t t[9]; f29_from_fp_shl5(t, x.v);
+#pragma unroll
+        for (int k = 0; k < 9; k++) tile[9 * e + k] = t[k];
+    }
+    __syncthreads();
+    ntt_nr_stages(tile, [lo_t](int mid, int l) { return mid * lo_t + l; }, b, lo_t, 0, 0u, 0, tw29, logn, true);
+    for (int e = threadIdx.x; e < elems; e += blockDim.x) {
+        const int mid = e / lo_t, l = e - mid * lo_t;
+        uint32_t r[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) r[k] = tile[9 * e + k];
+        f29_reduce_small<FrParams>(r);
+        st_fr(dst + (((size_t)mid << sh) + lo0 + l), f29_to_fp<FrParams>(r));
+    }
+}
+// NR stages logn-9 .. logn-1 of the inverse, the scale, RN stages 1 .. 9 of the forward transform: NTT_TILE consecutive positions = two blocks of 512
+extern "C" __global__ void __launch_bounds__(256)
+zkc_ntt_mid(Fr* __restrict__ data_all, const uint32_t* __restrict__ tw_inv29, const uint32_t* __restrict__ tw_fwd29, const Fr* __restrict__ scale_br, int logn) {
+    Fr* __restrict__ data = data_all + ((size_t)blockIdx.y << logn);
+    extern __shared__ uint32_t tile[];
+    constexpr int B = 9, MID = 1 << B, NSUB = NTT_TILE / MID;
+    const size_t base = (size_t)blockIdx.x * NTT_TILE;
+    for (int e = threadIdx.x; e < NTT_TILE; e += blockDim.x) {
+        const Fr x = ld_fr(data + base + e);
+        uint32_t t[9]; f29_from_fp_shl5(t, x.v);
+#pragma unroll
+        for (int k = 0; k < 9; k++) tile[9 * e + k] = t[k];
+    }
+    __syncthreads();
+    // slot(mid, l) = l * 512 + mid : sub-block l of the tile, position mid inside it; its prefix = the logn-9 position bits above = blockIdx.x * NSUB + l
+    ntt_nr_stages(tile, [](int mid, int l) { return l * MID + mid; }, B, NSUB, logn - B, (uint32_t)blockIdx.x * NSUB, 1, tw_inv29, logn, false);
+    // x g^k / n at bit-reversed positions (scale_br[p] = scale[brev(p)]): a product, so the value is back below 2 p
+    for (int e = threadIdx.x; e < NTT_TILE; e += blockDim.x) {
+        uint32_t r[9], s29[9], o[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) r[k] = tile[9 * e + k];
+        const Fr sc = ld_fr(scale_br + base + e);
+        f29_from_fp_shl5(s29, sc.v); f29_mul<FrParams>(o, r, s29);
+#pragma unroll
+        for (int k = 0; k < 9; k++) tile[9 * e + k] = o[k];
+    }
+    __syncthreads();
+    // RN stages 1 .. 9 (what zkc_ntt_pass does in its first pass, minus the bit-reversed load): stage t pairs mid and mid + 2^(t-1)
+    for (int t = 1; t <= B; t++) {
+        const int half = 1 << (t - 1);
+        for (int x = threadIdx.x; x < NTT_TILE / 2; x += blockDim.x) {
+            const int l = x / (MID / 2), pr = x - l * (MID / 2);
+            const int j = pr & (half - 1), blk = pr >> (t - 1);
+            const int m0 = (blk << t) + j, m1 = m0 + half;
+            uint32_t w[9]; ntt_ld_w(w, tw_fwd29, (size_t)j << (logn - t));
+            ntt_bfly(tile + 9 * (l * MID + m0), tile + 9 * (l * MID + m1), w, t == 1, (t & 1) == 0 || t == B);      // stage 1: twiddle 1, operands below 18 p after the scaling product
+        }
+        __syncthreads();
+    }
+    for (int e = threadIdx.x; e < NTT_TILE; e += blockDim.x) {
+        uint32_t r[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) r[k] = tile[9 * e + k];
+        f29_reduce_small<FrParams>(r);
+        st_fr(data + base + e, f29_to_fp<FrParams>(r));
+    }
+}
+extern "C" __global__ void __launch_bounds__(256)
+zkc_bitrev_copy(const Fr* __restrict__ src, Fr* __restrict__ dst, int logn) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> logn) return;
+    st_fr(dst + i, ld_fr(src + (__brev(i) >> (32 - logn))));
+}
+int ntt_bitrev_table(zkc_ctx* ctx, const Fr* d_src, Fr** out, int logn) {
+    ZKC_HIP_CHECK(ctx, hipMalloc((void**)out, sizeof(Fr) << logn));
+    hipLaunchKernelGGL(zkc_bitrev_copy, dim3(((1u << logn) + 255) / 256), dim3(256), 0, ctx->stream, d_src, *out, logn);
+    ZKC_HIP_CHECK(ctx, hipGetLastError());
+    return ZKC_OK;
+}
+// the prover's transform pair on `nvec` contiguous vectors: data <- NTT(scale x iNTT(data)), in place (tmp is not needed); logn >= 12
+int ntt_pair_run(zkc_ctx* ctx, hipStream_t st, Fr* data, const uint32_t* tw_inv29, const uint32_t* tw_fwd29, const Fr* scale_br, int logn, int nvec) {
+    if (logn < 12 || logn > 18) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "ntt_pair_run: 12 <= logn <= 18");
+    const int bh = logn - 9;                                     // head: NR stages 0 .. logn-10, tail: RN stages 10 .. logn (bh stages each)
+    hipLaunchKernelGGL(zkc_ntt_nr_head, dim3((1 << logn) / NTT_TILE, nvec), dim3(256), (size_t)NTT_TILE * 36, st, (const Fr*)data, data, tw_inv29, logn, bh);
+    hipLaunchKernelGGL(zkc_ntt_mid, dim3((1 << logn) / NTT_TILE, nvec), dim3(256), (size_t)NTT_TILE * 36, st, data, tw_inv29, tw_fwd29, scale_br, logn);
+    const int lo_t = NTT_TILE >> bh;
+    hipLaunchKernelGGL(zkc_ntt_pass, dim3((1 << logn) / ((1 << bh) * lo_t), nvec), dim3(256), (size_t)NTT_TILE * 36, st, (const Fr*)data, data, tw_fwd29, (const Fr*)nullptr, logn, 9, bh, 0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, std::string("ntt_pair_run: ") + hipGetErrorString(e));
+    return ZKC_OK;
+}
+
 // twiddle table (n/2 Montgomery-form Fr, device) -> the 12-word limb form the pass kernel reads
 int ntt_make_tw29(zkc_ctx* ctx, const Fr* d_tw, uint32_t count, uint32_t** out) {
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)out, (size_t)count * TW29_WORDS * 4));

@@ -68,7 +68,7 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     ZKC_LOCK(zk->ctx);
     (void)hipSetDevice(zk->ctx->device);
     (void)hipStreamSynchronize(zk->ctx->stream);
-    void* ptrs[] = {zk->d_perm, zk->d_rowlen, zk->d_jdptr, zk->d_col, zk->d_val, zk->d_tw_fwd, zk->d_tw_inv, zk->d_tw_fwd29, zk->d_tw_inv29, zk->d_coset, zk->d_g1, zk->d_g2, zk->d_g2_29, zk->d_flags,
+    void* ptrs[] = {zk->d_perm, zk->d_rowlen, zk->d_jdptr, zk->d_col, zk->d_val, zk->d_tw_fwd, zk->d_tw_inv, zk->d_tw_fwd29, zk->d_tw_inv29, zk->d_coset, zk->d_coset_br, zk->d_g1, zk->d_g2, zk->d_g2_29, zk->d_flags,
                     zk->d_tblDelta1, zk->d_tblAlpha1, zk->d_tblBeta1, zk->d_tblDelta2, zk->d_rs, zk->d_proofs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : zk->fold.vmaps) if (kv.second.d) (void)hipFree(kv.second.d);
@@ -188,6 +188,7 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
         ZKC_UP(zk->d_tw_inv, b.data(), b.size() * sizeof(Fr));
         ZKC_UP(zk->d_coset, cs.data(), cs.size() * sizeof(Fr));
         if ((rc = ntt_make_tw29(ctx, zk->d_tw_fwd, n / 2, &zk->d_tw_fwd29)) || (rc = ntt_make_tw29(ctx, zk->d_tw_inv, n / 2, &zk->d_tw_inv29))) return bail(rc);
+        if ((rc = ntt_bitrev_table(ctx, zk->d_coset, &zk->d_coset_br, (int)zk->logn))) return bail(rc);
     }
     // ---- bases: one G1 array [A | B1 | C | H] and one G2 array [B2]; window 0 = the zkey points as stored (affine,
     //      Montgomery), windows 1..19 pre-shifted on the device ----
@@ -326,8 +327,14 @@ static int h_evals_dev(zkc_zkey* zk, zkc_lane& L, const uint32_t* d_wtns0, int n
         ZKC_HIP_CHECK(ctx, hipGetLastError());
     }
     zkc_prof_scope _pn(ctx, ZKC_PROF_NTT, (uint64_t)nb * (6ull * 2 * n * 32 + 4ull * n * 32), st);   // 6 transforms r+w, joinABC
-    int rc = ntt_run(ctx, st, L.d_abc, L.d_t, zk->d_tw_inv29, zk->d_coset, (int)zk->logn, 3 * nb); if (rc) return rc;
-    rc = ntt_run(ctx, st, L.d_t, L.d_abc, zk->d_tw_fwd29, nullptr, (int)zk->logn, 3 * nb); if (rc) return rc;
+    int rc;
+    static const bool ntt_two_transforms = getenv("ZKC_NTT_SEPARATE") != nullptr;      // diagnostics: the round-1 path (two full transforms, four HBM round trips)
+    if (!ntt_two_transforms && zk->logn >= 12 && zk->logn <= 18) {
+        if ((rc = ntt_pair_run(ctx, st, L.d_abc, zk->d_tw_inv29, zk->d_tw_fwd29, zk->d_coset_br, (int)zk->logn, 3 * nb))) return rc;
+    } else {
+        if ((rc = ntt_run(ctx, st, L.d_abc, L.d_t, zk->d_tw_inv29, zk->d_coset, (int)zk->logn, 3 * nb))) return rc;
+        if ((rc = ntt_run(ctx, st, L.d_t, L.d_abc, zk->d_tw_fwd29, nullptr, (int)zk->logn, 3 * nb))) return rc;
+    }
     hipLaunchKernelGGL(zkc_join_abc, dim3((n + 255) / 256, nb), dim3(256), 0, st, L.d_abc, L.d_p, (int)n);
     ZKC_HIP_CHECK(ctx, hipGetLastError());
     return ZKC_OK;

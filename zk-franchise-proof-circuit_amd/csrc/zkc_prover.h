@@ -149,6 +149,7 @@ struct zkc_zkey {
     // device: section 4 in jagged-diagonal order (rows [0,n) = A, [n,2n) = B, sorted by length), values as stored (val * R^2)
     uint32_t *d_perm = nullptr, *d_rowlen = nullptr, *d_jdptr = nullptr, *d_col = nullptr; zkc::Fr* d_val = nullptr; uint32_t nlong = 0;
     zkc::Fr *d_tw_fwd = nullptr, *d_tw_inv = nullptr, *d_coset = nullptr;   // w^j, w^-j (j < n/2), g^i / n
+    zkc::Fr *d_coset_br = nullptr;                                          // g^i / n at bit-reversed positions (ntt_pair_run)
     uint32_t *d_tw_fwd29 = nullptr, *d_tw_inv29 = nullptr;                  // the twiddles in radix 2^29 (what the NTT passes read)
     // pre-shifted base tables, one allocation per group: G1 = [A | B1 | C | H], G2 = [B2]; T[w][i] = 2^(c*w) * P_i
     zkc::G1Affine* d_g1 = nullptr; zkc::G2Affine* d_g2 = nullptr;
@@ -178,7 +179,10 @@ struct zkc_zkey {
 
 namespace zkc {
 int ntt_run(zkc_ctx* ctx, hipStream_t st, const Fr* src, Fr* dst, const uint32_t* tw29, const Fr* scale, int logn, int nvec);
-int ntt_make_tw29(zkc_ctx* ctx, const Fr* d_tw, uint32_t count, uint32_t** out);      // twiddles in the 12-word radix-2^29 form ntt_run reads
+int ntt_make_tw29(zkc_ctx* ctx, const Fr* d_tw, uint32_t count, uint32_t** out);
+// [r2] the prover's pair iNTT -> x scale -> NTT in three HBM round trips without bit reversal (zkc_ntt.hip); scale_br = scale table in bit-reversed order
+int ntt_pair_run(zkc_ctx* ctx, hipStream_t st, Fr* data, const uint32_t* tw_inv29, const uint32_t* tw_fwd29, const Fr* scale_br, int logn, int nvec);
+int ntt_bitrev_table(zkc_ctx* ctx, const Fr* d_src, Fr** out, int logn);      // twiddles in the 12-word radix-2^29 form ntt_run reads
 int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, size_t max_buckets, int max_jobs, bool g2);
 void msm_work_free(MsmWork& w);
 // runs all jobs of `jl` through one pipeline pass; results (XYZZ per job) go to device slot `slot` (0/1) of w.results and, when
