@@ -67,3 +67,22 @@ def test_other_depths_vs_oracle(ctx):
         for v, w in zip(voters, ws):
             rc, wo = ol.witness(v, nLevels=nl)
             assert rc == 0 and w == wo
+
+
+def test_lane_and_wave_kernels_agree(ctx):
+    """Two witness kernels share the C ABI entry: a wave per Merkle path for launches of up to 128 voters (latency), a lane per path above
+    that (throughput).  Same voters through both -- including the reference-wasm vectors and the rejected inputs -- must give the same bytes
+    and the same statuses."""
+    vecs = [v['inputs'] for v in VEC['vectors']] + [v['inputs'] for v in VEC['negative']]
+    many = (vecs * 7)[:150]                                   # 150 > 128: lane-per-path kernel
+    ws_lane, st_lane = ctx.witness(many)
+    ws_wave, st_wave = [], []
+    for i in range(0, len(many), 50):                         # 50 <= 128: wave-per-path kernel
+        w, s = ctx.witness(many[i:i + 50]); ws_wave += w; st_wave += s
+    assert st_lane == st_wave
+    nv = len(VEC['vectors'])
+    for i, (a, b) in enumerate(zip(ws_lane, ws_wave)):
+        if st_lane[i] == 0:
+            assert a == b, i
+            assert hashlib.sha256(a).hexdigest() == VEC['vectors'][i % len(vecs)]['sha256']
+    assert sum(1 for s in st_lane if s) == len([i for i in range(150) if (i % len(vecs)) >= nv])

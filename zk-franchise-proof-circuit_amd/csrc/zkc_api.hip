@@ -8,6 +8,9 @@
 using namespace zkc;
 
 extern "C" __global__ void zkc_witness_chains(WitnessLayout L, PoseidonTable tab, const uint32_t* inputs, uint32_t* wtns, int32_t* status, int B, int tmpl_mode);
+extern "C" __global__ void zkc_witness_chains_wave(WitnessLayout L, PoseidonTable tab, const uint32_t* inputs, uint32_t* wtns, int32_t* status, int B, int tmpl_mode);
+// a wave per chain halves the latency of a chain and costs 64 times its issue slots: worth it while the chains alone cannot fill the part
+static constexpr int ZKC_WITNESS_WAVE_MAX_B = 128;
 extern "C" __global__ void zkc_witness_fill(const uint4* tmpl, uint4* wtns, int nWires, int B);
 extern "C" __global__ void zkc_witness_tostd(uint32_t* wtns, size_t nwires_total);
 
@@ -181,7 +184,7 @@ static int get_template(zkc_ctx* ctx, const WitnessLayout& L, uint32_t** out) {
     ZKC_HIP_CHECK(ctx, hipMalloc(&d_st, 3 * sizeof(int32_t)));
     ZKC_HIP_CHECK(ctx, hipMemsetAsync(d_t, 0, (size_t)L.nWires * 32, ctx->stream));
     ZKC_HIP_CHECK(ctx, hipMemsetAsync(d_in, 0, (size_t)L.nInputs * 32, ctx->stream));
-    hipLaunchKernelGGL(zkc_witness_chains, dim3(1), dim3(64), 0, ctx->stream, L, ctx->ptab, d_in, d_t, d_st, 1, 1);
+    hipLaunchKernelGGL(zkc_witness_chains_wave, dim3(3), dim3(64), 0, ctx->stream, L, ctx->ptab, d_in, d_t, d_st, 1, 1);
     hipLaunchKernelGGL(zkc_witness_tostd, dim3((L.nWires + 255) / 256), dim3(256), 0, ctx->stream, d_t, (size_t)L.nWires);
     ZKC_HIP_CHECK(ctx, hipGetLastError());
     ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -202,9 +205,10 @@ static int witness_dev3(zkc_ctx* ctx, const WitnessLayout& L, const void* d_inpu
     zkc_prof_scope _ps(ctx, ZKC_PROF_WITNESS, (uint64_t)B * ((uint64_t)L.nWires + L.nInputs) * 32);
     hipLaunchKernelGGL(zkc_witness_fill, dim3(fill_blocks), dim3(256), 0, ctx->stream, (const uint4*)tmpl, (uint4*)d_wtns, L.nWires, B);
     ZKC_HIP_CHECK(ctx, hipGetLastError());
-    // lanes of a wave share the chain kind; ceil so that kinds start on wave boundaries only when B % 64 == 0 (harmless otherwise)
-    hipLaunchKernelGGL(zkc_witness_chains, dim3((3 * B + 63) / 64), dim3(64), 0, ctx->stream, L, ctx->ptab, (const uint32_t*)d_inputs,
-                       (uint32_t*)d_wtns, d_status3, B, 0);
+    if (B <= ZKC_WITNESS_WAVE_MAX_B)             // one wave per (voter, chain): latency form
+        hipLaunchKernelGGL(zkc_witness_chains_wave, dim3(3 * B), dim3(64), 0, ctx->stream, L, ctx->ptab, (const uint32_t*)d_inputs, (uint32_t*)d_wtns, d_status3, B, 0);
+    else                                         // one lane per (voter, chain), lanes of a wave share the chain kind when B % 64 == 0 (harmless otherwise): throughput form
+        hipLaunchKernelGGL(zkc_witness_chains, dim3((3 * B + 63) / 64), dim3(64), 0, ctx->stream, L, ctx->ptab, (const uint32_t*)d_inputs, (uint32_t*)d_wtns, d_status3, B, 0);
     {   // the chains leave their wires in Montgomery form, marked: convert them (every lane busy, unlike the chains)
         const size_t nw = (size_t)L.nWires * (size_t)B;
         hipLaunchKernelGGL(zkc_witness_tostd, dim3((unsigned)std::min<size_t>((nw + 255) / 256, 256 * 64)), dim3(256), 0, ctx->stream, (uint32_t*)d_wtns, nw);

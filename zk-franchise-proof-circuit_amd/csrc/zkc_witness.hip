@@ -11,6 +11,8 @@
 //   zkc_witness_chains   one lane per (voter, chain) with chain in {census tree, sik tree, misc}: walks the
 //                        Merkle path leaf->root (Poseidon is sequential along a path), and stores every surviving
 //                        signal of the non-empty levels straight into its wire slot (Montgomery form, marked).
+//   zkc_witness_chains_wave  [r2] the same with one WAVE per chain (S-boxes and mix rows of a round dealt over the lanes): half the
+//                        latency for 64 times the issue slots -- used for small batches and for the first pass of a large one
 //   zkc_witness_tostd    wide: converts the marked wires to standard form
 // HBM layout: inputs  [B][nInputs][8 x u32]  standard form, census.circom declaration order
 //             witness [B][nWires ][8 x u32]  standard form (what .wtns section 2 holds and what MSM digits read)
@@ -22,22 +24,27 @@ namespace zkc {
 
 struct Emit {                       // writes Montgomery values as standard-form wires
     uint32_t* base;                 // witness of this voter
+    bool lead = true;               // [r2] a chain is walked by a whole wave: the chain-level stores below are made by its first lane only
     // The conversion out of Montgomery form is a product that nothing downstream in the chain waits for: the chain kernel is one long
     // dependency chain per lane, so it stores the Montgomery limbs with bit 255 set (values are below r < 2^254) and zkc_witness_tostd
     // converts all marked wires afterwards, fully parallel.  (239 of the ~840 products of a Poseidon(2) level were these conversions.)
-    __device__ __forceinline__ void put(int wire, const Fr& v) const {
+    __device__ __forceinline__ void put(int wire, const Fr& v) const { if (lead) put_any(wire, v); }
+    __device__ __forceinline__ void put_any(int wire, const Fr& v) const {      // from whichever lane holds the value (wave-wide Poseidon)
         uint4* d = reinterpret_cast<uint4*>(base + 8 * (size_t)wire);
         d[0] = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]); d[1] = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7] | 0x80000000u);
     }
     __device__ __forceinline__ void put_std(int wire, const uint32_t s[8]) const {
+        if (!lead) return;
         uint4* d = reinterpret_cast<uint4*>(base + 8 * (size_t)wire);
         d[0] = make_uint4(s[0], s[1], s[2], s[3]); d[1] = make_uint4(s[4], s[5], s[6], s[7]);
     }
     __device__ __forceinline__ void put_small(int wire, uint32_t x) const {
+        if (!lead) return;
         uint4* d = reinterpret_cast<uint4*>(base + 8 * (size_t)wire);
         d[0] = make_uint4(x, 0, 0, 0); d[1] = make_uint4(0, 0, 0, 0);
     }
     __device__ __forceinline__ void put_raw(int wire, const Fr& mont) const {      // scratch use of a wire slot
+        if (!lead) return;
         uint4* d = reinterpret_cast<uint4*>(base + 8 * (size_t)wire);
         d[0] = make_uint4(mont.v[0], mont.v[1], mont.v[2], mont.v[3]); d[1] = make_uint4(mont.v[4], mont.v[5], mont.v[6], mont.v[7]);
     }
@@ -180,6 +187,112 @@ __device__ Fr poseidon_trace29(const Fr* in, unsigned cmask, const PoseidonTable
     return f29_to_fp<FrParams>(out.l);
 }
 
+// ---- [r2] the same permutation (survivor layout 0, t = 3 or 4) walked by a whole WAVE: every lane calls it with the same arguments ----
+// The state is kept replicated in all lanes; what is expensive is dealt out and gathered back with v_readlane:
+//   full round    lane j < T : S-box of word j, its trace stores, + round constant; gather; lane i < T : row i of the mix; gather
+//   partial round every lane : the one S-box (3 products in a row -- lanes of a wave share their instruction stream, so this chain cannot be
+//                 split); then lane L < 2T-1 ONE product: L < T a term of the new word 0, L >= T the update of word L-T+1; gather
+// The three trace values of partial round r are parked in lane r and stored once, 57 lanes side by side, after the last partial round.
+// A partial round is about 1100 instructions instead of 1900 (S-box 650, one product 250, selects and 45 v_readlane), a full round 1450
+// instead of 4100.  Values are congruent to, not identical with, the single-lane routine's (separate reductions); the wires are canonical.
+__device__ __forceinline__ W29 bcast29(const W29& v, int src) {
+    W29 r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.l[k] = (uint32_t)__builtin_amdgcn_readlane((int)v.l[k], src);
+    return r;
+}
+__device__ __forceinline__ void emit29_any(const Emit& e, int wire, const W29& v) {
+    uint32_t t[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) t[k] = v.l[k];
+    f29_reduce_small<FrParams>(t);
+    e.put_any(wire, f29_to_fp<FrParams>(t));
+}
+template <int T>
+__device__ Fr poseidon_wave29(const Fr* in, unsigned cmask, const PoseidonTable& tab, const Emit& e, int blk) {
+    static_assert(T == 3 || T == 4, "survivor layout 0 only");
+    constexpr int RP = (T == 3) ? 57 : 56;
+    const int lane = threadIdx.x & 63;
+    const Fr* __restrict__ C = tab.C[T]; const Fr* __restrict__ S = tab.S[T];
+    const Fr* __restrict__ M = tab.M[T]; const Fr* __restrict__ Pm = tab.P[T];
+    const bool on = e.base != nullptr;
+    int nc1 = 0;
+#pragma unroll
+    for (int j = 0; j < T; j++) nc1 += !((cmask >> j) & 1);
+    const int nA = nc1 + 6 * T, oLast = nA, oMS = nA + T - 1, oF = oMS + RP, oP = oF + 2 * (nc1 + 7 * T);
+    auto rank_of = [&](int j) { return (int)__popc(~cmask & ((1u << j) - 1u)); };
+    auto ark_idx = [&](int r, int j) -> int { return r == 1 ? (((cmask >> j) & 1) ? -1 : rank_of(j)) : nc1 + (r - 2) * T + j; };
+    auto sF_idx = [&](int r, int j) -> int { return oF + 2 * (r == 0 ? (((cmask >> j) & 1) ? -1000 : rank_of(j)) : nc1 + (r - 1) * T + j); };
+    const int jl = lane < T ? lane : T - 1;                 // the word this lane serves in a full round (lanes >= T shadow the last one; never stored)
+    const bool serve = lane < T;
+    auto sel = [&](const W29* st, int idx) { W29 r = st[0];
+#pragma unroll
+        for (int j = 1; j < T; j++) if (idx == j) r = st[j];
+        return r; };
+    W29 st[T];
+#pragma unroll
+    for (int k = 0; k < 9; k++) st[0].l[k] = 0;
+#pragma unroll
+    for (int j = 1; j < T; j++) f29_from_fp_shl5(st[j].l, in[j - 1].v);
+#pragma unroll
+    for (int j = 0; j < T; j++) st[j] = add29(st[j], ld_c29(tab, C + j));
+    auto full_round = [&](int r_sf, int r_ark, const Fr* cst, const Fr* MM) {       // S-boxes dealt over the lanes, mix rows dealt over the lanes
+        W29 i2, i4; const W29 o = sbox29(sel(st, jl), i2, i4);
+        const int fi = sF_idx(r_sf, jl);
+        if (on && serve && fi >= 0) { emit29_any(e, blk + fi, i2); emit29_any(e, blk + fi + 1, i4); }
+        const W29 nsl = add29(o, ld_c29(tab, cst + jl));
+        const int ai = ark_idx(r_ark, jl);
+        if (on && serve && ai >= 0) emit29_any(e, blk + ai, nsl);
+        W29 ns[T];
+#pragma unroll
+        for (int j = 0; j < T; j++) ns[j] = bcast29(nsl, j);
+        const W29 row = dot29<T>(ns, [&](int j) { return ld_c29(tab, MM + j * T + jl); });
+#pragma unroll
+        for (int i = 0; i < T; i++) st[i] = bcast29(row, i);
+    };
+    for (int r = 0; r < 4; r++) full_round(r, r + 1, C + (r + 1) * T, r < 3 ? M : Pm);
+    W29 E1, E2, E3;
+#pragma unroll
+    for (int k = 0; k < 9; k++) E1.l[k] = E2.l[k] = E3.l[k] = 0;
+    const int role = lane < 2 * T - 1 ? lane : 0;          // which product of the sparse mix this lane computes
+    for (int r = 0; r < RP; r++) {
+        const Fr* __restrict__ Sr = S + (2 * T - 1) * r;
+        const W29 c = ld_c29(tab, Sr + role);               // Sr[0..T-1]: the row for word 0; Sr[T+i-1]: the column entry for word i
+        W29 i2, i4; const W29 o = sbox29(st[0], i2, i4);
+        const W29 s0 = add29(o, ld_c29(tab, C + 5 * T + r));
+        if (lane == r) { E1 = i2; E2 = i4; }
+        W29 X = s0, H;
+#pragma unroll
+        for (int k = 0; k < 9; k++) H.l[k] = 0;
+#pragma unroll
+        for (int j = 1; j < T; j++) { if (role == j) X = st[j]; if (role == T + j - 1) H = st[j]; }
+        W29 Pd; f29_mul_addhi<FrParams>(Pd.l, X.l, c.l, H.l);
+        W29 n0 = bcast29(Pd, 0);
+#pragma unroll
+        for (int j = 1; j < T; j++) { const W29 t = bcast29(Pd, j);
+#pragma unroll
+            for (int k = 0; k < 9; k++) n0.l[k] += t.l[k]; }
+        f29_carry(n0.l);
+#pragma unroll
+        for (int i = 1; i < T; i++) st[i] = bcast29(Pd, T + i - 1);
+        st[0] = n0;
+        if (lane == r) E3 = n0;
+    }
+    if (on && lane < RP) { emit29_any(e, blk + oP + 2 * lane, E1); emit29_any(e, blk + oP + 2 * lane + 1, E2); emit29_any(e, blk + oMS + lane, E3); }
+    for (int r = 0; r < 3; r++) full_round(4 + r, 5 + r, C + 5 * T + RP + r * T, M);
+    W29 i2, i4; const W29 osl = sbox29(sel(st, jl), i2, i4);                       // sigmaF[7] and mixLast
+    {
+        const int fi = sF_idx(7, jl);
+        if (on && serve) { emit29_any(e, blk + fi, i2); emit29_any(e, blk + fi + 1, i4); if (jl < T - 1) emit29_any(e, blk + oLast + jl, osl); }
+    }
+    W29 os[T];
+#pragma unroll
+    for (int j = 0; j < T; j++) os[j] = bcast29(osl, j);
+    W29 out = dot29<T>(os, [&](int j) { return ld_c29(tab, M + j * T); });
+    f29_reduce_small<FrParams>(out.l);
+    return f29_to_fp<FrParams>(out.l);
+}
+
 __device__ __forceinline__ Fr load_std(const uint32_t* p) {
     const uint4* d = reinterpret_cast<const uint4*>(p); uint4 a = d[0], b = d[1];
     uint32_t s[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -229,6 +342,7 @@ __device__ void emit_alias_check(const Emit& e, int wire, const uint32_t ks[8]) 
 
 // SMTVerifier(n) with enabled=1, fnc=0, old*=0 (census.circom:79-103): all non-template wires of one verifier block.
 // Returns the recomputed root; *bad_last = siblings[n-1] != 0.
+template <bool WAVE>
 __device__ Fr smt_verifier_chain(const WitnessLayout& L, const PoseidonTable& tab, const Emit& e, int blk,
                                  const uint32_t key_s[8], const Fr& key, const Fr& value, const uint32_t* sib /* n x 8, std */,
                                  bool* bad_last, bool tmpl_mode) {
@@ -241,7 +355,7 @@ __device__ Fr smt_verifier_chain(const WitnessLayout& L, const PoseidonTable& ta
     e.put_small(blk + 0, key0 ? 1u : 0u);                               // areKeyEquals.out
     e.put_small(blk + 2, 0u);                                           // checkRoot.isz.inv
     Fr hin[3] = {key, value, Fr::one()};
-    Fr h1new = poseidon_trace29<4, 0>(hin, 1u | 8u, tab, e, blk + 4);
+    Fr h1new = WAVE ? poseidon_wave29<4>(hin, 1u | 8u, tab, e, blk + 4) : poseidon_trace29<4, 0>(hin, 1u | 8u, tab, e, blk + 4);
     e.put(blk + 3, h1new);
     // levels d-1 .. 0 hold real hashes; levels >= d keep the template's Poseidon(0,0) trace
     Fr child = h1new;
@@ -256,7 +370,7 @@ __device__ Fr smt_verifier_chain(const WitnessLayout& L, const PoseidonTable& ta
         Fr s = load_std(sib + 8 * i);
         Fr in2[2];
         if (bit) { in2[0] = s; in2[1] = child; } else { in2[0] = child; in2[1] = s; }   // Switcher
-        Fr h = poseidon_trace29<3, 0>(in2, 1u, tab, e, lb + o + 3);
+        Fr h = WAVE ? poseidon_wave29<3>(in2, 1u, tab, e, lb + o + 3) : poseidon_trace29<3, 0>(in2, 1u, tab, e, lb + o + 3);
         e.put(lb + o, h);                                               // aux[0] = h * st_top (st_top = 1)
         e.put(lb + o + 1, h);                                           // proofHash.out
         e.put(lb + o + 2, in2[0]);                                      // proofHash.L
@@ -271,7 +385,7 @@ __device__ Fr smt_verifier_chain(const WitnessLayout& L, const PoseidonTable& ta
         if (tmpl_mode) {                                                // template: the Poseidon(0,0) trace of an empty level
             Fr z2[2] = {Fr::zero(), Fr::zero()};
             e.put_small(lb + o, 0u); e.put_small(lb + o + 1, 0u);       // child, aux[0]
-            Fr h = poseidon_trace29<3, 0>(z2, 1u, tab, e, lb + o + 4);
+            Fr h = WAVE ? poseidon_wave29<3>(z2, 1u, tab, e, lb + o + 4) : poseidon_trace29<3, 0>(z2, 1u, tab, e, lb + o + 4);
             e.put(lb + o + 2, h); e.put_small(lb + o + 3, 0u);          // proofHash.out, proofHash.L
         }
     }
@@ -302,6 +416,7 @@ __device__ Fr smt_verifier_chain(const WitnessLayout& L, const PoseidonTable& ta
         else { e.put_raw(inv_slot(i), acc); acc = acc * load_std(sib + 8 * i); }
     }
     Fr ai = fp_inv<FrParams>(acc);
+    if (WAVE) __threadfence();                                          // the prefix products parked by the first lane are read back by every lane
     for (int i = n - 2; i >= 0; i--) {
         if (raw_is_zero(sib + 8 * i)) continue;
         Fr pre = e.get_raw(inv_slot(i));
@@ -312,6 +427,8 @@ __device__ Fr smt_verifier_chain(const WitnessLayout& L, const PoseidonTable& ta
     return child;
 }
 
+// one LANE per (voter, chain): 64 chains per wave -- the throughput form (a wave per chain issues 64 times the wave-instructions for the same
+// hashes, 5 % of a pass' VALU work at batch 1024); zkc_witness_chains_wave below is the latency form (3.6 ms instead of 6.5 for one voter)
 extern "C" __global__ void __launch_bounds__(64)
 zkc_witness_chains(WitnessLayout L, PoseidonTable tab, const uint32_t* __restrict__ inputs, uint32_t* __restrict__ wtns,
                    int32_t* __restrict__ status, int B, int tmpl_mode) {
@@ -360,11 +477,71 @@ zkc_witness_chains(WitnessLayout L, PoseidonTable tab, const uint32_t* __restric
             sib = ss; root = sikRoot; blk = L.off_sikver;
         }
         bool bad_last;
-        Fr r = smt_verifier_chain(L, tab, e, blk, key_s, key, value, sib, &bad_last, tmpl_mode != 0);
+        Fr r = smt_verifier_chain<false>(L, tab, e, blk, key_s, key, value, sib, &bad_last, tmpl_mode != 0);
         if (bad_last) st = ZKC_W_ERR_LAST_SIBLING;
         else if (r != load_std(root)) st = kind == 0 ? ZKC_W_ERR_CENSUS_ROOT : ZKC_W_ERR_SIK_ROOT;
     }
     status[(size_t)b * 3 + kind] = st;
+}
+
+// [r2] one WAVE per (voter, chain): grid = 3 B workgroups of 64 lanes, workgroup g walks chain g / B of voter g % B.  The two tree chains spread
+// every Poseidon over the lanes (poseidon_wave29); everything else of a chain is small next to its 18 hashes and is done by all lanes in
+// lockstep with only the first lane storing.  The misc chain (two hashes: nullifier t = 5, sik t = 4) keeps the single-lane routine.
+extern "C" __global__ void __launch_bounds__(64)
+zkc_witness_chains_wave(WitnessLayout L, PoseidonTable tab, const uint32_t* __restrict__ inputs, uint32_t* __restrict__ wtns,
+                   int32_t* __restrict__ status, int B, int tmpl_mode) {
+    const int gid = blockIdx.x;
+    if (gid >= 3 * B) return;
+    const int kind = gid / B, b = gid - kind * B, lane = threadIdx.x;
+    const uint32_t* in = inputs + (size_t)b * L.nInputs * 8;
+    Emit e{wtns + (size_t)b * L.nWires * 8, lane == 0};
+    const int n = L.n;
+    // input slots (census.circom:51-67 declaration order)
+    const uint32_t *eid = in, *nullifier = in + 16, *avail = in + 24, *vh = in + 32, *sikRoot = in + 48, *censusRoot = in + 56,
+                   *address = in + 64, *password = in + 72, *signature = in + 80, *voteW = in + 88, *cs = in + 96, *ss = in + 96 + 8 * n;
+    int32_t st = ZKC_W_OK;
+    uint32_t key_s[8]; load_raw(key_s, address);
+    if (kind == 2) {
+        if (lane != 0) return;
+        // ---- misc chain: header copy, range check, checkWeight, computedNullifier, sik ----
+        bool in_range = true;
+        for (int i = 0; i < L.nInputs; i++) { uint32_t s[8]; load_raw(s, in + 8 * i); in_range &= fp_std_lt_p<FrParams>(s); }
+        if (!in_range) st = ZKC_W_ERR_INPUT_RANGE;
+        e.put_small(0, 1u);
+        const uint32_t* hdr[12] = {eid, eid + 8, nullifier, vh, vh + 8, sikRoot, censusRoot, voteW, avail, address, password, signature};
+        for (int i = 0; i < 12; i++) { uint32_t s[8]; load_raw(s, hdr[i]); e.put_std(1 + i, s); }
+        for (int i = 0; i < L.nL; i++) { uint32_t s[8]; load_raw(s, cs + 8 * i); e.put_std(13 + i, s); }
+        for (int i = 0; i < L.nL; i++) { uint32_t s[8]; load_raw(s, ss + 8 * i); e.put_std(13 + L.nL + i, s); }
+        e.put_small(L.off_checknull, 0u);
+        // LessEqThan(252): bits 0..250 of voteWeight + 2^252 - (availableWeight + 1); bit 252 must be clear
+        uint32_t p252[8] = {0, 0, 0, 0, 0, 0, 0, 1u << 28};
+        Fr x = load_std(voteW) + fp_from_std<FrParams>(p252) - load_std(avail) - Fr::one();
+        uint32_t xs[8]; fp_to_std<FrParams>(xs, x);
+        if ((bit_of(xs, 252) | bit_of(xs, 253)) && st == ZKC_W_OK) st = ZKC_W_ERR_WEIGHT;
+        for (int i = 0; i <= 250; i++) e.put_small(L.off_checkweight + i, (uint32_t)bit_of(xs, i));
+        Fr sig = load_std(signature), pw = load_std(password);
+        Fr nin[4] = {sig, pw, load_std(eid), load_std(eid + 8)};
+        Fr nul = poseidon_trace29<5, 1>(nin, 1u, tab, e, L.off_nullifier);
+        if (nul != load_std(nullifier) && st == ZKC_W_OK) st = ZKC_W_ERR_NULLIFIER;
+        Fr sin[3] = {load_std(address), pw, sig};
+        Fr sik = poseidon_trace29<4, 0>(sin, 1u, tab, e, L.off_sik + 1);
+        e.put(L.off_sik, sik);
+        status[(size_t)b * 3 + kind] = st;
+        return;
+    }
+    Fr key = load_std(address), value; const uint32_t *sib, *root; int blk;
+    if (kind == 0) { value = load_std(avail); sib = cs; root = censusRoot; blk = L.off_census; }
+    else {
+        Fr sin[3] = {key, load_std(password), load_std(signature)};
+        Emit none{nullptr, false};
+        value = poseidon_wave29<4>(sin, 1u, tab, none, 0);
+        sib = ss; root = sikRoot; blk = L.off_sikver;
+    }
+    bool bad_last;
+    Fr r = smt_verifier_chain<true>(L, tab, e, blk, key_s, key, value, sib, &bad_last, tmpl_mode != 0);
+    if (bad_last) st = ZKC_W_ERR_LAST_SIBLING;
+    else if (r != load_std(root)) st = kind == 0 ? ZKC_W_ERR_CENSUS_ROOT : ZKC_W_ERR_SIK_ROOT;
+    if (lane == 0) status[(size_t)b * 3 + kind] = st;
 }
 
 // Batched Poseidon (t = nin+1 in {3,4,5}), one lane per hash; standard-form in/out.  Used by the census builder (f1).
