@@ -243,7 +243,8 @@ def main():
     verified = None
     vk = json.load(open(vkey_path))
     inflight = int(os.environ.get('ZKC_INFLIGHT', '96'))
-    sample = sorted({i for i in (0, 1, inflight - 1, inflight, 2 * inflight - 1, 2 * inflight, B // 2, B - inflight, B - 2, B - 1) if 0 <= i < B})
+    npass = -(-B // inflight); per = -(-B // npass)                       # the library cuts a batch into equal passes of at most `inflight` proofs
+    sample = sorted({i for i in (0, 1, per - 1, per, 2 * per - 1, 2 * per, B // 2, (npass - 1) * per - 1, (npass - 1) * per, B - 2, B - 1) if 0 <= i < B})
     if not args.no_verify:
         ok_batch = groth16.verify_batch(ctx, vk, out['pubs'], out['proofs'])                  # all B proofs of the step, product batch verifier
         ok_gather = bool((out['records'][lo:hi].cpu() == out['rec']).all())                  # gathered records carry this rank's proofs

@@ -286,7 +286,7 @@ def test_optional_pipeline_modes_give_identical_proofs(env):
 
 def test_fullprove_batch_nl160_three_passes_config3(env):
     """BASELINE configs[2] regime at a size the oracle can follow: zkc_fullprove_batch_dev at nLevels = 160 over B = 200 voters of the
-    8 192-voter synthetic census (three pipeline passes of 96: 65 536-bucket H jobs, the pass boundaries 95/96 and 191/192 inside the
+    8 192-voter synthetic census (three pipeline passes of 67, 67 and 66 voters: 65 536-bucket H jobs, pass boundaries inside the
     batch).  Every proof goes through the product's batch verifier, the pass-boundary proofs through the oracle's pairing verifier,
     and two of them (first of pass 2, last of the batch) are re-proved by the CPU oracle from the device witness: identical bytes."""
     ctx, get, torch = env
@@ -304,10 +304,10 @@ def test_fullprove_batch_nl160_three_passes_config3(env):
     proofs, pubs = pk.fullprove_batch_dev(d_in.data_ptr(), B, d_w.data_ptr(), d_st.data_ptr(), rs)
     assert d_st.cpu().tolist() == [0] * B
     assert groth16.verify_batch(ctx, vk, pubs, proofs)
-    for i in (0, 95, 96, 191, 192, B - 1):
+    for i in (0, 66, 67, 95, 96, 133, 134, B - 1):
         assert ol.verify(vk, pubs[256 * i:256 * i + 256], proofs[256 * i:256 * i + 256]), i
     wt = d_w.view(B, nW * 32)
-    for i in (96, B - 1):
+    for i in (67, B - 1):
         w = wt[i].cpu().numpy().tobytes()
         rc, ow = ol.witness(voters[i], nLevels=nl)
         assert rc == 0 and ow == w

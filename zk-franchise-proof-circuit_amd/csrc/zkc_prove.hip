@@ -413,6 +413,7 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
         }
     }
     const int npasses = (B + zk->max_inflight - 1) / zk->max_inflight;
+    const int per_pass = (B + npasses - 1) / npasses;       // passes of equal size (1024 -> 10 x 94 + 84, not 10 x 96 + 64): the last pass' fixed-latency tail is not spent on a stub
     while ((int)zk->ev_chunk.size() < npasses) { hipEvent_t e; ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); zk->ev_chunk.push_back(e); }
     int32_t* d_status3 = nullptr;
     if (d_inputs) {
@@ -421,7 +422,7 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
     }
     static const int wgroup = [] { const char* e = getenv("ZKC_WITNESS_GROUP"); return e ? std::max(1, atoi(e)) : 8; }();      // same box: 2 -> 2452, 4 -> 2472, 8 -> 2482 proofs/s at batch 1024
     for (int c = 0; c < npasses; c++) {
-        const int p0 = c * zk->max_inflight, nb = std::min(zk->max_inflight, B - p0);
+        const int p0 = c * per_pass, nb = std::min(per_pass, B - p0);
         uint32_t* wc = (uint32_t*)d_wtns + (size_t)p0 * nv * 8;
         // the chain kernel is a latency chain (one lane per Merkle path, ~14 ms alone whatever the batch, several times that while the MSMs
         // own the SIMDs): one launch covers the voters of ZKC_WITNESS_GROUP passes so that it never becomes the pipeline's pace
@@ -429,7 +430,7 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
         // through in a third of the time, so the pipeline starts ~6 ms earlier; the rest of the first group follows behind its fold check
         if (d_inputs && (c % wgroup == 0 || c == 1)) {
             const int glast = c == 0 ? 1 : std::min(((c / wgroup) + 1) * wgroup, npasses);          // passes [c, glast)
-            const int g0 = p0, gn = std::min((glast - c) * zk->max_inflight, B - g0);
+            const int g0 = p0, gn = std::min((glast - c) * per_pass, B - g0);
             if (gn > 0 && (rc = zkc_witness_chunk_async(ctx, zk->nLevels, (const uint8_t*)d_inputs + (size_t)g0 * L.nInputs * 32, gn, wc, d_status3 + 3 * (size_t)g0, d_status + g0))) return rc;
         }
         if (can_fold) {
@@ -446,8 +447,8 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
     auto now_ms = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; };
     const double t_begin = now_ms(); double tr[6] = {0};
     int pass = 0;
-    for (int p0 = 0; p0 < B; p0 += zk->max_inflight, pass++) {
-        const int nb = std::min(zk->max_inflight, B - p0);
+    for (int p0 = 0; p0 < B; p0 += per_pass, pass++) {
+        const int nb = std::min(per_pass, B - p0);
         zkc_lane& LN = zk->lane[pass % zk->nlanes]; const int slot = LN.npass & 1;       // MSM results are double-buffered: the blinding of pass k overlaps pass k+1
         tr[0] = now_ms();
         ZKC_HIP_CHECK(ctx, hipEventSynchronize(zk->ev_chunk[pass]));              // host: this chunk's fold flags have arrived

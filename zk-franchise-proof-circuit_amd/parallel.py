@@ -18,13 +18,14 @@ def record_width(n_public=8):
 
 
 def pack_records(proofs, publics, status, n_public=8):
-    """bytes, bytes, list[int] -> uint8 tensor [B, 256 + 32*n_public + 1]"""
+    """bytes, bytes, list[int] -> uint8 tensor [B, 256 + 32*n_public + 1] (numpy views: this sits inside the timed step of bench.py)"""
+    import numpy as np
     B = len(status)
-    rec = torch.empty(B, record_width(n_public), dtype=torch.uint8)
-    rec[:, :PROOF_BYTES] = torch.frombuffer(bytearray(proofs), dtype=torch.uint8).view(B, PROOF_BYTES)
-    rec[:, PROOF_BYTES:-1] = torch.frombuffer(bytearray(publics), dtype=torch.uint8).view(B, 32 * n_public)
-    rec[:, -1] = torch.tensor(status, dtype=torch.uint8)
-    return rec
+    rec = np.empty((B, record_width(n_public)), dtype=np.uint8)
+    rec[:, :PROOF_BYTES] = np.frombuffer(proofs, dtype=np.uint8).reshape(B, PROOF_BYTES)
+    rec[:, PROOF_BYTES:-1] = np.frombuffer(publics, dtype=np.uint8).reshape(B, 32 * n_public)
+    rec[:, -1] = np.asarray(status, dtype=np.int64).astype(np.uint8)
+    return torch.from_numpy(rec)
 
 
 def gather_records(local, world, dist=None, total=None):
