@@ -492,7 +492,7 @@ static const bool g_debug_sync = getenv("ZKC_DEBUG_SYNC") != nullptr;   // seria
                     hipGetErrorString(_e)); fflush(stderr); } } while (0)
 
 template <class F>
-static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJobList& jl_in, int slot, bool to_host, hipStream_t st, hipEvent_t ev_sorted) {
+static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJobList& jl_in, int slot, bool to_host, hipStream_t st, hipEvent_t ev_sorted, hipEvent_t wait_before_acc = nullptr) {
     zkc_ctx* ctx = zk->ctx;
     const int nj = jl_in.njobs;
     if (nj <= 0 || nj > w.max_jobs) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: job count");
@@ -540,6 +540,7 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     XYZZ<F>* partial = reinterpret_cast<XYZZ<F>*>(w.partial);
     XYZZ<F>* wres = reinterpret_cast<XYZZ<F>*>(w.wres);
     XYZZ<F>* results = reinterpret_cast<XYZZ<F>*>(w.results) + (size_t)slot * w.max_jobs;
+    if (wait_before_acc) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, wait_before_acc, 0));      // hold the (VALU-bound) accumulation until the other stream reaches its memory-bound phase
     {
         zkc_prof_scope _ps(ctx, kG2 ? ZKC_PROF_MSM_ACC_G2 : ZKC_PROF_MSM_ACC_G1, alg_bytes, st);
         if (!kG2 && ((ctx->prof.mask >> ZKC_PROF_MSM_ACC_G1) & 1)) ctx->prof.bytes[ZKC_PROF_MSM_G1_STREAMED] += streamed_bytes;
@@ -581,6 +582,6 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     return ZKC_OK;
 }
 int msm_pass_g1(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st, hipEvent_t ev_sorted) { return msm_pass<Fq>(zk, w, zk->d_g1, jl, slot, to_host, st, ev_sorted); }
-int msm_pass_g2(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st) { return msm_pass<Fq2>(zk, w, zk->d_g2, jl, slot, to_host, st, nullptr); }
+int msm_pass_g2(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st, hipEvent_t wait_before_acc) { return msm_pass<Fq2>(zk, w, zk->d_g2, jl, slot, to_host, st, nullptr, wait_before_acc); }
 
 }  // namespace zkc

@@ -213,21 +213,73 @@ __device__ __forceinline__ void ntt_bfly(uint32_t* pu, uint32_t* pv, const uint3
 #pragma unroll
     for (int i = 0; i < 9; i++) { pu[i] = u[i]; pv[i] = v[i]; }
 }
+// two stages at once on four LDS slots (one LDS round trip, one carry pass for two stages): x1 = v1 wa, x3 = v3 wa, then (p0 +- x1), (p2 +- x3),
+// then the second stage pairs (0, 2) with wb and (1, 3) with wc.  Which slots are 0..3 differs between the RN and NR orders; the arithmetic is the
+// same.  Limbs: a carried value plus a dominator minus a product is below 2^30.6, and 2^30.6 x 2^29 still fits the column sums of the next product.
+__device__ __forceinline__ void ntt_r4(uint32_t* p0, uint32_t* p1, uint32_t* p2, uint32_t* p3, const uint32_t wa[9], const uint32_t wb[9], const uint32_t wc[9], bool swap_mid) {
+    uint32_t a[9], b[9], c[9], d[9], t[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { a[i] = p0[i]; b[i] = p1[i]; c[i] = p2[i]; d[i] = p3[i]; }
+    // first stage: (a, b) and (c, d) are the pairs, same twiddle
+    f29_mul<FrParams>(t, b, wa);
+#pragma unroll
+    for (int i = 0; i < 9; i++) { b[i] = a[i] + NttDom::D24.l[i] - t[i]; a[i] += t[i]; }
+    f29_mul<FrParams>(t, d, wa);
+#pragma unroll
+    for (int i = 0; i < 9; i++) { d[i] = c[i] + NttDom::D24.l[i] - t[i]; c[i] += t[i]; }
+    // second stage: (a, c) with wb, (b, d) with wc
+    f29_mul<FrParams>(t, c, wb);
+#pragma unroll
+    for (int i = 0; i < 9; i++) { c[i] = a[i] + NttDom::D24.l[i] - t[i]; a[i] += t[i]; }
+    f29_mul<FrParams>(t, d, wc);
+#pragma unroll
+    for (int i = 0; i < 9; i++) { d[i] = b[i] + NttDom::D24.l[i] - t[i]; b[i] += t[i]; }
+    f29_carry(a); f29_carry(b); f29_carry(c); f29_carry(d);
+    (void)swap_mid;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { p0[i] = a[i]; p1[i] = b[i]; p2[i] = c[i]; p3[i] = d[i]; }
+}
 // NR stages q0 .. q0+b-1 over a tile whose `mid` index (b bits) is the position bits those stages pair up; slot(mid, l) gives the LDS slot.
 // prefix = the position bits above mid (q0 of them): block index of stage q0 + r is (prefix << r) | (mid >> (b - r)).
-template <class Slot>
+template <bool R4, class Slot>
 __device__ __forceinline__ void ntt_nr_stages(uint32_t* tile, Slot slot, int b, int lo_t, int q0, uint32_t prefix_of_l0, int prefix_per_l, const uint32_t* __restrict__ tw29, int logn, bool fresh) {
-    const int mid_n = 1 << b, pairs = (mid_n >> 1) * lo_t;
-    for (int r = 0; r < b; r++) {
-        const int q = q0 + r, span = mid_n >> (r + 1);
+    const int mid_n = 1 << b;
+    auto tw_of = [&](int q, uint32_t i) -> size_t { return q ? (size_t)((__brev(i) >> (32 - q)) << (logn - q - 1)) : (size_t)0; };      // block i of the stage with 2^q blocks
+    int r = 0;
+    if (fresh) {                                    // stage 0 of a transform: twiddle 1, operands as large as 32 p -> plain butterflies, alone
+        const int span = mid_n >> 1, pairs = span * lo_t;
+        for (int x = threadIdx.x; x < pairs; x += blockDim.x) {
+            const int l = x % lo_t, j = x / lo_t;
+            uint32_t w[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            ntt_bfly(tile + 9 * slot(j, l), tile + 9 * slot(j + span, l), w, true, true);
+        }
+        __syncthreads();
+        r = 1;
+    }
+    for (; R4 && r + 1 < b; r += 2) {               // stages q, q + 1 together: slots m, m + span/2, m + span, m + 3 span/2
+        const int q = q0 + r, span = mid_n >> (r + 1), hspan = span >> 1, units = (mid_n >> 2) * lo_t;
+        for (int x = threadIdx.x; x < units; x += blockDim.x) {
+            const int l = x % lo_t, u = x / lo_t;
+            const int blk = u / hspan, j = u - blk * hspan;
+            const int m = blk * 2 * span + j;
+            const uint32_t i = ((prefix_of_l0 + (uint32_t)(prefix_per_l * l)) << r) | (uint32_t)blk;
+            uint32_t wa[9], wb[9], wc[9];
+            ntt_ld_w(wa, tw29, tw_of(q, i)); ntt_ld_w(wb, tw29, tw_of(q + 1, 2 * i)); ntt_ld_w(wc, tw29, tw_of(q + 1, 2 * i + 1));
+            // stage q pairs (m, m + span) and (m + hspan, m + span + hspan); stage q + 1 pairs (m, m + hspan) in block 2i and (m + span, m + span + hspan) in block 2i + 1
+            // ntt_r4 takes (a, b), (c, d) as first-stage pairs and (a, c), (b, d) as second-stage pairs: a = m, b = m + span, c = m + hspan, d = m + span + hspan
+            ntt_r4(tile + 9 * slot(m, l), tile + 9 * slot(m + span, l), tile + 9 * slot(m + hspan, l), tile + 9 * slot(m + span + hspan, l), wa, wb, wc, false);
+        }
+        __syncthreads();
+    }
+    for (; r < b; r++) {                            // one stage at a time (the odd one left over, or all of them: the head kernel measured slower two at a time)
+        const int q = q0 + r, span = mid_n >> (r + 1), pairs = (mid_n >> 1) * lo_t;
         for (int x = threadIdx.x; x < pairs; x += blockDim.x) {
             const int l = x % lo_t, pr = x / lo_t;
             const int blk = pr / span, j = pr - blk * span;
-            const int m0 = blk * 2 * span + j, m1 = m0 + span;
-            const uint32_t i = ((prefix_of_l0 + (uint32_t)(prefix_per_l * l)) << r) | (uint32_t)blk;          // block of stage q (q bits)
-            const uint32_t e = q ? (__brev(i) >> (32 - q)) << (logn - q - 1) : 0u;
-            uint32_t w[9]; ntt_ld_w(w, tw29, e);
-            ntt_bfly(tile + 9 * slot(m0, l), tile + 9 * slot(m1, l), w, fresh && r == 0 && q == 0, ((r & 1) == 1) || r == b - 1);
+            const int m0 = blk * 2 * span + j;
+            const uint32_t i = ((prefix_of_l0 + (uint32_t)(prefix_per_l * l)) << r) | (uint32_t)blk;
+            uint32_t w[9]; ntt_ld_w(w, tw29, tw_of(q, i));
+            ntt_bfly(tile + 9 * slot(m0, l), tile + 9 * slot(m0 + span, l), w, false, R4 || (r & 1) == 1 || r == b - 1);
         }
         __syncthreads();
     }
@@ -248,7 +300,7 @@ zkc_ntt_nr_head(const Fr* src_all, Fr* dst_all, const uint32_t* __restrict__ tw2
         for (int k = 0; k < 9; k++) tile[9 * e + k] = t[k];
     }
     __syncthreads();
-    ntt_nr_stages(tile, [lo_t](int mid, int l) { return mid * lo_t + l; }, b, lo_t, 0, 0u, 0, tw29, logn, true);
+    ntt_nr_stages<false>(tile, [lo_t](int mid, int l) { return mid * lo_t + l; }, b, lo_t, 0, 0u, 0, tw29, logn, true);
     for (int e = threadIdx.x; e < elems; e += blockDim.x) {
         const int mid = e / lo_t, l = e - mid * lo_t;
         uint32_t r[9];
@@ -273,7 +325,7 @@ zkc_ntt_mid(Fr* __restrict__ data_all, const uint32_t* __restrict__ tw_inv29, co
     }
     __syncthreads();
     // slot(mid, l) = l * 512 + mid : sub-block l of the tile, position mid inside it; its prefix = the logn-9 position bits above = blockIdx.x * NSUB + l
-    ntt_nr_stages(tile, [](int mid, int l) { return l * MID + mid; }, B, NSUB, logn - B, (uint32_t)blockIdx.x * NSUB, 1, tw_inv29, logn, false);
+    ntt_nr_stages<true>(tile, [](int mid, int l) { return l * MID + mid; }, B, NSUB, logn - B, (uint32_t)blockIdx.x * NSUB, 1, tw_inv29, logn, false);
     // x g^k / n at bit-reversed positions (scale_br[p] = scale[brev(p)]): a product, so the value is back below 2 p
     for (int e = threadIdx.x; e < NTT_TILE; e += blockDim.x) {
         uint32_t r[9], s29[9], o[9];
@@ -285,15 +337,24 @@ zkc_ntt_mid(Fr* __restrict__ data_all, const uint32_t* __restrict__ tw_inv29, co
         for (int k = 0; k < 9; k++) tile[9 * e + k] = o[k];
     }
     __syncthreads();
-    // RN stages 1 .. 9 (what zkc_ntt_pass does in its first pass, minus the bit-reversed load): stage t pairs mid and mid + 2^(t-1)
-    for (int t = 1; t <= B; t++) {
-        const int half = 1 << (t - 1);
-        for (int x = threadIdx.x; x < NTT_TILE / 2; x += blockDim.x) {
-            const int l = x / (MID / 2), pr = x - l * (MID / 2);
-            const int j = pr & (half - 1), blk = pr >> (t - 1);
-            const int m0 = (blk << t) + j, m1 = m0 + half;
-            uint32_t w[9]; ntt_ld_w(w, tw_fwd29, (size_t)j << (logn - t));
-            ntt_bfly(tile + 9 * (l * MID + m0), tile + 9 * (l * MID + m1), w, t == 1, (t & 1) == 0 || t == B);      // stage 1: twiddle 1, operands below 18 p after the scaling product
+    // RN stages 1 .. 9 (what zkc_ntt_pass does in its first pass, minus the bit-reversed load): stage t pairs mid and mid + 2^(t-1).
+    // Stage 1 alone (twiddle 1, operands below 18 p after the scaling product), then (2,3) (4,5) (6,7) (8,9) two at a time.
+    for (int x = threadIdx.x; x < NTT_TILE / 2; x += blockDim.x) {
+        const int l = x / (MID / 2), pr = x - l * (MID / 2);
+        uint32_t w[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        ntt_bfly(tile + 9 * (l * MID + 2 * pr), tile + 9 * (l * MID + 2 * pr + 1), w, true, true);
+    }
+    __syncthreads();
+    for (int t = 2; t + 1 <= B; t += 2) {
+        const int half = 1 << (t - 1);              // stage t: pairs (m, m + half), j < half; stage t + 1: pairs (m, m + 2 half) with j and (m + half, m + 3 half) with j + half
+        for (int x = threadIdx.x; x < NTT_TILE / 4; x += blockDim.x) {
+            const int l = x / (MID / 4), u = x - l * (MID / 4);
+            const int j = u & (half - 1), blk = u >> (t - 1);
+            const int m = (blk << (t + 1)) + j;
+            uint32_t wa[9], wb[9], wc[9];
+            ntt_ld_w(wa, tw_fwd29, (size_t)j << (logn - t)); ntt_ld_w(wb, tw_fwd29, (size_t)j << (logn - t - 1)); ntt_ld_w(wc, tw_fwd29, (size_t)(j + half) << (logn - t - 1));
+            uint32_t* p = tile + 9 * (l * MID + m);
+            ntt_r4(p, p + 9 * half, p + 9 * 2 * half, p + 9 * 3 * half, wa, wb, wc, false);
         }
         __syncthreads();
     }

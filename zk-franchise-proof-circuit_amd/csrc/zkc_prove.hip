@@ -80,7 +80,7 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     for (auto& L : zk->lane) {
         for (hipStream_t q : {L.st, L.st2, L.fin}) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
         for (void* q : {(void*)L.d_abc, (void*)L.d_t, (void*)L.d_p}) if (q) (void)hipFree(q);
-        for (hipEvent_t e : {L.ev_msm, L.ev_msm2, L.ev_sorted, L.ev_fin[0], L.ev_fin[1]}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {L.ev_msm, L.ev_msm2, L.ev_sorted, L.ev_ntt, L.ev_fin[0], L.ev_fin[1]}) if (e) (void)hipEventDestroy(e);
         msm_work_free(L.w1); msm_work_free(L.w2);
     }
     delete zk;
@@ -214,7 +214,7 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
         zkc_lane& L = zk->lane[l];
         ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking)); ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.st2, hipStreamNonBlocking));
         ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.fin, hipStreamNonBlocking));
-        ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_msm, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_msm2, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_sorted, hipEventDisableTiming));
+        ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_msm, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_msm2, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_sorted, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_ntt, hipEventDisableTiming));
         ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_fin[0], hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_fin[1], hipEventDisableTiming));
     }
     if ((rc = lanes_ensure(zk, 1))) return bail(rc);
@@ -470,6 +470,7 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
         if (LN.npass >= 2) { ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, LN.ev_fin[slot], 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st2, LN.ev_fin[slot], 0)); }   // slot still read by the blinding two passes back?
         LN.npass++;
         if ((rc = h_evals_dev(zk, LN, w0, nb))) return rc;
+        ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_ntt, st));
         tr[2] = now_ms();
         static thread_local MsmJobList j1, j2;     // 6 KB each: kept off the stack frame of a C-ABI entry point
         const uint32_t vws = nb <= 4 ? 64u : 256u;          // few proofs in the pass: favour latency in the bucket reduction
@@ -496,7 +497,10 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
         // until the G1 stream has finished its short kernels (they were seen to stall next to the G2 chain's low-occupancy kernels); the G2
         // kernels then starve behind the 13 ms G1 accumulation instead and spill into the next pass -- measured equal within noise.
         static const bool g2_early = getenv("ZKC_G2_LATE") == nullptr;
-        if (g2_early) { if ((rc = msm_pass_g2(zk, LN.w2, j2, slot, false, st2))) return rc; ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_msm2, st2)); }
+        // [r2] its bucketing starts with the pass, but its accumulation (VALU-bound, 3.3 ms alone) is held until the G1 stream leaves the NTT: it then
+        // runs beside the G1 bucketing and segment kernels, which wait on memory and LDS atomics, instead of beside the NTT, which is VALU-bound too
+        static const bool g2_acc_with_sort = getenv("ZKC_G2_ACC_EARLY") == nullptr;
+        if (g2_early) { if ((rc = msm_pass_g2(zk, LN.w2, j2, slot, false, st2, g2_acc_with_sort ? LN.ev_ntt : nullptr))) return rc; ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_msm2, st2)); }
         tr[3] = now_ms();
         if ((rc = msm_pass_g1(zk, LN.w1, j1, slot, false, st, LN.ev_sorted))) return rc;
         tr[4] = now_ms();

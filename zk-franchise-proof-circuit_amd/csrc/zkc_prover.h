@@ -136,7 +136,7 @@ struct zkc_lane {
     hipStream_t st = nullptr, st2 = nullptr, fin = nullptr;               // buildABC/NTT/G1 MSM ; G2 MSM ; blinding + D2H
     zkc::Fr *d_abc = nullptr, *d_t = nullptr; uint32_t* d_p = nullptr;   // [inflight][3n] x2 (d_t = NTT scratch), [inflight][n x 8]
     zkc::MsmWork w1, w2;                                                  // G1 and G2 pipelines
-    hipEvent_t ev_msm = nullptr, ev_msm2 = nullptr, ev_sorted = nullptr, ev_fin[2] = {nullptr, nullptr}; int npass = 0;      // ev_fin[slot]: blinding of the pass that used result slot `slot`
+    hipEvent_t ev_msm = nullptr, ev_msm2 = nullptr, ev_sorted = nullptr, ev_ntt = nullptr, ev_fin[2] = {nullptr, nullptr}; int npass = 0;      // ev_ntt: buildABC/NTT/joinABC of the pass are through      // ev_fin[slot]: blinding of the pass that used result slot `slot`
 };
 
 struct zkc_zkey {
@@ -189,7 +189,7 @@ void msm_work_free(MsmWork& w);
 // to_host is set, to w.h_results (valid after the caller syncs the stream)
 // ev_sorted (optional): recorded on st once the digit/sort/segment kernels are through, i.e. right before the long accumulation kernel
 int msm_pass_g1(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st, hipEvent_t ev_sorted = nullptr);
-int msm_pass_g2(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st);
+int msm_pass_g2(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st, hipEvent_t wait_before_acc = nullptr);
 // zkc_msm_sort.hip -- K4: scalars -> signed digits -> entries bucketed per job (vals2, off, bcnt), then the segment lists of the accumulation
 // (segcnt, segoff, seg2bucket, seglen, perm, heavy).  `jl` is the finished host copy of what w.d_jobs already holds on the device.
 int msm_bucket_entries(zkc_ctx* ctx, MsmWork& w, const MsmJobList& jl, hipStream_t st, unsigned long long* d_entry_counter = nullptr);
