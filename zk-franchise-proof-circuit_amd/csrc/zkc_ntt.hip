@@ -111,86 +111,6 @@ extern "C" __global__ void __launch_bounds__(256) zkc_tw29(const Fr* __restrict_
     o[0] = make_uint4(r[0], r[1], r[2], r[3]); o[1] = make_uint4(r[4], r[5], r[6], r[7]); o[2] = make_uint4(r[8], 0, 0, 0);
 }
 struct NttDom { static constexpr L9 D24 = f29_dominator<FrParams>(1u << 29, 1u << 24); static constexpr L9 D27 = f29_dominator<FrParams>(1u << 29, 1u << 27); };
-extern "C" __global__ void __launch_bounds__(256)
-zkc_ntt_pass(const Fr* __restrict__ src_all, Fr* __restrict__ dst_all, const uint32_t* __restrict__ tw29, const Fr* __restrict__ scale,
-             int logn, int s0, int b, int first) {
-    const Fr* __restrict__ src = src_all + ((size_t)blockIdx.y << logn);      // blockIdx.y = vector of the batch
-    Fr* __restrict__ dst = dst_all + ((size_t)blockIdx.y << logn);
-    extern __shared__ uint32_t tile[];                                      // 9 words per element (odd stride: conflict-free)
-    const int mid_n = 1 << b;
-    const int lo_bits = s0;
-    const int lo_t = (NTT_TILE >> b) < (1 << lo_bits) ? (NTT_TILE >> b) : (1 << lo_bits);   // neighbouring lo per tile
-    const int tiles_per_hi = (1 << lo_bits) / lo_t;
-    const int hi = blockIdx.x / tiles_per_hi, lo0 = (blockIdx.x % tiles_per_hi) * lo_t;
-    const int elems = mid_n * lo_t;
-    const size_t base = (size_t)hi << (s0 + b);
-    // load: LDS slot = mid * lo_t + l  <->  global index base + mid * 2^s0 + lo0 + l
-    for (int e = threadIdx.x; e < elems; e += blockDim.x) {
-        const int mid = e / lo_t, l = e - mid * lo_t;
-        size_t gi = base + ((size_t)mid << s0) + lo0 + l;
-        if (first) gi = __brev((unsigned)gi) >> (32 - logn);
-        const Fr x = ld_fr(src + gi);
-        uint32_t t[9]; f29_from_fp_shl5(t, x.v);
-#pragma unroll
-        for (int k = 0; k < 9; k++) tile[9 * e + k] = t[k];
-    }
-    __syncthreads();
-    for (int t = 1; t <= b; t++) {
-        const int half = 1 << (t - 1);
-        const int s = s0 + t;                                     // global stage, m = 2^s
-        for (int q = threadIdx.x; q < elems / 2; q += blockDim.x) {
-            const int l = q % lo_t, pr = q / lo_t;                // pr indexes the (mid) butterfly pair
-            const int j = pr & (half - 1), blk = pr >> (t - 1);
-            const int m0 = (blk << t) + j, m1 = m0 + half;
-            const unsigned k = ((unsigned)j << s0) + lo0 + l;     // butterfly index within the half-block of size 2^(s-1)
-            const uint4* wp = reinterpret_cast<const uint4*>(tw29 + (size_t)TW29_WORDS * ((size_t)k << (logn - s)));
-            const uint4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
-            const uint32_t w[9] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x};
-            uint32_t* pu = tile + 9 * (m0 * lo_t + l); uint32_t* pv = tile + 9 * (m1 * lo_t + l);
-            uint32_t u[9], v[9], tt[9];
-#pragma unroll
-            for (int i = 0; i < 9; i++) { u[i] = pu[i]; v[i] = pv[i]; }
-            if (s == 1) {                                         // first stage: every twiddle is w^0 = 1, no product (v < 32 p: dominator D27)
-#pragma unroll
-                for (int i = 0; i < 9; i++) { const uint32_t vi = v[i]; v[i] = u[i] + NttDom::D27.l[i] - vi; u[i] += vi; }
-            } else {
-                f29_mul<FrParams>(tt, v, w);
-#pragma unroll
-                for (int i = 0; i < 9; i++) { v[i] = u[i] + NttDom::D24.l[i] - tt[i]; u[i] += tt[i]; }
-            }
-            // limbs grow by at most 2^30 per stage (dominator) and a product tolerates 2^31.3 x 2^29: carrying every second stage is enough
-            if ((t & 1) == 0 || t == b) { f29_carry(u); f29_carry(v); }
-#pragma unroll
-            for (int i = 0; i < 9; i++) { pu[i] = u[i]; pv[i] = v[i]; }
-        }
-        __syncthreads();
-    }
-    for (int e = threadIdx.x; e < elems; e += blockDim.x) {
-        const int mid = e / lo_t, l = e - mid * lo_t;
-        const size_t gi = base + ((size_t)mid << s0) + lo0 + l;
-        uint32_t r[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) r[k] = tile[9 * e + k];
-        if (scale) { const Fr sc = ld_fr(scale + gi); uint32_t s29[9], o[9]; f29_from_fp_shl5(s29, sc.v); f29_mul<FrParams>(o, r, s29);
-#pragma unroll
-            for (int k = 0; k < 9; k++) r[k] = o[k]; }
-        else f29_reduce_small<FrParams>(r);
-        st_fr(dst + gi, f29_to_fp<FrParams>(r));
-    }
-}
-
-// ================= [round 2] the transform PAIR of the prover without bit reversal and with three HBM round trips =================
-// h_evals needs, per vector, iNTT -> multiply by g^i / n -> NTT.  Both transforms use multiply-then-add (Cooley-Tukey) butterflies:
-//   inverse : natural input -> BIT-REVERSED output ("NR": spans n/2 ... 1; every butterfly of block i of a stage with 2^q blocks uses the one
-//             twiddle w^-(brev_q(i) n / 2^(q+1)))
-//   forward : bit-reversed input -> natural output ("RN": spans 1 ... n/2, the stages zkc_ntt_pass runs)
-// so position p simply holds X[brev(p)] in between, the scale table is stored bit-reversed once per key, and no load or store of any pass is a
-// permutation (round 1 gathered 32-byte elements by bit-reversed index in the first pass of both transforms).  The last nine NR stages, the
-// scaling and the first nine RN stages all live on the same 512 consecutive positions, so they share one LDS residency:
-//   zkc_ntt_nr_head   NR stages 0 .. logn-10 : tile = (top bits) x 4 neighbouring positions           (HBM round trip 1)
-//   zkc_ntt_mid       NR stages logn-9 .. logn-1, x scale_br, RN stages 1 .. 9 on 2 x 512 positions    (HBM round trip 2)
-//   zkc_ntt_pass      RN stages 10 .. logn (the existing kernel, first = 0)                            (HBM round trip 3)
-// Element format between kernels stays 8 x u32 Montgomery (R = 2^256); inside a tile nine 29-bit limbs (R' = 2^261) as in zkc_ntt_pass.
 __device__ __forceinline__ void ntt_ld_w(uint32_t w[9], const uint32_t* __restrict__ tw29, size_t e) {
     const uint4* wp = reinterpret_cast<const uint4*>(tw29 + (size_t)TW29_WORDS * e);
     const uint4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
@@ -239,6 +159,88 @@ __device__ __forceinline__ void ntt_r4(uint32_t* p0, uint32_t* p1, uint32_t* p2,
 #pragma unroll
     for (int i = 0; i < 9; i++) { p0[i] = a[i]; p1[i] = b[i]; p2[i] = c[i]; p3[i] = d[i]; }
 }
+extern "C" __global__ void __launch_bounds__(256)
+zkc_ntt_pass(const Fr* __restrict__ src_all, Fr* __restrict__ dst_all, const uint32_t* __restrict__ tw29, const Fr* __restrict__ scale,
+             int logn, int s0, int b, int first) {
+    const Fr* __restrict__ src = src_all + ((size_t)blockIdx.y << logn);      // blockIdx.y = vector of the batch
+    Fr* __restrict__ dst = dst_all + ((size_t)blockIdx.y << logn);
+    extern __shared__ uint32_t tile[];                                      // 9 words per element (odd stride: conflict-free)
+    const int mid_n = 1 << b;
+    const int lo_bits = s0;
+    const int lo_t = (NTT_TILE >> b) < (1 << lo_bits) ? (NTT_TILE >> b) : (1 << lo_bits);   // neighbouring lo per tile
+    const int tiles_per_hi = (1 << lo_bits) / lo_t;
+    const int hi = blockIdx.x / tiles_per_hi, lo0 = (blockIdx.x % tiles_per_hi) * lo_t;
+    const int elems = mid_n * lo_t;
+    const size_t base = (size_t)hi << (s0 + b);
+    // load: LDS slot = mid * lo_t + l  <->  global index base + mid * 2^s0 + lo0 + l
+    for (int e = threadIdx.x; e < elems; e += blockDim.x) {
+        const int mid = e / lo_t, l = e - mid * lo_t;
+        size_t gi = base + ((size_t)mid << s0) + lo0 + l;
+        if (first) gi = __brev((unsigned)gi) >> (32 - logn);
+        const Fr x = ld_fr(src + gi);
+        uint32_t t[9]; f29_from_fp_shl5(t, x.v);
+#pragma unroll
+        for (int k = 0; k < 9; k++) tile[9 * e + k] = t[k];
+    }
+    __syncthreads();
+    // [r2] stages two at a time where possible (ntt_r4: one LDS round trip and one carry pass for two stages, three twiddles for four
+    // butterflies); the twiddle-free stage 1 of a transform and an odd stage left over run one at a time.
+    int t = 1;
+    auto single = [&](int t1, bool carry) {
+        const int half = 1 << (t1 - 1);
+        const int s = s0 + t1;                                    // global stage, m = 2^s
+        for (int q = threadIdx.x; q < elems / 2; q += blockDim.x) {
+            const int l = q % lo_t, pr = q / lo_t;                // pr indexes the (mid) butterfly pair
+            const int j = pr & (half - 1), blk = pr >> (t1 - 1);
+            const int m0 = (blk << t1) + j, m1 = m0 + half;
+            const unsigned k = ((unsigned)j << s0) + lo0 + l;     // butterfly index within the half-block of size 2^(s-1)
+            uint32_t w[9]; ntt_ld_w(w, tw29, (size_t)k << (logn - s));
+            ntt_bfly(tile + 9 * (m0 * lo_t + l), tile + 9 * (m1 * lo_t + l), w, s == 1, carry);   // s == 1: every twiddle is w^0 = 1, no product (v < 32 p: dominator D27)
+        }
+        __syncthreads();
+    };
+    if (s0 == 0) { single(1, true); t = 2; }
+    for (; t + 1 <= b; t += 2) {
+        const int half = 1 << (t - 1), s = s0 + t;
+        for (int q = threadIdx.x; q < elems / 4; q += blockDim.x) {
+            const int l = q % lo_t, u = q / lo_t;
+            const int j = u & (half - 1), blk = u >> (t - 1);
+            const int m = (blk << (t + 1)) + j;
+            const unsigned k = ((unsigned)j << s0) + lo0 + l, kh = k + ((unsigned)half << s0);
+            uint32_t wa[9], wb[9], wc[9];
+            ntt_ld_w(wa, tw29, (size_t)k << (logn - s)); ntt_ld_w(wb, tw29, (size_t)k << (logn - s - 1)); ntt_ld_w(wc, tw29, (size_t)kh << (logn - s - 1));
+            uint32_t* p = tile + 9 * (m * lo_t + l);
+            ntt_r4(p, p + 9 * half * lo_t, p + 9 * 2 * half * lo_t, p + 9 * 3 * half * lo_t, wa, wb, wc, false);
+        }
+        __syncthreads();
+    }
+    if (t <= b) single(t, true);
+    for (int e = threadIdx.x; e < elems; e += blockDim.x) {
+        const int mid = e / lo_t, l = e - mid * lo_t;
+        const size_t gi = base + ((size_t)mid << s0) + lo0 + l;
+        uint32_t r[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) r[k] = tile[9 * e + k];
+        if (scale) { const Fr sc = ld_fr(scale + gi); uint32_t s29[9], o[9]; f29_from_fp_shl5(s29, sc.v); f29_mul<FrParams>(o, r, s29);
+#pragma unroll
+            for (int k = 0; k < 9; k++) r[k] = o[k]; }
+        else f29_reduce_small<FrParams>(r);
+        st_fr(dst + gi, f29_to_fp<FrParams>(r));
+    }
+}
+
+// ================= [round 2] the transform PAIR of the prover without bit reversal and with three HBM round trips =================
+// h_evals needs, per vector, iNTT -> multiply by g^i / n -> NTT.  Both transforms use multiply-then-add (Cooley-Tukey) butterflies:
+//   inverse : natural input -> BIT-REVERSED output ("NR": spans n/2 ... 1; every butterfly of block i of a stage with 2^q blocks uses the one
+//             twiddle w^-(brev_q(i) n / 2^(q+1)))
+//   forward : bit-reversed input -> natural output ("RN": spans 1 ... n/2, the stages zkc_ntt_pass runs)
+// so position p simply holds X[brev(p)] in between, the scale table is stored bit-reversed once per key, and no load or store of any pass is a
+// permutation (round 1 gathered 32-byte elements by bit-reversed index in the first pass of both transforms).  The last nine NR stages, the
+// scaling and the first nine RN stages all live on the same 512 consecutive positions, so they share one LDS residency:
+//   zkc_ntt_nr_head   NR stages 0 .. logn-10 : tile = (top bits) x 4 neighbouring positions           (HBM round trip 1)
+//   zkc_ntt_mid       NR stages logn-9 .. logn-1, x scale_br, RN stages 1 .. 9 on 2 x 512 positions    (HBM round trip 2)
+//   zkc_ntt_pass      RN stages 10 .. logn (the existing kernel, first = 0)                            (HBM round trip 3)
+// Element format between kernels stays 8 x u32 Montgomery (R = 2^256); inside a tile nine 29-bit limbs (R' = 2^261) as in zkc_ntt_pass.
 // NR stages q0 .. q0+b-1 over a tile whose `mid` index (b bits) is the position bits those stages pair up; slot(mid, l) gives the LDS slot.
 // prefix = the position bits above mid (q0 of them): block index of stage q0 + r is (prefix << r) | (mid >> (b - r)).
 template <bool R4, class Slot>
