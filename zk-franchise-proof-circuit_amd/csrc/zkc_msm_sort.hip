@@ -106,6 +106,9 @@ zkc_msm_binscan(const MsmJobList* __restrict__ jlp, uint32_t* __restrict__ tilec
         bin_start[job.bin0 + b] = st; hist[job.bin0 + b] = en - st;
     }
 }
+// (Tried in round 2: grouping the tile's entries by bin in 45 KB of LDS and storing every (tile, bin) run with one contiguous store per wave.
+// The stores became cheap, but two workgroups per CU and a serial copy-out loop per wave made the kernel slower: 2.4 ms against 1.6 beside the G2
+// accumulation.  The direct form stays.)
 __global__ void __launch_bounds__(MSM_TILE)
 zkc_msm_split(const MsmJobList* __restrict__ jlp, const uint16_t* __restrict__ tilejob, const uint32_t* __restrict__ tilecnt, uint32_t* __restrict__ vals) {
     __shared__ uint32_t cur[1u << MSM_MAX_HBITS];      // next free position of this tile's run inside each bin
