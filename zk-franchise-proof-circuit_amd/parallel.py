@@ -28,10 +28,11 @@ def pack_records(proofs, publics, status, n_public=8):
     return torch.from_numpy(rec)
 
 
-def gather_records(local, world, dist=None, total=None):
+def gather_records(local, world, dist=None, total=None, force_collective=False):
     """all_gather of the per-rank record tensors -> [total, width] in voter order.  Ranks may hold blocks that differ by one
-    row (shard_range): blocks are padded to the largest one for the collective and trimmed afterwards."""
-    if world == 1:
+    row (shard_range): blocks are padded to the largest one for the collective and trimmed afterwards.  force_collective runs the
+    collective even for a single rank (the one-GPU test of the RCCL call path)."""
+    if world == 1 and not force_collective:
         return local
     sizes = [shard_range(r, world, total)[1] - shard_range(r, world, total)[0] for r in range(world)] if total is not None else [local.shape[0]] * world
     m = max(sizes)
