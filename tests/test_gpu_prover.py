@@ -317,3 +317,40 @@ def test_fullprove_batch_nl160_three_passes_config3(env):
     # a tampered proof in the middle of the batch is caught by the batch verifier
     bad = bytearray(proofs); bad[256 * 100 + 5] ^= 1
     assert not groth16.verify_batch(ctx, vk, pubs, bytes(bad))
+
+
+@pytest.mark.parametrize('B', [1, 2, 97, 193])
+def test_fullprove_batch_sizes_around_pass_boundaries_nl10(env, B):
+    """Batches that do not fill their passes (1, 2), spill one proof into a second pass (97 -> 49 + 48 after balancing) or into a third (193):
+    zkc_fullprove_batch_dev == witness + zkc_prove_batch_dev, every proof accepted by the batch verifier, first and last re-proved by the oracle.
+    Also the argument checks of the batch entry points."""
+    ctx, get, torch = env
+    import zkcensus_amd
+    from zkcensus_amd import groth16
+    nl = 10
+    zk, pk, vk = get(nl)
+    from census_gen import random_voter
+    rng = random.Random(1000 + B)
+    voters = [random_voter(rng, ol.poseidon, nLevels=nl, depth_c=rng.randint(0, nl), depth_s=rng.randint(0, nl)) for _ in range(B)]
+    flat = b''.join(zkcensus_amd.flatten_inputs(v, nl) for v in voters)
+    d_in = dev_bytes(torch, flat)
+    nW = ctx.n_wires(nl)
+    d_w = torch.zeros(B * nW * 32, dtype=torch.uint8, device='cuda'); d_st = torch.zeros(B, dtype=torch.int32, device='cuda')
+    rs = b''.join(rng.randrange(R).to_bytes(32, 'little') for _ in range(2 * B))
+    p1, pub1 = pk.fullprove_batch_dev(d_in.data_ptr(), B, d_w.data_ptr(), d_st.data_ptr(), rs)
+    assert d_st.cpu().tolist() == [0] * B
+    assert groth16.verify_batch(ctx, vk, pub1, p1)
+    p2, pub2 = pk.prove_batch_dev(d_w.data_ptr(), B, rs)
+    assert p1 == p2 and pub1 == pub2
+    wt = d_w.view(B, nW * 32)
+    for i in {0, B - 1}:
+        w = wt[i].cpu().numpy().tobytes()
+        rc, op, opub = ol.prove(zk, w, int.from_bytes(rs[64 * i:64 * i + 32], 'little'), int.from_bytes(rs[64 * i + 32:64 * i + 64], 'little'))
+        assert rc == 0 and op == p1[256 * i:256 * i + 256] and opub == pub1[256 * i:256 * i + 256]
+    if B == 1:
+        lib = pk._lib
+        buf = ctypes_buf = __import__('ctypes').create_string_buffer(256)
+        assert lib.zkc_prove_batch_dev(pk._h, d_w.data_ptr(), pk.n_vars, 0, rs, buf, None) == 4            # B = 0: ZKC_ERR_BAD_ARG
+        assert lib.zkc_prove_batch_dev(pk._h, d_w.data_ptr(), pk.n_vars - 1, 1, rs, buf, None) == 3        # ZKC_ERR_INVALID_WITNESS_LENGTH
+        assert lib.zkc_prove_batch_dev(pk._h, d_w.data_ptr(), pk.n_vars, 1, (R).to_bytes(32, 'little') * 2, buf, None) == 4    # r = field order: rejected
+        assert lib.zkc_fullprove_batch_dev(pk._h, None, 1, d_w.data_ptr(), d_st.data_ptr(), rs, buf, None) == 4
