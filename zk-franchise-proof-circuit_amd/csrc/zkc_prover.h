@@ -8,7 +8,7 @@ namespace zkc {
 // digit d of ANY window lands in the same bucket d: a job has 2^(c-1) buckets in total, not per window, so large windows are cheap.
 // H (2^17 random scalars): c = 17 -> 15 additions per scalar into 65536 buckets (about 30 entries each); the witness sections A, B1,
 // C, B2 (8-11 k wires after constant folding): c = 12 -> 22 additions per scalar into 2048 buckets (same box: c = 14 -> 1798, 13 -> 1919,
-// 12 -> 1958, 11 -> ~1856 proofs/s).
+// 12 -> 1958, 11 -> ~1856 proofs/s; round 2, per-job bucketing: 12 -> 3030, 13 -> 2965).
 constexpr int MSM_C_BIG = 17, MSM_C_SMALL = 12;
 constexpr int msm_nw(int c) { return (254 + c) / c; }          // 17 -> 15 windows (255 bits), 12 -> 22 windows (264 bits)
 constexpr int msm_half(int c) { return 1 << (c - 1); }         // buckets per job
