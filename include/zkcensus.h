@@ -75,6 +75,9 @@ int  zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, zkc_zkey** 
 void zkc_zkey_free(zkc_zkey* zk);
 int  zkc_zkey_info(const zkc_zkey* zk, uint32_t* nVars, uint32_t* nPublic, uint32_t* domainSize);
 int  zkc_zkey_sha256(const zkc_zkey* zk, uint8_t out[32]);      /* of the .zkey image it was loaded from (circuits-info.md:5 publishes this hash) */
+/* cheap identity of a .zkey image for resident-key caches (SHA-256 over the header, the IC points, the ends of every section and a 64-byte block
+ * of every 64 KB): what groth16_prover, the N-API addon and groth16.py compare on every call.  Host only. */
+int  zkc_zkey_fingerprint(const void* zkey_bytes, size_t len, uint8_t out[32]);
 
 /* ---- a2-a7: Groth16 prove (replaces snarkjs groth16.prove / rapidsnark groth16_prover internals).
  * wtns   : nWitness x 32 B standard form (the payload of .wtns section 2), host (zkc_prove) or device (zkc_prove_dev)
@@ -103,8 +106,8 @@ int zkc_fullprove_batch_dev(zkc_zkey* zk, const void* d_inputs, int B, void* d_w
 /* ---- the rapidsnark entry point (go-rapidsnark prover.h `groth16_prover`, reached from prover.Prove at
  * zk_census_test.go:89): whole .zkey and .wtns file images in, NUL-terminated proof / public-signal JSON out.
  * Returns 0 OK, 1 ERROR, 2 SHORT_BUFFER (required sizes written back; nothing is proved, so a size query is cheap),
- * 3 INVALID_WITNESS_LENGTH.  r, s are random, uniform in Fr.  Thread-safe / re-entrant; the last key stays resident, keyed by the
- * SHA-256 of the .zkey image. */
+ * 3 INVALID_WITNESS_LENGTH.  r, s are random, uniform in Fr.  Thread-safe / re-entrant; the last key stays resident, keyed by
+ * zkc_zkey_fingerprint of the image. */
 int groth16_prover(const void* zkey_buffer, unsigned long zkey_size, const void* wtns_buffer, unsigned long wtns_size,
                    char* proof_buffer, unsigned long* proof_size, char* public_buffer, unsigned long* public_size,
                    char* error_msg, unsigned long error_msg_maxsize);

@@ -29,7 +29,7 @@ struct Api {
     int (*verify)(const char*, const char*, const char*) = nullptr; const char* (*verify_err)() = nullptr;
     int (*wtns_parse)(const void*, unsigned long, const uint8_t**, uint32_t*) = nullptr;
     unsigned long (*wtns_write)(const void*, uint32_t, void*, unsigned long) = nullptr;
-    int (*from_wasm)(const void*, size_t, char*) = nullptr; void (*sha256)(const void*, size_t, uint8_t*) = nullptr;
+    int (*from_wasm)(const void*, size_t, char*) = nullptr; int (*fingerprint)(const void*, size_t, uint8_t*) = nullptr;
     void (*random_scalars)(uint8_t*, size_t) = nullptr;
     std::string err;
 } g;
@@ -46,7 +46,7 @@ bool load_api(const std::string& hint) {               // caller holds g_mu
     SYM(ctx_create, "zkc_ctx_create") SYM(last_error, "zkc_last_error") SYM(n_wires, "zkc_circuit_n_wires") SYM(n_inputs, "zkc_circuit_n_inputs")
     SYM(witness, "zkc_witness") SYM(zkey_load, "zkc_zkey_load") SYM(zkey_free, "zkc_zkey_free") SYM(zkey_info, "zkc_zkey_info") SYM(prove, "zkc_prove")
     SYM(verify, "zkc_verify") SYM(verify_err, "zkc_verify_last_error") SYM(wtns_parse, "zkc_wtns_parse") SYM(wtns_write, "zkc_wtns_write")
-    SYM(from_wasm, "zkc_circuit_nlevels_from_wasm") SYM(sha256, "zkc_sha256") SYM(random_scalars, "zkc_random_scalars")
+    SYM(from_wasm, "zkc_circuit_nlevels_from_wasm") SYM(fingerprint, "zkc_zkey_fingerprint") SYM(random_scalars, "zkc_random_scalars")
 #undef SYM
     g.h = h;
     return true;
@@ -57,8 +57,8 @@ bool ensure_ctx(std::string& err) {                     // caller holds g_mu
     if (g.ctx_create(d ? atoi(d) : 0, &g_ctx)) { g_ctx = nullptr; err = g.last_error(nullptr); return false; }
     return true;
 }
-bool ensure_key(const std::vector<uint8_t>& zkey, std::string& err) {      // caller holds g_mu; identity = sha256 of the .zkey image
-    uint8_t d[32]; g.sha256(zkey.data(), zkey.size(), d);
+bool ensure_key(const std::vector<uint8_t>& zkey, std::string& err) {      // caller holds g_mu; identity = zkc_zkey_fingerprint of the .zkey image
+    uint8_t d[32]; if (g.fingerprint(zkey.data(), zkey.size(), d)) { err = "not a zkey file"; return false; }
     if (g_key && !memcmp(d, g_key_sha, 32)) return true;
     if (g_key) { g.zkey_free(g_key); g_key = nullptr; }                     // one resident key: the old one's HBM is released first
     if (g.zkey_load(g_ctx, zkey.data(), zkey.size(), &g_key)) { g_key = nullptr; err = g.last_error(g_ctx); return false; }

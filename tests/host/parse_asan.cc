@@ -44,6 +44,7 @@ static bool load_like(const std::vector<uint8_t>& f) {
     touch(bs.sec[8], 64ull * (zh.nVars - zh.nPub - 1)); touch(bs.sec[9], 64ull * zh.n);
     std::vector<uint32_t> half(zh.n / 2); half[0] = 1;  // the twiddle table the loader fills: n >= 4 guaranteed by the parser
     uint8_t d[32]; sha256(copy.data(), copy.size(), d); sink += d[0];
+    zkey_fingerprint(copy.data(), copy.size(), bs, d); sink += d[1];
     return true;
 }
 static bool wtns_like(const std::vector<uint8_t>& f) {

@@ -138,3 +138,24 @@ def test_groth16_prover_argument_checks_before_any_gpu_work(tmp_path):
     assert rc == 1
     rc = lib.groth16_prover(zk, len(zk), b'wtnsXXXX' + bytes(40), 48, pb, ctypes.byref(ps), ub, ctypes.byref(us), err, 256)
     assert rc == 1 and b'Invalid witness file' in err.value
+
+
+def test_zkey_fingerprint_identifies_keys(tmp_path):
+    """The per-call identity of the resident-key caches (groth16_prover, N-API, groth16.py): equal for equal images, different for two keys of the same
+    circuit from different ceremonies, for a changed header byte and for a changed length; cheap (the full SHA-256 of a 55 MB key costs 0.27 s)."""
+    import time
+    from zkcensus_amd import setup
+    lib = _native.load()
+    _, za, _ = setup.ensure_test_artifacts(10, directory=str(tmp_path))
+    _, zb, _ = setup.ensure_test_artifacts(10, seed=1234, directory=str(tmp_path))
+    a, b = open(za, 'rb').read(), open(zb, 'rb').read()
+    fp = lambda raw: (lambda o: (lib.zkc_zkey_fingerprint(raw, len(raw), o), o.raw))(ctypes.create_string_buffer(32))
+    (ra, fa), (rb, fb) = fp(a), fp(b)
+    assert ra == 0 and rb == 0 and fa != fb and fp(bytes(a))[1] == fa
+    mut = bytearray(a); mut[12 + 12 + 4 + 12 + 100] ^= 1                    # a byte of alpha1 in the header section
+    assert fp(bytes(mut))[1] != fa
+    assert fp(a + b'\0')[1] != fa
+    assert fp(b'not a zkey')[0] != 0
+    t0 = time.perf_counter()
+    for _ in range(20): fp(a)
+    assert (time.perf_counter() - t0) / 20 < 0.02

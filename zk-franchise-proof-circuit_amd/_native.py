@@ -67,6 +67,7 @@ def load():
     L.zkc_circuit_nlevels_from_wasm.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
     L.zkc_sha256.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]; L.zkc_sha256.restype = None
     L.zkc_zkey_sha256.argtypes = [vp, ctypes.c_char_p]
+    L.zkc_zkey_fingerprint.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
     L.zkc_random_scalars.argtypes = [ctypes.c_char_p, ctypes.c_size_t]; L.zkc_random_scalars.restype = None
     L.zkc_pairing_bin.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
     _lib = L

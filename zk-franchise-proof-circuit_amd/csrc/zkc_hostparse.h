@@ -37,7 +37,7 @@ inline bool binfile_sections(const uint8_t* buf, size_t len, const char magic[4]
 
 // ---- Groth16 .zkey (snarkjs zkey format v1; circuit/circuit-compiler.sh:112-131 writes it) ----
 struct ZkeyHeader { uint32_t nVars, nPub, n, logn, nCoeffs; };
-inline bool zkey_check(const BinSections& s, ZkeyHeader& h, std::string& err) {
+inline bool zkey_check(const BinSections& s, ZkeyHeader& h, std::string& err, bool scan_coefficients = true) {
     for (int i = 1; i <= 9; i++) if (!s.sec[i]) { err = "zkey: missing section " + std::to_string(i); return false; }
     if (s.ssz[1] < 4 || rd32(s.sec[1]) != 1) { err = "zkey: protocol is not groth16"; return false; }
     // section 2: n8q(4) q(32) n8r(4) r(32) nVars nPub domainSize(4 each) alpha1 beta1(64 each) beta2 gamma2(128 each) delta1(64) delta2(128) = 660 bytes
@@ -56,7 +56,7 @@ inline bool zkey_check(const BinSections& s, ZkeyHeader& h, std::string& err) {
     h.nCoeffs = rd32(s.sec[4]);
     if (s.ssz[4] != 4 + 44ull * h.nCoeffs) { err = "zkey: coefficient section size"; return false; }
     const uint8_t* c = s.sec[4] + 4;
-    for (uint32_t i = 0; i < h.nCoeffs; i++) {
+    for (uint32_t i = 0; scan_coefficients && i < h.nCoeffs; i++) {
         const uint32_t m = rd32(c + 44ull * i), cc = rd32(c + 44ull * i + 4), w = rd32(c + 44ull * i + 8);
         if (m > 1 || cc >= h.n || w >= h.nVars) { err = "zkey: coefficient out of range"; return false; }
     }
@@ -188,6 +188,20 @@ struct Sha256 {
     }
 };
 inline void sha256(const void* data, size_t n, uint8_t out[32]) { Sha256 s; s.update(data, n); s.final(out); }
+// Identity of a .zkey image for the resident-key caches, cheap enough to take on every call (a 55 MB key hashes in 0.27 s, a proof takes 6 ms):
+// SHA-256 over the file length, the whole header section (it holds alpha, beta, gamma, delta of the ceremony: 660 bytes that differ between any two
+// real keys), the IC section, the first and last 4 KB of every other section and one 64-byte block out of every 64 KB of the file.  Two images
+// with equal fingerprints differ only if someone crafted them to; the full SHA-256 (what circuits-info.md publishes) is taken once, at load.
+inline void zkey_fingerprint(const uint8_t* buf, size_t len, const BinSections& bs, uint8_t out[32]) {
+    Sha256 s; const uint64_t l64 = len; s.update(&l64, 8);
+    for (int i = 1; i < 16; i++) if (bs.sec[i]) {
+        s.update(&bs.ssz[i], 8);
+        if (i == 2 || i == 3 || bs.ssz[i] <= 8192) s.update(bs.sec[i], (size_t)bs.ssz[i]);
+        else { s.update(bs.sec[i], 4096); s.update(bs.sec[i] + bs.ssz[i] - 4096, 4096); }
+    }
+    for (size_t off = 0; off + 64 <= len; off += 65536) s.update(buf + off, 64);
+    s.final(out);
+}
 inline std::string hex_of(const uint8_t* p, size_t n) { static const char* d = "0123456789abcdef"; std::string s; for (size_t i = 0; i < n; i++) { s.push_back(d[p[i] >> 4]); s.push_back(d[p[i] & 15]); } return s; }
 
 }}  // namespace zkc::parse

@@ -122,7 +122,7 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
     const uint8_t* h = sec[2];
     zkc_zkey* zk = new zkc_zkey(); zk->ctx = ctx;
     zk->nVars = zh.nVars; zk->nPub = zh.nPub; zk->n = zh.n; zk->logn = zh.logn; zk->nCoeffs = zh.nCoeffs;
-    parse::sha256(buf, len, zk->sha256);
+    parse::sha256(buf, len, zk->sha256); parse::zkey_fingerprint(buf, len, bs, zk->fingerprint);
     const uint32_t n = zk->n, nv = zk->nVars, np = zk->nPub, nc = nv - np - 1;
     zk->alpha1 = rd_g1(h + 84); zk->beta1 = rd_g1(h + 148); zk->beta2 = rd_g2(h + 212); zk->gamma2 = rd_g2(h + 340);
     zk->delta1 = rd_g1(h + 468); zk->delta2 = rd_g2(h + 532);

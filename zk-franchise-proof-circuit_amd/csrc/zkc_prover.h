@@ -158,7 +158,8 @@ struct zkc_zkey {
     // per-proof work buffers
     int max_inflight = 0;                                                   // proofs per pipeline pass (upper limit)
     int cur_inflight = 0;                                                   // what the lanes' work space is currently sized for (lanes_ensure)
-    uint8_t sha256[32] = {0};                                               // of the .zkey image: key-cache identity (groth16_prover)
+    uint8_t sha256[32] = {0};                                               // of the whole .zkey image (taken once, at load)
+    uint8_t fingerprint[32] = {0};                                          // parse::zkey_fingerprint of the image: the per-call identity of the resident-key caches
     zkc_lane lane[2]; int nlanes = 2;
     uint32_t *d_flags = nullptr, *h_flags = nullptr; size_t flags_cap = 0;  // fold check: [B][2][n]
     zkc::G1Affine *d_tblDelta1 = nullptr, *d_tblAlpha1 = nullptr, *d_tblBeta1 = nullptr; zkc::G2Affine* d_tblDelta2 = nullptr;

@@ -166,6 +166,12 @@ extern "C" int zkc_pairing_bin(const uint8_t g1[64], const uint8_t g2[128], uint
 }
 extern "C" void zkc_sha256(const void* data, size_t len, uint8_t out[32]) { parse::sha256(data, len, out); }
 extern "C" int zkc_zkey_sha256(const zkc_zkey* zk, uint8_t out[32]) { if (!zk || !out) return ZKC_ERR_BAD_ARG; memcpy(out, zk->sha256, 32); return ZKC_OK; }
+extern "C" int zkc_zkey_fingerprint(const void* zkey_bytes, size_t len, uint8_t out[32]) {
+    parse::BinSections bs; std::string perr;
+    if (!zkey_bytes || !out || !parse::binfile_sections((const uint8_t*)zkey_bytes, len, "zkey", 1, bs, perr)) return ZKC_ERR_FORMAT;
+    parse::zkey_fingerprint((const uint8_t*)zkey_bytes, len, bs, out);
+    return ZKC_OK;
+}
 // circuits this build has a native witness generator for, by the sha256 of their circom witness-calculator wasm
 extern "C" int zkc_circuit_nlevels_from_wasm(const void* wasm, size_t len, char sha256_hex[65]) {
     static const struct { const char* sha; int nLevels; } known[] = {
@@ -351,7 +357,7 @@ extern "C" int groth16_prover(const void* zkey_buffer, unsigned long zkey_size, 
     static std::mutex mu; static zkc_ctx* ctx = nullptr; static zkc_zkey* zk = nullptr;
     // everything that does not need the GPU first: file shapes and buffer sizes
     parse::BinSections bs; parse::ZkeyHeader zh; std::string perr;
-    if (!parse::binfile_sections((const uint8_t*)zkey_buffer, zkey_size, "zkey", 1, bs, perr) || !parse::zkey_check(bs, zh, perr)) return err(ZKC_ERR_GENERIC, perr);
+    if (!parse::binfile_sections((const uint8_t*)zkey_buffer, zkey_size, "zkey", 1, bs, perr) || !parse::zkey_check(bs, zh, perr, false)) return err(ZKC_ERR_GENERIC, perr);      // the coefficient scan is the loader's
     const uint8_t* payload; uint32_t nw;
     if (zkc_wtns_parse(wtns_buffer, wtns_size, &payload, &nw)) return err(ZKC_ERR_GENERIC, "Invalid witness file");
     if (nw != zh.nVars) return err(ZKC_ERR_INVALID_WITNESS_LENGTH, "Invalid witness length. Circuit: " + std::to_string(zh.nVars) + ", witness: " + std::to_string(nw));
@@ -360,10 +366,10 @@ extern "C" int groth16_prover(const void* zkey_buffer, unsigned long zkey_size, 
         *proof_size = need_proof; *public_size = need_public;
         return err(ZKC_ERR_SHORT_BUFFER, "Proof or public signals buffer is too short");
     }
-    uint8_t digest[32]; parse::sha256(zkey_buffer, zkey_size, digest);
+    uint8_t digest[32]; parse::zkey_fingerprint((const uint8_t*)zkey_buffer, zkey_size, bs, digest);      // per-call identity: 200 KB hashed, not the whole image
     std::lock_guard<std::mutex> guard(mu);
     if (!ctx) { const char* d = getenv("ZKC_DEVICE"); int rc = zkc_ctx_create(d ? atoi(d) : 0, &ctx); if (rc) { ctx = nullptr; return err(ZKC_ERR_GENERIC, zkc_last_error(nullptr)); } }
-    if (!zk || memcmp(zk->sha256, digest, 32) != 0) {
+    if (!zk || memcmp(zk->fingerprint, digest, 32) != 0) {
         if (zk) { zkc_zkey_free(zk); zk = nullptr; }
         int rc = zkc_zkey_load(ctx, zkey_buffer, zkey_size, &zk); if (rc) { zk = nullptr; return err(ZKC_ERR_GENERIC, zkc_last_error(ctx)); }
     }

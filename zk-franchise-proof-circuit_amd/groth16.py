@@ -40,19 +40,26 @@ def _read(f):
         return fh.read()
 
 
+def _fingerprint(raw):
+    out = ctypes.create_string_buffer(32)
+    if _native.load().zkc_zkey_fingerprint(raw, len(raw), out) != 0:
+        return hashlib.sha256(raw).digest()            # not a zkey: let the loader report it
+    return out.raw
+
+
 def _key(zkey_file):
-    """Resident proving key for a .zkey given as path / bytes / {type: 'mem'}.  Identity = SHA-256 of the file image (what
-    circuits-info.md publishes for the reference's key): a rewritten file or a second bytes object can never get a stale key."""
+    """Resident proving key for a .zkey given as path / bytes / {type: 'mem'}.  Identity = zkc_zkey_fingerprint of the image (SHA-256 over the
+    header, IC, section ends and sampled blocks: cheap enough per call): a rewritten file or a second bytes object never gets a stale key."""
     from . import ProvingKey
     raw = None
     if isinstance(zkey_file, str):
         st = os.stat(zkey_file); ident = (os.path.abspath(zkey_file), st.st_mtime_ns, st.st_size)
         digest = _path_digest.get(ident)
         if digest is None:
-            raw = _read(zkey_file); digest = hashlib.sha256(raw).digest()
+            raw = _read(zkey_file); digest = _fingerprint(raw)
             _path_digest.clear(); _path_digest[ident] = digest
     else:
-        raw = _read(zkey_file); digest = hashlib.sha256(raw).digest()
+        raw = _read(zkey_file); digest = _fingerprint(raw)
     if digest in _keys:
         _keys.move_to_end(digest)
         return _keys[digest]
