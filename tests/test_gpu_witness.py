@@ -73,12 +73,25 @@ def test_lane_and_wave_kernels_agree(ctx):
     """Two witness kernels share the C ABI entry: a wave per Merkle path for launches of up to 128 voters (latency), a lane per path above
     that (throughput).  Same voters through both -- including the reference-wasm vectors and the rejected inputs -- must give the same bytes
     and the same statuses."""
+    import numpy as np, torch, zkcensus_amd
     vecs = [v['inputs'] for v in VEC['vectors']] + [v['inputs'] for v in VEC['negative']]
-    many = (vecs * 7)[:150]                                   # 150 > 128: lane-per-path kernel
-    ws_lane, st_lane = ctx.witness(many)
-    ws_wave, st_wave = [], []
-    for i in range(0, len(many), 50):                         # 50 <= 128: wave-per-path kernel
-        w, s = ctx.witness(many[i:i + 50]); ws_wave += w; st_wave += s
+    many = (vecs * 7)[:150]
+    ws_wave, st_wave = ctx.witness(many)                      # stand-alone call, 150 <= 1024: wave-per-path kernel
+    # the lane-per-path kernel is what the batch pipeline uses for launches of more than 128 voters: reach it through zkc_fullprove_batch_dev's
+    # witness stage (first pass: wave; the rest of the group: lane) with a batch of 300 = passes of 75
+    from zkcensus_amd import setup
+    _, zp, _ = setup.ensure_test_artifacts(160)
+    pk = zkcensus_amd.ProvingKey(ctx, open(zp, 'rb').read())
+    big = (many * 2)[:300]
+    flat = b''.join(zkcensus_amd.flatten_inputs(v) for v in big)
+    d_in = torch.from_numpy(np.frombuffer(flat, dtype=np.uint8).copy()).cuda()
+    nW = ctx.n_wires(160)
+    d_w = torch.zeros(300 * nW * 32, dtype=torch.uint8, device='cuda'); d_st = torch.zeros(300, dtype=torch.int32, device='cuda')
+    pk.fullprove_batch_dev(d_in.data_ptr(), 300, d_w.data_ptr(), d_st.data_ptr(), bytes(64 * 300))
+    pk.close()
+    st_lane = d_st.cpu().tolist()[150:300]                    # voters 150..299 = `many` again, produced by the lane kernel (passes 2, 3 of the group)
+    wl = d_w.view(300, nW * 32)[150:300].cpu().numpy()
+    ws_lane = [wl[i].tobytes() for i in range(150)]
     assert st_lane == st_wave
     nv = len(VEC['vectors'])
     for i, (a, b) in enumerate(zip(ws_lane, ws_wave)):

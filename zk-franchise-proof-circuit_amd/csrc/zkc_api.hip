@@ -10,7 +10,9 @@ using namespace zkc;
 extern "C" __global__ void zkc_witness_chains(WitnessLayout L, PoseidonTable tab, const uint32_t* inputs, uint32_t* wtns, int32_t* status, int B, int tmpl_mode);
 extern "C" __global__ void zkc_witness_chains_wave(WitnessLayout L, PoseidonTable tab, const uint32_t* inputs, uint32_t* wtns, int32_t* status, int B, int tmpl_mode);
 // a wave per chain halves the latency of a chain and costs 64 times its issue slots: worth it while the chains alone cannot fill the part
-static constexpr int ZKC_WITNESS_WAVE_MAX_B = 128;
+// (5 % of a pass' VALU work for 1024 voters).  Inside the batch pipeline, where the chains run underneath the MSMs, only small launches take it; a
+// stand-alone zkc_witness[_dev] call has nothing to hide behind and takes it up to 1024 voters (3072 waves on 1024 SIMDs).
+static constexpr int ZKC_WITNESS_WAVE_MAX_B = 128, ZKC_WITNESS_WAVE_MAX_B_ALONE = 1024;
 extern "C" __global__ void zkc_witness_fill(const uint4* tmpl, uint4* wtns, int nWires, int B);
 extern "C" __global__ void zkc_witness_tostd(uint32_t* wtns, size_t nwires_total);
 
@@ -198,14 +200,14 @@ uint32_t* zkc_get_template(zkc_ctx* ctx, int nLevels) {
     return get_template(ctx, L, &t) == ZKC_OK ? t : nullptr;
 }
 
-static int witness_dev3(zkc_ctx* ctx, const WitnessLayout& L, const void* d_inputs, int B, void* d_wtns, int32_t* d_status3) {
+static int witness_dev3(zkc_ctx* ctx, const WitnessLayout& L, const void* d_inputs, int B, void* d_wtns, int32_t* d_status3, bool alone) {
     uint32_t* tmpl; int rc = get_template(ctx, L, &tmpl); if (rc) return rc;
     const size_t total = (size_t)L.nWires * 2 * (size_t)B;
     int fill_blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 16);
     zkc_prof_scope _ps(ctx, ZKC_PROF_WITNESS, (uint64_t)B * ((uint64_t)L.nWires + L.nInputs) * 32);
     hipLaunchKernelGGL(zkc_witness_fill, dim3(fill_blocks), dim3(256), 0, ctx->stream, (const uint4*)tmpl, (uint4*)d_wtns, L.nWires, B);
     ZKC_HIP_CHECK(ctx, hipGetLastError());
-    if (B <= ZKC_WITNESS_WAVE_MAX_B)             // one wave per (voter, chain): latency form
+    if (B <= (alone ? ZKC_WITNESS_WAVE_MAX_B_ALONE : ZKC_WITNESS_WAVE_MAX_B))             // one wave per (voter, chain): latency form
         hipLaunchKernelGGL(zkc_witness_chains_wave, dim3(3 * B), dim3(64), 0, ctx->stream, L, ctx->ptab, (const uint32_t*)d_inputs, (uint32_t*)d_wtns, d_status3, B, 0);
     else                                         // one lane per (voter, chain), lanes of a wave share the chain kind when B % 64 == 0 (harmless otherwise): throughput form
         hipLaunchKernelGGL(zkc_witness_chains, dim3((3 * B + 63) / 64), dim3(64), 0, ctx->stream, L, ctx->ptab, (const uint32_t*)d_inputs, (uint32_t*)d_wtns, d_status3, B, 0);
@@ -220,7 +222,7 @@ static int witness_dev3(zkc_ctx* ctx, const WitnessLayout& L, const void* d_inpu
 // one chunk of voters, enqueued on ctx->stream without any synchronisation (the full-prove pipeline of zkc_prove.hip issues a chunk per pass)
 int zkc_witness_chunk_async(zkc_ctx* ctx, int nLevels, const void* d_inputs, int B, void* d_wtns, int32_t* d_status3, int32_t* d_status) {
     WitnessLayout L = WitnessLayout::make(nLevels);
-    int rc = witness_dev3(ctx, L, d_inputs, B, d_wtns, d_status3); if (rc) return rc;
+    int rc = witness_dev3(ctx, L, d_inputs, B, d_wtns, d_status3, false); if (rc) return rc;
     hipLaunchKernelGGL(zkc_status_combine, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, d_status3, d_status, B);
     ZKC_HIP_CHECK(ctx, hipGetLastError());
     return ZKC_OK;
@@ -232,7 +234,7 @@ extern "C" int zkc_witness_dev(zkc_ctx* ctx, int nLevels, const void* d_inputs, 
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     WitnessLayout L = WitnessLayout::make(nLevels);
     int rc = zkc_ensure(ctx, (void**)&ctx->d_status3, &ctx->status3_n, (size_t)B * 3 * sizeof(int32_t)); if (rc) return rc;
-    rc = witness_dev3(ctx, L, d_inputs, B, d_wtns, ctx->d_status3); if (rc) return rc;
+    rc = witness_dev3(ctx, L, d_inputs, B, d_wtns, ctx->d_status3, true); if (rc) return rc;
     hipLaunchKernelGGL(zkc_status_combine, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_status3, d_status, B);
     ZKC_HIP_CHECK(ctx, hipGetLastError());
     return ZKC_OK;
