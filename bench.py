@@ -207,8 +207,8 @@ def main():
     for pmc_file in ('r02_pmc_hbm_traffic.json', 'r01_pmc_hbm_traffic.json'):
         try:      # HBM bytes per launch of the same kernel/geometry from the committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
             pm = json.load(open(os.path.join(ROOT, 'profiles', pmc_file)))
-            traffic = int(pm['hbm_bytes_per_launch_uncorrected'])
-            traffic_src = 'profiles/%s (separate --pmc run, %d proofs per launch)' % (pmc_file, pm['proofs_per_launch'])
+            traffic = int(pm.get('hbm_bytes_per_launch', pm['hbm_bytes_per_launch_uncorrected']))
+            traffic_src = 'profiles/%s (separate --pmc FETCH_SIZE / WRITE_SIZE runs, %d proofs per launch; FETCH_SIZE x %.2f as calibrated for 64-byte random gathers in profiles/r02_pmc_fetch_calibration.json)' % (pmc_file, pm['proofs_per_launch'], pm.get('fetch_calibration_factor', 1.0))
             break
         except Exception:
             pass

@@ -18,12 +18,20 @@ def main():
     fdir, wdir, ppl, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     fe, wr = load(fdir), load(wdir)
     kern = [k for k in fe if 'zkc_msm_accumulate29<' in k][0]
+    calib = {'gather64': 1.0}
+    try:
+        calib = json.load(open(os.path.join(os.path.dirname(os.path.abspath(out)), 'r02_pmc_fetch_calibration.json')))['bytes_per_reported_byte']
+    except Exception:
+        pass
     doc = {'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --batch %d --steps 1 --warmup 0 --no-cpu-baseline' % ppl,
            'kernel': kern, 'proofs_per_launch': ppl,
            'FETCH_SIZE_per_launch': fe[kern]['per_launch'], 'WRITE_SIZE_per_launch': wr[kern]['per_launch'],
            'hbm_bytes_per_launch_uncorrected': (fe[kern]['per_launch'] + wr[kern]['per_launch']) * 1024,
-           'note': 'counters are in KiB (guide: hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024).  The gfx950 x2 FETCH correction of the guide is calibrated for wide '
-                   'coalesced streams; this kernel gathers 64-byte points at random, so the uncorrected figure is reported and 2x is the upper bound.',
+           'fetch_calibration_factor': calib.get('gather64', 1.0),
+           'hbm_bytes_per_launch': (fe[kern]['per_launch'] * calib.get('gather64', 1.0) + wr[kern]['per_launch']) * 1024,
+           'note': 'counters are in KiB (guide: hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024).  The guide\'s gfx950 x2 FETCH correction holds for wide coalesced streams '
+                   '(reproduced: profiles/r02_pmc_fetch_calibration.json, stream16 = 2.00); for this kernel\'s pattern -- random 64-byte rows, four 16-byte loads per lane -- '
+                   'the same calibration run gives 0.95 bytes per reported byte (gather64), which is the factor applied to FETCH_SIZE here.',
            'all_zkc_kernels': {'pmc_fetch': fe, 'pmc_write': wr}}
     json.dump(doc, open(out, 'w'), indent=1)
     print(kern[:60], 'FETCH %.0f KiB WRITE %.0f KiB per launch -> %.3f GB' % (fe[kern]['per_launch'], wr[kern]['per_launch'], doc['hbm_bytes_per_launch_uncorrected'] / 1e9))
