@@ -43,7 +43,10 @@ enum {
     ZKC_W_ERR_INPUT_RANGE = 6
 };
 
-/* ---- context ---- */
+/* ---- context ----
+ * One context per (process, GPU).  SURVEY.md 8b sketched zkc_ctx_create(device_ids[], n); the build runs one process per GPU instead
+ * (bench.py / torch.distributed: independent proofs shard with no data-path collective), so a context names exactly one device; a host that
+ * wants several GPUs in one process creates one context per device and calls them from separate threads (contexts do not share state). */
 int  zkc_ctx_create(int hip_device, zkc_ctx** out);
 void zkc_ctx_destroy(zkc_ctx* ctx);
 const char* zkc_last_error(const zkc_ctx* ctx);        /* ctx may be NULL: last error of a failed zkc_ctx_create */

@@ -16,4 +16,5 @@ find $R/$O/prof -name "*kernel_trace.csv" -delete
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$O/pmc_fetch -- python3 $R/bench.py --batch 96 --steps 1 --warmup 0 --no-cpu-baseline --no-verify > $R/$O/pmc_fetch.log 2>&1; rc=$?; echo "pmc fetch rc=$rc" | tee -a $R/$O/steps.log; stop_if_killed $rc pmc_fetch
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$O/pmc_write -- python3 $R/bench.py --batch 96 --steps 1 --warmup 0 --no-cpu-baseline --no-verify > $R/$O/pmc_write.log 2>&1; rc=$?; echo "pmc write rc=$rc" | tee -a $R/$O/steps.log; stop_if_killed $rc pmc_write
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $R/$O/pmc_sq -- python3 $R/bench.py --batch 96 --steps 1 --warmup 0 --no-cpu-baseline --no-verify > $R/$O/pmc_sq.log 2>&1; rc=$?; echo "pmc sq rc=$rc" | tee -a $R/$O/steps.log
+hipcc --offload-arch=gfx950 -O3 -Wno-unused-result $R/tools/probe/gather_probe.hip -o /tmp/gather_probe > /dev/null 2>&1 && timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$O/pmc_calib -- /tmp/gather_probe > $R/$O/gather_probe.txt 2>&1; echo "calibration rc=$?" | tee -a $R/$O/steps.log
 exit 0
