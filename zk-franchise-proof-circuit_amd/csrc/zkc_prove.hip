@@ -80,7 +80,7 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     for (auto& L : zk->lane) {
         for (hipStream_t q : {L.st, L.st2, L.fin}) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
         for (void* q : {(void*)L.d_abc, (void*)L.d_t, (void*)L.d_p}) if (q) (void)hipFree(q);
-        for (hipEvent_t e : {L.ev_msm, L.ev_msm2, L.ev_sorted, L.ev_ntt, L.ev_fin[0], L.ev_fin[1]}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {L.ev_msm, L.ev_msm2, L.ev_sorted, L.ev_ntt, L.ev_mv, L.ev_fin[0], L.ev_fin[1]}) if (e) (void)hipEventDestroy(e);
         msm_work_free(L.w1); msm_work_free(L.w2);
     }
     delete zk;
@@ -214,7 +214,7 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
         zkc_lane& L = zk->lane[l];
         ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking)); ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.st2, hipStreamNonBlocking));
         ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.fin, hipStreamNonBlocking));
-        ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_msm, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_msm2, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_sorted, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_ntt, hipEventDisableTiming));
+        ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_msm, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_msm2, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_sorted, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_ntt, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_mv, hipEventDisableTiming));
         ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_fin[0], hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_fin[1], hipEventDisableTiming));
     }
     if ((rc = lanes_ensure(zk, 1))) return bail(rc);
@@ -317,15 +317,21 @@ static int fold_vmap(zkc_zkey* zk, int Dc, int Ds, zkc_zkey::Fold::VMap* out) {
 }
 
 // stages a2..a4 for `nb` proofs: leaves (A'B' - C') on the odd coset in d_p[q] (standard form), q < nb
-static int h_evals_dev(zkc_zkey* zk, zkc_lane& L, const uint32_t* d_wtns0, int nb) {
-    zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n, nv = zk->nVars; hipStream_t st = L.st;
-    {
-        zkc_prof_scope _ps(ctx, ZKC_PROF_MATVEC, (uint64_t)nb * ((uint64_t)zk->nCoeffs * 68 + 3ull * n * 32), st);
-        hipLaunchKernelGGL(zkc_matvec_jds, dim3((2 * n + 63 * zk->nlong + 255) / 256, nb), dim3(256), 0, st, zk->d_perm, zk->d_rowlen, zk->d_jdptr, zk->d_col, zk->d_val,
-                           (const Fr*)d_wtns0, (size_t)nv, L.d_abc, (int)n, zk->nlong);
-        hipLaunchKernelGGL(zkc_pointwise_mul, dim3((n + 255) / 256, nb), dim3(256), 0, st, L.d_abc, (int)n);
-        ZKC_HIP_CHECK(ctx, hipGetLastError());
-    }
+// buildABC (a2) for `nb` proofs on stream `mv`: A_w, B_w by the jagged-diagonal mat-vec, C_w = A_w o B_w
+static int h_matvec_dev(zkc_zkey* zk, zkc_lane& L, const uint32_t* d_wtns0, int nb, hipStream_t mv) {
+    zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n, nv = zk->nVars;
+    zkc_prof_scope _ps(ctx, ZKC_PROF_MATVEC, (uint64_t)nb * ((uint64_t)zk->nCoeffs * 68 + 3ull * n * 32), mv);
+    hipLaunchKernelGGL(zkc_matvec_jds, dim3((2 * n + 63 * zk->nlong + 255) / 256, nb), dim3(256), 0, mv, zk->d_perm, zk->d_rowlen, zk->d_jdptr, zk->d_col, zk->d_val,
+                       (const Fr*)d_wtns0, (size_t)nv, L.d_abc, (int)n, zk->nlong);
+    hipLaunchKernelGGL(zkc_pointwise_mul, dim3((n + 255) / 256, nb), dim3(256), 0, mv, L.d_abc, (int)n);
+    ZKC_HIP_CHECK(ctx, hipGetLastError());
+    return ZKC_OK;
+}
+// stages a2..a4 for `nb` proofs: leaves (A'B' - C') on the odd coset in d_p[q] (standard form), q < nb.  with_matvec = false: buildABC has been
+// run already (on another stream; L.st has been made to wait for it)
+static int h_evals_dev(zkc_zkey* zk, zkc_lane& L, const uint32_t* d_wtns0, int nb, bool with_matvec = true) {
+    zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n; hipStream_t st = L.st;
+    if (with_matvec) { int rc0 = h_matvec_dev(zk, L, d_wtns0, nb, st); if (rc0) return rc0; }
     zkc_prof_scope _pn(ctx, ZKC_PROF_NTT, (uint64_t)nb * (6ull * 2 * n * 32 + 4ull * n * 32), st);   // 6 transforms r+w, joinABC
     int rc;
     static const bool ntt_two_transforms = getenv("ZKC_NTT_SEPARATE") != nullptr;      // diagnostics: the round-1 path (two full transforms, four HBM round trips)
@@ -469,7 +475,13 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
         if (fold) for (int q = 0; q < nb; q++) if ((rc = fold_vmap(zk, dcq[q], dsq[q], &vms[q]))) return rc;
         if (LN.npass >= 2) { ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, LN.ev_fin[slot], 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st2, LN.ev_fin[slot], 0)); }   // slot still read by the blinding two passes back?
         LN.npass++;
-        if ((rc = h_evals_dev(zk, LN, w0, nb))) return rc;
+        // [r2] buildABC is gather-bound and needs only the witness: the one of pass p+1 is issued on the blinding stream as soon as the accumulation
+        // of pass p starts (VALU-bound, 15 ms) and is through long before the G1 stream gets there; only the first pass runs it in line
+        static const bool mv_prefetch_env = getenv("ZKC_MATVEC_INLINE") == nullptr;
+        const bool mv_prefetch = mv_prefetch_env && zk->nlanes == 1;
+        const bool mv_done = mv_prefetch && pass > 0;
+        if (mv_done) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, LN.ev_mv, 0));
+        if ((rc = h_evals_dev(zk, LN, w0, nb, !mv_done))) return rc;
         ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_ntt, st));
         tr[2] = now_ms();
         static thread_local MsmJobList j1, j2;     // 6 KB each: kept off the stack frame of a C-ABI entry point
@@ -512,6 +524,13 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
         if (publics)       // wires 1..nPublic of every witness, one strided copy
             ZKC_HIP_CHECK(ctx, hipMemcpy2DAsync(h_pub + 32ull * np * p0, 32ull * np, w0 + 8, 32ull * nv, 32ull * np, nb, hipMemcpyDeviceToHost, st));
         ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_msm, st));
+        if (mv_prefetch && p0 + per_pass < B) {                                   // buildABC of the next pass, beside this pass' accumulation
+            const int p1 = p0 + per_pass, nb1 = std::min(per_pass, B - p1);
+            ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_sorted, 0));         // this pass' NTT and joinABC are through (d_abc is free), its accumulation is next
+            ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, zk->ev_chunk[pass + 1], 0));
+            if ((rc = h_matvec_dev(zk, LN, (const uint32_t*)d_wtns + (size_t)p1 * nv * 8, nb1, fin))) return rc;
+            ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_mv, fin));
+        }
         // a7 on the second stream: overlaps the next pass
         FinalizeArgs fa{};
         fa.r1 = (const G1XYZZ*)LN.w1.results + (size_t)slot * LN.w1.max_jobs; fa.r2 = (const G2XYZZ*)LN.w2.results + (size_t)slot * LN.w2.max_jobs;
