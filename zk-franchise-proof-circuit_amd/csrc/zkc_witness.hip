@@ -195,10 +195,13 @@ __device__ Fr poseidon_trace29(const Fr* in, unsigned cmask, const PoseidonTable
 // The three trace values of partial round r are parked in lane r and stored once, 57 lanes side by side, after the last partial round.
 // A partial round is about 1100 instructions instead of 1900 (S-box 650, one product 250, selects and 45 v_readlane), a full round 1450
 // instead of 4100.  Values are congruent to, not identical with, the single-lane routine's (separate reductions); the wires are canonical.
+// The empty asm pins every gathered limb in a VGPR and hides from the compiler that it is wave-uniform: left alone, hipcc moved the whole S-box of
+// the (uniform) word 0 to the SCALAR unit -- 81 limb products as s_mul_i32 / s_mul_hi_u32 / s_add_u32 / s_addc_u32 quadruples, 1850 scalar
+// instructions per partial round where the vector unit needs 650 (v_mad_u64_u32 multiplies and accumulates in one instruction).
 __device__ __forceinline__ W29 bcast29(const W29& v, int src) {
     W29 r;
 #pragma unroll
-    for (int k = 0; k < 9; k++) r.l[k] = (uint32_t)__builtin_amdgcn_readlane((int)v.l[k], src);
+    for (int k = 0; k < 9; k++) { uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)v.l[k], src); asm volatile("" : "+v"(x)); r.l[k] = x; }
     return r;
 }
 __device__ __forceinline__ void emit29_any(const Emit& e, int wire, const W29& v) {
@@ -428,7 +431,7 @@ __device__ Fr smt_verifier_chain(const WitnessLayout& L, const PoseidonTable& ta
 }
 
 // one LANE per (voter, chain): 64 chains per wave -- the throughput form (a wave per chain issues 64 times the wave-instructions for the same
-// hashes, 5 % of a pass' VALU work at batch 1024); zkc_witness_chains_wave below is the latency form (3.6 ms instead of 6.5 for one voter)
+// hashes, 5 % of a pass' VALU work at batch 1024); zkc_witness_chains_wave below is the latency form (2.3 ms instead of 6.5 for one voter)
 extern "C" __global__ void __launch_bounds__(64)
 zkc_witness_chains(WitnessLayout L, PoseidonTable tab, const uint32_t* __restrict__ inputs, uint32_t* __restrict__ wtns,
                    int32_t* __restrict__ status, int B, int tmpl_mode) {
