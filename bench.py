@@ -48,9 +48,31 @@ def launch_ranks(args):
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode()); sys.stdout.flush()
+    # rank 0's stdout is read on a thread so that the parent can watch ALL children: if one rank dies, the others would sit in the collective until
+    # RCCL's own timeout; they are terminated (by their exact pids) instead and the failure is reported at once
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True); reader.start()
+    failed = None
+    while any(p.poll() is None for p in procs):
+        bad = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() is not None and p.returncode != 0]
+        if bad:
+            failed = bad[0]
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill(); p.wait()
+    reader.join(timeout=10)
+    sys.stdout.write(b''.join(c for c in chunks if c).decode()); sys.stdout.flush()
+    if failed:
+        sys.stderr.write('bench.py: rank %d exited with status %d; the other ranks were terminated\n' % failed)
+    rcs = [p.returncode for p in procs]
     return max(abs(rc) for rc in rcs)
 
 
@@ -78,6 +100,8 @@ def dry_run(args, rank, world):
     max-over-ranks timing as the real run, with fabricated 513-byte records instead of proofs.  The line it prints is marked invalid."""
     import torch, torch.distributed as dist
     from zkcensus_amd import parallel
+    if os.environ.get('ZKC_BENCH_TEST_FAIL_RANK') == str(rank):          # test hook: a rank that dies must not leave the launcher hanging
+        raise SystemExit(7)
     if world > 1:
         dist.init_process_group('gloo')
     B = min(args.batch, 64); total = B * world

@@ -29,3 +29,12 @@ def test_under_torch_distributed_run():
 def test_single_rank_dry_run():
     j = _line([sys.executable, 'bench.py', '--dry-run-cpu'])
     assert j['n_gpus'] == 1 and j['gathered_records_equal_per_rank_records']
+
+
+def test_launcher_does_not_hang_when_a_rank_dies():
+    """If one rank exits with an error the launcher terminates the others (they would wait in the collective until its time-out) and reports it."""
+    import time
+    env = dict(os.environ, ZKC_BENCH_TEST_FAIL_RANK='1'); env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--dry-run-cpu'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0 and 'rank 1 exited with status 7' in r.stderr and time.time() - t0 < 120
