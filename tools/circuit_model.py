@@ -6,7 +6,7 @@ wire order circom 2.1.5 chose can be recovered by value-matching against the was
 import json, os
 
 R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
-_C = json.load(open(os.path.join(os.path.dirname(__file__), '..', 'tests/golden/poseidon_constants.json')))
+_C = json.load(open(os.path.join(os.path.dirname(__file__), '..', 'zk-franchise-proof-circuit_amd/data/poseidon_constants.json')))
 PC = {int(t): {k: [int(x, 16) for x in v] for k, v in a.items()} for t, a in _C.items()}
 NROUNDSP = {3: 57, 4: 56, 5: 60}
 
