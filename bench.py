@@ -69,7 +69,10 @@ def launch_ranks(args):
         except subprocess.TimeoutExpired:
             p.kill(); p.wait()
     reader.join(timeout=10)
-    sys.stdout.write(b''.join(c for c in chunks if c).decode()); sys.stdout.flush()
+    # only the JSON line goes to stdout; anything else rank 0 printed there (a library banner such as gloo's "[Gloo] Rank 0 is connected ...") to stderr
+    for ln in b''.join(c for c in chunks if c).decode(errors='replace').splitlines():
+        (sys.stdout if ln.lstrip().startswith('{') else sys.stderr).write(ln + '\n')
+    sys.stdout.flush()
     if failed:
         sys.stderr.write('bench.py: rank %d exited with status %d; the other ranks were terminated\n' % failed)
     rcs = [p.returncode for p in procs]
