@@ -106,6 +106,24 @@ int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, int
  * of one pass run underneath the MSMs of the previous one.  Needs a key of ZkFranchiseProofCircuit(nLevels) shape. */
 int zkc_fullprove_batch_dev(zkc_zkey* zk, const void* d_inputs, int B, void* d_wtns, int32_t* d_status, const uint8_t* rs, uint8_t* proofs, uint8_t* publics);
 
+/* ---- e: several GPUs from ONE host process (SURVEY.md 8b's zkc_ctx_create(device_ids[], n), 8e's "one host thread + one HIP stream set per
+ * device").  The reference's hosts are single processes (the Go loop over prover.Prove, zk_census_test.go:89; Node's groth16.fullProve,
+ * ts_inputs/src/example.ts:358-362): a pool owns one context and one resident key per listed device and splits a batch into contiguous blocks
+ * (device g of G proves voters [g B/G, (g+1) B/G), sizes differing by at most one), one host thread per device, no exchange between devices.
+ * bench.py reaches the same split with one process per GPU over torch.distributed. ---- */
+typedef struct zkc_pool zkc_pool;
+int  zkc_pool_create(const int* hip_devices, int n, zkc_pool** out);
+void zkc_pool_destroy(zkc_pool* pool);
+int  zkc_pool_size(const zkc_pool* pool);
+zkc_ctx*  zkc_pool_ctx(zkc_pool* pool, int i);           /* the i-th device's context / resident key (NULL before zkc_pool_zkey_load) */
+zkc_zkey* zkc_pool_zkey(zkc_pool* pool, int i);
+const char* zkc_pool_last_error(const zkc_pool* pool); /* pool may be NULL: last error of a failed zkc_pool_create */
+int  zkc_pool_zkey_load(zkc_pool* pool, const void* zkey_bytes, size_t len);   /* every device or none */
+/* groth16.fullProve for B voters, HOST buffers: inputs B x zkc_circuit_n_inputs x 32 B; rs B x 64 B or NULL (drawn uniform in Fr);
+ * proofs B x 256 B; publics B x nPublic x 32 B or NULL; status B x int32 (ZKC_W_*) or NULL.  ZKC_ERR_WITNESS: every device finished and at
+ * least one voter failed a circuit assert (the other proofs are valid). */
+int  zkc_pool_fullprove_batch(zkc_pool* pool, const void* inputs, int B, const uint8_t* rs, uint8_t* proofs, uint8_t* publics, int32_t* status);
+
 /* ---- the rapidsnark entry point (go-rapidsnark prover.h `groth16_prover`, reached from prover.Prove at
  * zk_census_test.go:89): whole .zkey and .wtns file images in, NUL-terminated proof / public-signal JSON out.
  * Returns 0 OK, 1 ERROR, 2 SHORT_BUFFER (required sizes written back; nothing is proved, so a size query is cheap),

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Single-proof latency (BASELINE configs[1]): inputs_example.json verbatim through the C ABI, per stage, on one MI355X."""
-import json, os, sys, time
+import ctypes, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch, numpy as np
@@ -25,6 +25,18 @@ def main():
         ctx.witness_dev(d_in.data_ptr(), 1, d_w.data_ptr(), d_s.data_ptr()); pk.prove_dev(d_w.data_ptr(), 11 + it, 17 + it)   # device-resident path
         t3 = time.perf_counter()
         res = {'witness_host_ms': round((t1 - t0) * 1e3, 2), 'prove_host_ms': round((t2 - t1) * 1e3, 2), 'fullprove_device_resident_ms': round((t3 - t2) * 1e3, 2), 'status': st[0]}
+    # per-stage device time of ONE device-resident fullProve (HIP events around each kernel category on the stream it is launched on; the G2 pass,
+    # the blinding and the G1 pass run on three streams, so the categories overlap and do not add up to the end-to-end figure)
+    cats = {0: 'witness', 1: 'buildABC_matvec', 2: 'ntt_joinABC', 3: 'msm_bucketing', 4: 'msm_accumulate_g1', 5: 'msm_accumulate_g2', 6: 'msm_reduce'}
+    ctx._lib.zkc_profile_enable(ctx._h, 0x7f); torch.cuda.synchronize()
+    ctx.witness_dev(d_in.data_ptr(), 1, d_w.data_ptr(), d_s.data_ptr()); pk.prove_dev(d_w.data_ptr(), 23, 29); torch.cuda.synchronize()
+    stages = {}
+    for cat, name in cats.items():
+        ms, n, by = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
+        ctx._lib.zkc_profile_read(ctx._h, cat, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(by))
+        stages[name] = round(ms.value, 3)
+    ctx._lib.zkc_profile_enable(ctx._h, 0)
+    res['stage_ms_overlapped_not_additive'] = stages
     res['key_load_and_precompute_s'] = round(t_load, 2)
     print(json.dumps(res))
 

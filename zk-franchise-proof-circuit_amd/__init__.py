@@ -9,7 +9,7 @@ from . import _native
 from ._native import ZkcError
 from .inputs import INPUT_KEYS, flatten_inputs, R_MOD
 
-__all__ = ['Context', 'ProvingKey', 'groth16', 'ZkcError', 'INPUT_KEYS', 'flatten_inputs', 'R_MOD']
+__all__ = ['Context', 'ProvingKey', 'DevicePool', 'groth16', 'ZkcError', 'INPUT_KEYS', 'flatten_inputs', 'R_MOD']
 
 
 class Context:
@@ -133,6 +133,56 @@ class ProvingKey:
         out = ctypes.create_string_buffer(128 if which == 2 else 64)
         self.ctx._check(self._lib.zkc_msm_debug(self._h, which, d_scalars_ptr, count, out))
         return out.raw
+
+
+class DevicePool:
+    """Several GPUs from one host process (include/zkcensus.h zkc_pool_*): one context and one resident key per device, a batch split into
+    contiguous blocks with one host thread per device.  What a single-process host of the reference (the Go loop over prover.Prove,
+    zk_census_test.go:89) would hold; bench.py uses one process per GPU instead."""
+
+    def __init__(self, devices, zkey_bytes=None):
+        self._lib = _native.load()
+        arr = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        h = ctypes.c_void_p()
+        rc = self._lib.zkc_pool_create(arr, len(devices), ctypes.byref(h))
+        if rc != 0:
+            raise ZkcError(rc, (self._lib.zkc_pool_last_error(None) or b'').decode())
+        self._h = h
+        self.devices = list(devices)
+        self.n_public = None
+        if zkey_bytes is not None:
+            self.load_key(zkey_bytes)
+
+    def _check(self, rc, allow=()):
+        if rc != 0 and rc not in allow:
+            raise ZkcError(rc, (self._lib.zkc_pool_last_error(self._h) or b'').decode())
+        return rc
+
+    def load_key(self, zkey_bytes):
+        self._check(self._lib.zkc_pool_zkey_load(self._h, zkey_bytes, len(zkey_bytes)))
+        a, b, c = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        self._lib.zkc_zkey_info(self._lib.zkc_pool_zkey(self._h, 0), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+        self.n_vars, self.n_public, self.domain_size = a.value, b.value, c.value
+
+    def fullprove_batch(self, inputs, rs=None, nLevels=160):
+        """inputs: list of 12-key input objects or pre-flattened bytes.  rs: B x 64 bytes or None (drawn uniformly by the library).
+        Returns (proofs B x 256 B, publics B x n_public x 32 B, status list); raises unless every voter passed or only circuit asserts failed."""
+        flat = b''.join(x if isinstance(x, (bytes, bytearray)) else flatten_inputs(x, nLevels) for x in inputs)
+        B = len(inputs)
+        proofs = ctypes.create_string_buffer(256 * B); pubs = ctypes.create_string_buffer(32 * self.n_public * B); st = (ctypes.c_int32 * B)()
+        self._check(self._lib.zkc_pool_fullprove_batch(self._h, flat, B, None if rs is None else bytes(rs), proofs, pubs, st), allow=(7,))
+        return proofs.raw, pubs.raw, list(st)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.zkc_pool_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 from . import groth16  # noqa: E402  (snarkjs-shaped surface: groth16.fullProve / prove / verify, groth16.wtns.calculate)

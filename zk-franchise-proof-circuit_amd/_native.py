@@ -70,6 +70,14 @@ def load():
     L.zkc_zkey_fingerprint.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
     L.zkc_random_scalars.argtypes = [ctypes.c_char_p, ctypes.c_size_t]; L.zkc_random_scalars.restype = None
     L.zkc_pairing_bin.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
+    L.zkc_pool_create.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(vp)]
+    L.zkc_pool_destroy.argtypes = [vp]; L.zkc_pool_destroy.restype = None
+    L.zkc_pool_size.argtypes = [vp]
+    L.zkc_pool_ctx.argtypes = [vp, ctypes.c_int]; L.zkc_pool_ctx.restype = vp
+    L.zkc_pool_zkey.argtypes = [vp, ctypes.c_int]; L.zkc_pool_zkey.restype = vp
+    L.zkc_pool_last_error.argtypes = [vp]; L.zkc_pool_last_error.restype = ctypes.c_char_p
+    L.zkc_pool_zkey_load.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
+    L.zkc_pool_fullprove_batch.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, i32p]
     _lib = L
     return L
 
