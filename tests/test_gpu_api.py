@@ -92,3 +92,42 @@ def test_key_cache_is_keyed_by_content(tmp_path):
     k2 = groth16._key(path)
     assert k1 is ka and k2 is kb
     assert len(groth16._keys) <= groth16.MAX_RESIDENT_KEYS
+
+
+def test_key_and_context_lifecycle_returns_device_memory():
+    """Every load / prove / free cycle gives its HBM back (early-return leaks in zkc_zkey_load): free memory after ten cycles of
+    (context, key, proof, batch of 70, malformed key, close) is where it was after the first."""
+    import torch, random, numpy as np
+    import zkcensus_amd
+    from zkcensus_amd import setup
+    import sys, os
+    sys.path.insert(0, os.path.join(ol.ROOT, 'tools'))
+    from census_gen import random_voter
+    _, zp, _ = setup.ensure_test_artifacts(10)
+    zk = open(zp, 'rb').read()
+    rng = random.Random(3)
+    voters = [random_voter(rng, ol.poseidon, nLevels=10, depth_c=3, depth_s=2) for _ in range(70)]
+    flat = b''.join(zkcensus_amd.flatten_inputs(v, 10) for v in voters)
+    rs = b''.join(rng.randrange(ol.R).to_bytes(32, 'little') for _ in range(140))
+    torch.cuda.init(); torch.cuda.synchronize()
+
+    def cycle():
+        ctx = zkcensus_amd.Context(0)
+        pk = zkcensus_amd.ProvingKey(ctx, zk)
+        ws, st = ctx.witness(voters[:1], nLevels=10)
+        pk.prove(ws[0], 3, 4)
+        d_in = torch.from_numpy(np.frombuffer(flat, dtype=np.uint8).copy()).cuda()
+        d_w = torch.empty(70 * ctx.n_wires(10) * 32, dtype=torch.uint8, device='cuda'); d_st = torch.zeros(70, dtype=torch.int32, device='cuda')
+        pk.fullprove_batch_dev(d_in.data_ptr(), 70, d_w.data_ptr(), d_st.data_ptr(), rs)
+        for cut in (len(zk) // 2, 4096, 64):                      # truncated images: the loader must release what it had allocated
+            with pytest.raises(zkcensus_amd.ZkcError):
+                zkcensus_amd.ProvingKey(ctx, zk[:cut])
+        pk.close(); ctx.close()
+        del d_in, d_w, d_st
+        torch.cuda.synchronize(); torch.cuda.empty_cache()
+        return torch.cuda.mem_get_info()[0]
+
+    first = cycle()
+    for _ in range(9):
+        last = cycle()
+    assert first - last < 64 << 20, 'device memory shrank by %.1f MB over nine load/free cycles' % ((first - last) / 1e6)
