@@ -148,7 +148,16 @@ def main():
     # ZKC_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box only): ranks share the visible devices and gather over gloo, because RCCL refuses two
     # ranks on one device.  Never set for a measurement.
     share = os.environ.get('ZKC_BENCH_SHARE_GPU') == '1'
-    dev = local % torch.cuda.device_count() if share else local
+    ndev = torch.cuda.device_count()
+    isolated = ndev == 1 and any(os.environ.get(k) for k in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'))
+    if share:
+        dev = local % ndev
+    elif local < ndev:
+        dev = local
+    elif isolated:
+        dev = 0                    # a launcher that hands every rank its own card through *_VISIBLE_DEVICES
+    else:
+        raise SystemExit('bench.py: local rank %d but only %d visible GPU(s); one rank per GPU (ZKC_BENCH_SHARE_GPU=1 is the one-GPU rehearsal)' % (local, ndev))
     torch.cuda.set_device(dev)
     if world > 1:
         if share:
