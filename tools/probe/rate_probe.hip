@@ -3,7 +3,8 @@
 //
 // Each lane runs 8 independent dependency chains of ITER x 8 instructions.  The grid is sized so that every wave is resident from
 // the first cycle to the last (W waves per SIMD on all 1024 SIMDs), so besides the wall-clock rate the probe reports the shader clock
-// actually sustained (s_memtime ticks of a wave / kernel time) and the issue cost in cycles per wave-instruction per SIMD.
+// estimate (s_memtime ticks of a wave / kernel time) and the issue cost in those ticks per wave-instruction per SIMD.  NOTE: on gfx950 s_memtime does not
+// follow sclk (rocm-smi and GRBM_GUI_ACTIVE give 2.1-2.2 GHz under these loops, profiles/r02_power_clock_trace.json): only the lane-ops/s column is used.
 //   hipcc --offload-arch=gfx950 -O3 tools/probe/rate_probe.hip -o /tmp/rate_probe && /tmp/rate_probe > profiles/r02_rate_probe.txt
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -70,7 +71,7 @@ template <int OP> void run(const char* name, int waves_per_simd, int ops_per_slo
     double avg = 0; for (auto v : t) avg += (double)v; avg /= t.size();
     const double ops = (double)blocks * threads * ITER * 8 * ops_per_slot;
     const double wave_instr = (double)ITER * 8 * ops_per_slot;
-    printf("%-34s W=%d  %8.3f ms  %7.2f T lane-ops/s  clock %.2f GHz  %5.2f cycles per wave-instruction per SIMD\n", name, waves_per_simd, ms, ops / ms / 1e9,
+    printf("%-34s W=%d  %8.3f ms  %7.2f T lane-ops/s  s_memtime %.2f GHz  %5.2f ticks per wave-instruction per SIMD\n", name, waves_per_simd, ms, ops / ms / 1e9,
            avg / (ms * 1e-3) / 1e9, avg / (wave_instr * waves_per_simd));
 }
 int main() {

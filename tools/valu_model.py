@@ -55,12 +55,12 @@ def main():
     doc = {'kernel': name, 'hot_blocks': hot, 'per_block': per_block,
            'instr_per_madd': valu, 'mad_u64_u32_per_madd': cnt['mad_u64_u32'], 'half_rate_per_madd': cnt['half_rate'], 'full_rate_per_madd': cnt['full_rate'],
            'scalar_or_memory_per_madd': cnt['scalar_or_memory'],
-           'rate_mad_u64_u32': r_mad, 'rate_half_rate_class': r_slow, 'rate_valu32': r_fast, 'rates_measured_at': 'W = 3 waves per SIMD, all 1024 SIMDs busy (clock sags to ~1.5-1.8 GHz under this load)',
+           'rate_mad_u64_u32': r_mad, 'rate_half_rate_class': r_slow, 'rate_valu32': r_fast, 'rates_measured_at': 'W = 3 waves per SIMD, all 1024 SIMDs busy (sclk 2.1-2.2 GHz under this load: profiles/r02_power_clock_trace.json)',
            'capacity_madd_per_s_from_single_op_rates': 1.0 / t,
            'mix_probe_lane_ops_per_s_by_waves_per_simd': mix, 'mix_probe_best': mix_best,
            'capacity_madd_per_s': (mix_best / valu) if mix_best else 1.0 / t,
            'capacity_note': 'capacity = best rate the mix probe sustains at any occupancy / VALU instructions of one mixed addition; the single-op rates give a lower '
-                            'figure because a lone instruction type draws a different clock (the part is power-limited: 1.4-2.2 GHz in these loops)',
+                            'figure because the mix interleaves 2-cycle and 4-cycle instructions (one 4-cycle wave-instruction per SIMD at 2.15 GHz is 35 T lane-ops/s)',
            'unmeasured_ops_priced_fast': dict(unknown),
            'source': 'profiles/r02_rate_probe.txt + profiles/r02_accumulate_isa_histogram.txt via tools/valu_model.py'}
     json.dump(doc, open(out, 'w'), indent=1)
