@@ -22,9 +22,14 @@ const inputs = require("../tests/golden/ref/inputs_example.json");
   const many = await Promise.all([0, 1, 2, 3].map(() => groth16.fullProve(inputs, wasm, zkey)));
   let concurrentOk = true;
   for (const m of many) concurrentOk = concurrentOk && JSON.stringify(m.publicSignals) === JSON.stringify(publicSignals) && (!vk || await groth16.verify(vk, m.publicSignals, m.proof));
+  // a batch over a pool of devices (device 0 listed twice: two contexts, two host threads): voter 1 fails an assert, the others equal fullProve with the same (r, s)
+  const batch = await groth16.fullProveBatch([inputs, Object.assign({}, inputs, { nullifier: "1" }), inputs], wasm, zkey,
+    { devices: [0, 0], rs: [[12345n, 67890n], [1n, 2n], [12345n, 67890n]] });
+  const batchOk = batch.length === 3 && JSON.stringify(batch[0]) === JSON.stringify(b) && JSON.stringify(batch[2]) === JSON.stringify(b) &&
+    batch[1] instanceof Error && /Assert Failed/.test(String(batch[1]));
   let badInputRejected = false;
   try { await groth16.fullProve(Object.assign({}, inputs, { nullifier: "1" }), wasm, zkey); } catch (e) { badInputRejected = /Assert Failed/.test(String(e)); }
   let unknownWasmRejected = false;
   try { await groth16.fullProve(inputs, Buffer.from("not a circuit"), zkey); } catch (e) { unknownWasmRejected = /unknown circuit wasm/.test(String(e)); }
-  console.log(JSON.stringify({ ms, publicSignals, verified, twoStepEqual, concurrentOk, badInputRejected, unknownWasmRejected, wasm: wasm ? "by sha256" : "native nLevels=160" }));
+  console.log(JSON.stringify({ ms, publicSignals, verified, twoStepEqual, concurrentOk, batchOk, badInputRejected, unknownWasmRejected, wasm: wasm ? "by sha256" : "native nLevels=160" }));
 })().catch((e) => { console.error(String(e)); process.exit(1); });

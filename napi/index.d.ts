@@ -7,6 +7,9 @@ export declare const groth16: {
   /** wasmFile names the circuit by its SHA-256 (dev/160 circuit.wasm -> native nLevels = 160); null + opts.nLevels for the build's test keys */
   fullProve(input: CircuitInput, wasmFile: Artifact | null, zkeyFile: Artifact, logger?: unknown, opts?: ProveOptions):
     Promise<{ proof: Groth16Proof; publicSignals: string[] }>;
+  /** not in snarkjs: many voters in one call over opts.devices (one context, key and host thread per GPU); an Error entry = that voter failed a circuit assert */
+  fullProveBatch(inputs: CircuitInput[], wasmFile: Artifact | null, zkeyFile: Artifact,
+    opts?: { nLevels?: number; devices?: number[]; rs?: Array<[bigint | string, bigint | string]> }): Promise<Array<{ proof: Groth16Proof; publicSignals: string[] } | Error>>;
   prove(zkeyFile: Artifact, wtnsFile: Artifact, logger?: unknown, opts?: ProveOptions): Promise<{ proof: Groth16Proof; publicSignals: string[] }>;
   verify(vk: object, publicSignals: string[], proof: Groth16Proof): Promise<boolean>;
 };

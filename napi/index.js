@@ -57,6 +57,8 @@ function toJson(out) {
   for (let i = 0; i < out.publicSignals.length / 32; i++) publicSignals.push(fromLe(out.publicSignals, 32 * i).toString());
   return { proof, publicSignals };
 }
+const ASSERT_SITE = { 1: "ZkFranchiseProofCircuit line: 72", 2: "ZkFranchiseProofCircuit line: 90", 3: "ZkFranchiseProofCircuit line: 103",
+  4: "ZkFranchiseProofCircuit line: 114", 5: "SMTLevIns line: 93", 6: "input >= field order" };
 const blind = (opts, k) => (opts && opts[k] !== undefined ? le32(opts[k]) : null);      // null: drawn uniformly in Fr by the library
 
 const wtns = {
@@ -73,6 +75,22 @@ const groth16 = {
   async fullProve(input, wasmFile, zkeyFile, logger, opts) {
     const nLevels = circuitNLevels(wasmFile, opts);
     return toJson(await native.fullProveRaw(flatten(input, nLevels), nLevels, readArtifact(zkeyFile), blind(opts, "r"), blind(opts, "s"), LIB));
+  },
+  // Not in snarkjs: a census worth of voters in one call, split over opts.devices (default [0]) -- one context, resident key and host thread per GPU
+  // (zkc_pool_* in include/zkcensus.h).  Resolves to one entry per voter, in order: {proof, publicSignals}, or an Error for a voter whose inputs fail
+  // a circuit assert (the others are unaffected).  opts.rs: [[r, s], ...] per voter for reproducible bytes.
+  async fullProveBatch(inputs, wasmFile, zkeyFile, opts) {
+    const nLevels = circuitNLevels(wasmFile, opts);
+    const devs = Buffer.alloc(4 * ((opts && opts.devices) || [0]).length);
+    ((opts && opts.devices) || [0]).forEach((d, i) => devs.writeInt32LE(d, 4 * i));
+    const rs = opts && opts.rs ? Buffer.concat(opts.rs.map(([r, s]) => Buffer.concat([le32(r), le32(s)]))) : null;
+    const out = await native.fullProveBatchRaw(Buffer.concat(inputs.map((x) => flatten(x, nLevels))), nLevels, readArtifact(zkeyFile), devs, rs, LIB);
+    const np = out.publicSignals.length / inputs.length;
+    return inputs.map((_, i) => {
+      const st = out.status.readInt32LE(4 * i);
+      if (st !== 0) return new Error(`Error: Assert Failed. Error in template ${ASSERT_SITE[st] || "?"}`);
+      return toJson({ proof: out.proofs.subarray(256 * i, 256 * i + 256), publicSignals: out.publicSignals.subarray(np * i, np * i + np) });
+    });
   },
   async prove(zkeyFile, wtnsFile, logger, opts) {
     return toJson(await native.proveRaw(readArtifact(zkeyFile), readArtifact(wtnsFile), blind(opts, "r"), blind(opts, "s"), LIB));

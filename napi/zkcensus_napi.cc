@@ -31,10 +31,14 @@ struct Api {
     unsigned long (*wtns_write)(const void*, uint32_t, void*, unsigned long) = nullptr;
     int (*from_wasm)(const void*, size_t, char*) = nullptr; int (*fingerprint)(const void*, size_t, uint8_t*) = nullptr;
     void (*random_scalars)(uint8_t*, size_t) = nullptr;
+    int (*pool_create)(const int*, int, void**) = nullptr; void (*pool_destroy)(void*) = nullptr; const char* (*pool_err)(const void*) = nullptr;
+    int (*pool_zkey_load)(void*, const void*, size_t) = nullptr; void* (*pool_zkey)(void*, int) = nullptr;
+    int (*pool_fullprove)(void*, const void*, int, const uint8_t*, uint8_t*, uint8_t*, int32_t*) = nullptr;
     std::string err;
 } g;
 std::mutex g_mu;                       // guards everything below and every use of the shared context / key
 void* g_ctx = nullptr; void* g_key = nullptr; uint8_t g_key_sha[32];
+void* g_pool = nullptr; std::vector<int> g_pool_devs; uint8_t g_pool_sha[32]; bool g_pool_has_key = false;      // fullProveBatch: one context + key per listed device
 
 bool load_api(const std::string& hint) {               // caller holds g_mu
     if (g.h) return true;
@@ -47,6 +51,8 @@ bool load_api(const std::string& hint) {               // caller holds g_mu
     SYM(witness, "zkc_witness") SYM(zkey_load, "zkc_zkey_load") SYM(zkey_free, "zkc_zkey_free") SYM(zkey_info, "zkc_zkey_info") SYM(prove, "zkc_prove")
     SYM(verify, "zkc_verify") SYM(verify_err, "zkc_verify_last_error") SYM(wtns_parse, "zkc_wtns_parse") SYM(wtns_write, "zkc_wtns_write")
     SYM(from_wasm, "zkc_circuit_nlevels_from_wasm") SYM(fingerprint, "zkc_zkey_fingerprint") SYM(random_scalars, "zkc_random_scalars")
+    SYM(pool_create, "zkc_pool_create") SYM(pool_destroy, "zkc_pool_destroy") SYM(pool_err, "zkc_pool_last_error") SYM(pool_zkey_load, "zkc_pool_zkey_load")
+    SYM(pool_zkey, "zkc_pool_zkey") SYM(pool_fullprove, "zkc_pool_fullprove_batch")
 #undef SYM
     g.h = h;
     return true;
@@ -73,10 +79,11 @@ const char* assert_site(int status) {                   // census.circom line of
     return "?";
 }
 
-enum Kind { FULLPROVE, PROVE, WITNESS };
+enum Kind { FULLPROVE, PROVE, WITNESS, BATCH };
 struct Work {
     napi_async_work work = nullptr; napi_deferred deferred = nullptr; Kind kind = FULLPROVE;
     std::vector<uint8_t> inputs, zkey, wtns_file, r, s, proof, pub, out; int nLevels = 160; std::string err; std::string libhint;
+    std::vector<int> devices; std::vector<uint8_t> rs; std::vector<int32_t> status;      // BATCH
 };
 // inputs -> witness payload (nw x 32 B); caller holds g_mu
 bool run_witness(Work* w, std::vector<uint8_t>& wtns) {
@@ -98,10 +105,35 @@ bool run_prove(Work* w, const uint8_t* payload, uint32_t nw) {      // caller ho
     if (g.prove(g_key, payload, nw, rs, rs + 32, w->proof.data(), w->pub.data())) { w->err = g.last_error(g_ctx); return false; }
     return true;
 }
+// B voters over the listed devices (zkc_pool_*): one context, resident key and host thread per device; caller holds g_mu
+bool run_batch(Work* w) {
+    const int ni = g.n_inputs(w->nLevels);
+    if (ni <= 0 || w->inputs.empty() || w->inputs.size() % ((size_t)ni * 32)) { w->err = "Not all inputs have been set"; return false; }
+    const int B = (int)(w->inputs.size() / ((size_t)ni * 32));
+    if (!w->rs.empty() && w->rs.size() != (size_t)B * 64) { w->err = "rs must hold 64 bytes (r || s) per voter"; return false; }
+    if (w->devices.empty()) w->devices.push_back(0);
+    uint8_t d[32]; if (g.fingerprint(w->zkey.data(), w->zkey.size(), d)) { w->err = "not a zkey file"; return false; }
+    if (g_pool && g_pool_devs != w->devices) { g.pool_destroy(g_pool); g_pool = nullptr; g_pool_has_key = false; }
+    if (!g_pool) {
+        if (g.pool_create(w->devices.data(), (int)w->devices.size(), &g_pool)) { g_pool = nullptr; w->err = g.pool_err(nullptr); return false; }
+        g_pool_devs = w->devices;
+    }
+    if (!g_pool_has_key || memcmp(d, g_pool_sha, 32)) {
+        g_pool_has_key = false;
+        if (g.pool_zkey_load(g_pool, w->zkey.data(), w->zkey.size())) { w->err = g.pool_err(g_pool); return false; }
+        memcpy(g_pool_sha, d, 32); g_pool_has_key = true;
+    }
+    uint32_t nv, np, dn; g.zkey_info(g.pool_zkey(g_pool, 0), &nv, &np, &dn);
+    w->proof.resize(256 * (size_t)B); w->pub.resize(32 * (size_t)np * B); w->status.assign((size_t)B, 0);
+    const int rc = g.pool_fullprove(g_pool, w->inputs.data(), B, w->rs.empty() ? nullptr : w->rs.data(), w->proof.data(), w->pub.data(), w->status.data());
+    if (rc && rc != 7 /* ZKC_ERR_WITNESS: per-voter status says which */) { w->err = g.pool_err(g_pool); return false; }
+    return true;
+}
 void execute(napi_env, void* data) {
     Work* w = (Work*)data;
     std::lock_guard<std::mutex> guard(g_mu);
     if (!load_api(w->libhint)) { w->err = g.err; return; }
+    if (w->kind == BATCH) { run_batch(w); return; }
     if (!ensure_ctx(w->err)) return;
     if (w->kind == PROVE) {
         const uint8_t* payload; uint32_t nw;
@@ -127,6 +159,13 @@ void complete(napi_env env, napi_status, void* data) {
     } else if (w->kind == WITNESS) {
         napi_value b; void* dst; napi_create_buffer_copy(env, w->out.size(), w->out.data(), &dst, &b);
         napi_resolve_deferred(env, w->deferred, b);
+    } else if (w->kind == BATCH) {
+        napi_value obj, p, q, st; void* dst;
+        napi_create_object(env, &obj);
+        napi_create_buffer_copy(env, w->proof.size(), w->proof.data(), &dst, &p); napi_create_buffer_copy(env, w->pub.size(), w->pub.data(), &dst, &q);
+        napi_create_buffer_copy(env, w->status.size() * 4, w->status.data(), &dst, &st);
+        napi_set_named_property(env, obj, "proofs", p); napi_set_named_property(env, obj, "publicSignals", q); napi_set_named_property(env, obj, "status", st);
+        napi_resolve_deferred(env, w->deferred, obj);
     } else {
         napi_value obj, p, q; void* dst;
         napi_create_object(env, &obj);
@@ -154,6 +193,17 @@ napi_value FullProveRaw(napi_env env, napi_callback_info info) {
     w->inputs = buf_arg(env, a[0]); napi_get_value_int32(env, a[1], &w->nLevels); w->zkey = buf_arg(env, a[2]); w->r = buf_arg(env, a[3]); w->s = buf_arg(env, a[4]);
     w->libhint = str_arg(env, a[5]);
     return queue(env, w, "zkcensus.fullProve");
+}
+// fullProveBatchRaw(flatInputs: Buffer (B x nInputs x 32), nLevels, zkey: Buffer, devices: Buffer (int32 LE each), rs: Buffer (B x 64)|null, libPath)
+//   -> Promise<{proofs: Buffer (B x 256), publicSignals: Buffer (B x nPublic x 32), status: Buffer (B x int32 LE, ZKC_W_*)}>
+napi_value FullProveBatchRaw(napi_env env, napi_callback_info info) {
+    size_t argc = 6; napi_value a[6]; napi_get_cb_info(env, info, &argc, a, nullptr, nullptr);
+    Work* w = new Work(); w->kind = BATCH;
+    w->inputs = buf_arg(env, a[0]); napi_get_value_int32(env, a[1], &w->nLevels); w->zkey = buf_arg(env, a[2]);
+    const std::vector<uint8_t> dv = buf_arg(env, a[3]);
+    for (size_t i = 0; i + 4 <= dv.size(); i += 4) { int32_t x; memcpy(&x, dv.data() + i, 4); w->devices.push_back(x); }
+    w->rs = buf_arg(env, a[4]); w->libhint = str_arg(env, a[5]);
+    return queue(env, w, "zkcensus.fullProveBatch");
 }
 // proveRaw(zkey: Buffer, wtnsFileImage: Buffer, r|null, s|null, libPath) -> Promise<{proof, publicSignals}>          (snarkjs groth16.prove)
 napi_value ProveRaw(napi_env env, napi_callback_info info) {
@@ -191,7 +241,7 @@ napi_value VerifyJson(napi_env env, napi_callback_info info) {
 napi_value Init(napi_env env, napi_value exports) {
     napi_value f;
 #define EXPORT(name, fn) napi_create_function(env, name, NAPI_AUTO_LENGTH, fn, nullptr, &f); napi_set_named_property(env, exports, name, f);
-    EXPORT("fullProveRaw", FullProveRaw) EXPORT("proveRaw", ProveRaw) EXPORT("witnessRaw", WitnessRaw) EXPORT("circuitFromWasm", CircuitFromWasm) EXPORT("verifyJson", VerifyJson)
+    EXPORT("fullProveRaw", FullProveRaw) EXPORT("fullProveBatchRaw", FullProveBatchRaw) EXPORT("proveRaw", ProveRaw) EXPORT("witnessRaw", WitnessRaw) EXPORT("circuitFromWasm", CircuitFromWasm) EXPORT("verifyJson", VerifyJson)
 #undef EXPORT
     return exports;
 }

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 def test_node_addon_full_surface_on_gpu():
     """The reference's host language: node napi/example.js <zkey> <vkey> = the ts_inputs/src/example.ts:358-362 call through the N-API addon on the
-    GPU -- fullProve, wtns.calculate + prove with injected (r, s), four concurrent fullProve calls, a failing assert, an unknown wasm."""
+    GPU -- fullProve, wtns.calculate + prove with injected (r, s), four concurrent fullProve calls, a batch over a two-entry device pool, a failing assert, an unknown wasm."""
     import os, shutil, subprocess
     from zkcensus_amd import setup
     node = shutil.which('node')
@@ -25,4 +25,4 @@ def test_node_addon_full_surface_on_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads(r.stdout.strip().splitlines()[-1])
     assert j['verified'] is True and j['publicSignals'] == ol.load_json('ref/signals.json')
-    assert j['twoStepEqual'] and j['concurrentOk'] and j['badInputRejected'] and j['unknownWasmRejected']
+    assert j['twoStepEqual'] and j['concurrentOk'] and j['batchOk'] and j['badInputRejected'] and j['unknownWasmRejected']
