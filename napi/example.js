@@ -12,6 +12,8 @@ const inputs = require("../tests/golden/ref/inputs_example.json");
   const { proof, publicSignals } = await groth16.fullProve(inputs, wasm, zkey);
   const ms = Date.now() - t0;
   const verified = vk ? await groth16.verify(vk, publicSignals, proof) : null;
+  let msWarm = 1e9;                                  // key resident, artifact cached: what a service sees per voter
+  for (let i = 0; i < 5; i++) { const t = process.hrtime.bigint(); await groth16.fullProve(inputs, wasm, zkey); msWarm = Math.min(msWarm, Number(process.hrtime.bigint() - t) / 1e6); }
   // two-step path with injected (r, s): deterministic, equal to fullProve with the same scalars
   const mem = { type: "mem" };
   await wtns.calculate(inputs, wasm, mem);
@@ -31,5 +33,5 @@ const inputs = require("../tests/golden/ref/inputs_example.json");
   try { await groth16.fullProve(Object.assign({}, inputs, { nullifier: "1" }), wasm, zkey); } catch (e) { badInputRejected = /Assert Failed/.test(String(e)); }
   let unknownWasmRejected = false;
   try { await groth16.fullProve(inputs, Buffer.from("not a circuit"), zkey); } catch (e) { unknownWasmRejected = /unknown circuit wasm/.test(String(e)); }
-  console.log(JSON.stringify({ ms, publicSignals, verified, twoStepEqual, concurrentOk, batchOk, badInputRejected, unknownWasmRejected, wasm: wasm ? "by sha256" : "native nLevels=160" }));
+  console.log(JSON.stringify({ ms, msWarm: Math.round(msWarm * 100) / 100, publicSignals, verified, twoStepEqual, concurrentOk, batchOk, badInputRejected, unknownWasmRejected, wasm: wasm ? "by sha256" : "native nLevels=160" }));
 })().catch((e) => { console.error(String(e)); process.exit(1); });

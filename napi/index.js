@@ -33,8 +33,17 @@ function flatten(input, nLevels) {
   }
   return Buffer.concat(parts);
 }
+// a path is read once per (path, size, mtime): snarkjs re-reads the 55 MB .zkey on every fullProve, which here would cost more than the proof
+const fileCache = new Map();
 function readArtifact(f) {
-  if (typeof f === "string") return fs.readFileSync(f);
+  if (typeof f === "string") {
+    const st = fs.statSync(f), key = `${st.size}:${st.mtimeMs}`, hit = fileCache.get(f);
+    if (hit && hit.key === key) return hit.data;
+    const data = fs.readFileSync(f);
+    if (fileCache.size >= 4) fileCache.delete(fileCache.keys().next().value);
+    fileCache.set(f, { key, data });
+    return data;
+  }
   if (f && f.type === "mem") return Buffer.from(f.data);
   return Buffer.from(f);
 }

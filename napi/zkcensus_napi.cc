@@ -63,11 +63,11 @@ bool ensure_ctx(std::string& err) {                     // caller holds g_mu
     if (g.ctx_create(d ? atoi(d) : 0, &g_ctx)) { g_ctx = nullptr; err = g.last_error(nullptr); return false; }
     return true;
 }
-bool ensure_key(const std::vector<uint8_t>& zkey, std::string& err) {      // caller holds g_mu; identity = zkc_zkey_fingerprint of the .zkey image
-    uint8_t d[32]; if (g.fingerprint(zkey.data(), zkey.size(), d)) { err = "not a zkey file"; return false; }
+bool ensure_key(const uint8_t* zkey, size_t zkey_n, std::string& err) {      // caller holds g_mu; identity = zkc_zkey_fingerprint of the .zkey image
+    uint8_t d[32]; if (!zkey || g.fingerprint(zkey, zkey_n, d)) { err = "not a zkey file"; return false; }
     if (g_key && !memcmp(d, g_key_sha, 32)) return true;
     if (g_key) { g.zkey_free(g_key); g_key = nullptr; }                     // one resident key: the old one's HBM is released first
-    if (g.zkey_load(g_ctx, zkey.data(), zkey.size(), &g_key)) { g_key = nullptr; err = g.last_error(g_ctx); return false; }
+    if (g.zkey_load(g_ctx, zkey, zkey_n, &g_key)) { g_key = nullptr; err = g.last_error(g_ctx); return false; }
     memcpy(g_key_sha, d, 32);
     return true;
 }
@@ -84,6 +84,8 @@ struct Work {
     napi_async_work work = nullptr; napi_deferred deferred = nullptr; Kind kind = FULLPROVE;
     std::vector<uint8_t> inputs, zkey, wtns_file, r, s, proof, pub, out; int nLevels = 160; std::string err; std::string libhint;
     std::vector<int> devices; std::vector<uint8_t> rs; std::vector<int32_t> status;      // BATCH
+    // the .zkey image is NOT copied (tens of MB per call): the JS Buffer is pinned by a reference until complete() and read in place by the worker
+    napi_ref zkey_ref = nullptr; const uint8_t* zkey_p = nullptr; size_t zkey_n = 0;
 };
 // inputs -> witness payload (nw x 32 B); caller holds g_mu
 bool run_witness(Work* w, std::vector<uint8_t>& wtns) {
@@ -95,7 +97,7 @@ bool run_witness(Work* w, std::vector<uint8_t>& wtns) {
     return true;
 }
 bool run_prove(Work* w, const uint8_t* payload, uint32_t nw) {      // caller holds g_mu
-    if (!ensure_key(w->zkey, w->err)) return false;
+    if (!ensure_key(w->zkey_p, w->zkey_n, w->err)) return false;
     uint32_t nv, np, dn; g.zkey_info(g_key, &nv, &np, &dn);
     if (nw != nv) { w->err = "Invalid witness length. Circuit: " + std::to_string(nv) + ", witness: " + std::to_string(nw); return false; }
     uint8_t rs[64];
@@ -112,7 +114,7 @@ bool run_batch(Work* w) {
     const int B = (int)(w->inputs.size() / ((size_t)ni * 32));
     if (!w->rs.empty() && w->rs.size() != (size_t)B * 64) { w->err = "rs must hold 64 bytes (r || s) per voter"; return false; }
     if (w->devices.empty()) w->devices.push_back(0);
-    uint8_t d[32]; if (g.fingerprint(w->zkey.data(), w->zkey.size(), d)) { w->err = "not a zkey file"; return false; }
+    uint8_t d[32]; if (!w->zkey_p || g.fingerprint(w->zkey_p, w->zkey_n, d)) { w->err = "not a zkey file"; return false; }
     if (g_pool && g_pool_devs != w->devices) { g.pool_destroy(g_pool); g_pool = nullptr; g_pool_has_key = false; }
     if (!g_pool) {
         if (g.pool_create(w->devices.data(), (int)w->devices.size(), &g_pool)) { g_pool = nullptr; w->err = g.pool_err(nullptr); return false; }
@@ -120,7 +122,7 @@ bool run_batch(Work* w) {
     }
     if (!g_pool_has_key || memcmp(d, g_pool_sha, 32)) {
         g_pool_has_key = false;
-        if (g.pool_zkey_load(g_pool, w->zkey.data(), w->zkey.size())) { w->err = g.pool_err(g_pool); return false; }
+        if (g.pool_zkey_load(g_pool, w->zkey_p, w->zkey_n)) { w->err = g.pool_err(g_pool); return false; }
         memcpy(g_pool_sha, d, 32); g_pool_has_key = true;
     }
     uint32_t nv, np, dn; g.zkey_info(g.pool_zkey(g_pool, 0), &nv, &np, &dn);
@@ -173,11 +175,18 @@ void complete(napi_env env, napi_status, void* data) {
         napi_set_named_property(env, obj, "proof", p); napi_set_named_property(env, obj, "publicSignals", q);
         napi_resolve_deferred(env, w->deferred, obj);
     }
+    if (w->zkey_ref) napi_delete_reference(env, w->zkey_ref);
     napi_delete_async_work(env, w->work); delete w;
 }
 std::vector<uint8_t> buf_arg(napi_env env, napi_value v) {
     bool isb = false; napi_is_buffer(env, v, &isb); if (!isb) return {};
     void* p; size_t n; napi_get_buffer_info(env, v, &p, &n); return std::vector<uint8_t>((uint8_t*)p, (uint8_t*)p + n);
+}
+void pin_zkey(napi_env env, napi_value v, Work* w) {
+    bool isb = false; napi_is_buffer(env, v, &isb); if (!isb) return;
+    void* p; size_t n; napi_get_buffer_info(env, v, &p, &n);
+    if (napi_create_reference(env, v, 1, &w->zkey_ref) != napi_ok) { w->zkey_ref = nullptr; w->zkey.assign((uint8_t*)p, (uint8_t*)p + n); p = w->zkey.data(); }
+    w->zkey_p = (const uint8_t*)p; w->zkey_n = n;
 }
 std::string str_arg(napi_env env, napi_value v) { size_t n = 0; napi_get_value_string_utf8(env, v, nullptr, 0, &n); std::string s(n, 0); napi_get_value_string_utf8(env, v, &s[0], n + 1, &n); return s; }
 napi_value queue(napi_env env, Work* w, const char* what) {
@@ -190,7 +199,7 @@ napi_value queue(napi_env env, Work* w, const char* what) {
 napi_value FullProveRaw(napi_env env, napi_callback_info info) {
     size_t argc = 6; napi_value a[6]; napi_get_cb_info(env, info, &argc, a, nullptr, nullptr);
     Work* w = new Work(); w->kind = FULLPROVE;
-    w->inputs = buf_arg(env, a[0]); napi_get_value_int32(env, a[1], &w->nLevels); w->zkey = buf_arg(env, a[2]); w->r = buf_arg(env, a[3]); w->s = buf_arg(env, a[4]);
+    w->inputs = buf_arg(env, a[0]); napi_get_value_int32(env, a[1], &w->nLevels); pin_zkey(env, a[2], w); w->r = buf_arg(env, a[3]); w->s = buf_arg(env, a[4]);
     w->libhint = str_arg(env, a[5]);
     return queue(env, w, "zkcensus.fullProve");
 }
@@ -199,7 +208,7 @@ napi_value FullProveRaw(napi_env env, napi_callback_info info) {
 napi_value FullProveBatchRaw(napi_env env, napi_callback_info info) {
     size_t argc = 6; napi_value a[6]; napi_get_cb_info(env, info, &argc, a, nullptr, nullptr);
     Work* w = new Work(); w->kind = BATCH;
-    w->inputs = buf_arg(env, a[0]); napi_get_value_int32(env, a[1], &w->nLevels); w->zkey = buf_arg(env, a[2]);
+    w->inputs = buf_arg(env, a[0]); napi_get_value_int32(env, a[1], &w->nLevels); pin_zkey(env, a[2], w);
     const std::vector<uint8_t> dv = buf_arg(env, a[3]);
     for (size_t i = 0; i + 4 <= dv.size(); i += 4) { int32_t x; memcpy(&x, dv.data() + i, 4); w->devices.push_back(x); }
     w->rs = buf_arg(env, a[4]); w->libhint = str_arg(env, a[5]);
@@ -209,7 +218,7 @@ napi_value FullProveBatchRaw(napi_env env, napi_callback_info info) {
 napi_value ProveRaw(napi_env env, napi_callback_info info) {
     size_t argc = 5; napi_value a[5]; napi_get_cb_info(env, info, &argc, a, nullptr, nullptr);
     Work* w = new Work(); w->kind = PROVE;
-    w->zkey = buf_arg(env, a[0]); w->wtns_file = buf_arg(env, a[1]); w->r = buf_arg(env, a[2]); w->s = buf_arg(env, a[3]); w->libhint = str_arg(env, a[4]);
+    pin_zkey(env, a[0], w); w->wtns_file = buf_arg(env, a[1]); w->r = buf_arg(env, a[2]); w->s = buf_arg(env, a[3]); w->libhint = str_arg(env, a[4]);
     return queue(env, w, "zkcensus.prove");
 }
 // witnessRaw(flatInputs: Buffer, nLevels, libPath) -> Promise<Buffer>  (.wtns file image; snarkjs wtns.calculate)

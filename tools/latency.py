@@ -37,6 +37,18 @@ def main():
         stages[name] = round(ms.value, 3)
     ctx._lib.zkc_profile_enable(ctx._h, 0)
     res['stage_ms_overlapped_not_additive'] = stages
+    # the rapidsnark entry point a Go caller reaches through prover.Prove (zk_census_test.go:89): whole file images in, JSON out, key identified per call
+    from zkcensus_amd import groth16
+    zk = open(zp, 'rb').read(); wt = groth16.wtns.calculate(ex)
+    pb, ub, err = ctypes.create_string_buffer(4096), ctypes.create_string_buffer(4096), ctypes.create_string_buffer(256)
+    best = None
+    for it in range(5):
+        ps, us = ctypes.c_ulong(4096), ctypes.c_ulong(4096)
+        t0 = time.perf_counter(); rc = ctx._lib.groth16_prover(zk, len(zk), wt, len(wt), pb, ctypes.byref(ps), ub, ctypes.byref(us), err, 256); dt = time.perf_counter() - t0
+        assert rc == 0, err.value
+        if it > 0:                                           # the first call loads the key into the entry point's own context
+            best = dt if best is None else min(best, dt)
+    res['groth16_prover_file_images_ms'] = round(best * 1e3, 2)
     res['key_load_and_precompute_s'] = round(t_load, 2)
     print(json.dumps(res))
 
