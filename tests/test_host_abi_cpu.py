@@ -110,7 +110,9 @@ def test_verifier_strictness_and_return_codes():
 def test_random_scalars_are_field_elements():
     lib = _native.load()
     buf = ctypes.create_string_buffer(32 * 4000)
-    lib.zkc_random_scalars(buf, 4000)
+    import time
+    t0 = time.perf_counter(); lib.zkc_random_scalars(buf, 4000); dt = time.perf_counter() - t0
+    assert dt < 0.1, 'drawing 4000 scalars took %.0f ms: the blinding of a 1024-voter batch must not cost more than the proofs' % (dt * 1e3)
     v = [int.from_bytes(buf.raw[32 * i:32 * i + 32], 'little') for i in range(4000)]
     assert max(v) < ol.R and len(set(v)) == 4000
     assert max(v) > ol.R * 0.99 and sum(1 for x in v if x >> 248) > 3000        # uniform in Fr, not capped at 2^248 as in round 1
