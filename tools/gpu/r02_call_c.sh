@@ -17,4 +17,5 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$O/pmc_fe
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$O/pmc_write -- python3 $R/bench.py --batch 96 --steps 1 --warmup 0 --no-cpu-baseline --no-verify > $R/$O/pmc_write.log 2>&1; rc=$?; echo "pmc write rc=$rc" | tee -a $R/$O/steps.log; stop_if_killed $rc pmc_write
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $R/$O/pmc_sq -- python3 $R/bench.py --batch 96 --steps 1 --warmup 0 --no-cpu-baseline --no-verify > $R/$O/pmc_sq.log 2>&1; rc=$?; echo "pmc sq rc=$rc" | tee -a $R/$O/steps.log
 hipcc --offload-arch=gfx950 -O3 -Wno-unused-result $R/tools/probe/gather_probe.hip -o /tmp/gather_probe > /dev/null 2>&1 && timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$O/pmc_calib -- /tmp/gather_probe > $R/$O/gather_probe.txt 2>&1; echo "calibration rc=$?" | tee -a $R/$O/steps.log
+timeout -k 10 300 python $R/bench.py --steps 200 --warmup 2 --no-cpu-baseline --no-verify > $R/$O/bench_200.json 2> $R/$O/bench_200.err; echo "bench200 rc=$?" | tee -a $R/$O/steps.log; head -c 260 $R/$O/bench_200.json; echo
 exit 0
