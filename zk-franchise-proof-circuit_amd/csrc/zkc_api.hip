@@ -158,6 +158,7 @@ extern "C" void zkc_ctx_destroy(zkc_ctx* ctx) {
     for (auto& r : ctx->prof.pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : ctx->prof.free_events) (void)hipEventDestroy(e);
     for (auto& kv : ctx->tmpl) (void)hipFree(kv.second);
+    for (auto& kv : ctx->ntt_tw) { if (kv.second.fwd) (void)hipFree(kv.second.fwd); if (kv.second.inv) (void)hipFree(kv.second.inv); if (kv.second.ninv) (void)hipFree(kv.second.ninv); }
     if (ctx->d_ptab_mem) (void)hipFree(ctx->d_ptab_mem);
     if (ctx->d_ptab29_mem) (void)hipFree(ctx->d_ptab29_mem);
     if (ctx->d_scratch_in) (void)hipFree(ctx->d_scratch_in);

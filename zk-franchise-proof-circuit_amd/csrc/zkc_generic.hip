@@ -19,8 +19,6 @@ Fr root_of_unity(int logn) {            // 5^((r-1)/2^28) squared down to order 
     for (int i = 28; i > logn; i--) w = w * w;
     return w;
 }
-struct TwiddleSet { uint32_t *fwd = nullptr, *inv = nullptr; Fr* ninv = nullptr; };
-std::map<std::pair<zkc_ctx*, int>, TwiddleSet> g_tw;      // per (context, log n); lives as long as the process (a few MB)
 
 __global__ void __launch_bounds__(256) zkc_fill_fr(Fr* __restrict__ dst, Fr v, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -66,26 +64,24 @@ extern "C" int zkc_ntt_dev(zkc_ctx* ctx, const void* d_src, void* d_dst, int log
     ZKC_LOCK(ctx);
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const uint32_t n = 1u << logn;
-    static std::mutex g_tw_mu;                      // the map is shared by all contexts
-    TwiddleSet* tp; { std::lock_guard<std::mutex> g(g_tw_mu); tp = &g_tw[{ctx, logn}]; }      // std::map nodes are stable
-    TwiddleSet& t = *tp;
+    zkc_ctx::TwiddleSet& t = ctx->ntt_tw[logn];     // owned by the context (its lock is held): released with it, never inherited by another device's context
     if (!t.fwd) {
         const Fr w = root_of_unity(logn), wi = fp_inv<FrParams>(w);
         std::vector<Fr> f(n / 2), b(n / 2);
         f[0] = b[0] = Fr::one(); for (uint32_t i = 1; i < n / 2; i++) { f[i] = f[i - 1] * w; b[i] = b[i - 1] * wi; }
         Fr* d_tmp = nullptr; int rc;
         ZKC_HIP_CHECK(ctx, hipMalloc((void**)&d_tmp, (size_t)(n / 2) * sizeof(Fr)));
-        ZKC_HIP_CHECK(ctx, hipMalloc((void**)&t.ninv, (size_t)n * sizeof(Fr)));
+        ZKC_HIP_CHECK(ctx, hipMalloc(&t.ninv, (size_t)n * sizeof(Fr)));
         ZKC_HIP_CHECK(ctx, hipMemcpy(d_tmp, f.data(), f.size() * sizeof(Fr), hipMemcpyHostToDevice));
         if ((rc = ntt_make_tw29(ctx, d_tmp, n / 2, &t.fwd))) return rc;
         ZKC_HIP_CHECK(ctx, hipMemcpy(d_tmp, b.data(), b.size() * sizeof(Fr), hipMemcpyHostToDevice));
         if ((rc = ntt_make_tw29(ctx, d_tmp, n / 2, &t.inv))) return rc;
         ZKC_HIP_CHECK(ctx, hipFree(d_tmp));
-        hipLaunchKernelGGL(zkc_fill_fr, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, t.ninv, fp_inv<FrParams>(fp_from_u32<FrParams>(n)), n);
+        hipLaunchKernelGGL(zkc_fill_fr, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (Fr*)t.ninv, fp_inv<FrParams>(fp_from_u32<FrParams>(n)), n);
         ZKC_HIP_CHECK(ctx, hipGetLastError());
     }
     zkc_prof_scope _pn(ctx, ZKC_PROF_NTT, (uint64_t)nvec * 2ull * n * 32, ctx->stream);
-    return ntt_run(ctx, ctx->stream, (const Fr*)d_src, (Fr*)d_dst, inverse ? t.inv : t.fwd, inverse ? t.ninv : nullptr, logn, nvec);
+    return ntt_run(ctx, ctx->stream, (const Fr*)d_src, (Fr*)d_dst, inverse ? t.inv : t.fwd, inverse ? (const Fr*)t.ninv : nullptr, logn, nvec);
 }
 
 // d_out[i] = k_i * base for n scalars (device, standard form 32 B each); base and outputs are affine points in standard form (64 B).

@@ -35,6 +35,8 @@ struct zkc_ctx {
     void* d_ptab_mem = nullptr;
     void* d_ptab29_mem = nullptr;         // the Poseidon constants again as radix-2^29 limbs (witness chains)
     std::map<int, uint32_t*> tmpl;        // nLevels -> device template witness (nWires x 8 u32)
+    struct TwiddleSet { uint32_t *fwd = nullptr, *inv = nullptr; void* ninv = nullptr; };
+    std::map<int, TwiddleSet> ntt_tw;     // log n -> twiddles of the stand-alone NTT entry point (zkc_ntt_dev); freed with the context
     // scratch reused by the host-buffer entry points
     void* d_scratch_in = nullptr; size_t scratch_in_sz = 0;
     void* d_scratch_out = nullptr; size_t scratch_out_sz = 0;
