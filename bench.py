@@ -315,9 +315,11 @@ def main():
             return i, w, p, pub
         t1 = time.perf_counter(); done = []
         with ThreadPoolExecutor(cores) as ex:
-            k = 0
-            while not done or time.perf_counter() - t1 < 12.0:
+            k = 0; budget = float(os.environ.get('ZKC_CPU_BASELINE_SECONDS', '12')); said = t1     # a long budget turns this leg into a parity check of the whole batch
+            while k < B and (not done or time.perf_counter() - t1 < budget):
                 done += list(ex.map(one, order[k:k + cores])); k += cores
+                if time.perf_counter() - said > 30:
+                    said = time.perf_counter(); sys.stderr.write('bench.py: cpu_baseline / parity leg: %d oracle proofs so far\n' % len(done)); sys.stderr.flush()
         cdt = time.perf_counter() - t1
         for i, w, p, pub in done:
             assert bytes(wt[i].cpu().numpy().tobytes()) == w, 'GPU witness of voter %d differs from the CPU oracle' % i
