@@ -79,7 +79,7 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     for (hipEvent_t e : zk->ev_chunk) (void)hipEventDestroy(e);
     for (auto& L : zk->lane) {
         for (hipStream_t q : {L.st, L.st2, L.fin}) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
-        for (void* q : {(void*)L.d_abc, (void*)L.d_t, (void*)L.d_p}) if (q) (void)hipFree(q);
+        for (void* q : {(void*)L.d_abc, (void*)L.d_t, (void*)L.d_p, L.d_fin}) if (q) (void)hipFree(q);
         for (hipEvent_t e : {L.ev_msm, L.ev_msm2, L.ev_sorted, L.ev_ntt, L.ev_mv, L.ev_fin[0], L.ev_fin[1]}) if (e) (void)hipEventDestroy(e);
         msm_work_free(L.w1); msm_work_free(L.w2);
     }
@@ -100,10 +100,11 @@ static int lanes_ensure(zkc_zkey* zk, int inflight) {
     for (int l = 0; l < zk->nlanes; l++) {
         zkc_lane& L = zk->lane[l];
         for (hipStream_t q : {L.st, L.st2, L.fin}) ZKC_HIP_CHECK(ctx, hipStreamSynchronize(q));
-        for (void** q : {(void**)&L.d_abc, (void**)&L.d_t, (void**)&L.d_p}) if (*q) { ZKC_HIP_CHECK(ctx, hipFree(*q)); *q = nullptr; }
+        for (void** q : {(void**)&L.d_abc, (void**)&L.d_t, (void**)&L.d_p, &L.d_fin}) if (*q) { ZKC_HIP_CHECK(ctx, hipFree(*q)); *q = nullptr; }
         msm_work_free(L.w1); msm_work_free(L.w2);
         if ((rc = dmalloc(ctx, &L.d_abc, 3 * (size_t)n * inflight)) || (rc = dmalloc(ctx, &L.d_t, 3 * (size_t)n * inflight)) ||
             (rc = dmalloc(ctx, &L.d_p, 8 * (size_t)n * inflight))) return rc;
+        ZKC_HIP_CHECK(ctx, hipMalloc(&L.d_fin, finalize_scratch_bytes(inflight)));
         if ((rc = msm_work_alloc(ctx, L.w1, per_proof_entries * inflight, per_proof_buckets * inflight, 4 * inflight, false))) return rc;
         if ((rc = msm_work_alloc(ctx, L.w2, (size_t)NWS * nv * inflight, (size_t)msm_half(MSM_C_SMALL) * inflight, inflight, true))) return rc;
     }
@@ -537,7 +538,7 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
         fa.foldA = zk->fold.d_foldA; fa.foldB1 = zk->fold.d_foldB1; fa.foldC = zk->fold.d_foldC; fa.foldB2 = zk->fold.d_foldB2; fa.fold_n = can_fold ? L.n : 0;
         for (int q = 0; q < nb; q++) { fa.dc[q] = fold ? dcq[q] : (uint8_t)255; fa.ds[q] = fold ? dsq[q] : (uint8_t)255; }
         fa.tblDelta1 = zk->d_tblDelta1; fa.tblAlpha1 = zk->d_tblAlpha1; fa.tblBeta1 = zk->d_tblBeta1; fa.tblDelta2 = zk->d_tblDelta2;
-        fa.alpha1 = zk->alpha1; fa.beta2 = zk->beta2; fa.rs = zk->d_rs + 64 * (size_t)p0; fa.out = zk->d_proofs + 256 * (size_t)p0;
+        fa.alpha1 = zk->alpha1; fa.beta2 = zk->beta2; fa.rs = zk->d_rs + 64 * (size_t)p0; fa.out = zk->d_proofs + 256 * (size_t)p0; fa.scratch = LN.d_fin;
         ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm, 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm2, 0));
         if ((rc = finalize_launch(ctx, fin, fa, nb))) return rc;
         ZKC_HIP_CHECK(ctx, hipMemcpyAsync(zk->h_out + 256ull * p0, zk->d_proofs + 256 * (size_t)p0, 256ull * nb, hipMemcpyDeviceToHost, fin));

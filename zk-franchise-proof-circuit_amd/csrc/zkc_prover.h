@@ -46,6 +46,7 @@ struct FinalizeArgs {
     const G1Affine *tblDelta1, *tblAlpha1, *tblBeta1; const G2Affine* tblDelta2;   // 32 x 255 fixed-base tables
     G1Affine alpha1; G2Affine beta2;
     const uint8_t* rs; uint8_t* out;                    // device: nproofs x 64 (r || s) -> nproofs x 256 proof bytes
+    void* scratch;                                      // finalize_scratch_bytes(nproofs) of device memory: products and window tables of the lane-per-product kernels (nullptr: one wave per task)
 };
 // The (digit, point) entries of a pass are bucketed JOB BY JOB (an entry never leaves its job's region [ent_off, ent_off + count nw) of the
 // value arrays), in two counting passes instead of a device-wide key sort: the job is implicit in the position, the key is never stored.
@@ -135,6 +136,7 @@ struct MsmWork {
 struct zkc_lane {
     hipStream_t st = nullptr, st2 = nullptr, fin = nullptr;               // buildABC/NTT/G1 MSM ; G2 MSM ; blinding + D2H
     zkc::Fr *d_abc = nullptr, *d_t = nullptr; uint32_t* d_p = nullptr;   // [inflight][3n] x2 (d_t = NTT scratch), [inflight][n x 8]
+    void* d_fin = nullptr;                                                // blinding scratch, finalize_scratch_bytes(inflight)
     zkc::MsmWork w1, w2;                                                  // G1 and G2 pipelines
     hipEvent_t ev_msm = nullptr, ev_msm2 = nullptr, ev_sorted = nullptr, ev_ntt = nullptr, ev_mv = nullptr, ev_fin[2] = {nullptr, nullptr}; int npass = 0;      // ev_ntt: buildABC/NTT/joinABC of the pass are through      // ev_fin[slot]: blinding of the pass that used result slot `slot`
 };
@@ -196,6 +198,7 @@ int msm_pass_g2(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool t
 int msm_bucket_entries(zkc_ctx* ctx, MsmWork& w, const MsmJobList& jl, hipStream_t st, unsigned long long* d_entry_counter = nullptr);
 int msm_build_segments(zkc_ctx* ctx, MsmWork& w, const MsmJobList& jl, uint32_t seg, size_t seg_bound, hipStream_t st);
 int finalize_launch(zkc_ctx* ctx, hipStream_t st, const FinalizeArgs& a, int nproofs);
+size_t finalize_scratch_bytes(int nproofs);
 int msm_precompute_g1(zkc_ctx* ctx, uint32_t count, G1Affine* d_table, int c);   // d_table[0..count) = base on entry
 int msm_precompute_g2(zkc_ctx* ctx, uint32_t count, G2Affine* d_table, int c);
 int msm_g2_table29(zkc_ctx* ctx, const G2Affine* d_table, uint32_t* d_out, size_t count);       // d_out: 60 words per point
