@@ -225,6 +225,9 @@ zkc_msm_merge29(XYZZ<typename G::F>* __restrict__ partial, const uint32_t* __res
 
 // ---- K6 ---- one wave per virtual window of 64 x per consecutive buckets of a job; lane t owns buckets per t .. per t + per - 1.
 // Output per virtual window: W = sum_j j * B_j (local weights) and S = sum_j B_j; zkc_msm_final applies the window's offset.
+// [r2] tried and not kept: splitting this kernel into its dense half (per-lane sums to memory, 1.49 ms instead of 2.26 on the G1 stream) and a
+// lane-per-window fold of the 64 pairs on the blinding stream (1.7 ms, 103 waves).  Same box: pass period 29.39 against 29.53 ms, 3069 / 3062 against
+// 3067 / 3051 proofs/s -- the fold and the blinding then run beside the next pass' first NTT kernel, which slows down by what this stream gained.
 // K6 for G1 with radix-2^29 coordinates (zkc_f29_g1.h): same walk, 1.7x fewer instructions per group addition than the generic code
 // through the out-of-line product.  Partials are read as canonical 8 x u32 points and sliced; W and S leave in canonical form.
 __global__ void __launch_bounds__(64)
