@@ -1,10 +1,11 @@
-// zkc_finalize.hip -- K9: the constant-size blinding step of Groth16 on the device (stage a7), one workgroup per proof.
+// zkc_finalize.hip -- K9: the constant-size blinding step of Groth16 on the device (stage a7): one lane per scalar product and then one lane per
+// proof element for a pass of proofs (zkc_finalize_products / _combine), one workgroup of four waves for a single proof (zkc_finalize).
 //
 //   piA = alpha + A + r delta ;  piB = beta2 + B2 + s delta2 ;  piC = C + H + s piA + r piB1 - r s delta
 // (snarkjs groth16_prove.js tail / rapidsnark; reached from ts_inputs/src/example.ts:358-362, zk_census_test.go:89).
 // Expanded so that nothing depends on piA / piB1:  s piA + r piB1 - rs delta = s A' + s alpha + r B1' + r beta1 + rs delta,
-// i.e. two variable-base products and six fixed-base ones read from 8-bit window tables.
-// Runs on the context's second stream so that it overlaps the next pipeline pass.
+// i.e. two variable-base products and five fixed-base ones in G1 plus one in G2, the fixed-base ones read from 8-bit window tables.
+// Runs on the lane's blinding stream so that it overlaps the next pipeline pass.
 #include "zkc_prover.h"
 #include "zkc_f29_g1.h"
 
