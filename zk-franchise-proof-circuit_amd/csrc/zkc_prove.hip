@@ -209,7 +209,8 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
     //      the number of proofs a call actually puts in flight (a single-proof caller does not reserve the work space of 96) ----
     const char* e_inf = getenv("ZKC_INFLIGHT");
     zk->max_inflight = e_inf ? std::max(1, std::min(atoi(e_inf), MSM_MAX_JOBS / 4)) : 96;      // same box, batch 1024: 64 -> 1955, 80 -> 1985, 96 -> 2015, 112 -> 2000, 128 -> 2022 proofs/s; round 2: 96 -> 3010, 114 -> 3004, 128 -> 3031
-    // ZKC_LANES=2 lets two lanes take alternate passes; measured no gain (the GPU is already saturated), so one lane is the default
+    // ZKC_LANES=2 lets two lanes take alternate passes; measured no gain in round 1 (the GPU is already saturated) and -4 % at the end of round 2 (3005
+    // against 3142 proofs/s on one box: the second lane has no buildABC prefetch), so one lane is the default
     { const char* e_l = getenv("ZKC_LANES"); zk->nlanes = e_l ? std::max(1, std::min(atoi(e_l), 2)) : 1; }
     for (int l = 0; l < zk->nlanes; l++) {
         zkc_lane& L = zk->lane[l];
