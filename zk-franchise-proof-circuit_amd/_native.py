@@ -5,7 +5,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libzkcensus.so')
+LIB_PATH = os.environ.get('ZKCENSUS_LIB') or os.path.join(_HERE, 'libzkcensus.so')      # ZKCENSUS_LIB: the same override the N-API addon honours
 _lib = None
 
 
