@@ -83,6 +83,9 @@ int main() {
         t = good; v = 8; memcpy(t.data() + c0 + 8, &v, 4); CHECK(!load_like(t));
         t = good; v = 6; memcpy(t.data() + c0 + 12, &v, 4); CHECK(!load_like(t));
         t = good; v = 0x5d1745d2u; memcpy(t.data() + c0, &v, 4); CHECK(!load_like(t));       // 4 + 44 * nCoeffs wraps 32 bits
+        t = good; memset(t.data() + c0 + 4 + 12, 0xff, 32); CHECK(!load_like(t));              // a coefficient value that is not a reduced field element
+        t = good; memcpy(t.data() + c0 + 4 + 12, kFrP, 32); CHECK(!load_like(t));               // ... exactly r
+        { t = good; uint32_t rm1[8]; memcpy(rm1, kFrP, 32); rm1[0] -= 1; memcpy(t.data() + c0 + 4 + 12, rm1, 32); CHECK(load_like(t)); }      // r - 1 is one
     }
     for (int it = 0; it < 20000; it++) {                 // random mutations: accepted or not, never out of bounds
         std::vector<uint8_t> t(good); const int k = 1 + (int)(rnd() % 4);
