@@ -59,7 +59,7 @@ inline bool zkey_check(const BinSections& s, ZkeyHeader& h, std::string& err, bo
     for (uint32_t i = 0; scan_coefficients && i < h.nCoeffs; i++) {
         const uint32_t m = rd32(c + 44ull * i), cc = rd32(c + 44ull * i + 4), w = rd32(c + 44ull * i + 8);
         if (m > 1 || cc >= h.n || w >= h.nVars) { err = "zkey: coefficient out of range"; return false; }
-        const uint8_t* v = c + 44ull * i + 12; int k = 7;                          // the value is a field element: little endian, below r (buildABC's lazy reduction counts on it)
+        const uint8_t* v = c + 44ull * i + 12; int k = 7;                          // the value is a field element: little endian, below r
         while (k >= 0 && rd32(v + 4 * k) == kFrP[k]) k--;
         if (k < 0 || rd32(v + 4 * k) > kFrP[k]) { err = "zkey: coefficient value is not a reduced field element"; return false; }
     }

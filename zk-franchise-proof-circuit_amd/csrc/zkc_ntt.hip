@@ -31,47 +31,19 @@ __device__ __forceinline__ void st_fr(Fr* p, const Fr& r) {
 // Batched over the proofs of a pass: blockIdx.y = proof.
 // The first `nlong` rows (more than MATVEC_LONG coefficients; up to 319 in the zkCensus R1CS) get a wave each: a lane walking such a row
 // alone is a 319-deep chain of dependent gathers and held the whole kernel for 2 ms.
-// [r2] The dot product of a row is accumulated in the 64-bit column sums of the radix-2^29 product (zkc_f29.h) and reduced once per four terms
-// instead of once per term: both operands enter as 32 x value (nine 29-bit limbs), a term is 81 mads into the columns, four terms plus the carried
-// sum of the terms before stay below 2^64 per column, and one Montgomery reduction by 2^261 per chunk (not per term) leaves 32 x (sum / 2^256) --
-// the R' form of the Montgomery-form result.  A row of L coefficients costs 135 L + 180 instructions instead of 400 L (a generic product, its
-// conditional subtraction and a carry-chain addition per term).  Any 256-bit witness word is accepted: magnitudes are cut back below 3 p at every
-// chunk boundary (f29_reduce_small), so a non-canonical wire gives the same residue as before.
-struct RowAcc {
-    uint64_t c[18]; int pend;
-    __device__ __forceinline__ void clear() {
-#pragma unroll
-        for (int k = 0; k < 18; k++) c[k] = 0;
-        pend = 0;
-    }
-    __device__ __forceinline__ void fold(uint32_t r[9]) { f29_reduce_cols<FrParams>(r, c); f29_reduce_small<FrParams>(r); }       // carried, below 3 p
-    __device__ __forceinline__ void mac(const Fr& a, const Fr& b) {
-        if (pend == 4) {
-            uint32_t r[9]; fold(r);
-#pragma unroll
-            for (int k = 0; k < 9; k++) { c[k] = 0; c[9 + k] = r[k]; }        // r 2^261 in the columns comes out of the next reduction as "+ r"
-            pend = 0;
-        }
-        uint32_t A[9], B[9]; f29_from_fp_shl5(A, a.v); f29_from_fp_shl5(B, b.v);
-#pragma unroll
-        for (int i = 0; i < 9; i++)
-#pragma unroll
-            for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)A[i] * B[j];
-        pend++;
-    }
-    __device__ __forceinline__ Fr result() { uint32_t r[9]; fold(r); return f29_to_fp<FrParams>(r); }                              // canonical, Montgomery form
-};
+// [r2] tried and not kept: accumulating a row in the 64-bit column sums of the radix-2^29 product with one reduction per four terms.  It costs
+// 218 instructions per term + 323 for the way back to a canonical element, against ~450 per term here; the zkCensus rows hold 1.77 coefficients on
+// average (most hold one), so nothing is gained: 1.877 M VALU-busy cycles per pass either way (rocprofv3 SQ counters).
 extern "C" __global__ void __launch_bounds__(256)
 zkc_matvec_jds(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ rowlen, const uint32_t* __restrict__ jdptr,
                const uint32_t* __restrict__ col, const Fr* __restrict__ val, const Fr* __restrict__ wtns_std, size_t wtns_stride,
                Fr* __restrict__ abc, int n, uint32_t nlong) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;      // rows [0,n) = A, [n,2n) = B ; abc layout [proof][3][n]
     const Fr* __restrict__ w = wtns_std + (size_t)blockIdx.y * wtns_stride;
-    RowAcc ra; ra.clear();
+    Fr acc = Fr::zero();
     if ((t >> 6) < nlong) {                         // wave-uniform
         const uint32_t r = t >> 6, len = rowlen[r];
-        for (uint32_t k = lane; k < len; k += 64) { const uint32_t idx = jdptr[k] + r; ra.mac(ld_fr(val + idx), ld_fr(w + col[idx])); }
-        Fr acc = ra.result();
+        for (uint32_t k = lane; k < len; k += 64) { const uint32_t idx = jdptr[k] + r; acc = acc + ld_fr(val + idx) * ld_fr(w + col[idx]); }
         for (int d = 32; d > 0; d >>= 1) {
             Fr o;
 #pragma unroll
@@ -84,8 +56,8 @@ zkc_matvec_jds(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ r
     const uint32_t r = t - nlong * 63u;             // = nlong + (t - 64 nlong)
     if (r >= 2u * (uint32_t)n) return;
     const uint32_t len = rowlen[r];
-    for (uint32_t k = 0; k < len; k++) { const uint32_t idx = jdptr[k] + r; ra.mac(ld_fr(val + idx), ld_fr(w + col[idx])); }
-    st_fr(abc + (size_t)blockIdx.y * 3 * n + perm[r], ra.result());
+    for (uint32_t k = 0; k < len; k++) { const uint32_t idx = jdptr[k] + r; acc = acc + ld_fr(val + idx) * ld_fr(w + col[idx]); }
+    st_fr(abc + (size_t)blockIdx.y * 3 * n + perm[r], acc);
 }
 // c = a * b
 extern "C" __global__ void __launch_bounds__(256)
