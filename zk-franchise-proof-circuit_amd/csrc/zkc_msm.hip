@@ -445,7 +445,7 @@ int fold_group_sums_g2(zkc_ctx* ctx, const G2Affine* tbl, const uint32_t* s, con
 }
 
 // ---- work space ----
-int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, size_t max_buckets, int max_jobs, bool g2) {
+static int msm_work_alloc_impl(zkc_ctx* ctx, MsmWork& w, size_t max_entries, size_t max_buckets, int max_jobs, bool g2) {
     w.max_entries = max_entries; w.max_jobs = max_jobs; w.max_buckets = max_buckets; w.xyzz_size = g2 ? sizeof(G2XYZZ) : sizeof(G1XYZZ);
     const size_t nb = max_buckets;
     w.max_segments = max_entries / MSM_SEG_MIN + nb;    // every non-empty bucket has at most one short segment
@@ -476,6 +476,12 @@ int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, size_t max_buck
     ZKC_HIP_CHECK(ctx, hipMalloc(&w.results, 2 * (size_t)max_jobs * w.xyzz_size));
     ZKC_HIP_CHECK(ctx, hipHostMalloc(&w.h_results, (size_t)max_jobs * w.xyzz_size));
     return ZKC_OK;
+}
+// all or nothing: a failed allocation leaves `w` empty (capacities zero), so that msm_pass' capacity checks refuse it instead of launching on null buffers
+int msm_work_alloc(zkc_ctx* ctx, MsmWork& w, size_t max_entries, size_t max_buckets, int max_jobs, bool g2) {
+    const int rc = msm_work_alloc_impl(ctx, w, max_entries, max_buckets, max_jobs, g2);
+    if (rc != ZKC_OK) msm_work_free(w);
+    return rc;
 }
 void msm_work_free(MsmWork& w) {
     void* p[] = {w.vals, w.vals2, w.hist, w.bin_start, w.tilecnt, w.off, w.bcnt, w.segcnt, w.segoff, w.seg2bucket, w.seglen, w.perm, w.scan_blk, w.lencnt, w.heavy, w.d_jobs, w.d_windows,

@@ -97,16 +97,29 @@ static int lanes_ensure(zkc_zkey* zk, int inflight) {
     constexpr int NWS = msm_nw(MSM_C_SMALL), NWB = msm_nw(MSM_C_BIG);
     const size_t per_proof_entries = (size_t)NWS * 3 * nv + (size_t)NWB * n;
     const size_t per_proof_buckets = 3 * (size_t)msm_half(MSM_C_SMALL) + msm_half(MSM_C_BIG);
+    // the old work space goes first (a key at nLevels = 160 with 96 proofs in flight holds ~6 GB): from here until every allocation has succeeded the key
+    // has NO work space, and says so (cur_inflight = 0), so a failure leaves a key that re-allocates on its next call instead of launching on freed buffers
+    zk->cur_inflight = 0;
+    auto release = [&]() {
+        for (int l = 0; l < zk->nlanes; l++) {
+            zkc_lane& L = zk->lane[l];
+            for (void** q : {(void**)&L.d_abc, (void**)&L.d_t, (void**)&L.d_p, &L.d_fin}) if (*q) { (void)hipFree(*q); *q = nullptr; }
+            msm_work_free(L.w1); msm_work_free(L.w2);
+        }
+    };
+    for (int l = 0; l < zk->nlanes; l++) for (hipStream_t q : {zk->lane[l].st, zk->lane[l].st2, zk->lane[l].fin}) ZKC_HIP_CHECK(ctx, hipStreamSynchronize(q));
+    release();
+    const char* fail_at = getenv("ZKC_TEST_FAIL_ALLOC");          // test hook: pretend the allocation for this many proofs in flight (or more) fails
     for (int l = 0; l < zk->nlanes; l++) {
         zkc_lane& L = zk->lane[l];
-        for (hipStream_t q : {L.st, L.st2, L.fin}) ZKC_HIP_CHECK(ctx, hipStreamSynchronize(q));
-        for (void** q : {(void**)&L.d_abc, (void**)&L.d_t, (void**)&L.d_p, &L.d_fin}) if (*q) { ZKC_HIP_CHECK(ctx, hipFree(*q)); *q = nullptr; }
-        msm_work_free(L.w1); msm_work_free(L.w2);
-        if ((rc = dmalloc(ctx, &L.d_abc, 3 * (size_t)n * inflight)) || (rc = dmalloc(ctx, &L.d_t, 3 * (size_t)n * inflight)) ||
-            (rc = dmalloc(ctx, &L.d_p, 8 * (size_t)n * inflight))) return rc;
-        ZKC_HIP_CHECK(ctx, hipMalloc(&L.d_fin, finalize_scratch_bytes(inflight)));
-        if ((rc = msm_work_alloc(ctx, L.w1, per_proof_entries * inflight, per_proof_buckets * inflight, 4 * inflight, false))) return rc;
-        if ((rc = msm_work_alloc(ctx, L.w2, (size_t)NWS * nv * inflight, (size_t)msm_half(MSM_C_SMALL) * inflight, inflight, true))) return rc;
+        rc = (fail_at && inflight >= atoi(fail_at)) ? zkc_fail(ctx, ZKC_ERR_HIP, "lanes_ensure: allocation failure injected by ZKC_TEST_FAIL_ALLOC") : ZKC_OK;
+        if (!rc) rc = dmalloc(ctx, &L.d_abc, 3 * (size_t)n * inflight);
+        if (!rc) rc = dmalloc(ctx, &L.d_t, 3 * (size_t)n * inflight);
+        if (!rc) rc = dmalloc(ctx, &L.d_p, 8 * (size_t)n * inflight);
+        if (!rc && hipMalloc(&L.d_fin, finalize_scratch_bytes(inflight)) != hipSuccess) rc = zkc_fail(ctx, ZKC_ERR_HIP, "lanes_ensure: hipMalloc failed (blinding scratch)");
+        if (!rc) rc = msm_work_alloc(ctx, L.w1, per_proof_entries * inflight, per_proof_buckets * inflight, 4 * inflight, false);
+        if (!rc) rc = msm_work_alloc(ctx, L.w2, (size_t)NWS * nv * inflight, (size_t)msm_half(MSM_C_SMALL) * inflight, inflight, true);
+        if (rc) { (void)hipGetLastError(); release(); return rc; }
     }
     zk->cur_inflight = inflight;
     return ZKC_OK;
