@@ -11,8 +11,8 @@
  *
  * Threads: every entry point may be called from any thread.  Calls that take the same zkc_ctx (directly or through a zkc_zkey /
  * zkc_msm made on it) are serialised by a mutex inside the context -- one GPU pipeline per context; different contexts (one per
- * GPU) run concurrently.  groth16_prover is re-entrant the way rapidsnark's is (callable from concurrent goroutines): it keeps one
- * process-wide context and the last key behind its own lock.  zkc_last_error(ctx) is the last error of that context (read it before
+ * GPU) run concurrently.  groth16_prover is re-entrant the way rapidsnark's is (callable from concurrent goroutines): its callers share the
+ * process-wide proving service (zkc_service_default), which coalesces them into pipeline passes.  zkc_last_error(ctx) is the last error of that context (read it before
  * another thread's call on the same context fails); zkc_verify_last_error is per thread.
  */
 #ifndef ZKCENSUS_H
@@ -77,9 +77,11 @@ int zkc_witness_dev(zkc_ctx* ctx, int nLevels, const void* d_inputs, int B, void
 int  zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, zkc_zkey** out);
 void zkc_zkey_free(zkc_zkey* zk);
 int  zkc_zkey_info(const zkc_zkey* zk, uint32_t* nVars, uint32_t* nPublic, uint32_t* domainSize);
+int  zkc_zkey_header_info(const void* zkey_bytes, size_t len, uint32_t* nVars, uint32_t* nPublic, uint32_t* domainSize);   /* from the file image alone: host only, nothing is loaded */
 int  zkc_zkey_sha256(const zkc_zkey* zk, uint8_t out[32]);      /* of the .zkey image it was loaded from (circuits-info.md:5 publishes this hash) */
-/* cheap identity of a .zkey image for resident-key caches (SHA-256 over the header, the IC points, the ends of every section and a 64-byte block
- * of every 64 KB): what groth16_prover, the N-API addon and groth16.py compare on every call.  Host only. */
+/* cheap identity of a .zkey image for resident-key caches: a SAMPLED hash (SHA-256 over the header, the IC points, the ends of every section and a
+ * 64-byte block of every 64 KB), not the SHA-256 of the image -- two images that differ only in unsampled bytes share it.  The proving service,
+ * the N-API addon and groth16.py compare it on every call; the service also compares the full SHA-256 once per (image, resident key).  Host only. */
 int  zkc_zkey_fingerprint(const void* zkey_bytes, size_t len, uint8_t out[32]);
 
 /* ---- a2-a7: Groth16 prove (replaces snarkjs groth16.prove / rapidsnark groth16_prover internals).
@@ -124,11 +126,41 @@ int  zkc_pool_zkey_load(zkc_pool* pool, const void* zkey_bytes, size_t len);   /
  * least one voter failed a circuit assert (the other proofs are valid). */
 int  zkc_pool_fullprove_batch(zkc_pool* pool, const void* inputs, int B, const uint8_t* rs, uint8_t* proofs, uint8_t* publics, int32_t* status);
 
+/* ---- the reference's own call shape, one voter per call, made fast: a submission queue behind the single-proof entry points.
+ * prover.Prove is called per voter, from a loop or from goroutines (zk_census_test.go:89), groth16.fullProve per ballot
+ * (ts_inputs/src/example.ts:358-362).  A service owns a pair of worker threads per GPU; callers enqueue one voter each and a worker proves
+ * whatever has accumulated in ONE pipeline pass sequence (zkc_fullprove_batch_dev / zkc_prove_batch_dev): a lone caller is served at once,
+ * concurrent callers share passes (64 concurrent callers reach most of the batch rate instead of 64 x the single-proof latency).
+ * Devices: hip_devices[n], or n = 0: $ZKC_DEVICE ("2", "0,1,2,3", "all"), unset = every visible device; a device is brought up (context, key
+ * tables) only when the queue is long enough to pay for it.  The resident key of a device is identified per call by zkc_zkey_fingerprint
+ * of the .zkey image (a SAMPLED hash); the first time an image (pointer, length) meets a resident key its full SHA-256 is compared too.
+ * The blocking calls return the voter's own result: ZKC_OK, ZKC_ERR_WITNESS (status = ZKC_W_*: that voter failed a circuit assert; other
+ * callers of the same pass are not affected), or an error with text in err.  rs = r || s (64 B) or NULL (drawn uniform in Fr).
+ * The submit calls return at once; `done` runs on a service thread when the proof (or error) is in the caller's buffers, which -- like the
+ * .zkey image, inputs / witness -- must stay valid until then.  zkc_service_default(): the process-wide instance groth16_prover uses. */
+typedef struct zkc_service zkc_service;
+typedef void (*zkc_done_fn)(void* user, int rc, int32_t witness_status, const char* error_text /* valid during the call */);
+int  zkc_service_create(const int* hip_devices, int n, zkc_service** out);
+void zkc_service_destroy(zkc_service* svc);               /* waits for the batches in flight; queued requests fail with ZKC_ERR_GENERIC */
+zkc_service* zkc_service_default(void);                   /* NULL when no GPU is visible (zkc_service_last_error) */
+const char* zkc_service_last_error(void);                 /* per thread */
+int zkc_service_fullprove(zkc_service* svc, const void* zkey, size_t zkey_len, int nLevels, const void* inputs /* n_inputs x 32 B */, const uint8_t* rs,
+                          uint8_t proof[256], uint8_t* publics /* nPublic x 32 B or NULL */, int32_t* status, char* err, size_t errlen);
+int zkc_service_prove(zkc_service* svc, const void* zkey, size_t zkey_len, const void* wtns /* nWitness x 32 B, host */, uint32_t nWitness, const uint8_t* rs,
+                      uint8_t proof[256], uint8_t* publics, char* err, size_t errlen);
+int zkc_service_submit_fullprove(zkc_service* svc, const void* zkey, size_t zkey_len, int nLevels, const void* inputs, const uint8_t* rs,
+                                 uint8_t proof[256], uint8_t* publics, zkc_done_fn done, void* user);
+int zkc_service_submit_prove(zkc_service* svc, const void* zkey, size_t zkey_len, const void* wtns, uint32_t nWitness, const uint8_t* rs,
+                             uint8_t proof[256], uint8_t* publics, zkc_done_fn done, void* user);
+/* out[0] requests accepted, [1] batches run, [2] largest batch, [3] key loads, [4] devices listed, [5] devices that ran a batch, [6] requests failed
+ * wholesale (HIP / key errors), [7] requests waiting now */
+int zkc_service_stats(zkc_service* svc, uint64_t out[8]);
+
 /* ---- the rapidsnark entry point (go-rapidsnark prover.h `groth16_prover`, reached from prover.Prove at
  * zk_census_test.go:89): whole .zkey and .wtns file images in, NUL-terminated proof / public-signal JSON out.
  * Returns 0 OK, 1 ERROR, 2 SHORT_BUFFER (required sizes written back; nothing is proved, so a size query is cheap),
- * 3 INVALID_WITNESS_LENGTH.  r, s are random, uniform in Fr.  Thread-safe / re-entrant; the last key stays resident, keyed by
- * zkc_zkey_fingerprint of the image. */
+ * 3 INVALID_WITNESS_LENGTH.  r, s are random, uniform in Fr.  Thread-safe / re-entrant the way rapidsnark's is, and concurrent callers
+ * (goroutines) are coalesced: every call goes through zkc_service_default() above. */
 int groth16_prover(const void* zkey_buffer, unsigned long zkey_size, const void* wtns_buffer, unsigned long wtns_size,
                    char* proof_buffer, unsigned long* proof_size, char* public_buffer, unsigned long* public_size,
                    char* error_msg, unsigned long error_msg_maxsize);

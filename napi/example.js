@@ -1,13 +1,15 @@
 // The reference's ts_inputs/src/example.ts:358-362 call, against this package (needs an MI355X and a test zkey):
-//     node napi/example.js <zkey> [verification_key.json] [circuit.wasm]
+//     node napi/example.js <zkey> [verification_key.json] [circuit.wasm | -] [voters.json]
 // With a wasm path the circuit is selected by its sha256 exactly as a snarkjs caller names it; without one the native nLevels = 160
-// circuit is used.  Also drives the two-step path (wtns.calculate -> groth16.prove) and four concurrent fullProve calls.
+// circuit is used.  Also drives the two-step path (wtns.calculate -> groth16.prove), four concurrent fullProve calls and, with a file of voters
+// (a JSON array of input objects), the reference's call shape under load: Promise.all over one fullProve PER VOTER, which the library's proving service
+// coalesces into pipeline passes.
 const { groth16, wtns } = require("./index.js");
 const fs = require("fs");
 const inputs = require("../tests/golden/ref/inputs_example.json");
 (async () => {
   const zkey = process.argv[2], vk = process.argv[3] ? JSON.parse(fs.readFileSync(process.argv[3])) : null;
-  const wasm = process.argv[4] && fs.existsSync(process.argv[4]) ? process.argv[4] : null;
+  const wasm = process.argv[4] && process.argv[4] !== "-" && fs.existsSync(process.argv[4]) ? process.argv[4] : null;
   const t0 = Date.now();
   const { proof, publicSignals } = await groth16.fullProve(inputs, wasm, zkey);
   const ms = Date.now() - t0;
@@ -20,10 +22,28 @@ const inputs = require("../tests/golden/ref/inputs_example.json");
   const a = await groth16.prove(zkey, mem, null, { r: 12345n, s: 67890n });
   const b = await groth16.fullProve(inputs, wasm, zkey, null, { r: 12345n, s: 67890n });
   const twoStepEqual = JSON.stringify(a) === JSON.stringify(b) && (!vk || await groth16.verify(vk, a.publicSignals, a.proof));
-  // libuv runs these on several pool threads at once: the addon serialises them on its context
+  // submitted back to back from this thread: the proving service takes them in one or two passes
   const many = await Promise.all([0, 1, 2, 3].map(() => groth16.fullProve(inputs, wasm, zkey)));
   let concurrentOk = true;
   for (const m of many) concurrentOk = concurrentOk && JSON.stringify(m.publicSignals) === JSON.stringify(publicSignals) && (!vk || await groth16.verify(vk, m.publicSignals, m.proof));
+  // one fullProve per voter, all at once (what a ballot-box service does with example.ts:358): every proof verified, rate = voters / wall time
+  let burst = null;
+  if (process.argv[5]) {
+    const voters = JSON.parse(fs.readFileSync(process.argv[5]));
+    const run = async (list) => { const t = process.hrtime.bigint(); const out = await Promise.all(list.map((v) => groth16.fullProve(v, wasm, zkey))); return [out, Number(process.hrtime.bigint() - t) / 1e6]; };
+    await run(voters);                                                   // work space grows to the burst size once
+    const [out64, ms64] = await run(voters);
+    const many4 = [].concat(voters, voters, voters, voters);
+    const [out256, ms256] = await run(many4);
+    let allVerified = true, signalsOk = true;
+    for (let i = 0; i < out64.length; i++) {
+      signalsOk = signalsOk && out64[i].publicSignals[2] === String(voters[i].nullifier) && out64[i].publicSignals[6] === String(voters[i].censusRoot);
+      if (vk) allVerified = allVerified && await groth16.verify(vk, out64[i].publicSignals, out64[i].proof);
+    }
+    for (let i = 0; i < out256.length; i += 5) if (vk) allVerified = allVerified && await groth16.verify(vk, out256[i].publicSignals, out256[i].proof);
+    burst = { voters: voters.length, ms: Math.round(ms64 * 10) / 10, proofsPerSec: Math.round(voters.length / ms64 * 1e3), voters4x: many4.length, ms4x: Math.round(ms256 * 10) / 10,
+      proofsPerSec4x: Math.round(many4.length / ms256 * 1e3), allVerified, signalsOk };
+  }
   // a batch over a pool of devices (device 0 listed twice: two contexts, two host threads): voter 1 fails an assert, the others equal fullProve with the same (r, s)
   const batch = await groth16.fullProveBatch([inputs, Object.assign({}, inputs, { nullifier: "1" }), inputs], wasm, zkey,
     { devices: [0, 0], rs: [[12345n, 67890n], [1n, 2n], [12345n, 67890n]] });
@@ -33,5 +53,5 @@ const inputs = require("../tests/golden/ref/inputs_example.json");
   try { await groth16.fullProve(Object.assign({}, inputs, { nullifier: "1" }), wasm, zkey); } catch (e) { badInputRejected = /Assert Failed/.test(String(e)); }
   let unknownWasmRejected = false;
   try { await groth16.fullProve(inputs, Buffer.from("not a circuit"), zkey); } catch (e) { unknownWasmRejected = /unknown circuit wasm/.test(String(e)); }
-  console.log(JSON.stringify({ ms, msWarm: Math.round(msWarm * 100) / 100, publicSignals, verified, twoStepEqual, concurrentOk, batchOk, badInputRejected, unknownWasmRejected, wasm: wasm ? "by sha256" : "native nLevels=160" }));
+  console.log(JSON.stringify({ ms, msWarm: Math.round(msWarm * 100) / 100, publicSignals, verified, twoStepEqual, concurrentOk, batchOk, badInputRejected, unknownWasmRejected, burst, wasm: wasm ? "by sha256" : "native nLevels=160" }));
 })().catch((e) => { console.error(String(e)); process.exit(1); });

@@ -4,9 +4,11 @@
 //     groth16.fullProve(input, wasmFile, zkeyFile) -> Promise<{proof, publicSignals}>
 //     groth16.prove(zkeyFile, wtnsFile), groth16.verify(vk, publicSignals, proof), wtns.calculate(input, wasmFile, wtnsFile)
 // The JS wrapper (index.js) flattens the input object, reads artifact files and formats decimal strings; this file only moves buffers
-// across the ABI.  All GPU work runs in napi_create_async_work so the event loop is never blocked.  Those work items run on libuv pool
-// threads, several at a time (Promise.all([...fullProve])): the process-wide context and the resident key below are guarded by one mutex
-// held across witness + prove, on top of the per-context lock inside the library.  libzkcensus.so is dlopen'ed at first use
+// across the ABI.  The event loop is never blocked: fullProve / prove hand their request to the library's proving service (zkc_service_*,
+// csrc/zkc_service.hip) from the main thread and return a promise at once; the service coalesces whatever is pending -- Promise.all over 64
+// fullProve calls is a handful of pipeline passes, not 64 serialised proofs -- and its completion callback comes back to JavaScript through a
+// thread-safe function.  (libuv's pool has four threads: blocking one per proof, as round 2 did, capped a burst at four requests in flight.)
+// wtns.calculate and fullProveBatch run in napi_create_async_work behind one mutex.  libzkcensus.so is dlopen'ed at first use
 // (path: $ZKCENSUS_LIB or next to the package), so the addon itself builds with plain g++ and N-API >= 4 headers:
 //     g++ -std=c++17 -shared -fPIC -I/usr/include/node napi/zkcensus_napi.cc -o napi/zkcensus.node -ldl
 #include <node_api.h>
@@ -34,10 +36,15 @@ struct Api {
     int (*pool_create)(const int*, int, void**) = nullptr; void (*pool_destroy)(void*) = nullptr; const char* (*pool_err)(const void*) = nullptr;
     int (*pool_zkey_load)(void*, const void*, size_t) = nullptr; void* (*pool_zkey)(void*, int) = nullptr;
     int (*pool_fullprove)(void*, const void*, int, const uint8_t*, uint8_t*, uint8_t*, int32_t*) = nullptr;
+    typedef void (*done_fn)(void*, int, int32_t, const char*);
+    void* (*service_default)() = nullptr; const char* (*service_err)() = nullptr;
+    int (*submit_fullprove)(void*, const void*, size_t, int, const void*, const uint8_t*, uint8_t*, uint8_t*, done_fn, void*) = nullptr;
+    int (*submit_prove)(void*, const void*, size_t, const void*, uint32_t, const uint8_t*, uint8_t*, uint8_t*, done_fn, void*) = nullptr;
+    int (*header_info)(const void*, size_t, uint32_t*, uint32_t*, uint32_t*) = nullptr;
     std::string err;
 } g;
 std::mutex g_mu;                       // guards everything below and every use of the shared context / key
-void* g_ctx = nullptr; void* g_key = nullptr; uint8_t g_key_sha[32];
+void* g_ctx = nullptr;                 // wtns.calculate only: the proving paths go through the library's service
 void* g_pool = nullptr; std::vector<int> g_pool_devs; uint8_t g_pool_sha[32]; bool g_pool_has_key = false;      // fullProveBatch: one context + key per listed device
 
 bool load_api(const std::string& hint) {               // caller holds g_mu
@@ -53,6 +60,8 @@ bool load_api(const std::string& hint) {               // caller holds g_mu
     SYM(from_wasm, "zkc_circuit_nlevels_from_wasm") SYM(fingerprint, "zkc_zkey_fingerprint") SYM(random_scalars, "zkc_random_scalars")
     SYM(pool_create, "zkc_pool_create") SYM(pool_destroy, "zkc_pool_destroy") SYM(pool_err, "zkc_pool_last_error") SYM(pool_zkey_load, "zkc_pool_zkey_load")
     SYM(pool_zkey, "zkc_pool_zkey") SYM(pool_fullprove, "zkc_pool_fullprove_batch")
+    SYM(service_default, "zkc_service_default") SYM(service_err, "zkc_service_last_error") SYM(submit_fullprove, "zkc_service_submit_fullprove")
+    SYM(submit_prove, "zkc_service_submit_prove") SYM(header_info, "zkc_zkey_header_info")
 #undef SYM
     g.h = h;
     return true;
@@ -61,14 +70,6 @@ bool ensure_ctx(std::string& err) {                     // caller holds g_mu
     if (g_ctx) return true;
     const char* d = getenv("ZKC_DEVICE");
     if (g.ctx_create(d ? atoi(d) : 0, &g_ctx)) { g_ctx = nullptr; err = g.last_error(nullptr); return false; }
-    return true;
-}
-bool ensure_key(const uint8_t* zkey, size_t zkey_n, std::string& err) {      // caller holds g_mu; identity = zkc_zkey_fingerprint of the .zkey image
-    uint8_t d[32]; if (!zkey || g.fingerprint(zkey, zkey_n, d)) { err = "not a zkey file"; return false; }
-    if (g_key && !memcmp(d, g_key_sha, 32)) return true;
-    if (g_key) { g.zkey_free(g_key); g_key = nullptr; }                     // one resident key: the old one's HBM is released first
-    if (g.zkey_load(g_ctx, zkey, zkey_n, &g_key)) { g_key = nullptr; err = g.last_error(g_ctx); return false; }
-    memcpy(g_key_sha, d, 32);
     return true;
 }
 const char* assert_site(int status) {                   // census.circom line of each assert, as the wasm's "Assert Failed" message names it
@@ -84,6 +85,7 @@ struct Work {
     napi_async_work work = nullptr; napi_deferred deferred = nullptr; Kind kind = FULLPROVE;
     std::vector<uint8_t> inputs, zkey, wtns_file, r, s, proof, pub, out; int nLevels = 160; std::string err; std::string libhint;
     std::vector<int> devices; std::vector<uint8_t> rs; std::vector<int32_t> status;      // BATCH
+    uint8_t rs64[64]; bool has_rs = false;                                                // FULLPROVE / PROVE through the service
     // the .zkey image is NOT copied (tens of MB per call): the JS Buffer is pinned by a reference until complete() and read in place by the worker
     napi_ref zkey_ref = nullptr; const uint8_t* zkey_p = nullptr; size_t zkey_n = 0;
 };
@@ -94,17 +96,6 @@ bool run_witness(Work* w, std::vector<uint8_t>& wtns) {
     wtns.resize((size_t)nw * 32); int32_t status = 0;
     const int rc = g.witness(g_ctx, w->nLevels, w->inputs.data(), 1, wtns.data(), &status);
     if (rc) { w->err = status ? std::string("Error: Assert Failed. Error in template ") + assert_site(status) : std::string(g.last_error(g_ctx)); return false; }
-    return true;
-}
-bool run_prove(Work* w, const uint8_t* payload, uint32_t nw) {      // caller holds g_mu
-    if (!ensure_key(w->zkey_p, w->zkey_n, w->err)) return false;
-    uint32_t nv, np, dn; g.zkey_info(g_key, &nv, &np, &dn);
-    if (nw != nv) { w->err = "Invalid witness length. Circuit: " + std::to_string(nv) + ", witness: " + std::to_string(nw); return false; }
-    uint8_t rs[64];
-    if (w->r.size() == 32 && w->s.size() == 32) { memcpy(rs, w->r.data(), 32); memcpy(rs + 32, w->s.data(), 32); }
-    else g.random_scalars(rs, 2);                                    // uniform in Fr, like snarkjs' Fr.random()
-    w->proof.resize(256); w->pub.resize(32 * (size_t)np);
-    if (g.prove(g_key, payload, nw, rs, rs + 32, w->proof.data(), w->pub.data())) { w->err = g.last_error(g_ctx); return false; }
     return true;
 }
 // B voters over the listed devices (zkc_pool_*): one context, resident key and host thread per device; caller holds g_mu
@@ -137,24 +128,13 @@ void execute(napi_env, void* data) {
     if (!load_api(w->libhint)) { w->err = g.err; return; }
     if (w->kind == BATCH) { run_batch(w); return; }
     if (!ensure_ctx(w->err)) return;
-    if (w->kind == PROVE) {
-        const uint8_t* payload; uint32_t nw;
-        if (g.wtns_parse(w->wtns_file.data(), w->wtns_file.size(), &payload, &nw)) { w->err = "Invalid witness file"; return; }
-        run_prove(w, payload, nw);
-        return;
-    }
-    std::vector<uint8_t> wtns;
+    std::vector<uint8_t> wtns;                                        // WITNESS: inputs -> .wtns file image
     if (!run_witness(w, wtns)) return;
-    if (w->kind == WITNESS) {
-        const uint32_t nw = (uint32_t)(wtns.size() / 32);
-        w->out.resize(g.wtns_write(wtns.data(), nw, nullptr, 0));
-        g.wtns_write(wtns.data(), nw, w->out.data(), w->out.size());
-        return;
-    }
-    run_prove(w, wtns.data(), (uint32_t)(wtns.size() / 32));
+    const uint32_t nw = (uint32_t)(wtns.size() / 32);
+    w->out.resize(g.wtns_write(wtns.data(), nw, nullptr, 0));
+    g.wtns_write(wtns.data(), nw, w->out.data(), w->out.size());
 }
-void complete(napi_env env, napi_status, void* data) {
-    Work* w = (Work*)data;
+void settle(napi_env env, Work* w) {                                  // main thread: resolve or reject the promise of w, release what it pinned
     if (!w->err.empty()) {
         napi_value msg, e; napi_create_string_utf8(env, w->err.c_str(), NAPI_AUTO_LENGTH, &msg); napi_create_error(env, nullptr, msg, &e);
         napi_reject_deferred(env, w->deferred, e);
@@ -176,7 +156,43 @@ void complete(napi_env env, napi_status, void* data) {
         napi_resolve_deferred(env, w->deferred, obj);
     }
     if (w->zkey_ref) napi_delete_reference(env, w->zkey_ref);
-    napi_delete_async_work(env, w->work); delete w;
+    if (w->work) napi_delete_async_work(env, w->work);
+    delete w;
+}
+void complete(napi_env env, napi_status, void* data) { settle(env, (Work*)data); }
+
+// ---- fullProve / prove through the proving service: submitted from the main thread, completed on a service thread, settled back on the main thread ----
+napi_threadsafe_function g_tsfn = nullptr; int g_inflight = 0;        // g_inflight: main thread only
+void on_done(void* user, int rc, int32_t status, const char* text) {  // service thread
+    Work* w = (Work*)user;
+    if (rc == 7 /* ZKC_ERR_WITNESS */) w->err = std::string("Error: Assert Failed. Error in template ") + assert_site(status);
+    else if (rc) w->err = text && *text ? text : "proving failed";
+    napi_call_threadsafe_function(g_tsfn, w, napi_tsfn_blocking);
+}
+void settle_js(napi_env env, napi_value, void*, void* data) {         // main thread
+    if (env) settle(env, (Work*)data);
+    if (--g_inflight == 0 && env) napi_unref_threadsafe_function(env, g_tsfn);      // nothing pending: do not keep the event loop alive
+}
+napi_value submit(napi_env env, Work* w, const uint8_t* payload, uint32_t nw) {
+    napi_value promise; napi_create_promise(env, &w->deferred, &promise);
+    { std::lock_guard<std::mutex> guard(g_mu); if (!load_api(w->libhint)) w->err = g.err; }
+    uint32_t nv = 0, np = 0, dn = 0; void* svc = nullptr;
+    if (w->err.empty() && (!w->zkey_p || g.header_info(w->zkey_p, w->zkey_n, &nv, &np, &dn))) w->err = "not a zkey file";
+    if (w->err.empty() && w->kind == FULLPROVE && (int)w->inputs.size() != g.n_inputs(w->nLevels) * 32) w->err = "Not all inputs have been set";
+    if (w->err.empty() && !(svc = g.service_default())) w->err = g.service_err();
+    if (w->err.empty()) {
+        w->proof.resize(256); w->pub.resize(32 * (size_t)np);
+        if (w->r.size() == 32 && w->s.size() == 32) { memcpy(w->rs64, w->r.data(), 32); memcpy(w->rs64 + 32, w->s.data(), 32); w->has_rs = true; }
+        if (g_inflight++ == 0) napi_ref_threadsafe_function(env, g_tsfn);
+        const int rc = w->kind == FULLPROVE
+            ? g.submit_fullprove(svc, w->zkey_p, w->zkey_n, w->nLevels, w->inputs.data(), w->has_rs ? w->rs64 : nullptr, w->proof.data(), w->pub.data(), on_done, w)
+            : g.submit_prove(svc, w->zkey_p, w->zkey_n, payload, nw, w->has_rs ? w->rs64 : nullptr, w->proof.data(), w->pub.data(), on_done, w);
+        if (rc == 0) return promise;
+        w->err = g.service_err();
+        if (--g_inflight == 0) napi_unref_threadsafe_function(env, g_tsfn);
+    }
+    settle(env, w);                                                   // rejected before anything was queued
+    return promise;
 }
 std::vector<uint8_t> buf_arg(napi_env env, napi_value v) {
     bool isb = false; napi_is_buffer(env, v, &isb); if (!isb) return {};
@@ -201,7 +217,7 @@ napi_value FullProveRaw(napi_env env, napi_callback_info info) {
     Work* w = new Work(); w->kind = FULLPROVE;
     w->inputs = buf_arg(env, a[0]); napi_get_value_int32(env, a[1], &w->nLevels); pin_zkey(env, a[2], w); w->r = buf_arg(env, a[3]); w->s = buf_arg(env, a[4]);
     w->libhint = str_arg(env, a[5]);
-    return queue(env, w, "zkcensus.fullProve");
+    return submit(env, w, nullptr, 0);
 }
 // fullProveBatchRaw(flatInputs: Buffer (B x nInputs x 32), nLevels, zkey: Buffer, devices: Buffer (int32 LE each), rs: Buffer (B x 64)|null, libPath)
 //   -> Promise<{proofs: Buffer (B x 256), publicSignals: Buffer (B x nPublic x 32), status: Buffer (B x int32 LE, ZKC_W_*)}>
@@ -219,7 +235,10 @@ napi_value ProveRaw(napi_env env, napi_callback_info info) {
     size_t argc = 5; napi_value a[5]; napi_get_cb_info(env, info, &argc, a, nullptr, nullptr);
     Work* w = new Work(); w->kind = PROVE;
     pin_zkey(env, a[0], w); w->wtns_file = buf_arg(env, a[1]); w->r = buf_arg(env, a[2]); w->s = buf_arg(env, a[3]); w->libhint = str_arg(env, a[4]);
-    return queue(env, w, "zkcensus.prove");
+    const uint8_t* payload = nullptr; uint32_t nw = 0;
+    { std::lock_guard<std::mutex> guard(g_mu); if (!load_api(w->libhint)) w->err = g.err; }
+    if (w->err.empty() && g.wtns_parse(w->wtns_file.data(), w->wtns_file.size(), &payload, &nw)) w->err = "Invalid witness file";
+    return submit(env, w, payload, nw);
 }
 // witnessRaw(flatInputs: Buffer, nLevels, libPath) -> Promise<Buffer>  (.wtns file image; snarkjs wtns.calculate)
 napi_value WitnessRaw(napi_env env, napi_callback_info info) {
@@ -248,7 +267,10 @@ napi_value VerifyJson(napi_env env, napi_callback_info info) {
     napi_value out; napi_get_boolean(env, rc == 1, &out); return out;
 }
 napi_value Init(napi_env env, napi_value exports) {
-    napi_value f;
+    napi_value f, name;
+    napi_create_string_utf8(env, "zkcensus.settle", NAPI_AUTO_LENGTH, &name);
+    napi_create_threadsafe_function(env, nullptr, nullptr, name, 0, 1, nullptr, nullptr, nullptr, settle_js, &g_tsfn);
+    napi_unref_threadsafe_function(env, g_tsfn);
 #define EXPORT(name, fn) napi_create_function(env, name, NAPI_AUTO_LENGTH, fn, nullptr, &f); napi_set_named_property(env, exports, name, f);
     EXPORT("fullProveRaw", FullProveRaw) EXPORT("fullProveBatchRaw", FullProveBatchRaw) EXPORT("proveRaw", ProveRaw) EXPORT("witnessRaw", WitnessRaw) EXPORT("circuitFromWasm", CircuitFromWasm) EXPORT("verifyJson", VerifyJson)
 #undef EXPORT

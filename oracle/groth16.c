@@ -4,8 +4,10 @@
  * reaches at ts_inputs/src/example.ts:358-362, and from go-rapidsnark's verifier (zk_census_test.go:122).
  * snarkjs / ffjavascript / rapidsnark are un-vendored, so: verify is pinned by the reference's committed
  * (proof.json, signals.json, verification_key.json); prove is "parity unpinned" against the reference provers
- * (random r,s, proving_key.zkey is a missing blob) and is validated by own-verify plus the exponent-space
- * closed form of the test setup (tests/). */
+ * (random r,s, proving_key.zkey is a missing blob) and is pinned instead by the toxic-waste closed form of the test
+ * setup: tests/closed_form.py evaluates pi_a, pi_b, pi_c as scalars from (seed, .r1cs, witness, r, s) with Lagrange
+ * evaluation at tau -- no NTT, no MSM, no .zkey -- and tests/test_closed_form_prover.py requires byte equality with
+ * this file's proofs at nLevels 10 and 160 (and with the GPU's). */
 #include "zkc_oracle.h"
 #include <string.h>
 #include <stdlib.h>

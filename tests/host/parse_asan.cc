@@ -118,6 +118,12 @@ int main() {
     }
     { uint8_t d[32]; sha256("abc", 3, d); CHECK(hex_of(d, 32) == "ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad");
       std::string m(1000, 'a'); sha256(m.data(), m.size(), d); CHECK(hex_of(d, 32) == "41edece42d63e8d9bf515a9ba6932e1c20cbc9f5a5d134645adb5db1b9737ea3"); }
+    // the SHA-extension rounds against the portable ones: every length around the block boundaries, split updates
+    { std::vector<uint8_t> m(70000); uint32_t x = 12345; for (auto& b : m) { x = x * 1664525u + 1013904223u; b = (uint8_t)(x >> 24); }
+      for (size_t len : {0ul, 1ul, 55ul, 56ul, 63ul, 64ul, 65ul, 119ul, 120ul, 127ul, 128ul, 129ul, 1000ul, 4096ul, 65536ul, 69999ul}) {
+          uint8_t a[32], b[32]; Sha256 p(false); p.update(m.data(), len); p.final(a);
+          Sha256 q(true); const size_t cut = len / 3; q.update(m.data(), cut); q.update(m.data() + cut, len - cut); q.final(b);
+          CHECK(memcmp(a, b, 32) == 0); } }
     printf("host parsers: ok\n");
     return 0;
 }

@@ -8,7 +8,7 @@ import oracle_lib as ol
 pytestmark = pytest.mark.gpu
 
 
-def test_node_addon_full_surface_on_gpu():
+def test_node_addon_full_surface_on_gpu(tmp_path):
     """The reference's host language: node napi/example.js <zkey> <vkey> = the ts_inputs/src/example.ts:358-362 call through the N-API addon on the
     GPU -- fullProve, wtns.calculate + prove with injected (r, s), four concurrent fullProve calls, a batch over a two-entry device pool, a failing assert, an unknown wasm."""
     import os, shutil, subprocess
@@ -18,11 +18,22 @@ def test_node_addon_full_surface_on_gpu():
     if not node or not os.path.exists(addon):
         pytest.skip('node or the built addon is not available on this box')
     _, zkey_path, vkey_path = setup.ensure_test_artifacts(160)
+    # 64 different voters for the Promise.all burst (one fullProve per voter, the reference's call shape under load)
+    import random, sys
+    sys.path.insert(0, os.path.join(ol.ROOT, 'tools'))
+    from census_gen import random_voter
+    rng = random.Random(64)
+    voters_path = str(tmp_path / 'voters.json')
+    json.dump([random_voter(rng, ol.poseidon, nLevels=160, depth_c=rng.randrange(10, 18), depth_s=rng.randrange(10, 18)) for _ in range(64)], open(voters_path, 'w'))
     try:
-        r = subprocess.run([node, os.path.join(ol.ROOT, 'napi', 'example.js'), zkey_path, vkey_path], cwd=ol.ROOT, capture_output=True, text=True, timeout=900)
+        r = subprocess.run([node, os.path.join(ol.ROOT, 'napi', 'example.js'), zkey_path, vkey_path, '-', voters_path], cwd=ol.ROOT, capture_output=True, text=True, timeout=900)
     except OSError as e:                                   # the box refused to start a child program from this process
         pytest.skip('cannot start node from this process: %s' % e)
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads(r.stdout.strip().splitlines()[-1])
     assert j['verified'] is True and j['publicSignals'] == ol.load_json('ref/signals.json')
     assert j['twoStepEqual'] and j['concurrentOk'] and j['batchOk'] and j['badInputRejected'] and j['unknownWasmRejected']
+    b = j['burst']
+    print('\nPromise.all over %d fullProve: %.1f ms = %d proofs/s; over %d: %d proofs/s' % (b['voters'], b['ms'], b['proofsPerSec'], b['voters4x'], b['proofsPerSec4x']))
+    assert b['allVerified'] and b['signalsOk']
+    assert b['proofsPerSec4x'] > 800, b            # r02 (one proof per libuv work item behind a mutex): ~130 proofs/s

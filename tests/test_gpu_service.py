@@ -1,0 +1,156 @@
+"""GPU: the submission queue behind the single-proof entry points (include/zkcensus.h zkc_service_*, csrc/zkc_service.hip).
+
+The reference proves one voter per call -- prover.Prove per voter, from goroutines (zk_census_test.go:89, ending in rapidsnark's groth16_prover) and
+groth16.fullProve per ballot (ts_inputs/src/example.ts:358-362).  These tests call the same way from many threads and check that every caller gets
+ITS proof (bytes equal the oracle's for its own (witness, r, s)), that callers were really coalesced into shared pipeline passes, that a voter who
+fails a circuit assert fails alone, and that the rapidsnark entry point sustains the batch regime from 64 concurrent callers."""
+import ctypes, json, os, random, sys, threading, time
+import pytest
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(ol.ROOT, 'tools'))
+
+
+def _voters(n, nl, seed, **kw):
+    from census_gen import random_voter
+    rng = random.Random(seed)
+    return [random_voter(rng, ol.poseidon, nLevels=nl, depth_c=rng.randrange(2, 8), depth_s=rng.randrange(2, 8), **kw) for _ in range(n)]
+
+
+def test_concurrent_callers_share_passes_and_get_their_own_proofs():
+    import torch  # noqa: F401
+    import zkcensus_amd
+    from zkcensus_amd import setup
+    nl, T, per = 10, 48, 3
+    _, zkey_path, vkey_path = setup.ensure_test_artifacts(nl)
+    zk = open(zkey_path, 'rb').read(); vk = json.load(open(vkey_path))
+    voters = _voters(T * per, nl, 11)
+    bad = 7                                                             # this caller's ballot claims more weight than the census gives it
+    voters[bad] = dict(voters[bad], voteWeight=str(int(voters[bad]['availableWeight']) + 1))
+    rng = random.Random(5)
+    rs = [rng.randrange(ol.R).to_bytes(32, 'little') + rng.randrange(ol.R).to_bytes(32, 'little') for _ in voters]
+    svc = zkcensus_amd.ProvingService([0])
+    out = [None] * len(voters)
+
+    def caller(t):
+        for k in range(per):
+            i = t * per + k
+            out[i] = svc.fullprove(zk, voters[i], nLevels=nl, rs=rs[i])
+    th = [threading.Thread(target=caller, args=(t,)) for t in range(T)]
+    for t in th: t.start()
+    for t in th: t.join()
+    st = svc.stats()
+    assert st['requests'] == T * per and st['failed'] == 0 and st['waiting'] == 0
+    assert st['batches'] < st['requests'] // 2 and st['largest_batch'] >= 8, st        # coalesced: far fewer batches than callers
+    assert st['key_loads'] == 1 and st['devices_used'] == 1
+    for i, (proof, pub, status) in enumerate(out):
+        if i == bad:
+            assert status == 1                                          # ZKC_W_ERR_WEIGHT (census.circom:72); nobody else was affected
+            continue
+        assert status == 0
+        rc, w = ol.witness(voters[i], nl); assert rc == 0
+        rc, oproof, opub = ol.prove(zk, w, int.from_bytes(rs[i][:32], 'little'), int.from_bytes(rs[i][32:], 'little'))
+        assert rc == 0 and proof == oproof and pub == opub, 'caller %d got a proof that is not the oracle\'s for its own inputs' % i
+        if i % 16 == 0:
+            assert ol.verify(vk, pub, proof)
+    # the witness path (groth16.prove shape): same queue, host witnesses
+    rc, w0 = ol.witness(voters[0], nl)
+    p, u = svc.prove(zk, w0, rs=rs[0])
+    assert (p, u) == (out[0][0], out[0][1])
+    with pytest.raises(zkcensus_amd.ZkcError) as e:
+        svc.prove(zk, w0[:-64])
+    assert e.value.code == 3                                            # INVALID_WITNESS_LENGTH, that caller alone
+    # a second key through the same service replaces the resident one and both keep producing valid proofs
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        _, z2, v2 = setup.ensure_test_artifacts(nl, seed=77, directory=d)
+        zk2 = open(z2, 'rb').read(); vk2 = json.load(open(v2))
+        p2, u2, s2 = svc.fullprove(zk2, voters[1], nLevels=nl)
+        assert s2 == 0 and ol.verify(vk2, u2, p2) and not ol.verify(vk, u2, p2)
+        p1, u1, s1 = svc.fullprove(zk, voters[1], nLevels=nl)
+        assert s1 == 0 and ol.verify(vk, u1, p1)
+    assert svc.stats()['key_loads'] == 3
+    svc.close()
+
+
+def test_rapidsnark_entry_point_from_64_threads_nl160():
+    """groth16_prover (the symbol go-rapidsnark binds, zk_census_test.go:89) called from 64 threads with 64 different witnesses: every proof verifies, the
+    callers were coalesced, and the rate is that of the batch regime, not 64 x the single-proof latency."""
+    import torch  # noqa: F401
+    import zkcensus_amd
+    from zkcensus_amd import groth16, setup, _native
+    nl, T, per = 160, 64, 4
+    _, zkey_path, vkey_path = setup.ensure_test_artifacts(nl)
+    zk = open(zkey_path, 'rb').read(); vk = json.load(open(vkey_path))
+    ctx = zkcensus_amd.Context(0)
+    from census_gen import random_voter
+    rng = random.Random(21)
+    voters = [random_voter(rng, ol.poseidon, nLevels=nl, depth_c=rng.randrange(10, 18), depth_s=rng.randrange(10, 18)) for _ in range(T)]
+    ws, st = ctx.witness(voters, nLevels=nl)
+    assert st == [0] * T
+    lib = _native.load()
+    images = []
+    for w in ws:
+        n = lib.zkc_wtns_write(w, len(w) // 32, None, 0); buf = ctypes.create_string_buffer(n); lib.zkc_wtns_write(w, len(w) // 32, buf, n); images.append(buf.raw)
+    ctx.close()
+    results = [[] for _ in range(T)]
+
+    def caller(t):
+        for _ in range(per):
+            ps, us = ctypes.c_ulong(2048), ctypes.c_ulong(2048)
+            pb, ub, eb = ctypes.create_string_buffer(2048), ctypes.create_string_buffer(2048), ctypes.create_string_buffer(256)
+            rc = lib.groth16_prover(zk, len(zk), images[t], len(images[t]), pb, ctypes.byref(ps), ub, ctypes.byref(us), eb, 256)
+            results[t].append((rc, pb.value, ub.value, eb.value))
+    caller(0); results[0].clear()                                       # key load and work-space growth are not part of the rate
+    svc = zkcensus_amd.ProvingService(default=True)
+    before = svc.stats()
+    th = [threading.Thread(target=caller, args=(t,)) for t in range(T)]
+    t0 = time.time()
+    for t in th: t.start()
+    for t in th: t.join()
+    dt = time.time() - t0
+    after = svc.stats()
+    n = T * per
+    for t in range(T):
+        assert len(results[t]) == per
+        for rc, pjs, ujs, e in results[t]:
+            assert rc == 0, e
+            assert [int(x) for x in json.loads(ujs)] == [int.from_bytes(ws[t][32 * (1 + k):32 * (2 + k)], 'little') for k in range(8)]
+    sample = [(t, k) for t in range(0, T, 7) for k in range(per)]
+    for t, k in sample:
+        assert groth16.verify(vk, json.loads(results[t][k][2]), json.loads(results[t][k][1]))
+    assert len({results[t][k][1] for t in range(T) for k in range(per)}) == n           # fresh (r, s) per call
+    batches = after['batches'] - before['batches']
+    rate = n / dt
+    print('\ngroth16_prover x %d threads: %d proofs in %.3f s = %.0f proofs/s, %d batches (largest %d)' % (T, n, dt, rate, batches, after['largest_batch']))
+    assert batches <= n // 4, (before, after)
+    assert rate > 800, 'rapidsnark entry point from %d threads: %.0f proofs/s' % (T, rate)      # r02's global mutex: ~250 proofs/s; measured here: see profiles/r03_service_*.json
+
+
+def test_failed_work_space_growth_leaves_the_key_usable(monkeypatch):
+    """a failed hipMalloc inside lanes_ensure used to leave freed buffers behind a stale capacity.  ZKC_TEST_FAIL_ALLOC makes the growth to
+    >= N proofs in flight fail: the call must return an error, and the next smaller call must re-allocate and prove."""
+    import torch, numpy as np
+    import zkcensus_amd
+    from zkcensus_amd import setup
+    nl = 10
+    _, zkey_path, vkey_path = setup.ensure_test_artifacts(nl)
+    zk = open(zkey_path, 'rb').read(); vk = json.load(open(vkey_path))
+    voters = _voters(12, nl, 4)
+    ctx = zkcensus_amd.Context(0); pk = zkcensus_amd.ProvingKey(ctx, zk)
+    flat = b''.join(zkcensus_amd.flatten_inputs(v, nl) for v in voters)
+    rs = b''.join(random.Random(9).randrange(ol.R).to_bytes(32, 'little') for _ in range(24))
+    d_in = torch.from_numpy(np.frombuffer(flat, dtype=np.uint8).copy()).cuda()
+    d_w = torch.empty(12 * ctx.n_wires(nl) * 32, dtype=torch.uint8, device='cuda'); d_st = torch.zeros(12, dtype=torch.int32, device='cuda')
+    p2, u2 = pk.fullprove_batch_dev(d_in.data_ptr(), 2, d_w.data_ptr(), d_st.data_ptr(), rs[:128])          # work space for 2 in flight
+    monkeypatch.setenv('ZKC_TEST_FAIL_ALLOC', '8')
+    with pytest.raises(zkcensus_amd.ZkcError) as e:
+        pk.fullprove_batch_dev(d_in.data_ptr(), 12, d_w.data_ptr(), d_st.data_ptr(), rs)                     # growth to 12 fails
+    assert e.value.code == 6 and 'ZKC_TEST_FAIL_ALLOC' in str(e.value)
+    p2b, u2b = pk.fullprove_batch_dev(d_in.data_ptr(), 2, d_w.data_ptr(), d_st.data_ptr(), rs[:128])        # re-allocates for 2 and proves
+    assert (p2b, u2b) == (p2, u2)
+    monkeypatch.delenv('ZKC_TEST_FAIL_ALLOC')
+    p12, u12 = pk.fullprove_batch_dev(d_in.data_ptr(), 12, d_w.data_ptr(), d_st.data_ptr(), rs)
+    assert p12[:512] == p2 and ol.verify(vk, u12[-256:], p12[-256:])
+    pk.close(); ctx.close()

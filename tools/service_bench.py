@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""The reference's call shape under load, measured: ONE voter per call, many callers at once.
+
+  1. node napi/example.js ... voters.json   Promise.all over one groth16.fullProve per voter (ts_inputs/src/example.ts:358-362), 64 and 256 at once
+  2. groth16_prover from T threads          the symbol go-rapidsnark binds (zk_census_test.go:89), whole .zkey / .wtns images per call
+  3. zkc_service_fullprove from T threads   inputs in, proof out (what a cgo prover.Prove replacement calls)
+All three end in the library's proving service (csrc/zkc_service.hip), which coalesces concurrent callers into pipeline passes.  Every proof of 2 and 3 is
+checked by the batch verifier, every proof of 1 by groth16.verify inside the script.  usage: service_bench.py [threads] [calls per thread]  -> one JSON object.
+node runs first, as a child started before this process touches the GPU."""
+import ctypes, json, os, random, shutil, subprocess, sys, tempfile, threading, time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, os.path.join(ROOT, 'tools'))
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+PER = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+NL = 160
+
+
+def main():
+    import oracle_lib as ol                                   # voter generation only (Poseidon on the CPU); nothing timed goes through it
+    from census_gen import random_voter
+    from zkcensus_amd import setup
+    _, zkey_path, vkey_path = setup.ensure_test_artifacts(NL)
+    rng = random.Random(2024)
+    voters = [random_voter(rng, ol.poseidon, nLevels=NL, depth_c=rng.randrange(12, 18), depth_s=rng.randrange(12, 18)) for _ in range(T)]
+    out = {'threads': T, 'calls_per_thread': PER, 'nLevels': NL}
+    node = shutil.which('node')
+    if node and os.path.exists(os.path.join(ROOT, 'napi', 'zkcensus.node')):
+        with tempfile.TemporaryDirectory() as d:
+            vp = os.path.join(d, 'voters.json'); json.dump(voters[:64], open(vp, 'w'))
+            r = subprocess.run([node, os.path.join(ROOT, 'napi', 'example.js'), zkey_path, vkey_path, '-', vp], cwd=ROOT, capture_output=True, text=True, timeout=600)
+            if r.returncode == 0:
+                j = json.loads(r.stdout.strip().splitlines()[-1]); out['node_promise_all_fullProve'] = j['burst']; out['node_single_fullProve_ms_warm'] = j['msWarm']
+            else:
+                out['node_error'] = r.stderr[-400:]
+    import torch  # noqa: F401
+    import zkcensus_amd
+    from zkcensus_amd import _native
+    lib = _native.load()
+    zk = open(zkey_path, 'rb').read(); vk = ol.vk_bytes(json.load(open(vkey_path)))
+    ctx = zkcensus_amd.Context(0)
+    ws, st = ctx.witness(voters, nLevels=NL)
+    assert st == [0] * T
+    images = []
+    for w in ws:
+        n = lib.zkc_wtns_write(w, len(w) // 32, None, 0); buf = ctypes.create_string_buffer(n); lib.zkc_wtns_write(w, len(w) // 32, buf, n); images.append(buf.raw)
+    flats = [zkcensus_amd.flatten_inputs(v, NL) for v in voters]
+    svc = zkcensus_amd.ProvingService(default=True)
+
+    def run(kind):
+        res = [[] for _ in range(T)]
+
+        def caller(t):
+            for _ in range(PER):
+                if kind == 'groth16_prover':
+                    ps, us = ctypes.c_ulong(2048), ctypes.c_ulong(2048)
+                    pb, ub, eb = ctypes.create_string_buffer(2048), ctypes.create_string_buffer(2048), ctypes.create_string_buffer(256)
+                    rc = lib.groth16_prover(zk, len(zk), images[t], len(images[t]), pb, ctypes.byref(ps), ub, ctypes.byref(us), eb, 256)
+                    assert rc == 0, eb.value
+                    res[t].append((ol.proof_bytes(json.loads(pb.value)), b''.join(ol.le32(x) for x in json.loads(ub.value))))
+                else:
+                    p, u, s = svc.fullprove(zk, flats[t], nLevels=NL); assert s == 0
+                    res[t].append((p, u))
+        caller(0); res[0].clear()                                  # key load, work space
+        s0 = svc.stats(); th = [threading.Thread(target=caller, args=(t,)) for t in range(T)]
+        t0 = time.time()
+        for x in th: x.start()
+        for x in th: x.join()
+        dt = time.time() - t0; s1 = svc.stats()
+        proofs = b''.join(p for r in res for p, _ in r); pubs = b''.join(u for r in res for _, u in r); n = T * PER
+        ok = lib.zkc_verify_batch(ctx._h, vk, 8, pubs, proofs, n, None)
+        return {'proofs': n, 'seconds': round(dt, 4), 'proofs_per_s': round(n / dt, 1), 'batches': s1['batches'] - s0['batches'], 'largest_batch': s1['largest_batch'],
+                'all_verified_by_batch_verifier': ok == 1, 'devices_used': s1['devices_used']}
+    out['groth16_prover_threads'] = run('groth16_prover')
+    out['service_fullprove_threads'] = run('fullprove')
+    # one caller, one call at a time: the latency a lone sequential caller sees through the same entry points
+    t0 = time.time(); [svc.fullprove(zk, flats[0], nLevels=NL) for _ in range(20)]; out['sequential_fullprove_ms'] = round((time.time() - t0) / 20 * 1e3, 2)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

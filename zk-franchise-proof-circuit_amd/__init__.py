@@ -9,7 +9,7 @@ from . import _native
 from ._native import ZkcError
 from .inputs import INPUT_KEYS, flatten_inputs, R_MOD
 
-__all__ = ['Context', 'ProvingKey', 'DevicePool', 'groth16', 'ZkcError', 'INPUT_KEYS', 'flatten_inputs', 'R_MOD']
+__all__ = ['Context', 'ProvingKey', 'DevicePool', 'ProvingService', 'groth16', 'ZkcError', 'INPUT_KEYS', 'flatten_inputs', 'R_MOD']
 
 
 class Context:
@@ -177,6 +177,62 @@ class DevicePool:
         if getattr(self, '_h', None):
             self._lib.zkc_pool_destroy(self._h)
             self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ProvingService:
+    """The submission queue behind the single-proof entry points (include/zkcensus.h zkc_service_*): callers -- one thread per voter, the way the
+    reference's hosts call prover.Prove (zk_census_test.go:89) and groth16.fullProve (ts_inputs/src/example.ts:358-362) -- enqueue one voter each and
+    a worker per GPU proves whatever has accumulated in one pipeline pass sequence.  The calls block; ctypes releases the GIL meanwhile."""
+
+    def __init__(self, devices=None, default=False):
+        self._lib = _native.load()
+        self._own = not default
+        if default:
+            h = self._lib.zkc_service_default()
+            if not h:
+                raise ZkcError(6, (self._lib.zkc_service_last_error() or b'').decode())
+            self._h = ctypes.c_void_p(h)
+        else:
+            devices = list(devices or [])
+            arr = (ctypes.c_int * max(1, len(devices)))(*[int(d) for d in devices])
+            h = ctypes.c_void_p()
+            rc = self._lib.zkc_service_create(arr if devices else None, len(devices), ctypes.byref(h))
+            if rc != 0:
+                raise ZkcError(rc, (self._lib.zkc_service_last_error() or b'').decode())
+            self._h = h
+
+    def fullprove(self, zkey_bytes, inputs, nLevels=160, rs=None, n_public=8):
+        """One voter: inputs = 12-key object or pre-flattened bytes.  Returns (proof 256 B, publics, status); raises on anything but a circuit assert."""
+        flat = inputs if isinstance(inputs, (bytes, bytearray)) else flatten_inputs(inputs, nLevels)
+        proof = ctypes.create_string_buffer(256); pub = ctypes.create_string_buffer(32 * n_public); st = ctypes.c_int32(0); err = ctypes.create_string_buffer(512)
+        rc = self._lib.zkc_service_fullprove(self._h, zkey_bytes, len(zkey_bytes), nLevels, bytes(flat), None if rs is None else bytes(rs), proof, pub, ctypes.byref(st), err, 512)
+        if rc not in (0, 7):
+            raise ZkcError(rc, err.value.decode())
+        return proof.raw, pub.raw, st.value
+
+    def prove(self, zkey_bytes, wtns, rs=None, n_public=8):
+        """One witness (n_vars x 32 B, standard form, host).  Returns (proof, publics)."""
+        proof = ctypes.create_string_buffer(256); pub = ctypes.create_string_buffer(32 * n_public); err = ctypes.create_string_buffer(512)
+        rc = self._lib.zkc_service_prove(self._h, zkey_bytes, len(zkey_bytes), wtns, len(wtns) // 32, None if rs is None else bytes(rs), proof, pub, err, 512)
+        if rc != 0:
+            raise ZkcError(rc, err.value.decode())
+        return proof.raw, pub.raw
+
+    def stats(self):
+        out = (ctypes.c_uint64 * 8)()
+        self._lib.zkc_service_stats(self._h, out)
+        return dict(zip(('requests', 'batches', 'largest_batch', 'key_loads', 'devices', 'devices_used', 'failed', 'waiting'), [int(x) for x in out]))
+
+    def close(self):
+        if getattr(self, '_h', None) and self._own:
+            self._lib.zkc_service_destroy(self._h)
+        self._h = None
 
     def __del__(self):
         try:

@@ -51,6 +51,7 @@ zkc_prof_scope::~zkc_prof_scope() {
 extern "C" int zkc_profile_enable(zkc_ctx* ctx, uint32_t mask) {
     if (!ctx) return ZKC_ERR_BAD_ARG;
     ZKC_LOCK(ctx);
+    ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));          // the counter below must live on THIS context's device (a pool leaves the thread on its last device)
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& r : ctx->prof.pending) { ctx->prof.free_events.push_back(r.a); ctx->prof.free_events.push_back(r.b); }
     ctx->prof.pending.clear();
@@ -63,14 +64,15 @@ extern "C" int zkc_profile_enable(zkc_ctx* ctx, uint32_t mask) {
 extern "C" int zkc_profile_read(zkc_ctx* ctx, int cat, double* total_ms, uint64_t* launches, uint64_t* alg_bytes) {
     if (!ctx || cat < 0 || cat >= ZKC_PROF_NCAT) return ZKC_ERR_BAD_ARG;
     ZKC_LOCK(ctx);
-    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream2));
+    ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream2)); ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->fin_stream));
     for (auto& r : ctx->prof.pending) {
         float ms = 0; (void)hipEventElapsedTime(&ms, r.a, r.b); ctx->prof.ms[r.cat] += ms;
         ctx->prof.free_events.push_back(r.a); ctx->prof.free_events.push_back(r.b);
     }
     ctx->prof.pending.clear();
     if (cat == ZKC_PROF_MSM_G1_STREAMED && ctx->d_prof_entries) {      // launches of this bytes-only category = mixed additions the G1 accumulation really performed
-        unsigned long long v = 0; (void)hipDeviceSynchronize(); (void)hipMemcpy(&v, ctx->d_prof_entries, 8, hipMemcpyDeviceToHost); ctx->prof.launches[cat] = v;
+        unsigned long long v = 0; (void)hipMemcpyAsync(&v, ctx->d_prof_entries, 8, hipMemcpyDeviceToHost, ctx->stream); (void)hipStreamSynchronize(ctx->stream); ctx->prof.launches[cat] = v;
     }
     if (total_ms) *total_ms = ctx->prof.ms[cat]; if (launches) *launches = ctx->prof.launches[cat]; if (alg_bytes) *alg_bytes = ctx->prof.bytes[cat];
     return ZKC_OK;

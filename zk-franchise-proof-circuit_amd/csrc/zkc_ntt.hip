@@ -163,10 +163,10 @@ __device__ __forceinline__ void ntt_r4(uint32_t* p0, uint32_t* p1, uint32_t* p2,
     for (int i = 0; i < 9; i++) { p0[i] = a[i]; p1[i] = b[i]; p2[i] = c[i]; p3[i] = d[i]; }
 }
 extern "C" __global__ void __launch_bounds__(256)
-zkc_ntt_pass(const Fr* __restrict__ src_all, Fr* __restrict__ dst_all, const uint32_t* __restrict__ tw29, const Fr* __restrict__ scale,
+zkc_ntt_pass(const Fr* src_all, Fr* dst_all, const uint32_t* __restrict__ tw29, const Fr* __restrict__ scale,      // src_all == dst_all when ntt_pair_run calls it in place: no __restrict__ on the data pointers
              int logn, int s0, int b, int first) {
-    const Fr* __restrict__ src = src_all + ((size_t)blockIdx.y << logn);      // blockIdx.y = vector of the batch
-    Fr* __restrict__ dst = dst_all + ((size_t)blockIdx.y << logn);
+    const Fr* src = src_all + ((size_t)blockIdx.y << logn);      // blockIdx.y = vector of the batch
+    Fr* dst = dst_all + ((size_t)blockIdx.y << logn);
     extern __shared__ uint32_t tile[];                                      // 9 words per element (odd stride: conflict-free)
     const int mid_n = 1 << b;
     const int lo_bits = s0;

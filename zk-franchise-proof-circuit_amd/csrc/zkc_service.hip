@@ -1,0 +1,314 @@
+// zkc_service.hip -- the reference's own call shape made fast: concurrent SINGLE-proof callers coalesced into pipeline passes.
+//
+// The reference proves one voter per call: prover.Prove(zkey, wasm, inputs) in a loop or from goroutines (zk_census_test.go:89, reaching
+// rapidsnark's groth16_prover through cgo) and groth16.fullProve(inputs, wasm, zkey) per ballot (ts_inputs/src/example.ts:358-362).  A GPU pipeline
+// pass proves up to 96 voters in the time two single proofs take, so behind those entry points sits a submission queue: callers enqueue
+// (inputs | witness, r, s) and one pair of worker threads per GPU drains whatever has accumulated -- group commit, no timer: a lone caller is
+// served at once with a batch of one, callers that arrive while the GPU is busy share its next pass -- into one zkc_fullprove_batch_dev /
+// zkc_prove_batch_dev call, and every caller gets its own proof, status and error back.  Two workers per device: while one holds the GPU the
+// other collects and uploads the next batch and tops it up until the GPU is free.  Devices: an explicit list, $ZKC_DEVICE ("2", "0,1,2,3", "all")
+// or, unset, every visible device -- but a device is only brought up (context + 1 GB of key tables, 0.6 s) when the queue is long enough to pay for
+// it, so a sequential caller stays on the first one.
+// Host code over the public batch entry points; launches no kernel of its own.
+#include "zkc_prover.h"
+#include "zkc_hostparse.h"
+#include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <set>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+enum { KIND_FULLPROVE = 0, KIND_PROVE = 1 };
+struct Req {
+    int kind; uint8_t fp[32]; const uint8_t* zkey; size_t zkey_len; int nLevels; const uint8_t* data; uint32_t nW;
+    uint8_t rs[64]; uint8_t* proof; uint8_t* pub;
+    zkc_done_fn done; void* user;
+    bool same_class(const Req& o) const { return kind == o.kind && nLevels == o.nLevels && !memcmp(fp, o.fp, 32); }
+};
+struct Waiter { std::mutex m; std::condition_variable cv; bool finished = false; int rc = 0; int32_t status = 0; std::string err; };
+void waiter_done(void* u, int rc, int32_t status, const char* err) {
+    Waiter* w = (Waiter*)u; std::lock_guard<std::mutex> g(w->m);
+    w->rc = rc; w->status = status; w->err = err ? err : ""; w->finished = true; w->cv.notify_one();
+}
+struct HipBuf {     // grow-only buffer on the calling thread's current device (or pinned host memory)
+    void* p = nullptr; size_t sz = 0; bool host = false;
+    bool ensure(size_t want) {
+        if (sz >= want) return true;
+        release();
+        const hipError_t e = host ? hipHostMalloc(&p, want) : hipMalloc(&p, want);
+        if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; return false; }
+        sz = want; return true;
+    }
+    void release() { if (p) { if (host) (void)hipHostFree(p); else (void)hipFree(p); } p = nullptr; sz = 0; }
+};
+}  // namespace
+
+struct zkc_service {
+    struct Dev {
+        int device = 0; std::mutex gpu_mu;              // held while a worker owns the GPU pipeline of this device (key switch + batch call)
+        zkc_ctx* ctx = nullptr; zkc_zkey* key = nullptr;
+        std::set<std::pair<const void*, size_t>> confirmed;   // .zkey images whose FULL SHA-256 was compared with the resident key's (fingerprints are sampled)
+        // under zkc_service::mu: what this device holds or is about to load
+        bool has_want = false; uint8_t want_fp[32] = {0};
+        uint64_t batches = 0, proofs = 0;
+    };
+    struct Worker {
+        Dev* dev = nullptr; int index = 0; std::thread th; std::condition_variable cv; bool wake = false, idle = false;
+        HipBuf h_in{nullptr, 0, true}, d_in, d_wtns, d_status, h_proofs{nullptr, 0, true}, h_pubs{nullptr, 0, true}, h_status{nullptr, 0, true};
+        hipStream_t st = nullptr; size_t cap = 0;        // requests the staging buffers hold (grows geometrically with the batches this worker has seen)
+    };
+    std::mutex mu; std::deque<Req*> q; bool stop = false;
+    std::vector<std::unique_ptr<Dev>> devs; std::vector<std::unique_ptr<Worker>> workers;
+    int max_batch = 256, spill = 32;
+    uint64_t n_requests = 0, n_batches = 0, largest_batch = 0, key_loads = 0, n_failed = 0;
+};
+static thread_local std::string g_service_err;
+
+namespace {
+void finish(Req* r, int rc, int32_t status, const std::string& err) { r->done(r->user, rc, status, err.c_str()); delete r; }
+
+// ---- dispatch (all under svc->mu) ----
+bool any_dev_wants(zkc_service* s, const uint8_t fp[32]) { for (auto& d : s->devs) if (d->has_want && !memcmp(d->want_fp, fp, 32)) return true; return false; }
+// the requests worker w takes now: the class of the first queued request its device already holds the key for, else (device cold, key unknown to every
+// device, or the queue long enough to pay for a load) the class of the head; up to `cap` of that class, in arrival order
+std::vector<Req*> grab(zkc_service* s, zkc_service::Worker* w, size_t cap, const Req* like = nullptr) {
+    std::vector<Req*> out;
+    if (s->q.empty() || cap == 0) return out;
+    zkc_service::Dev* d = w->dev;
+    const Req* cls = like;
+    if (!cls && d->has_want) for (Req* r : s->q) if (!memcmp(r->fp, d->want_fp, 32)) { cls = r; break; }
+    if (!cls) {
+        const Req* head = s->q.front();
+        if (!d->has_want || !any_dev_wants(s, head->fp) || s->q.size() >= (size_t)s->spill) cls = head;
+    }
+    if (!cls) return out;
+    const Req key = *cls;
+    for (auto it = s->q.begin(); it != s->q.end() && out.size() < cap;) { if ((*it)->same_class(key)) { out.push_back(*it); it = s->q.erase(it); } else ++it; }
+    if (!like) { d->has_want = true; memcpy(d->want_fp, key.fp, 32); }
+    return out;
+}
+// wake at most one idle worker for the head of the queue: first a worker on a device that holds (or is loading) its key, then -- when no device does, or the
+// queue has grown past `spill` requests -- a worker on a cold device
+void dispatch(zkc_service* s) {
+    if (s->q.empty()) return;
+    const Req* head = s->q.front();
+    zkc_service::Worker* pick = nullptr;
+    for (auto& w : s->workers) if (w->idle && !w->wake && w->dev->has_want && !memcmp(w->dev->want_fp, head->fp, 32)) { pick = w.get(); break; }
+    if (!pick && (!any_dev_wants(s, head->fp) || s->q.size() >= (size_t)s->spill)) {
+        for (auto& w : s->workers) if (w->idle && !w->wake && !w->dev->has_want) { pick = w.get(); break; }
+        if (!pick && !any_dev_wants(s, head->fp)) for (auto& w : s->workers) if (w->idle && !w->wake) { pick = w.get(); break; }
+    }
+    if (pick) { pick->wake = true; pick->cv.notify_one(); }
+}
+
+// ---- one batch on one device ----
+struct Batch { std::vector<Req*> reqs; std::vector<uint8_t> rs; };
+// uploads requests [from, reqs.size()) of the batch into the worker's device buffers; false = HIP failure (text in err)
+bool stage(zkc_service::Worker* w, Batch& b, size_t from, size_t nIn, size_t nW, std::string& err) {
+    const size_t B = b.reqs.size();
+    if (from >= B) return true;
+    const bool full = b.reqs[0]->kind == KIND_FULLPROVE;
+    if (full) {
+        uint8_t* h = (uint8_t*)w->h_in.p;
+        for (size_t i = from; i < B; i++) memcpy(h + i * nIn * 32, b.reqs[i]->data, nIn * 32);
+        if (hipMemcpyAsync((uint8_t*)w->d_in.p + from * nIn * 32, h + from * nIn * 32, (B - from) * nIn * 32, hipMemcpyHostToDevice, w->st) != hipSuccess) { err = "hipMemcpyAsync of the inputs"; return false; }
+    } else {
+        for (size_t i = from; i < B; i++)
+            if (hipMemcpyAsync((uint8_t*)w->d_wtns.p + i * nW * 32, b.reqs[i]->data, nW * 32, hipMemcpyHostToDevice, w->st) != hipSuccess) { err = "hipMemcpyAsync of a witness"; return false; }
+    }
+    if (hipStreamSynchronize(w->st) != hipSuccess) { err = "hipStreamSynchronize after the uploads"; return false; }
+    return true;
+}
+void fail_all(zkc_service* s, Batch& b, int rc, const std::string& err) {
+    { std::lock_guard<std::mutex> g(s->mu); s->n_failed += b.reqs.size(); }
+    for (Req* r : b.reqs) finish(r, rc, 0, err);
+    b.reqs.clear();
+}
+void process(zkc_service* s, zkc_service::Worker* w, std::vector<Req*>&& first) {
+    zkc_service::Dev* d = w->dev;
+    Batch b; b.reqs = std::move(first);
+    const Req cls = *b.reqs[0];
+    const bool full = cls.kind == KIND_FULLPROVE;
+    std::string err;
+    if (hipSetDevice(d->device) != hipSuccess) { (void)hipGetLastError(); return fail_all(s, b, ZKC_ERR_HIP, "hipSetDevice failed"); }
+    // shapes from the file header alone (the key may not be resident yet)
+    zkc::parse::BinSections bs; zkc::parse::ZkeyHeader zh;
+    if (!zkc::parse::binfile_sections(cls.zkey, cls.zkey_len, "zkey", 1, bs, err) || !zkc::parse::zkey_check(bs, zh, err, false)) return fail_all(s, b, ZKC_ERR_FORMAT, err);
+    const size_t nW = zh.nVars, nPub = zh.nPub, nIn = full ? (size_t)zkc_circuit_n_inputs(cls.nLevels) : 0;
+    if (full && (nIn == 0 || (size_t)zkc_circuit_n_wires(cls.nLevels) != nW)) return fail_all(s, b, ZKC_ERR_BAD_ARG, "the key is not a ZkFranchiseProofCircuit(" + std::to_string(cls.nLevels) + ") key");
+    if (!full) {                                            // a witness of the wrong length fails alone, like rapidsnark's INVALID_WITNESS_LENGTH
+        std::vector<Req*> keep;
+        for (Req* r : b.reqs) { if (r->nW == nW) keep.push_back(r); else finish(r, ZKC_ERR_INVALID_WITNESS_LENGTH, 0, "Invalid witness length. Circuit: " + std::to_string(nW) + ", witness: " + std::to_string(r->nW)); }
+        b.reqs.swap(keep);
+        if (b.reqs.empty()) return;
+    }
+    // staging grows with the batches this worker actually sees (a lone sequential caller reserves room for 8 witnesses, not for max_batch = 256 of them)
+    size_t want = 8; while (want < 2 * b.reqs.size()) want *= 2;
+    w->cap = std::max(w->cap, std::min(want, (size_t)s->max_batch));
+    const size_t cap = w->cap;
+    if (!w->st && hipStreamCreateWithFlags(&w->st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); w->st = nullptr; return fail_all(s, b, ZKC_ERR_HIP, "hipStreamCreate failed"); }
+    if ((full && (!w->h_in.ensure(cap * nIn * 32) || !w->d_in.ensure(cap * nIn * 32))) || !w->d_wtns.ensure(cap * nW * 32) || !w->d_status.ensure(cap * 4) ||
+        !w->h_proofs.ensure(cap * 256) || !w->h_pubs.ensure(cap * nPub * 32 + 32) || !w->h_status.ensure(cap * 4))
+        return fail_all(s, b, ZKC_ERR_HIP, "out of memory for the service's staging buffers on device " + std::to_string(d->device));
+    if (!stage(w, b, 0, nIn, nW, err)) { (void)hipGetLastError(); return fail_all(s, b, ZKC_ERR_HIP, err); }      // beside the other worker's batch, which owns the GPU now
+    int rc = ZKC_OK;
+    {
+        std::lock_guard<std::mutex> gpu(d->gpu_mu);
+        // whoever queued up meanwhile for the same key rides along
+        size_t from = b.reqs.size();
+        { std::lock_guard<std::mutex> g(s->mu); std::vector<Req*> more = grab(s, w, cap - b.reqs.size(), &cls); for (Req* r : more) if (full || r->nW == nW) b.reqs.push_back(r); else finish(r, ZKC_ERR_INVALID_WITNESS_LENGTH, 0, "Invalid witness length"); }
+        if (!stage(w, b, from, nIn, nW, err)) { (void)hipGetLastError(); return fail_all(s, b, ZKC_ERR_HIP, err); }
+        const int B = (int)b.reqs.size();
+        if (!d->ctx && (rc = zkc_ctx_create(d->device, &d->ctx))) { d->ctx = nullptr; return fail_all(s, b, rc, std::string("device ") + std::to_string(d->device) + ": " + zkc_last_error(nullptr)); }
+        // resident key: the sampled fingerprint decides per call; the first time a given image (pointer, length) meets a resident key the FULL SHA-256 is
+        // compared as well, so two images that differ only in bytes the fingerprint does not sample cannot alias in a long-lived process
+        bool reload = !d->key || memcmp(d->key->fingerprint, cls.fp, 32) != 0;
+        if (!reload && !d->confirmed.count({cls.zkey, cls.zkey_len})) {
+            uint8_t full_sha[32]; zkc::parse::sha256(cls.zkey, cls.zkey_len, full_sha);
+            if (memcmp(full_sha, d->key->sha256, 32) != 0) reload = true; else { if (d->confirmed.size() > 64) d->confirmed.clear(); d->confirmed.insert({cls.zkey, cls.zkey_len}); }
+        }
+        if (reload) {
+            if (d->key) { zkc_zkey_free(d->key); d->key = nullptr; }
+            d->confirmed.clear();
+            rc = zkc_zkey_load(d->ctx, cls.zkey, cls.zkey_len, &d->key);
+            { std::lock_guard<std::mutex> g(s->mu); s->key_loads++; }
+            if (rc) { d->key = nullptr; const std::string why = zkc_last_error(d->ctx); { std::lock_guard<std::mutex> g(s->mu); d->has_want = false; } return fail_all(s, b, rc, why); }
+            d->confirmed.insert({cls.zkey, cls.zkey_len});          // loaded from this very image
+        }
+        if (full && d->key->nLevels != cls.nLevels) return fail_all(s, b, ZKC_ERR_BAD_ARG, "the key is not a ZkFranchiseProofCircuit(" + std::to_string(cls.nLevels) + ") key");
+        b.rs.resize((size_t)B * 64);
+        for (int i = 0; i < B; i++) memcpy(b.rs.data() + 64 * (size_t)i, b.reqs[i]->rs, 64);
+        if (full) rc = zkc_fullprove_batch_dev(d->key, w->d_in.p, B, w->d_wtns.p, (int32_t*)w->d_status.p, b.rs.data(), (uint8_t*)w->h_proofs.p, (uint8_t*)w->h_pubs.p);
+        else rc = zkc_prove_batch_dev(d->key, w->d_wtns.p, (uint32_t)nW, B, b.rs.data(), (uint8_t*)w->h_proofs.p, (uint8_t*)w->h_pubs.p);
+        if (rc) return fail_all(s, b, rc, zkc_last_error(d->ctx));
+        if (full) {
+            if (hipMemcpyAsync(w->h_status.p, w->d_status.p, (size_t)B * 4, hipMemcpyDeviceToHost, w->st) != hipSuccess || hipStreamSynchronize(w->st) != hipSuccess) { (void)hipGetLastError(); return fail_all(s, b, ZKC_ERR_HIP, "hipMemcpy of the status words"); }
+        }
+    }
+    const size_t B = b.reqs.size();
+    { std::lock_guard<std::mutex> g(s->mu); s->n_batches++; s->largest_batch = std::max<uint64_t>(s->largest_batch, B); d->batches++; d->proofs += B; }
+    for (size_t i = 0; i < B; i++) {
+        Req* r = b.reqs[i];
+        const int32_t st = full ? ((const int32_t*)w->h_status.p)[i] : 0;
+        if (st == ZKC_W_OK) { memcpy(r->proof, (const uint8_t*)w->h_proofs.p + 256 * i, 256); if (r->pub) memcpy(r->pub, (const uint8_t*)w->h_pubs.p + nPub * 32 * i, nPub * 32); }
+        finish(r, st == ZKC_W_OK ? ZKC_OK : ZKC_ERR_WITNESS, st, st == ZKC_W_OK ? "" : "a circuit assert failed (see status)");
+    }
+}
+void worker_main(zkc_service* s, zkc_service::Worker* w) {
+    std::unique_lock<std::mutex> lk(s->mu);
+    for (;;) {
+        std::vector<Req*> batch;
+        while (!s->stop && (batch = grab(s, w, std::max<size_t>(w->cap, 8) >= (size_t)s->max_batch ? (size_t)s->max_batch : std::max<size_t>(w->cap, 8) * 2)).empty()) {
+            w->idle = true; w->cv.wait(lk, [&] { return w->wake || s->stop; }); w->wake = false; w->idle = false;
+        }
+        if (s->stop) { for (Req* r : batch) s->q.push_front(r); break; }
+        dispatch(s);                                        // what is left in the queue may be another worker's
+        lk.unlock();
+        process(s, w, std::move(batch));
+        lk.lock();
+    }
+    lk.unlock();
+    (void)hipSetDevice(w->dev->device);
+    for (HipBuf* hb : {&w->h_in, &w->d_in, &w->d_wtns, &w->d_status, &w->h_proofs, &w->h_pubs, &w->h_status}) hb->release();
+    if (w->st) (void)hipStreamDestroy(w->st);
+}
+int service_fail(int code, const std::string& msg) { g_service_err = msg; return code; }
+bool parse_device_list(const char* e, std::vector<int>& out) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); count = 0; }
+    if (!e || !*e || !strcmp(e, "all")) { for (int i = 0; i < count; i++) out.push_back(i); return !out.empty(); }
+    for (const char* p = e; *p;) { char* end; const long v = strtol(p, &end, 10); if (end == p || v < 0) return false; out.push_back((int)v); p = *end == ',' ? end + 1 : end; if (*end && *end != ',') return false; }
+    return !out.empty();
+}
+}  // namespace
+
+extern "C" const char* zkc_service_last_error(void) { return g_service_err.c_str(); }
+extern "C" int zkc_service_create(const int* hip_devices, int n, zkc_service** out) {
+    if (!out || n < 0 || n > 64 || (n > 0 && !hip_devices)) return service_fail(ZKC_ERR_BAD_ARG, "zkc_service_create: bad argument");
+    std::vector<int> devs(hip_devices, hip_devices + n);
+    if (n == 0 && !parse_device_list(getenv("ZKC_DEVICE"), devs)) return service_fail(ZKC_ERR_HIP, "zkc_service_create: no GPU visible (or $ZKC_DEVICE is not a list of device numbers)");
+    zkc_service* s = new zkc_service();
+    if (const char* e = getenv("ZKC_SERVICE_MAX_BATCH")) s->max_batch = std::max(1, std::min(atoi(e), 4096));
+    if (const char* e = getenv("ZKC_SERVICE_SPILL")) s->spill = std::max(1, atoi(e));
+    for (int dv : devs) { s->devs.emplace_back(new zkc_service::Dev()); s->devs.back()->device = dv; }
+    int idx = 0;
+    for (auto& d : s->devs) for (int k = 0; k < 2; k++) { s->workers.emplace_back(new zkc_service::Worker()); s->workers.back()->dev = d.get(); s->workers.back()->index = idx++; }
+    for (auto& w : s->workers) w->th = std::thread(worker_main, s, w.get());
+    *out = s; return ZKC_OK;
+}
+extern "C" void zkc_service_destroy(zkc_service* s) {
+    if (!s) return;
+    { std::lock_guard<std::mutex> g(s->mu); s->stop = true; for (auto& w : s->workers) w->cv.notify_all(); }
+    for (auto& w : s->workers) if (w->th.joinable()) w->th.join();
+    for (Req* r : s->q) finish(r, ZKC_ERR_GENERIC, 0, "the proving service was shut down");
+    s->q.clear();
+    for (auto& d : s->devs) { (void)hipSetDevice(d->device); if (d->key) zkc_zkey_free(d->key); if (d->ctx) zkc_ctx_destroy(d->ctx); }
+    delete s;
+}
+extern "C" zkc_service* zkc_service_default(void) {
+    static std::mutex mu; static zkc_service* svc = nullptr;          // lives as long as the process: never destroyed, its idle workers sleep on a condition variable
+    static std::string why;
+    std::lock_guard<std::mutex> g(mu);
+    if (!svc && zkc_service_create(nullptr, 0, &svc)) { svc = nullptr; why = g_service_err; }
+    if (!svc) g_service_err = why;                                    // every thread that asks gets the reason, not only the first
+    return svc;
+}
+static int submit(zkc_service* s, int kind, const void* zkey, size_t zkey_len, int nLevels, const void* data, uint32_t nW, const uint8_t* rs, uint8_t* proof, uint8_t* pub,
+                  zkc_done_fn done, void* user) {
+    if (!s || !zkey || !data || !proof || !done) return service_fail(ZKC_ERR_BAD_ARG, "zkc_service_submit: bad argument");
+    Req* r = new Req();
+    r->kind = kind; r->zkey = (const uint8_t*)zkey; r->zkey_len = zkey_len; r->nLevels = kind == KIND_FULLPROVE ? nLevels : 0; r->data = (const uint8_t*)data; r->nW = nW;
+    r->proof = proof; r->pub = pub; r->done = done; r->user = user;
+    if (zkc_zkey_fingerprint(zkey, zkey_len, r->fp)) { delete r; return service_fail(ZKC_ERR_FORMAT, "not a zkey file"); }
+    if (rs) {
+        for (int k = 0; k < 2; k++) { uint32_t t[8]; memcpy(t, rs + 32 * k, 32); if (!zkc::fp_std_lt_p<zkc::FrParams>(t)) { delete r; return service_fail(ZKC_ERR_BAD_ARG, "r or s >= field order"); } }
+        memcpy(r->rs, rs, 64);
+    } else zkc_random_scalars(r->rs, 2);
+    std::lock_guard<std::mutex> g(s->mu);
+    if (s->stop) { delete r; return service_fail(ZKC_ERR_GENERIC, "the proving service was shut down"); }
+    s->q.push_back(r); s->n_requests++;
+    dispatch(s);
+    return ZKC_OK;
+}
+extern "C" int zkc_service_submit_fullprove(zkc_service* s, const void* zkey, size_t zkey_len, int nLevels, const void* inputs, const uint8_t* rs,
+                                            uint8_t proof[256], uint8_t* publics, zkc_done_fn done, void* user) {
+    return submit(s, KIND_FULLPROVE, zkey, zkey_len, nLevels, inputs, 0, rs, proof, publics, done, user);
+}
+extern "C" int zkc_service_submit_prove(zkc_service* s, const void* zkey, size_t zkey_len, const void* wtns, uint32_t nWitness, const uint8_t* rs,
+                                        uint8_t proof[256], uint8_t* publics, zkc_done_fn done, void* user) {
+    return submit(s, KIND_PROVE, zkey, zkey_len, 0, wtns, nWitness, rs, proof, publics, done, user);
+}
+static int wait_for(Waiter& w, int32_t* status, char* err, size_t errlen) {
+    std::unique_lock<std::mutex> lk(w.m); w.cv.wait(lk, [&] { return w.finished; });
+    if (status) *status = w.status;
+    if (err && errlen) snprintf(err, errlen, "%s", w.err.c_str());
+    if (w.rc) g_service_err = w.err;
+    return w.rc;
+}
+extern "C" int zkc_service_fullprove(zkc_service* s, const void* zkey, size_t zkey_len, int nLevels, const void* inputs, const uint8_t* rs,
+                                     uint8_t proof[256], uint8_t* publics, int32_t* status, char* err, size_t errlen) {
+    Waiter w; if (status) *status = 0;
+    const int rc = zkc_service_submit_fullprove(s, zkey, zkey_len, nLevels, inputs, rs, proof, publics, waiter_done, &w);
+    if (rc) { if (err && errlen) snprintf(err, errlen, "%s", g_service_err.c_str()); return rc; }
+    return wait_for(w, status, err, errlen);
+}
+extern "C" int zkc_service_prove(zkc_service* s, const void* zkey, size_t zkey_len, const void* wtns, uint32_t nWitness, const uint8_t* rs,
+                                 uint8_t proof[256], uint8_t* publics, char* err, size_t errlen) {
+    Waiter w;
+    const int rc = zkc_service_submit_prove(s, zkey, zkey_len, wtns, nWitness, rs, proof, publics, waiter_done, &w);
+    if (rc) { if (err && errlen) snprintf(err, errlen, "%s", g_service_err.c_str()); return rc; }
+    return wait_for(w, nullptr, err, errlen);
+}
+extern "C" int zkc_service_stats(zkc_service* s, uint64_t out[8]) {
+    if (!s || !out) return ZKC_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> g(s->mu);
+    int used = 0; for (auto& d : s->devs) used += d->batches > 0;
+    out[0] = s->n_requests; out[1] = s->n_batches; out[2] = s->largest_batch; out[3] = s->key_loads; out[4] = (uint64_t)s->devs.size(); out[5] = (uint64_t)used;
+    out[6] = s->n_failed; out[7] = (uint64_t)s->q.size();
+    return ZKC_OK;
+}

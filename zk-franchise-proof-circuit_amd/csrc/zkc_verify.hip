@@ -175,6 +175,13 @@ extern "C" int zkc_zkey_fingerprint(const void* zkey_bytes, size_t len, uint8_t 
     return ZKC_OK;
 }
 // circuits this build has a native witness generator for, by the sha256 of their circom witness-calculator wasm
+// the shape of a key straight from the file image (no GPU, no load): what a host needs to size its buffers before it submits a request
+extern "C" int zkc_zkey_header_info(const void* zkey_bytes, size_t len, uint32_t* nVars, uint32_t* nPublic, uint32_t* domainSize) {
+    parse::BinSections bs; parse::ZkeyHeader zh; std::string perr;
+    if (!zkey_bytes || !parse::binfile_sections((const uint8_t*)zkey_bytes, len, "zkey", 1, bs, perr) || !parse::zkey_check(bs, zh, perr, false)) { g_err = perr; return ZKC_ERR_FORMAT; }
+    if (nVars) *nVars = zh.nVars; if (nPublic) *nPublic = zh.nPub; if (domainSize) *domainSize = zh.n;
+    return ZKC_OK;
+}
 extern "C" int zkc_circuit_nlevels_from_wasm(const void* wasm, size_t len, char sha256_hex[65]) {
     static const struct { const char* sha; int nLevels; } known[] = {
         {"80a73567f6a4655d4332301efcff4bc5711bb48176d1c71fdb1e48df222ac139", 160},      // artifacts/zkCensus/dev/circuits-info.md:7
@@ -364,16 +371,16 @@ extern "C" void zkc_random_scalars(uint8_t* out, size_t n) {
 }
 
 // rapidsnark's entry point (prover.h), byte for byte: whole .zkey and .wtns buffers in, NUL-terminated JSON out.
-// r and s are drawn from the OS generator like the reference provers do.  Re-entrant: one process-wide context on device $ZKC_DEVICE
-// (default 0) behind a mutex; the last key stays resident and is identified by the SHA-256 of the .zkey image (the identity the reference
-// publishes for its keys, artifacts/zkCensus/dev/circuits-info.md:5), so repeated calls with the same key skip the load and a different key
-// can never alias.  When a buffer is too short the required sizes are written back WITHOUT proving (they depend only on nPublic).
+// r and s are drawn from the OS generator like the reference provers do.  Re-entrant, and concurrent callers (goroutines over prover.Prove,
+// zk_census_test.go:89) are coalesced: the call enqueues its witness with the process-wide proving service (zkc_service.hip; devices from
+// $ZKC_DEVICE) and waits for its own proof.  The resident key is identified per call by the sampled fingerprint of the .zkey image and, once per
+// (image, resident key), by the SHA-256 of the whole image (the identity the reference publishes for its keys,
+// artifacts/zkCensus/dev/circuits-info.md:5).  When a buffer is too short the required sizes are written back WITHOUT proving (they depend only on nPublic).
 extern "C" int groth16_prover(const void* zkey_buffer, unsigned long zkey_size, const void* wtns_buffer, unsigned long wtns_size,
                               char* proof_buffer, unsigned long* proof_size, char* public_buffer, unsigned long* public_size,
                               char* error_msg, unsigned long error_msg_maxsize) {
     auto err = [&](int code, const std::string& m) { if (error_msg && error_msg_maxsize) snprintf(error_msg, error_msg_maxsize, "%s", m.c_str()); return code; };
     if (!zkey_buffer || !wtns_buffer || !proof_size || !public_size) return err(ZKC_ERR_GENERIC, "groth16_prover: null argument");
-    static std::mutex mu; static zkc_ctx* ctx = nullptr; static zkc_zkey* zk = nullptr;
     // everything that does not need the GPU first: file shapes and buffer sizes
     parse::BinSections bs; parse::ZkeyHeader zh; std::string perr;
     if (!parse::binfile_sections((const uint8_t*)zkey_buffer, zkey_size, "zkey", 1, bs, perr) || !parse::zkey_check(bs, zh, perr, false)) return err(ZKC_ERR_GENERIC, perr);      // the coefficient scan is the loader's
@@ -385,17 +392,11 @@ extern "C" int groth16_prover(const void* zkey_buffer, unsigned long zkey_size, 
         *proof_size = need_proof; *public_size = need_public;
         return err(ZKC_ERR_SHORT_BUFFER, "Proof or public signals buffer is too short");
     }
-    uint8_t digest[32]; parse::zkey_fingerprint((const uint8_t*)zkey_buffer, zkey_size, bs, digest);      // per-call identity: 200 KB hashed, not the whole image
-    std::lock_guard<std::mutex> guard(mu);
-    if (!ctx) { const char* d = getenv("ZKC_DEVICE"); int rc = zkc_ctx_create(d ? atoi(d) : 0, &ctx); if (rc) { ctx = nullptr; return err(ZKC_ERR_GENERIC, zkc_last_error(nullptr)); } }
-    if (!zk || memcmp(zk->fingerprint, digest, 32) != 0) {
-        if (zk) { zkc_zkey_free(zk); zk = nullptr; }
-        int rc = zkc_zkey_load(ctx, zkey_buffer, zkey_size, &zk); if (rc) { zk = nullptr; return err(ZKC_ERR_GENERIC, zkc_last_error(ctx)); }
-    }
-    uint8_t rs[64], proof[256]; std::vector<uint8_t> pub(32 * (size_t)zh.nPub + 1);
-    zkc_random_scalars(rs, 2);
-    int rc = zkc_prove(zk, payload, nw, rs, rs + 32, proof, pub.data());
-    if (rc) return err(rc == ZKC_ERR_INVALID_WITNESS_LENGTH ? rc : ZKC_ERR_GENERIC, zkc_last_error(ctx));
+    zkc_service* svc = zkc_service_default();
+    if (!svc) return err(ZKC_ERR_GENERIC, zkc_service_last_error());
+    uint8_t proof[256]; std::vector<uint8_t> pub(32 * (size_t)zh.nPub + 1); char etext[512] = {0};
+    int rc = zkc_service_prove(svc, zkey_buffer, zkey_size, payload, nw, nullptr, proof, pub.data(), etext, sizeof etext);
+    if (rc) return err(rc == ZKC_ERR_INVALID_WITNESS_LENGTH ? rc : ZKC_ERR_GENERIC, etext);
     rc = zkc_proof_to_json(proof, pub.data(), (int)zh.nPub, proof_buffer, proof_size, public_buffer, public_size);
     if (rc == ZKC_ERR_SHORT_BUFFER) return err(ZKC_ERR_SHORT_BUFFER, "Proof or public signals buffer is too short");
     return rc;
