@@ -31,6 +31,7 @@ def parse_args():
     ap.add_argument('--nlevels', type=int, default=160)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-verify', action='store_true', help='skip the post-run verification of the timed proofs')
+    ap.add_argument('--no-extras', action='store_true', help='skip the extra legs after the timed region (host-to-host rate, unfolded / worst-case rates, isolated per-stage times)')
     ap.add_argument('--dry-run-cpu', action='store_true',
                     help='launcher / rendezvous / gather rehearsal on the CPU (gloo, fabricated records, no prover): NOT a measurement')
     return ap.parse_args()
@@ -127,6 +128,105 @@ def dry_run(args, rank, world):
     if world > 1:
         dist.destroy_process_group()
     return 0 if okt.item() else 1
+
+
+def read_prof(ctx):
+    prof = {}
+    for cat, name in CATS.items():
+        ms, n, by = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
+        ctx._lib.zkc_profile_read(ctx._h, cat, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(by))
+        prof[name] = {'ms': ms.value, 'launches': n.value, 'alg_bytes': by.value}
+    return prof
+
+
+def extra_legs(args, ctx, pk, zkey_bytes, vk, B, d_inputs, d_wtns, d_status, flat, out, rs, madds_folded):
+    """What the headline does not say, measured after the timed region on rank 0 at N = 1 (each leg 1 warm-up + 2 timed calls, seconds in all):
+      host_to_host     the same step with the input blocks in pinned HOST memory when the clock starts (H2D inside the step; SURVEY.md 8d config 3's wording)
+      folding          the headline relies on constant folding (a real census puts leaves 13-17 levels deep, every level below carries the voter-independent
+                       empty-subtree trace).  (a) voters whose leaves sit at the very bottom of both trees, through the same key: nothing folds; (b) the same
+                       witnesses through a key loaded with ZKC_NO_FOLD=1, witness given -- the groth16.prove(zkey, wtns) path for a foreign witness -- with
+                       bytes compared against the folded proofs of the timed step
+      stages_isolated  one pass with every stage on ONE stream (ZKC_SERIAL_STREAMS=1): the HIP-event brackets per kernel category are then isolated kernel
+                       times, priced against their algorithmic bytes and the 8 TB/s roof"""
+    import numpy as np, torch
+    import zkcensus_amd
+    from zkcensus_amd import census, groth16
+    res = {}
+    nW = pk.n_vars; nl = args.nlevels
+    # ---- host to host ----
+    h_in = torch.from_numpy(np.frombuffer(flat, dtype=np.uint8).copy()).pin_memory()
+
+    def h2h():
+        d_inputs.copy_(h_in)
+        return pk.fullprove_batch_dev(d_inputs.data_ptr(), B, d_wtns.data_ptr(), d_status.data_ptr(), draw_rs(rs, 2 * B).tobytes())
+    h2h(); torch.cuda.synchronize(); t0 = time.perf_counter(); h2h(); h2h(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    res['host_to_host'] = {'value': round(2 * B / dt, 1), 'unit': 'proofs/s', 'note': 'input blocks (334 x 32 B per voter) in pinned host memory when the clock starts, proofs and public '
+                           'signals in host memory when it stops; 2 steps of %d' % B}
+    # ---- folding: worst cases ----
+    Bd = min(B, 188)
+    deep = census.deep_voters(ctx, Bd, nl)
+    dflat = b''.join(zkcensus_amd.flatten_inputs(v, nl) for v in deep)
+    dd_in = torch.from_numpy(np.frombuffer(dflat, dtype=np.uint8).copy()).cuda()
+    dd_w = torch.empty(Bd * nW * 32, dtype=torch.uint8, device='cuda'); dd_st = torch.zeros(Bd, dtype=torch.int32, device='cuda')
+    rsd = draw_rs(rs, 2 * Bd).tobytes()
+    pk.fullprove_batch_dev(dd_in.data_ptr(), Bd, dd_w.data_ptr(), dd_st.data_ptr(), rsd)
+    assert int(dd_st.abs().sum().item()) == 0
+    ctx._lib.zkc_profile_enable(ctx._h, 0x10); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(2):
+        pd, ud = pk.fullprove_batch_dev(dd_in.data_ptr(), Bd, dd_w.data_ptr(), dd_st.data_ptr(), rsd)
+    torch.cuda.synchronize(); dt_deep = time.perf_counter() - t0
+    madds_deep = read_prof(ctx)['msm_g1_streamed']['launches'] / (2 * Bd); ctx._lib.zkc_profile_enable(ctx._h, 0)
+    ok_deep = groth16.verify_batch(ctx, vk, ud, pd)
+    # the same key without the folding tables, witness given (no witness generation in this leg): the foreign-witness path of groth16.prove(zkey, wtns)
+    Bu = min(B, 188)
+    os.environ['ZKC_NO_FOLD'] = '1'
+    try:
+        pk_nf = zkcensus_amd.ProvingKey(ctx, zkey_bytes)
+    finally:
+        del os.environ['ZKC_NO_FOLD']
+    rsu = out['rs'][:64 * Bu]
+    pu, uu = pk_nf.prove_batch_dev(d_wtns.data_ptr(), Bu, rsu)
+    same = pu == out['proofs'][:256 * Bu] and uu == out['pubs'][:256 * Bu]
+    ctx._lib.zkc_profile_enable(ctx._h, 0x10); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(2):
+        pk_nf.prove_batch_dev(d_wtns.data_ptr(), Bu, rsu)
+    torch.cuda.synchronize(); dt_nf = time.perf_counter() - t0
+    madds_nf = read_prof(ctx)['msm_g1_streamed']['launches'] / (2 * Bu); ctx._lib.zkc_profile_enable(ctx._h, 0)
+    pk_nf.close()
+    res['folding'] = {'enabled': os.environ.get('ZKC_NO_FOLD') is None, 'madds_per_proof': madds_folded, 'madds_unfolded': round(madds_nf),
+                      'unfolded_proofs_per_s': round(2 * Bu / dt_nf, 1), 'unfolded_bytes_equal_folded': bool(same),
+                      'unfolded_note': 'key loaded with ZKC_NO_FOLD=1, %d witnesses of the timed step given (groth16.prove(zkey, wtns) shape: no witness generation in this leg), '
+                                       'same (r, s): proofs byte-identical to the folded ones of the timed step' % Bu,
+                      'depth160_proofs_per_s': round(2 * Bd / dt_deep, 1), 'depth160_madds_per_proof': round(madds_deep), 'depth160_all_valid': bool(ok_deep),
+                      'depth160_note': '%d voters whose leaves sit %d levels down both trees (every sibling non-zero), inputs -> witness -> proof through the SAME key as the headline: folding '
+                                       'stays enabled and removes only the old-key block' % (Bd, nl)}
+    del dd_in, dd_w, dd_st
+    # ---- isolated stage times: one pass, one stream ----
+    Bs = min(B, int(os.environ.get('ZKC_INFLIGHT', '96')) - 2)
+    os.environ['ZKC_SERIAL_STREAMS'] = '1'
+    try:
+        pk_s = zkcensus_amd.ProvingKey(ctx, zkey_bytes)
+    finally:
+        del os.environ['ZKC_SERIAL_STREAMS']
+    rss = out['rs'][:64 * Bs]
+    ps, us = pk_s.fullprove_batch_dev(d_inputs.data_ptr(), Bs, d_wtns.data_ptr(), d_status.data_ptr(), rss)
+    same_s = ps == out['proofs'][:256 * Bs]
+    ctx._lib.zkc_profile_enable(ctx._h, 0x7f); torch.cuda.synchronize(); t0 = time.perf_counter()
+    pk_s.fullprove_batch_dev(d_inputs.data_ptr(), Bs, d_wtns.data_ptr(), d_status.data_ptr(), rss)
+    torch.cuda.synchronize(); dt_s = time.perf_counter() - t0
+    prof = read_prof(ctx); ctx._lib.zkc_profile_enable(ctx._h, 0)
+    pk_s.close()
+    stages = {}
+    for k, v in prof.items():
+        if k == 'msm_g1_streamed' or v['ms'] <= 0:
+            continue
+        gbps = v['alg_bytes'] / (v['ms'] * 1e-3) / 1e9
+        stages[k] = {'ms_isolated': round(v['ms'], 3), 'alg_bytes': v['alg_bytes'], 'GBps': round(gbps, 1), 'frac': round(gbps / HBM_PEAK_GBPS, 4)}
+    res['stages_isolated'] = {'proofs_in_pass': Bs, 'pass_ms_serial': round(dt_s * 1e3, 2), 'sum_of_stage_ms': round(sum(v['ms_isolated'] for v in stages.values()), 2),
+                              'bytes_equal_pipelined_proofs': bool(same_s), 'stages': stages,
+                              'note': 'one pass of %d proofs with every kernel on one stream (ZKC_SERIAL_STREAMS=1): isolated, additive stage times; alg_bytes per SURVEY.md 8d '
+                                      '(whole sections for the MSMs, 6 transforms + joinABC for ntt_joinABC); frac = GB/s over 8000.  The pipelined pass overlaps these on three streams' % Bs}
+    return res
 
 
 def main():
@@ -228,11 +328,7 @@ def main():
     assert int(d_status.abs().sum().item()) == 0, 'a synthetic voter failed a circuit assert'
 
     # ---- per-category device time from HIP events on the library's stream ----
-    prof = {}
-    for cat, name in CATS.items():
-        ms, n, by = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
-        ctx._lib.zkc_profile_read(ctx._h, cat, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(by))
-        prof[name] = {'ms': ms.value, 'launches': n.value, 'alg_bytes': by.value}
+    prof = read_prof(ctx)
     ctx._lib.zkc_profile_enable(ctx._h, 0)
     # the kernel BASELINE.json's metric names ("MSM HBM GB/s vs peak") and the one that moves most algorithmic bytes: G1 bucket
     # accumulation.  (Per-category times overlap across the three streams, so 'largest time' is not a reliable selector.)
@@ -303,7 +399,8 @@ def main():
         # CPU baseline = the oracle's witness + Groth16 prove, one proof per host thread (ctypes releases the GIL), on voters of the timed batch
         # with the (r, s) the GPU used for them: each oracle proof doubles as a byte-for-byte parity check of a proof that was timed.
         from concurrent.futures import ThreadPoolExecutor
-        cores = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get('ZKC_CPU_BASELINE_THREADS', '16'))))
+        avail = len(os.sched_getaffinity(0))
+        cores = max(1, min(avail, int(os.environ.get('ZKC_CPU_BASELINE_THREADS', '64'))))            # every core this process may run on (the GPU box gives one GPU's share of the host)
         wt = d_wtns.view(B, nW * 32)
         order = sample + [i for i in range(B) if i not in set(sample)]
         ol.lib()
@@ -325,10 +422,13 @@ def main():
             assert bytes(wt[i].cpu().numpy().tobytes()) == w, 'GPU witness of voter %d differs from the CPU oracle' % i
             assert out['proofs'][256 * i:256 * i + 256] == p and out['pubs'][256 * i:256 * i + 256] == pub, 'GPU proof of voter %d differs from the CPU oracle' % i
         verified['oracle_prover_bytes_equal'] = len(done); verified['oracle_prover_indices'] = [i for i, *_ in done]
-        cpu = {'value': round(len(done) / cdt, 4), 'unit': 'proofs/s', 'cores': cores, 'kind': 'port',
+        cpu = {'value': round(len(done) / cdt, 4), 'unit': 'proofs/s', 'cores': cores, 'cores_available': avail, 'cores_on_host': os.cpu_count(), 'kind': 'port',
                'sample': '%d full proofs (witness + Groth16 prove) of voters of the timed batch, %d at a time on %d threads, %.1f s; '
                          'the build\'s own C oracle, not snarkjs/rapidsnark (neither can run here)' % (len(done), cores, cores, cdt)}
 
+    extras = None
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_verify:
+        extras = extra_legs(args, ctx, pk, zkey_bytes, vk, B, d_inputs, d_wtns, d_status, flat, out, rs, roofline['valu']['madds_per_proof'])
     if rank == 0:
         total = args.steps * B * world
         line = {
@@ -340,6 +440,7 @@ def main():
                                    'own test zkey seed 0x5A4B43454E535553, synthetic %d-voter census' % (args.nlevels, B, max(8192, B * world)),
                        'batch_per_gpu': B, 'nVars': pk.n_vars, 'domainSize': pk.domain_size, 'parallelism': 'independent proofs per GPU, RCCL all_gather of 513 B/proof'},
             'roofline': roofline, 'cpu_baseline': cpu, 'verified': verified,
+            'host_to_host': (extras or {}).get('host_to_host'), 'folding': (extras or {}).get('folding'), 'stages_isolated': (extras or {}).get('stages_isolated'),
             'stage_ms_per_proof_overlapped_not_additive': {k: round(v['ms'] / (args.steps * B), 4) for k, v in prof.items() if k != 'msm_g1_streamed'},
         }
         if share:

@@ -155,6 +155,9 @@ int zkc_service_submit_prove(zkc_service* svc, const void* zkey, size_t zkey_len
 /* out[0] requests accepted, [1] batches run, [2] largest batch, [3] key loads, [4] devices listed, [5] devices that ran a batch, [6] requests failed
  * wholesale (HIP / key errors), [7] requests waiting now */
 int zkc_service_stats(zkc_service* svc, uint64_t out[8]);
+/* where the workers' time went, microseconds summed over all batches: out[0] uploads before the GPU is free, [1] waiting for the GPU (the other worker's
+ * batch), [2] key check / load + top-up upload, [3] the batch call itself, [4] handing results back; [5] proofs, [6] batches */
+int zkc_service_timing(zkc_service* svc, uint64_t out[8]);
 
 /* ---- the rapidsnark entry point (go-rapidsnark prover.h `groth16_prover`, reached from prover.Prove at
  * zk_census_test.go:89): whole .zkey and .wtns file images in, NUL-terminated proof / public-signal JSON out.

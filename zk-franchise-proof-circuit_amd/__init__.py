@@ -229,6 +229,11 @@ class ProvingService:
         self._lib.zkc_service_stats(self._h, out)
         return dict(zip(('requests', 'batches', 'largest_batch', 'key_loads', 'devices', 'devices_used', 'failed', 'waiting'), [int(x) for x in out]))
 
+    def timing(self):
+        out = (ctypes.c_uint64 * 8)()
+        self._lib.zkc_service_timing(self._h, out)
+        return dict(zip(('us_upload', 'us_wait_gpu', 'us_key', 'us_prove', 'us_finish', 'proofs', 'batches'), [int(x) for x in out]))
+
     def close(self):
         if getattr(self, '_h', None) and self._own:
             self._lib.zkc_service_destroy(self._h)

@@ -85,6 +85,8 @@ def load():
     L.zkc_service_fullprove.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, i32p, ctypes.c_char_p, ctypes.c_size_t]
     L.zkc_service_prove.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
     L.zkc_service_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    L.zkc_service_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    L.zkc_service_submit_fullprove.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, vp, vp]
     _lib = L
     return L
 

@@ -109,3 +109,31 @@ def synthetic_census(ctx, n_voters, nLevels=160, election_id_hex=ELECTION_ID_HEX
             'censusSiblings': pad(census.siblings[i]), 'sikSiblings': pad(siktree.siblings[i]),
         })
     return out
+
+
+def deep_voters(ctx, n_voters, nLevels=160, depth=None, seed=160):
+    """n_voters valid voters whose leaves sit `depth` levels down BOTH trees (default nLevels: the bottom), every sibling on the way non-zero: no level of
+    their witnesses equals the voter-independent empty-subtree template, so the prover's constant folding removes nothing -- the worst case a real census
+    cannot produce (8 192 voters put leaves 13-17 levels deep) but a foreign or adversarial witness can.  Each voter gets its own pair of roots: the
+    proofs are independent anyway.  Hashing on the GPU, one zkc_poseidon_batch call per level."""
+    import random
+    rng = random.Random(seed); depth = nLevels if depth is None else depth
+    eid = bytes_to_arbo(bytes.fromhex(ELECTION_ID_HEX))
+    address = [rng.getrandbits(160) for _ in range(n_voters)]
+    password = [rng.getrandbits(88) for _ in range(n_voters)]
+    signature = [rng.getrandbits(512) % R_MOD for _ in range(n_voters)]
+    avail = [1 + rng.randrange(100) for _ in range(n_voters)]
+    sik = poseidon_batch(ctx, list(zip(address, password, signature)))
+    nullifier = poseidon_batch(ctx, [(s, p, int(eid[0]), int(eid[1])) for s, p in zip(signature, password)])
+
+    def climb(values):
+        sibs = [[rng.randrange(1, R_MOD) for _ in range(depth)] for _ in range(n_voters)]
+        cur = poseidon_batch(ctx, [(k, v, 1) for k, v in zip(address, values)])
+        for lvl in range(depth - 1, -1, -1):
+            cur = poseidon_batch(ctx, [(sibs[v][lvl], cur[v]) if (address[v] >> lvl) & 1 else (cur[v], sibs[v][lvl]) for v in range(n_voters)])
+        return cur, sibs
+    croot, csib = climb(avail); sroot, ssib = climb(sik)
+    pad = lambda s: [str(x) for x in s] + ['0'] * (nLevels + 1 - len(s))
+    return [{'electionId': list(eid), 'nullifier': str(nullifier[i]), 'availableWeight': str(avail[i]), 'voteHash': ['1', '2'], 'sikRoot': str(sroot[i]),
+             'censusRoot': str(croot[i]), 'address': str(address[i]), 'password': str(password[i]), 'signature': str(signature[i]), 'voteWeight': '1',
+             'censusSiblings': pad(csib[i]), 'sikSiblings': pad(ssib[i])} for i in range(n_voters)]

@@ -69,16 +69,16 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     (void)hipSetDevice(zk->ctx->device);
     (void)hipStreamSynchronize(zk->ctx->stream);
     void* ptrs[] = {zk->d_perm, zk->d_rowlen, zk->d_jdptr, zk->d_col, zk->d_val, zk->d_tw_fwd, zk->d_tw_inv, zk->d_tw_fwd29, zk->d_tw_inv29, zk->d_coset, zk->d_coset_br, zk->d_g1, zk->d_g2, zk->d_g2_29, zk->d_flags,
-                    zk->d_tblDelta1, zk->d_tblAlpha1, zk->d_tblBeta1, zk->d_tblDelta2, zk->d_rs, zk->d_proofs};
+                    zk->d_tblDelta1, zk->d_tblAlpha1, zk->d_tblBeta1, zk->d_tblDelta2, zk->call[0].d_rs, zk->call[0].d_proofs, zk->call[1].d_rs, zk->call[1].d_proofs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : zk->fold.vmaps) if (kv.second.d) (void)hipFree(kv.second.d);
     for (void* q : {(void*)zk->fold.d_foldA, (void*)zk->fold.d_foldB1, (void*)zk->fold.d_foldC, (void*)zk->fold.d_foldB2}) if (q) (void)hipFree(q);
     if (zk->h_flags) (void)hipHostFree(zk->h_flags);
-    if (zk->h_out) (void)hipHostFree(zk->h_out);
+    for (auto& c : zk->call) { if (c.h_out) (void)hipHostFree(c.h_out); for (hipEvent_t e : c.ev_done) if (e) (void)hipEventDestroy(e); }
     if (zk->ev_start) (void)hipEventDestroy(zk->ev_start);
     for (hipEvent_t e : zk->ev_chunk) (void)hipEventDestroy(e);
     for (auto& L : zk->lane) {
-        for (hipStream_t q : {L.st, L.st2, L.fin}) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+        for (hipStream_t q : {L.st, L.st2, L.fin}) if (q) { (void)hipStreamSynchronize(q); if (!zk->serial_streams) (void)hipStreamDestroy(q); }
         for (void* q : {(void*)L.d_abc, (void*)L.d_t, (void*)L.d_p, L.d_fin}) if (q) (void)hipFree(q);
         for (hipEvent_t e : {L.ev_msm, L.ev_msm2, L.ev_sorted, L.ev_ntt, L.ev_mv, L.ev_fin[0], L.ev_fin[1]}) if (e) (void)hipEventDestroy(e);
         msm_work_free(L.w1); msm_work_free(L.w2);
@@ -227,8 +227,14 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
     { const char* e_l = getenv("ZKC_LANES"); zk->nlanes = e_l ? std::max(1, std::min(atoi(e_l), 2)) : 1; }
     for (int l = 0; l < zk->nlanes; l++) {
         zkc_lane& L = zk->lane[l];
-        ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking)); ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.st2, hipStreamNonBlocking));
-        ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.fin, hipStreamNonBlocking));
+        // ZKC_SERIAL_STREAMS=1 (measurement only): every stage of a pass on the context's one stream, so that the per-category HIP-event brackets of
+        // zkc_profile_* are ISOLATED kernel times (bench.py's per-stage roofline); the pipeline's overlap is gone, the proofs are the same bytes
+        zk->serial_streams = getenv("ZKC_SERIAL_STREAMS") != nullptr;
+        if (zk->serial_streams) L.st = L.st2 = L.fin = ctx->stream;
+        else {
+            ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking)); ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.st2, hipStreamNonBlocking));
+            ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.fin, hipStreamNonBlocking));
+        }
         ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_msm, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_msm2, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_sorted, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_ntt, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_mv, hipEventDisableTiming));
         ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_fin[0], hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_fin[1], hipEventDisableTiming));
     }
@@ -400,9 +406,8 @@ extern "C" int zkc_msm_debug(zkc_zkey* zk, int which, const void* d_scalars, uin
 // d_inputs != nullptr: the witnesses are computed here as well, a chunk per pass on ctx->stream, so that the (latency-bound, few-wave)
 // witness kernels of pass p+1 run underneath the MSMs of pass p
 int zkc_witness_chunk_async(zkc_ctx* ctx, int nLevels, const void* d_inputs, int B, void* d_wtns, int32_t* d_status3, int32_t* d_status);
-static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, int B, const uint8_t* rs, uint8_t* proofs, uint8_t* publics,
-                            const void* d_inputs, int32_t* d_status) {
-    if (!zk || !d_wtns || !rs || !proofs || B <= 0) return zkc_fail(zk ? zk->ctx : nullptr, ZKC_ERR_BAD_ARG, "zkc_prove_batch_dev: bad argument");
+int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nWitness, int B, const uint8_t* rs, bool want_publics, const void* d_inputs, int32_t* d_status) {
+    if (!zk || !d_wtns || !rs || B <= 0 || cs < 0 || cs > 1) return zkc_fail(zk ? zk->ctx : nullptr, ZKC_ERR_BAD_ARG, "zkc_prove_batch_dev: bad argument");
     zkc_ctx* ctx = zk->ctx;
     ZKC_LOCK(ctx);
     if (nWitness != zk->nVars) return zkc_fail(ctx, ZKC_ERR_INVALID_WITNESS_LENGTH, "Invalid witness length. Circuit: " + std::to_string(zk->nVars) + ", witness: " + std::to_string(nWitness));
@@ -413,13 +418,17 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
     hipStream_t st0 = ctx->stream;
     WitnessLayout L{}; int rc;
     if ((rc = lanes_ensure(zk, B))) return rc;
-    if (zk->rs_cap < (size_t)B) {
-        if (zk->d_rs) { ZKC_HIP_CHECK(ctx, hipFree(zk->d_rs)); ZKC_HIP_CHECK(ctx, hipFree(zk->d_proofs)); ZKC_HIP_CHECK(ctx, hipHostFree(zk->h_out)); zk->d_rs = zk->d_proofs = zk->h_out = nullptr; }
-        ZKC_HIP_CHECK(ctx, hipMalloc((void**)&zk->d_rs, 64 * (size_t)B)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&zk->d_proofs, 256 * (size_t)B));
-        ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&zk->h_out, (256 + 32 * (size_t)zk->nPub) * B)); zk->rs_cap = B;
+    zkc_zkey::CallSlot& CS = zk->call[cs];
+    if (CS.pending) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "prove_batch_begin: this call slot has a call in flight (finish it first)");
+    if (CS.cap < (size_t)B) {                                    // the slot is idle (finished), so its buffers are nobody's
+        if (CS.d_rs) { ZKC_HIP_CHECK(ctx, hipFree(CS.d_rs)); ZKC_HIP_CHECK(ctx, hipFree(CS.d_proofs)); ZKC_HIP_CHECK(ctx, hipHostFree(CS.h_out)); CS.d_rs = CS.d_proofs = CS.h_out = nullptr; CS.cap = 0; }
+        const size_t want = std::max<size_t>((size_t)B, std::min<size_t>(2 * CS.cap, 4096));
+        ZKC_HIP_CHECK(ctx, hipMalloc((void**)&CS.d_rs, 64 * want)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&CS.d_proofs, 256 * want));
+        ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&CS.h_out, (256 + 32 * (size_t)zk->nPub) * want)); CS.cap = want;
     }
-    uint8_t* const h_pub = zk->h_out + 256ull * zk->rs_cap;      // results land in pinned memory so that no copy blocks the enqueueing thread
-    ZKC_HIP_CHECK(ctx, hipMemcpyAsync(zk->d_rs, rs, 64 * (size_t)B, hipMemcpyHostToDevice, st0));
+    for (int l = 0; l < zk->nlanes; l++) if (!CS.ev_done[l]) ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&CS.ev_done[l], hipEventDisableTiming));
+    uint8_t* const h_pub = CS.h_out + 256ull * CS.cap;      // results land in pinned memory so that no copy blocks the enqueueing thread
+    ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.d_rs, rs, 64 * (size_t)B, hipMemcpyHostToDevice, st0));
     // per pass (chunk of max_inflight proofs), all enqueued now on st0: [witness kernels] -> fold check (which levels of the witness differ
     // from the voter-independent template?) -> flags to the host -> event.  The pass loop below waits for a chunk's event only.
     uint32_t* tmpl = nullptr;
@@ -462,7 +471,7 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
         }
         ZKC_HIP_CHECK(ctx, hipEventRecord(zk->ev_chunk[c], st0));                // wtns of this chunk (and rs) ready, flags on the host
     }
-    for (int l = 0; l < zk->nlanes; l++) zk->lane[l].npass = 0;
+    // (npass is NOT reset per call: the result slots and their ev_fin guards carry over, because the previous call's last blinding may still be reading them)
     // ZKC_TRACE_HOST=1: where the enqueueing thread spends its time, per pass (diagnostics: a blocking call here idles a stream)
     static const bool trace_host = getenv("ZKC_TRACE_HOST") != nullptr;
     auto now_ms = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; };
@@ -536,7 +545,7 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
             if ((rc = msm_pass_g2(zk, LN.w2, j2, slot, false, st2))) return rc;
             ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_msm2, st2));
         }
-        if (publics)       // wires 1..nPublic of every witness, one strided copy
+        if (want_publics)       // wires 1..nPublic of every witness, one strided copy
             ZKC_HIP_CHECK(ctx, hipMemcpy2DAsync(h_pub + 32ull * np * p0, 32ull * np, w0 + 8, 32ull * nv, 32ull * np, nb, hipMemcpyDeviceToHost, st));
         ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_msm, st));
         if (mv_prefetch && p0 + per_pass < B) {                                   // buildABC of the next pass, beside this pass' accumulation
@@ -552,19 +561,43 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
         fa.foldA = zk->fold.d_foldA; fa.foldB1 = zk->fold.d_foldB1; fa.foldC = zk->fold.d_foldC; fa.foldB2 = zk->fold.d_foldB2; fa.fold_n = can_fold ? L.n : 0;
         for (int q = 0; q < nb; q++) { fa.dc[q] = fold ? dcq[q] : (uint8_t)255; fa.ds[q] = fold ? dsq[q] : (uint8_t)255; }
         fa.tblDelta1 = zk->d_tblDelta1; fa.tblAlpha1 = zk->d_tblAlpha1; fa.tblBeta1 = zk->d_tblBeta1; fa.tblDelta2 = zk->d_tblDelta2;
-        fa.alpha1 = zk->alpha1; fa.beta2 = zk->beta2; fa.rs = zk->d_rs + 64 * (size_t)p0; fa.out = zk->d_proofs + 256 * (size_t)p0; fa.scratch = LN.d_fin;
+        fa.alpha1 = zk->alpha1; fa.beta2 = zk->beta2; fa.rs = CS.d_rs + 64 * (size_t)p0; fa.out = CS.d_proofs + 256 * (size_t)p0; fa.scratch = LN.d_fin;
         ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm, 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm2, 0));
         if ((rc = finalize_launch(ctx, fin, fa, nb))) return rc;
-        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(zk->h_out + 256ull * p0, zk->d_proofs + 256 * (size_t)p0, 256ull * nb, hipMemcpyDeviceToHost, fin));
+        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.h_out + 256ull * p0, CS.d_proofs + 256 * (size_t)p0, 256ull * nb, hipMemcpyDeviceToHost, fin));
         ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_fin[slot], fin));
         tr[5] = now_ms();
         if (trace_host) fprintf(stderr, "[zkc host] pass %2d: start %8.2f | chunk wait %6.2f | h_evals %6.2f | g2 pass %6.2f | g1 pass %6.2f | blinding %6.2f ms\n", pass, tr[0] - t_begin,
                                 tr[1] - tr[0], tr[2] - tr[1], tr[3] - tr[2], tr[4] - tr[3], tr[5] - tr[4]);
     }
-    for (int l = 0; l < zk->nlanes; l++) { ZKC_HIP_CHECK(ctx, hipStreamSynchronize(zk->lane[l].st)); ZKC_HIP_CHECK(ctx, hipStreamSynchronize(zk->lane[l].st2)); ZKC_HIP_CHECK(ctx, hipStreamSynchronize(zk->lane[l].fin)); }
-    memcpy(proofs, zk->h_out, 256ull * B);
-    if (publics) memcpy(publics, h_pub, 32ull * np * B);
+    // every lane's blinding stream already waits for its G1 and G2 streams (ev_msm, ev_msm2) and carries the last copies: one event per lane closes the call
+    for (int l = 0; l < zk->nlanes; l++) ZKC_HIP_CHECK(ctx, hipEventRecord(CS.ev_done[l], zk->lane[l].fin));
+    CS.B = B; CS.pending = true;
     return ZKC_OK;
+}
+// second half of a batch call: wait for call slot cs, copy proofs (B x 256 B) and public signals (B x nPublic x 32 B, may be NULL) out of the pinned staging.
+// Takes no context lock while it waits, so that the next call's begin (the other slot) can run meanwhile.
+int zkc::prove_batch_finish(zkc_zkey* zk, int cs, uint8_t* proofs, uint8_t* publics) {
+    if (!zk || !proofs || cs < 0 || cs > 1) return zkc_fail(zk ? zk->ctx : nullptr, ZKC_ERR_BAD_ARG, "prove_batch_finish: bad argument");
+    zkc_zkey::CallSlot& CS = zk->call[cs];
+    if (!CS.pending) return zkc_fail(zk->ctx, ZKC_ERR_BAD_ARG, "prove_batch_finish: no call in flight on this slot");
+    hipError_t e = hipSuccess;
+    for (int l = 0; l < zk->nlanes && e == hipSuccess; l++) e = hipEventSynchronize(CS.ev_done[l]);
+    CS.pending = false;
+    if (e != hipSuccess) { ZKC_LOCK(zk->ctx); return zkc_fail(zk->ctx, ZKC_ERR_HIP, std::string("prove_batch_finish: ") + hipGetErrorString(e)); }
+    memcpy(proofs, CS.h_out, 256ull * CS.B);
+    if (publics) memcpy(publics, CS.h_out + 256ull * CS.cap, 32ull * zk->nPub * CS.B);
+    return ZKC_OK;
+}
+// the synchronous form: begin + finish on slot 0 under the context lock
+static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, int B, const uint8_t* rs, uint8_t* proofs, uint8_t* publics,
+                            const void* d_inputs, int32_t* d_status) {
+    if (!zk || !proofs) return zkc_fail(zk ? zk->ctx : nullptr, ZKC_ERR_BAD_ARG, "zkc_prove_batch_dev: bad argument");
+    ZKC_LOCK(zk->ctx);
+    if (zk->call[1].pending) return zkc_fail(zk->ctx, ZKC_ERR_BAD_ARG, "zkc_prove_batch_dev: the key has a split call in flight (proving service)");
+    int rc = prove_batch_begin(zk, 0, d_wtns, nWitness, B, rs, publics != nullptr, d_inputs, d_status);
+    if (rc) return rc;
+    return prove_batch_finish(zk, 0, proofs, publics);
 }
 
 // B witnesses resident in HBM -> B proofs.  rs: B x 64 B (r || s).  proofs: B x 256 B, publics: B x nPublic x 32 B (host).

@@ -162,11 +162,17 @@ struct zkc_zkey {
     int cur_inflight = 0;                                                   // what the lanes' work space is currently sized for (lanes_ensure)
     uint8_t sha256[32] = {0};                                               // of the whole .zkey image (taken once, at load)
     uint8_t fingerprint[32] = {0};                                          // parse::zkey_fingerprint of the image: the per-call identity of the resident-key caches
-    zkc_lane lane[2]; int nlanes = 2;
+    zkc_lane lane[2]; int nlanes = 2; bool serial_streams = false;          // serial_streams: the lanes borrow ctx->stream (ZKC_SERIAL_STREAMS, measurement only)
     uint32_t *d_flags = nullptr, *h_flags = nullptr; size_t flags_cap = 0;  // fold check: [B][2][n]
     zkc::G1Affine *d_tblDelta1 = nullptr, *d_tblAlpha1 = nullptr, *d_tblBeta1 = nullptr; zkc::G2Affine* d_tblDelta2 = nullptr;
-    uint8_t *d_rs = nullptr, *d_proofs = nullptr; size_t rs_cap = 0;        // [B][64], [B][256]
-    uint8_t* h_out = nullptr;                                               // pinned: [B][256] proofs then [B][nPub][32] public signals (async D2H target)
+    // per CALL state, two slots: a call is begin (everything enqueued, returns) + finish (wait, copy out), and the proving service lets the begin of the next
+    // call run while the previous one drains (its witness kernels beside the other call's MSMs, its transforms beside the other's bucket reduction and blinding)
+    struct CallSlot {
+        uint8_t *d_rs = nullptr, *d_proofs = nullptr; size_t cap = 0;       // [B][64], [B][256]
+        uint8_t* h_out = nullptr;                                           // pinned: [B][256] proofs then [B][nPub][32] public signals (async D2H target)
+        hipEvent_t ev_done[2] = {nullptr, nullptr};                         // per lane: recorded on its blinding stream behind the call's last copy
+        int B = 0; bool pending = false;
+    } call[2];
     hipEvent_t ev_start = nullptr; std::vector<hipEvent_t> ev_chunk;        // ev_chunk[p]: witness (if made here) and fold flags of pass p are ready
     // constant folding of the voter-independent witness part (SURVEY.md hard part 4)
     struct Fold {
@@ -198,6 +204,11 @@ int msm_pass_g2(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool t
 int msm_bucket_entries(zkc_ctx* ctx, MsmWork& w, const MsmJobList& jl, hipStream_t st, unsigned long long* d_entry_counter = nullptr);
 int msm_build_segments(zkc_ctx* ctx, MsmWork& w, const MsmJobList& jl, uint32_t seg, size_t seg_bound, hipStream_t st);
 int finalize_launch(zkc_ctx* ctx, hipStream_t st, const FinalizeArgs& a, int nproofs);
+// a batch call in two halves (zkc_prove.hip; the public zkc_[full]prove_batch_dev are begin + finish on slot 0): begin validates, enqueues every pass and returns
+// without waiting for the GPU; finish waits for that call and copies proofs / public signals out.  cs = call slot 0 / 1; a slot must be finished before it is
+// begun again; d_wtns (and d_inputs, d_status) stay the caller's until finish returns.  d_inputs == nullptr: the witnesses are given.
+int prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nWitness, int B, const uint8_t* rs, bool want_publics, const void* d_inputs, int32_t* d_status);
+int prove_batch_finish(zkc_zkey* zk, int cs, uint8_t* proofs, uint8_t* publics);
 size_t finalize_scratch_bytes(int nproofs);
 int msm_precompute_g1(zkc_ctx* ctx, uint32_t count, G1Affine* d_table, int c);   // d_table[0..count) = base on entry
 int msm_precompute_g2(zkc_ctx* ctx, uint32_t count, G2Affine* d_table, int c);

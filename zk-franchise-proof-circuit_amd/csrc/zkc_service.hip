@@ -13,6 +13,7 @@
 #include "zkc_prover.h"
 #include "zkc_hostparse.h"
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -56,16 +57,18 @@ struct zkc_service {
         // under zkc_service::mu: what this device holds or is about to load
         bool has_want = false; uint8_t want_fp[32] = {0};
         uint64_t batches = 0, proofs = 0;
+        std::mutex fl_mu; std::condition_variable fl_cv; int in_flight = 0;      // split calls begun on this device's key and not finished yet (a key switch waits for zero)
     };
     struct Worker {
         Dev* dev = nullptr; int index = 0; std::thread th; std::condition_variable cv; bool wake = false, idle = false;
-        HipBuf h_in{nullptr, 0, true}, d_in, d_wtns, d_status, h_proofs{nullptr, 0, true}, h_pubs{nullptr, 0, true}, h_status{nullptr, 0, true};
+        HipBuf h_in{nullptr, 0, true}, h_wtns{nullptr, 0, true}, d_in, d_wtns, d_status, h_proofs{nullptr, 0, true}, h_pubs{nullptr, 0, true}, h_status{nullptr, 0, true};
         hipStream_t st = nullptr; size_t cap = 0;        // requests the staging buffers hold (grows geometrically with the batches this worker has seen)
     };
     std::mutex mu; std::deque<Req*> q; bool stop = false;
     std::vector<std::unique_ptr<Dev>> devs; std::vector<std::unique_ptr<Worker>> workers;
     int max_batch = 256, spill = 32;
     uint64_t n_requests = 0, n_batches = 0, largest_batch = 0, key_loads = 0, n_failed = 0;
+    uint64_t us_stage = 0, us_gpu_wait = 0, us_key = 0, us_prove = 0, us_finish = 0, n_proved = 0;      // where the workers' time went (microseconds, summed over batches)
 };
 static thread_local std::string g_service_err;
 
@@ -118,8 +121,11 @@ bool stage(zkc_service::Worker* w, Batch& b, size_t from, size_t nIn, size_t nW,
         for (size_t i = from; i < B; i++) memcpy(h + i * nIn * 32, b.reqs[i]->data, nIn * 32);
         if (hipMemcpyAsync((uint8_t*)w->d_in.p + from * nIn * 32, h + from * nIn * 32, (B - from) * nIn * 32, hipMemcpyHostToDevice, w->st) != hipSuccess) { err = "hipMemcpyAsync of the inputs"; return false; }
     } else {
-        for (size_t i = from; i < B; i++)
-            if (hipMemcpyAsync((uint8_t*)w->d_wtns.p + i * nW * 32, b.reqs[i]->data, nW * 32, hipMemcpyHostToDevice, w->st) != hipSuccess) { err = "hipMemcpyAsync of a witness"; return false; }
+        // witnesses arrive in the callers' pageable memory (2.6 MB each at nLevels = 160).  hipMemcpyAsync from there moved 1.8 GB/s; copied first into this worker's
+        // pinned staging (beside the other worker's GPU batch) they go up in one transfer at PCIe speed
+        uint8_t* h = (uint8_t*)w->h_wtns.p;
+        for (size_t i = from; i < B; i++) memcpy(h + i * nW * 32, b.reqs[i]->data, nW * 32);
+        if (hipMemcpyAsync((uint8_t*)w->d_wtns.p + from * nW * 32, h + from * nW * 32, (B - from) * nW * 32, hipMemcpyHostToDevice, w->st) != hipSuccess) { err = "hipMemcpyAsync of the witnesses"; return false; }
     }
     if (hipStreamSynchronize(w->st) != hipSuccess) { err = "hipStreamSynchronize after the uploads"; return false; }
     return true;
@@ -147,18 +153,28 @@ void process(zkc_service* s, zkc_service::Worker* w, std::vector<Req*>&& first) 
         b.reqs.swap(keep);
         if (b.reqs.empty()) return;
     }
-    // staging grows with the batches this worker actually sees (a lone sequential caller reserves room for 8 witnesses, not for max_batch = 256 of them)
-    size_t want = 8; while (want < 2 * b.reqs.size()) want *= 2;
-    w->cap = std::max(w->cap, std::min(want, (size_t)s->max_batch));
+    // staging: a lone sequential caller reserves room for 8 voters; the first batch of more than one caller sizes it for good (max_batch voters for the
+    // inputs path -- 11 KB each, plus 2.6 MB of device memory per witness -- and at most 128 for the witness path, whose pinned staging is 2.6 MB per request too)
+    const size_t kind_max = full ? (size_t)s->max_batch : std::min<size_t>((size_t)s->max_batch, 128);
+    w->cap = std::min(kind_max, std::max(w->cap, b.reqs.size() > 1 ? kind_max : (size_t)8));
+    if (b.reqs.size() > w->cap) {                            // the other kind sized this worker before: give the tail back to the queue
+        std::lock_guard<std::mutex> g(s->mu);
+        while (b.reqs.size() > w->cap) { s->q.push_front(b.reqs.back()); b.reqs.pop_back(); }
+        dispatch(s);
+    }
     const size_t cap = w->cap;
     if (!w->st && hipStreamCreateWithFlags(&w->st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); w->st = nullptr; return fail_all(s, b, ZKC_ERR_HIP, "hipStreamCreate failed"); }
-    if ((full && (!w->h_in.ensure(cap * nIn * 32) || !w->d_in.ensure(cap * nIn * 32))) || !w->d_wtns.ensure(cap * nW * 32) || !w->d_status.ensure(cap * 4) ||
+    if ((full && (!w->h_in.ensure(cap * nIn * 32) || !w->d_in.ensure(cap * nIn * 32))) || !w->d_wtns.ensure(cap * nW * 32) || (!full && !w->h_wtns.ensure(cap * nW * 32)) || !w->d_status.ensure(cap * 4) ||
         !w->h_proofs.ensure(cap * 256) || !w->h_pubs.ensure(cap * nPub * 32 + 32) || !w->h_status.ensure(cap * 4))
         return fail_all(s, b, ZKC_ERR_HIP, "out of memory for the service's staging buffers on device " + std::to_string(d->device));
+    auto now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const uint64_t t_a = now_us();
     if (!stage(w, b, 0, nIn, nW, err)) { (void)hipGetLastError(); return fail_all(s, b, ZKC_ERR_HIP, err); }      // beside the other worker's batch, which owns the GPU now
-    int rc = ZKC_OK;
+    int rc = ZKC_OK; zkc_zkey* zk = nullptr; int slot = 0;
+    uint64_t t_b = now_us(), t_c = 0, t_d = 0, t_e = 0;
     {
         std::lock_guard<std::mutex> gpu(d->gpu_mu);
+        t_c = now_us();
         // whoever queued up meanwhile for the same key rides along
         size_t from = b.reqs.size();
         { std::lock_guard<std::mutex> g(s->mu); std::vector<Req*> more = grab(s, w, cap - b.reqs.size(), &cls); for (Req* r : more) if (full || r->nW == nW) b.reqs.push_back(r); else finish(r, ZKC_ERR_INVALID_WITNESS_LENGTH, 0, "Invalid witness length"); }
@@ -173,6 +189,7 @@ void process(zkc_service* s, zkc_service::Worker* w, std::vector<Req*>&& first) 
             if (memcmp(full_sha, d->key->sha256, 32) != 0) reload = true; else { if (d->confirmed.size() > 64) d->confirmed.clear(); d->confirmed.insert({cls.zkey, cls.zkey_len}); }
         }
         if (reload) {
+            { std::unique_lock<std::mutex> fl(d->fl_mu); d->fl_cv.wait(fl, [&] { return d->in_flight == 0; }); }      // the other worker's call still reads the old key
             if (d->key) { zkc_zkey_free(d->key); d->key = nullptr; }
             d->confirmed.clear();
             rc = zkc_zkey_load(d->ctx, cls.zkey, cls.zkey_len, &d->key);
@@ -183,27 +200,39 @@ void process(zkc_service* s, zkc_service::Worker* w, std::vector<Req*>&& first) 
         if (full && d->key->nLevels != cls.nLevels) return fail_all(s, b, ZKC_ERR_BAD_ARG, "the key is not a ZkFranchiseProofCircuit(" + std::to_string(cls.nLevels) + ") key");
         b.rs.resize((size_t)B * 64);
         for (int i = 0; i < B; i++) memcpy(b.rs.data() + 64 * (size_t)i, b.reqs[i]->rs, 64);
-        if (full) rc = zkc_fullprove_batch_dev(d->key, w->d_in.p, B, w->d_wtns.p, (int32_t*)w->d_status.p, b.rs.data(), (uint8_t*)w->h_proofs.p, (uint8_t*)w->h_pubs.p);
-        else rc = zkc_prove_batch_dev(d->key, w->d_wtns.p, (uint32_t)nW, B, b.rs.data(), (uint8_t*)w->h_proofs.p, (uint8_t*)w->h_pubs.p);
+        t_d = now_us();
+        // the call in two halves: begin enqueues every pass and returns (its witness kernels run beside the other worker's MSMs); the GPU lock is given up
+        // before finish waits, so that the other worker's next begin overlaps this call's bucket reduction, blinding and copies
+        zk = d->key; slot = w->index & 1;
+        rc = zkc::prove_batch_begin(zk, slot, w->d_wtns.p, (uint32_t)nW, B, b.rs.data(), true, full ? w->d_in.p : nullptr, full ? (int32_t*)w->d_status.p : nullptr);
         if (rc) return fail_all(s, b, rc, zkc_last_error(d->ctx));
-        if (full) {
-            if (hipMemcpyAsync(w->h_status.p, w->d_status.p, (size_t)B * 4, hipMemcpyDeviceToHost, w->st) != hipSuccess || hipStreamSynchronize(w->st) != hipSuccess) { (void)hipGetLastError(); return fail_all(s, b, ZKC_ERR_HIP, "hipMemcpy of the status words"); }
-        }
+        { std::lock_guard<std::mutex> fl(d->fl_mu); d->in_flight++; }
+    }
+    {
+        const int B = (int)b.reqs.size();
+        rc = zkc::prove_batch_finish(zk, slot, (uint8_t*)w->h_proofs.p, (uint8_t*)w->h_pubs.p);
+        if (!rc && full && (hipMemcpyAsync(w->h_status.p, w->d_status.p, (size_t)B * 4, hipMemcpyDeviceToHost, w->st) != hipSuccess || hipStreamSynchronize(w->st) != hipSuccess)) { (void)hipGetLastError(); rc = ZKC_ERR_HIP; }
+        const std::string why = rc ? (rc == ZKC_ERR_HIP ? std::string("HIP failure while the batch finished: ") : std::string()) + zkc_last_error(d->ctx) : std::string();
+        { std::lock_guard<std::mutex> fl(d->fl_mu); d->in_flight--; } d->fl_cv.notify_all();
+        if (rc) return fail_all(s, b, rc, why);
     }
     const size_t B = b.reqs.size();
-    { std::lock_guard<std::mutex> g(s->mu); s->n_batches++; s->largest_batch = std::max<uint64_t>(s->largest_batch, B); d->batches++; d->proofs += B; }
+    t_e = now_us();
+    { std::lock_guard<std::mutex> g(s->mu); s->n_batches++; s->largest_batch = std::max<uint64_t>(s->largest_batch, B); d->batches++; d->proofs += B; s->n_proved += B;
+      s->us_stage += t_b - t_a; s->us_gpu_wait += t_c - t_b; s->us_key += t_d - t_c; s->us_prove += t_e - t_d; }
     for (size_t i = 0; i < B; i++) {
         Req* r = b.reqs[i];
         const int32_t st = full ? ((const int32_t*)w->h_status.p)[i] : 0;
         if (st == ZKC_W_OK) { memcpy(r->proof, (const uint8_t*)w->h_proofs.p + 256 * i, 256); if (r->pub) memcpy(r->pub, (const uint8_t*)w->h_pubs.p + nPub * 32 * i, nPub * 32); }
         finish(r, st == ZKC_W_OK ? ZKC_OK : ZKC_ERR_WITNESS, st, st == ZKC_W_OK ? "" : "a circuit assert failed (see status)");
     }
+    { std::lock_guard<std::mutex> g(s->mu); s->us_finish += now_us() - t_e; }
 }
 void worker_main(zkc_service* s, zkc_service::Worker* w) {
     std::unique_lock<std::mutex> lk(s->mu);
     for (;;) {
         std::vector<Req*> batch;
-        while (!s->stop && (batch = grab(s, w, std::max<size_t>(w->cap, 8) >= (size_t)s->max_batch ? (size_t)s->max_batch : std::max<size_t>(w->cap, 8) * 2)).empty()) {
+        while (!s->stop && (batch = grab(s, w, (size_t)s->max_batch)).empty()) {
             w->idle = true; w->cv.wait(lk, [&] { return w->wake || s->stop; }); w->wake = false; w->idle = false;
         }
         if (s->stop) { for (Req* r : batch) s->q.push_front(r); break; }
@@ -214,7 +243,7 @@ void worker_main(zkc_service* s, zkc_service::Worker* w) {
     }
     lk.unlock();
     (void)hipSetDevice(w->dev->device);
-    for (HipBuf* hb : {&w->h_in, &w->d_in, &w->d_wtns, &w->d_status, &w->h_proofs, &w->h_pubs, &w->h_status}) hb->release();
+    for (HipBuf* hb : {&w->h_in, &w->h_wtns, &w->d_in, &w->d_wtns, &w->d_status, &w->h_proofs, &w->h_pubs, &w->h_status}) hb->release();
     if (w->st) (void)hipStreamDestroy(w->st);
 }
 int service_fail(int code, const std::string& msg) { g_service_err = msg; return code; }
@@ -303,6 +332,12 @@ extern "C" int zkc_service_prove(zkc_service* s, const void* zkey, size_t zkey_l
     const int rc = zkc_service_submit_prove(s, zkey, zkey_len, wtns, nWitness, rs, proof, publics, waiter_done, &w);
     if (rc) { if (err && errlen) snprintf(err, errlen, "%s", g_service_err.c_str()); return rc; }
     return wait_for(w, nullptr, err, errlen);
+}
+extern "C" int zkc_service_timing(zkc_service* s, uint64_t out[8]) {
+    if (!s || !out) return ZKC_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> g(s->mu);
+    out[0] = s->us_stage; out[1] = s->us_gpu_wait; out[2] = s->us_key; out[3] = s->us_prove; out[4] = s->us_finish; out[5] = s->n_proved; out[6] = s->n_batches; out[7] = 0;
+    return ZKC_OK;
 }
 extern "C" int zkc_service_stats(zkc_service* s, uint64_t out[8]) {
     if (!s || !out) return ZKC_ERR_BAD_ARG;
