@@ -400,7 +400,7 @@ def main():
         # with the (r, s) the GPU used for them: each oracle proof doubles as a byte-for-byte parity check of a proof that was timed.
         from concurrent.futures import ThreadPoolExecutor
         avail = len(os.sched_getaffinity(0))
-        cores = max(1, min(avail, int(os.environ.get('ZKC_CPU_BASELINE_THREADS', '64'))))            # every core this process may run on (the GPU box gives one GPU's share of the host)
+        cores = max(1, min(avail, int(os.environ.get('ZKC_CPU_BASELINE_THREADS', '32'))))            # the oracle stops scaling past ~16-32 threads on the GPU boxes (64 threads: 1.98 proofs/s, 16: 2.2); cores_available is printed beside it
         wt = d_wtns.view(B, nW * 32)
         order = sample + [i for i in range(B) if i not in set(sample)]
         ol.lib()

@@ -173,7 +173,8 @@ static void emit_smt_verifier(wout_t *W, int n, const fe_t *key, const fe_t *val
         put_u(W, (uint64_t)bit_of(ks, i)); put(W, &childv[i]); put(W, &aux0[i]); put(W, &LT[i].out); put(W, &Lv[i]);
         emit_poseidon_std(W, &LT[i], 1u);
     }
-    put_u(W, (uint64_t)sttop[n - 2]); put_u(W, (uint64_t)bit_of(ks, n - 1));
+    put_u(W, (uint64_t)sttop[n - 2]);
+    if (n <= 253) put_u(W, (uint64_t)bit_of(ks, n - 1));                    /* n = 254 (nLevels = 253): key bit 253 is the bit Num2Bits' linear constraint solves for, not a wire */
     for (int i = n; i <= 252; i++) put_u(W, (uint64_t)bit_of(ks, i));      /* n2bNew.out[n..252] */
     emit_alias_check(W, ks);
     uint64_t z4[4] = {0, 0, 0, 0};

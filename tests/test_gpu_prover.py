@@ -196,14 +196,15 @@ def test_batch_prove_nl160_verifies(env):
     assert rc == 0 and op == proofs[256 * 7:256 * 8]
 
 
-def test_max_levels_nl252_config5(env):
-    """the circuit at the largest nLevels this build's generator supports (252: 128 386 wires, domain 2^17).
+def test_max_levels_nl253_config5(env):
+    """the circuit at nLevels = 253, the largest circomlib permits (SMTVerifier indexes a 254-bit Num2Bits_strict): 128 882 wires,
+    domain 2^17.  All 254 key bits steer a level there, so the bit Num2Bits solves for is the last level's (tests/test_r1cs_setup_cpu.py).
     Witness and proof bytes equal the oracle's, the pinned verifier accepts -- for a shallow voter (most levels fold) and for a voter at
     the maximum depth (nothing folds)."""
     ctx, get, torch = env
-    nl = 252
+    nl = 253
     zk, pk, vk = get(nl)
-    assert pk.n_vars == ol.lib().zko_n_wires(nl) == 128386 and pk.domain_size == 1 << 17
+    assert pk.n_vars == ol.lib().zko_n_wires(nl) == 128882 and pk.domain_size == 1 << 17
     from census_gen import random_voter
     rng = random.Random(5)
     voters = [random_voter(rng, ol.poseidon, nLevels=nl, depth_c=7, depth_s=5), random_voter(rng, ol.poseidon, nLevels=nl, depth_c=nl, depth_s=nl)]

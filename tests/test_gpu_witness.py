@@ -18,7 +18,7 @@ def ctx():
 def test_shape(ctx):
     assert ctx.n_wires(160) == 82754 and ctx.n_inputs(160) == 334
     assert ctx.n_wires(160) == ol.lib().zko_n_wires(160)
-    for nl in (10, 32, 100, 252):
+    for nl in (10, 32, 100, 252, 253):
         assert ctx.n_wires(nl) == ol.lib().zko_n_wires(nl)
 
 
@@ -60,8 +60,10 @@ def test_other_depths_vs_oracle(ctx):
     sys.path.insert(0, os.path.join(ol.ROOT, 'tools'))
     from census_gen import random_voter
     rng = random.Random(7)
-    for nl in (10, 31):
-        voters = [random_voter(rng, ol.poseidon, nLevels=nl, depth_c=rng.randrange(0, nl + 1), depth_s=rng.randrange(0, nl + 1)) for _ in range(8)]
+    for nl in (10, 31, 253):                               # 253: the largest circuit circomlib permits (key bit 253 is the solved bit there, not a wire)
+        voters = [random_voter(rng, ol.poseidon, nLevels=nl, depth_c=rng.randrange(0, nl + 1), depth_s=rng.randrange(0, nl + 1)) for _ in range(8 if nl < 100 else 3)]
+        if nl == 253:
+            voters.append(random_voter(rng, ol.poseidon, nLevels=nl, depth_c=253, depth_s=253))
         ws, st = ctx.witness(voters, nLevels=nl)
         assert st == [0] * len(voters)
         for v, w in zip(voters, ws):

@@ -23,7 +23,7 @@ def wires(w):
 def test_layout_matches_oracle_and_abi(circuit160):
     L, cs = circuit160
     lib = _native.load()
-    for nl in (10, 31, 160, 252):
+    for nl in (10, 31, 160, 252, 253):
         assert r1cs.Layout(nl).nWires == ol.lib().zko_n_wires(nl) == lib.zkc_circuit_n_wires(nl)
         assert r1cs.Layout(nl).nInputs == lib.zkc_circuit_n_inputs(nl)
     assert L.nWires == 82754 and len(cs.cons) + 9 <= 131072 and len(cs.cons) + 9 > 65536    # domain 2^17
@@ -164,3 +164,26 @@ def test_napi_shim_loads_and_verifies_reference_triple():
     r = json.loads(subprocess.check_output([node, '-e', js], cwd=ol.ROOT, timeout=120).decode().strip().splitlines()[-1])
     assert r['api'] == ['function'] * 4 and 'unknown circuit wasm' in r['unknown']
     assert ('nLevels=160 circuit but nLevels=10' in r['mism']) if os.path.exists(wasm) else ('unknown circuit wasm' in r['mism'])
+
+
+def test_nlevels_253_the_largest_circuit_circomlib_permits():
+    """SMTVerifier indexes a 254-bit Num2Bits_strict, so nLevels = 253 (realNLevels = 254) is the largest circuit that
+    compiles.  There all 254 key bits steer a level and the bit Num2Bits' linear constraint solves for is the last level's: no reference wasm
+    exists for this size, so the convention is this build's own -- what is checked is that the three restatements (R1CS generator, CPU oracle, and
+    through the layout the GPU kernels) agree: the oracle's witnesses satisfy the R1CS, mutations do not, the domain is still 2^17."""
+    L, cs = r1cs.build(253)
+    assert L.nWires == ol.lib().zko_n_wires(253) == 128882            # 128 386 at nLevels = 252 plus one level per tree (2 x 249 wires) minus the two solved bits
+    assert len(cs.cons) + 9 <= 131072
+    sys.path.insert(0, os.path.join(ol.ROOT, 'tools'))
+    from census_gen import random_voter
+    rng = random.Random(253)
+    for dc, ds in ((9, 4), (253, 253), (254, 1)):
+        v = random_voter(rng, ol.poseidon, nLevels=253, depth_c=dc, depth_s=ds)
+        rc, w = ol.witness(v, 253)
+        assert rc == 0, (dc, ds)
+        ww = wires(w)
+        assert cs.check(ww) == -1, (dc, ds)
+        for _ in range(20):                                         # a flipped wire inside the tail of either verifier block breaks a constraint
+            blk = rng.choice((L.off_census, L.off_sikver)); i = blk + L.lvl_off(L.n - 1) + rng.randrange(0, 12)
+            m = list(ww); m[i] = (m[i] + 1) % ol.R
+            assert cs.check(m) != -1, i

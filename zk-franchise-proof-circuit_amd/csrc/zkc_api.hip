@@ -232,7 +232,7 @@ int zkc_witness_chunk_async(zkc_ctx* ctx, int nLevels, const void* d_inputs, int
 }
 
 extern "C" int zkc_witness_dev(zkc_ctx* ctx, int nLevels, const void* d_inputs, int B, void* d_wtns, int32_t* d_status) {
-    if (!ctx || !d_inputs || !d_wtns || !d_status || B <= 0 || nLevels < 3 || nLevels > 252) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_witness_dev: bad argument");
+    if (!ctx || !d_inputs || !d_wtns || !d_status || B <= 0 || nLevels < 3 || nLevels > 253) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_witness_dev: bad argument");
     ZKC_LOCK(ctx);
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     WitnessLayout L = WitnessLayout::make(nLevels);
@@ -244,7 +244,7 @@ extern "C" int zkc_witness_dev(zkc_ctx* ctx, int nLevels, const void* d_inputs, 
 }
 
 extern "C" int zkc_witness(zkc_ctx* ctx, int nLevels, const void* inputs, int B, void* wtns, int32_t* status) {
-    if (!ctx || !inputs || !wtns || !status || B <= 0 || nLevels < 3 || nLevels > 252) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_witness: bad argument");
+    if (!ctx || !inputs || !wtns || !status || B <= 0 || nLevels < 3 || nLevels > 253) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_witness: bad argument");
     ZKC_LOCK(ctx);
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     WitnessLayout L = WitnessLayout::make(nLevels);

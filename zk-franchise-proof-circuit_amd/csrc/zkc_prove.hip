@@ -147,7 +147,7 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
         for (uint32_t i = 0; i < nv; i++) { zk->fold.infA[i] = zero64(sec[5] + 64ull * i); zk->fold.infB[i] = zero64(sec[6] + 64ull * i); if (i > np) zk->fold.infC[i] = zero64(sec[8] + 64ull * (i - np - 1)); }
     }
     // a key whose shape is ZkFranchiseProofCircuit(nLevels) can use the voter-independent witness template
-    if (np == 8 && !getenv("ZKC_NO_FOLD")) for (int nl = 3; nl <= 252; nl++) if ((uint32_t)WitnessLayout::make(nl).nWires == nv) { zk->nLevels = nl; break; }
+    if (np == 8 && !getenv("ZKC_NO_FOLD")) for (int nl = 3; nl <= 253; nl++) if ((uint32_t)WitnessLayout::make(nl).nWires == nv) { zk->nLevels = nl; break; }
     int rc = ZKC_OK;
     auto bail = [&](int code) { zkc_zkey_free(zk); return code; };
     // from here on every failure releases the half-built key: no early return without bail()

@@ -395,9 +395,9 @@ __device__ Fr smt_verifier_chain(const WitnessLayout& L, const PoseidonTable& ta
     {   // level n-1: st_top[n-2] (== st_inew[n-1]) and lrbit
         const int lb = blk + L.lvl_off(n - 1);
         e.put_small(lb, (d == n - 1) ? 1u : 0u);
-        e.put_small(lb + 1, (uint32_t)bit_of(key_s, n - 1));
+        if (n <= 253) e.put_small(lb + 1, (uint32_t)bit_of(key_s, n - 1));      // n = 254 (nLevels = 253): key bit 253 is the solved bit of Num2Bits, not a wire; the alias check starts here
     }
-    int w = blk + L.off_n2bnew;
+    int w = blk + L.off_n2bnew + (n > 253 ? 253 - n : 0);
     for (int i = n; i <= 252; i++) e.put_small(w++, (uint32_t)bit_of(key_s, i));
     emit_alias_check(e, w, key_s);
     if (tmpl_mode) {                                                    // n2bOld: oldKey = 0 (voter independent)

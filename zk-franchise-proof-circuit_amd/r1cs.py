@@ -365,7 +365,10 @@ def smt_verifier(cs, L, blk, key_w, value_lc, root_w, sib_w0):
     def lvl(i):
         lb = blk + L.lvl_off(i); o = 0; d = {}
         if i == n - 1:
-            d['T'] = lb; d['bit'] = lb + 1; return d
+            d['T'] = lb
+            if n <= 253:
+                d['bit'] = lb + 1        # n = 254 (nLevels = 253, the largest circomlib allows): all 254 key bits steer a level, so the one bit Num2Bits' linear
+            return d                     # constraint solves for is this level's; it is not a wire and the alias check's wires start one place earlier (off_n2bnew - 1)
         if i == n - 3:
             d['T'] = lb + o; o += 1
         if 0 < i < n - 2:
@@ -374,7 +377,7 @@ def smt_verifier(cs, L, blk, key_w, value_lc, root_w, sib_w0):
         return d
     lv = [lvl(i) for i in range(n)]
     # key bits: lrbit wires for 0..n-1, n2bNew.out wires for n..252, bit 253 solved
-    bits = {i: lc_wire(lv[i]['bit']) for i in range(n)}
+    bits = {i: lc_wire(lv[i]['bit']) for i in range(n) if 'bit' in lv[i]}
     for i in range(n, 253):
         bits[i] = lc_wire(blk + L.off_n2bnew + i - n)
     num2bits(cs, key, bits, 254)
