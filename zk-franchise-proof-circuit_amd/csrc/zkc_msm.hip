@@ -503,7 +503,7 @@ static const bool g_debug_sync = getenv("ZKC_DEBUG_SYNC") != nullptr;   // seria
                     hipGetErrorString(_e)); fflush(stderr); } } while (0)
 
 template <class F>
-static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJobList& jl_in, int slot, bool to_host, hipStream_t st, hipEvent_t ev_sorted, hipEvent_t wait_before_acc = nullptr) {
+static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJobList& jl_in, int slot, bool to_host, hipStream_t st, hipEvent_t ev_sorted, hipEvent_t wait_before_acc = nullptr, hipEvent_t ev_acc = nullptr) {
     zkc_ctx* ctx = zk->ctx;
     const int nj = jl_in.njobs;
     if (nj <= 0 || nj > w.max_jobs) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: job count");
@@ -563,6 +563,7 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
                                reinterpret_cast<const Affine<Fq>*>(table), (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.bcnt, w.segoff, w.seg2bucket, w.perm, nb,
                                reinterpret_cast<XYZZ<Fq>*>(partial), (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_accumulate");
+        if (ev_acc) ZKC_HIP_CHECK(ctx, hipEventRecord(ev_acc, st));                 // the long kernel of the pass is through: what follows (bucket reduction, blinding) is the latency-bound tail
     }
     {
         zkc_prof_scope _pr(ctx, ZKC_PROF_MSM_REDUCE, 0, st);
@@ -592,7 +593,7 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     if (to_host) ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.h_results, results, (size_t)nj * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
     return ZKC_OK;
 }
-int msm_pass_g1(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st, hipEvent_t ev_sorted) { return msm_pass<Fq>(zk, w, zk->d_g1, jl, slot, to_host, st, ev_sorted); }
+int msm_pass_g1(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st, hipEvent_t ev_sorted, hipEvent_t ev_acc) { return msm_pass<Fq>(zk, w, zk->d_g1, jl, slot, to_host, st, ev_sorted, nullptr, ev_acc); }
 int msm_pass_g2(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st, hipEvent_t wait_before_acc) { return msm_pass<Fq2>(zk, w, zk->d_g2, jl, slot, to_host, st, nullptr, wait_before_acc); }
 
 }  // namespace zkc

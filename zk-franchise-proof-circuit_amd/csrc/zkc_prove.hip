@@ -80,7 +80,7 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     for (auto& L : zk->lane) {
         for (hipStream_t q : {L.st, L.st2, L.fin}) if (q) { (void)hipStreamSynchronize(q); if (!zk->serial_streams) (void)hipStreamDestroy(q); }
         for (void* q : {(void*)L.d_abc, (void*)L.d_t, (void*)L.d_p, L.d_fin}) if (q) (void)hipFree(q);
-        for (hipEvent_t e : {L.ev_msm, L.ev_msm2, L.ev_sorted, L.ev_ntt, L.ev_mv, L.ev_fin[0], L.ev_fin[1]}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {L.ev_msm, L.ev_msm2, L.ev_sorted, L.ev_ntt, L.ev_mv, L.ev_acc, L.ev_fin[0], L.ev_fin[1]}) if (e) (void)hipEventDestroy(e);
         msm_work_free(L.w1); msm_work_free(L.w2);
     }
     delete zk;
@@ -92,7 +92,11 @@ static int fold_prepare(zkc_zkey* zk);
 static int lanes_ensure(zkc_zkey* zk, int inflight) {
     inflight = std::max(1, std::min(inflight, zk->max_inflight));
     if (inflight <= zk->cur_inflight) return ZKC_OK;
-    inflight = std::max(inflight, std::min(2 * zk->cur_inflight, zk->max_inflight));          // grow geometrically: no reallocation per call for B = 2, 3, 4 ...
+    // grow in two steps only: a caller of one to four proofs at a time reserves four proofs' work space (0.25 GB at nLevels = 160), anything larger the full pass
+    // (96 proofs, 6 GB of the card's 288): every growth frees and re-allocates the whole work space, which a burst of growing batches (the proving service
+    // under a rising load) would otherwise pay five or six times, hundreds of milliseconds each
+    inflight = inflight <= 4 ? 4 : zk->max_inflight;
+    inflight = std::min(inflight, zk->max_inflight);
     zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n, nv = zk->nVars; int rc;
     constexpr int NWS = msm_nw(MSM_C_SMALL), NWB = msm_nw(MSM_C_BIG);
     const size_t per_proof_entries = (size_t)NWS * 3 * nv + (size_t)NWB * n;
@@ -235,7 +239,7 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
             ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking)); ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.st2, hipStreamNonBlocking));
             ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.fin, hipStreamNonBlocking));
         }
-        ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_msm, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_msm2, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_sorted, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_ntt, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_mv, hipEventDisableTiming));
+        ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_msm, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_msm2, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_sorted, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_ntt, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_mv, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_acc, hipEventDisableTiming));
         ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_fin[0], hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_fin[1], hipEventDisableTiming));
     }
     if ((rc = lanes_ensure(zk, 1))) return bail(rc);
@@ -538,7 +542,8 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         static const bool g2_acc_with_sort = getenv("ZKC_G2_ACC_EARLY") == nullptr;
         if (g2_early) { if ((rc = msm_pass_g2(zk, LN.w2, j2, slot, false, st2, g2_acc_with_sort ? LN.ev_ntt : nullptr))) return rc; ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_msm2, st2)); }
         tr[3] = now_ms();
-        if ((rc = msm_pass_g1(zk, LN.w1, j1, slot, false, st, LN.ev_sorted))) return rc;
+        if ((rc = msm_pass_g1(zk, LN.w1, j1, slot, false, st, LN.ev_sorted, LN.ev_acc))) return rc;
+        zk->last_lane = pass % zk->nlanes;
         tr[4] = now_ms();
         if (!g2_early) {
             ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st2, LN.ev_sorted, 0));
@@ -588,6 +593,13 @@ int zkc::prove_batch_finish(zkc_zkey* zk, int cs, uint8_t* proofs, uint8_t* publ
     memcpy(proofs, CS.h_out, 256ull * CS.B);
     if (publics) memcpy(publics, CS.h_out + 256ull * CS.cap, 32ull * zk->nPub * CS.B);
     return ZKC_OK;
+}
+bool zkc::prove_tail_reached(zkc_zkey* zk) {
+    if (!zk || zk->last_lane < 0) return true;
+    const hipError_t e = hipEventQuery(zk->lane[zk->last_lane].ev_acc);
+    if (e == hipErrorNotReady) return false;
+    if (e != hipSuccess) (void)hipGetLastError();
+    return true;
 }
 // the synchronous form: begin + finish on slot 0 under the context lock
 static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, int B, const uint8_t* rs, uint8_t* proofs, uint8_t* publics,

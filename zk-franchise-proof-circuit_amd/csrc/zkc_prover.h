@@ -138,7 +138,7 @@ struct zkc_lane {
     zkc::Fr *d_abc = nullptr, *d_t = nullptr; uint32_t* d_p = nullptr;   // [inflight][3n] x2 (d_t = NTT scratch), [inflight][n x 8]
     void* d_fin = nullptr;                                                // blinding scratch, finalize_scratch_bytes(inflight)
     zkc::MsmWork w1, w2;                                                  // G1 and G2 pipelines
-    hipEvent_t ev_msm = nullptr, ev_msm2 = nullptr, ev_sorted = nullptr, ev_ntt = nullptr, ev_mv = nullptr, ev_fin[2] = {nullptr, nullptr}; int npass = 0;      // ev_ntt: buildABC/NTT/joinABC of the pass are through      // ev_fin[slot]: blinding of the pass that used result slot `slot`
+    hipEvent_t ev_msm = nullptr, ev_msm2 = nullptr, ev_sorted = nullptr, ev_ntt = nullptr, ev_mv = nullptr, ev_acc = nullptr, ev_fin[2] = {nullptr, nullptr}; int npass = 0;      // ev_acc: the G1 accumulation of the lane's latest pass is through      // ev_ntt: buildABC/NTT/joinABC of the pass are through      // ev_fin[slot]: blinding of the pass that used result slot `slot`
 };
 
 struct zkc_zkey {
@@ -173,6 +173,7 @@ struct zkc_zkey {
         hipEvent_t ev_done[2] = {nullptr, nullptr};                         // per lane: recorded on its blinding stream behind the call's last copy
         int B = 0; bool pending = false;
     } call[2];
+    int last_lane = -1;                                                     // lane of the latest pass that was enqueued (prove_tail_reached)
     hipEvent_t ev_start = nullptr; std::vector<hipEvent_t> ev_chunk;        // ev_chunk[p]: witness (if made here) and fold flags of pass p are ready
     // constant folding of the voter-independent witness part (SURVEY.md hard part 4)
     struct Fold {
@@ -197,7 +198,7 @@ void msm_work_free(MsmWork& w);
 // runs all jobs of `jl` through one pipeline pass; results (XYZZ per job) go to device slot `slot` (0/1) of w.results and, when
 // to_host is set, to w.h_results (valid after the caller syncs the stream)
 // ev_sorted (optional): recorded on st once the digit/sort/segment kernels are through, i.e. right before the long accumulation kernel
-int msm_pass_g1(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st, hipEvent_t ev_sorted = nullptr);
+int msm_pass_g1(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st, hipEvent_t ev_sorted = nullptr, hipEvent_t ev_acc = nullptr);
 int msm_pass_g2(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st, hipEvent_t wait_before_acc = nullptr);
 // zkc_msm_sort.hip -- K4: scalars -> signed digits -> entries bucketed per job (vals2, off, bcnt), then the segment lists of the accumulation
 // (segcnt, segoff, seg2bucket, seglen, perm, heavy).  `jl` is the finished host copy of what w.d_jobs already holds on the device.
@@ -209,6 +210,9 @@ int finalize_launch(zkc_ctx* ctx, hipStream_t st, const FinalizeArgs& a, int npr
 // begun again; d_wtns (and d_inputs, d_status) stay the caller's until finish returns.  d_inputs == nullptr: the witnesses are given.
 int prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nWitness, int B, const uint8_t* rs, bool want_publics, const void* d_inputs, int32_t* d_status);
 int prove_batch_finish(zkc_zkey* zk, int cs, uint8_t* proofs, uint8_t* publics);
+// has the call begun last on this key reached its tail (the last pass' G1 accumulation is through; bucket reduction, blinding and copies remain)?  The proving
+// service begins the next call then: its witness kernels and transforms run beside that tail, and until then it keeps collecting requests.
+bool prove_tail_reached(zkc_zkey* zk);
 size_t finalize_scratch_bytes(int nproofs);
 int msm_precompute_g1(zkc_ctx* ctx, uint32_t count, G1Affine* d_table, int c);   // d_table[0..count) = base on entry
 int msm_precompute_g2(zkc_ctx* ctx, uint32_t count, G2Affine* d_table, int c);

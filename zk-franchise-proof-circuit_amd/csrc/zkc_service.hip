@@ -172,6 +172,22 @@ void process(zkc_service* s, zkc_service::Worker* w, std::vector<Req*>&& first) 
     if (!stage(w, b, 0, nIn, nW, err)) { (void)hipGetLastError(); return fail_all(s, b, ZKC_ERR_HIP, err); }      // beside the other worker's batch, which owns the GPU now
     int rc = ZKC_OK; zkc_zkey* zk = nullptr; int slot = 0;
     uint64_t t_b = now_us(), t_c = 0, t_d = 0, t_e = 0;
+    // while the other worker's call is in its body (accumulations still running) there is nothing to gain from beginning: this call's kernels would only queue
+    // behind it.  Keep collecting requests instead and begin when that call reaches its tail (bucket reduction, blinding, copies: 4-5 ms of latency chains that
+    // this call's witness kernels and transforms run beside).  The key cannot change meanwhile: a switch waits for in_flight == 0.
+    for (;;) {
+        bool other = false;
+        { std::lock_guard<std::mutex> fl(d->fl_mu); other = d->in_flight > 0; }
+        if (!other || zkc::prove_tail_reached(d->key)) break;
+        const size_t from = b.reqs.size();
+        if (from < cap) {
+            std::lock_guard<std::mutex> g(s->mu);
+            std::vector<Req*> more = grab(s, w, cap - from, &cls);
+            for (Req* r : more) if (full || r->nW == nW) b.reqs.push_back(r); else finish(r, ZKC_ERR_INVALID_WITNESS_LENGTH, 0, "Invalid witness length");
+        }
+        if (b.reqs.size() > from) { if (!stage(w, b, from, nIn, nW, err)) { (void)hipGetLastError(); return fail_all(s, b, ZKC_ERR_HIP, err); } }
+        else std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
     {
         std::lock_guard<std::mutex> gpu(d->gpu_mu);
         t_c = now_us();
