@@ -336,11 +336,13 @@ def main():
     d = prof[dom]
     achieved = d['alg_bytes'] / (d['ms'] * 1e-3) / 1e9 if d['ms'] > 0 else 0.0
     traffic, traffic_src = None, None
-    for pmc_file in ('r02_pmc_hbm_traffic.json', 'r01_pmc_hbm_traffic.json'):
+    for pmc_file in ('r03_pmc_hbm_traffic.json', 'r02_pmc_hbm_traffic.json', 'r01_pmc_hbm_traffic.json'):
         try:      # HBM bytes per launch of the same kernel/geometry from the committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
             pm = json.load(open(os.path.join(ROOT, 'profiles', pmc_file)))
             traffic = int(pm.get('hbm_bytes_per_launch', pm['hbm_bytes_per_launch_uncorrected']))
-            traffic_src = 'profiles/%s (separate --pmc FETCH_SIZE / WRITE_SIZE runs, %d proofs per launch; FETCH_SIZE x %.2f as calibrated for 64-byte random gathers in profiles/r02_pmc_fetch_calibration.json)' % (pmc_file, pm['proofs_per_launch'], pm.get('fetch_calibration_factor', 1.0))
+            traffic_src = ('profiles/%s (separate --pmc FETCH_SIZE / WRITE_SIZE runs, %d proofs per launch; FETCH_SIZE x %.2f: the factor the guide asks to calibrate for one\'s own access pattern, '
+                           'measured for random 64-byte gathers in profiles/r02_pmc_fetch_calibration.json -- with the guide\'s factor 2 for wide coalesced streams it would be %.1f GB)'
+                           % (pmc_file, pm['proofs_per_launch'], pm.get('fetch_calibration_factor', 1.0), pm.get('hbm_bytes_per_launch_with_stream_factor_2', 0) / 1e9))
             break
         except Exception:
             pass
@@ -350,7 +352,7 @@ def main():
     # from committed files.
     vm = {'mad_u64_u32_per_madd': 1476, 'instr_per_madd': 2400, 'rate_mad_u64_u32': 34.8e12, 'rate_valu32': 57.2e12, 'source': 'round-1 constants (no committed probe output)'}
     try:
-        vm = json.load(open(os.path.join(ROOT, 'profiles', 'r02_valu_model.json')))
+        vm = json.load(open(os.path.join(ROOT, 'profiles', 'r03_valu_model.json' if os.path.exists(os.path.join(ROOT, 'profiles', 'r03_valu_model.json')) else 'r02_valu_model.json')))
     except Exception:
         pass
     nproofs = args.steps * B

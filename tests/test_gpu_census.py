@@ -22,6 +22,26 @@ def test_poseidon_batch_and_census():
     for v, w in list(zip(voters, ws))[:8]:
         rc, wo = ol.witness(v)
         assert rc == 0 and wo == w
-    # the example voter's roots follow the same tree semantics: recompute its census root from its siblings
+    # the one arbo-built path the reference holds (inputs_example.json, written by internal/helpers.go:36-85 GenTree / GenProof): climbing it with the GPU
+    # Poseidon and this module's leaf / node / path-bit conventions must land on the roots arbo computed.  (The reference has no arbo-built multi-leaf tree
+    # fixture, so SparseMerkleTree's branching is pinned only through the circuit accepting its paths -- above -- and through this path.)
     ex = ol.load_json('ref/inputs_example.json')
+    key = int(ex['address'])
+
+    def climb(value, siblings):
+        sib = [int(x) for x in siblings]
+        d = max([i + 1 for i, x in enumerate(sib) if x] or [0])
+        cur = census.poseidon_batch(ctx, [(key, value, 1)])[0]
+        for i in range(d - 1, -1, -1):
+            cur = census.poseidon_batch(ctx, [(sib[i], cur) if (key >> i) & 1 else (cur, sib[i])])[0]
+        return cur
+    assert climb(int(ex['availableWeight']), ex['censusSiblings']) == int(ex['censusRoot'])
+    sik = census.poseidon_batch(ctx, [(key, int(ex['password']), int(ex['signature']))])[0]
+    assert climb(sik, ex['sikSiblings']) == int(ex['sikRoot'])
+    # voters at the very bottom of both trees (bench.py's worst case for constant folding) are valid voters too
+    deep = census.deep_voters(ctx, 3, 160)
+    ws, st = ctx.witness(deep)
+    assert st == [0, 0, 0]
+    rc, wo = ol.witness(deep[1]); assert rc == 0 and wo == ws[1]
+    assert all(v['censusSiblings'][159] != '0' and v['censusSiblings'][160] == '0' for v in deep)
     ctx.close()
