@@ -1,0 +1,107 @@
+"""GPU: the edges of the boundary that the main parity tests do not visit -- empty and malformed calls, input values at and above the field order, the
+shallowest and deepest voters, the extreme blinding scalars, a witness of the wrong length.  Everything goes through the C ABI (ctypes) and is compared
+with the CPU oracle where there is something to compare."""
+import ctypes, json, os, random, sys
+import pytest
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(ol.ROOT, 'tools'))
+
+
+@pytest.fixture(scope='module')
+def env():
+    import torch  # noqa: F401
+    import zkcensus_amd
+    from zkcensus_amd import setup
+    nl = 10
+    _, zp, vp = setup.ensure_test_artifacts(nl)
+    zk = open(zp, 'rb').read()
+    ctx = zkcensus_amd.Context(0); pk = zkcensus_amd.ProvingKey(ctx, zk)
+    yield zkcensus_amd, ctx, pk, zk, json.load(open(vp)), nl
+    pk.close(); ctx.close()
+
+
+def test_empty_and_null_calls_are_refused_not_crashed(env):
+    zkc, ctx, pk, zk, vk, nl = env
+    lib = ctx._lib
+    nw, ni = ctx.n_wires(nl), ctx.n_inputs(nl)
+    buf = ctypes.create_string_buffer(nw * 32); st = (ctypes.c_int32 * 1)()
+    assert lib.zkc_witness(ctx._h, nl, bytes(ni * 32), 0, buf, st) == 4                       # B = 0: ZKC_ERR_BAD_ARG
+    assert lib.zkc_witness(ctx._h, nl, None, 1, buf, st) == 4
+    assert lib.zkc_witness(ctx._h, 2, bytes(ni * 32), 1, buf, st) == 4                         # nLevels below the circuit's minimum
+    assert lib.zkc_witness(ctx._h, 254, bytes(ni * 32), 1, buf, st) == 4                       # above the largest circuit circomlib permits (253)
+    proof = ctypes.create_string_buffer(256); pub = ctypes.create_string_buffer(256)
+    assert lib.zkc_prove_batch_dev(pk._h, None, nw, 1, bytes(64), proof, pub) == 4
+    assert lib.zkc_prove_batch_dev(pk._h, 1, nw, 0, bytes(64), proof, pub) == 4                # B = 0
+    assert lib.zkc_zkey_load(ctx._h, b'', 0, ctypes.byref(ctypes.c_void_p())) in (4, 5)
+    assert lib.zkc_zkey_load(ctx._h, zk[:11], 11, ctypes.byref(ctypes.c_void_p())) == 5       # ZKC_ERR_FORMAT
+    # and the context still works
+    from census_gen import random_voter
+    ws, s = ctx.witness([random_voter(random.Random(1), ol.poseidon, nLevels=nl, depth_c=3, depth_s=3)], nLevels=nl)
+    assert s == [0]
+
+
+def test_input_values_at_and_above_the_field_order(env):
+    """census.circom's inputs are field elements: the C ABI takes 32-byte values below r.  r - 1 is a legal value (and fails the circuit's own checks, not the range check);
+    r and 2^256 - 1 are refused with ZKC_W_ERR_INPUT_RANGE for that voter alone, exactly where the oracle refuses them."""
+    zkc, ctx, pk, zk, vk, nl = env
+    from census_gen import random_voter
+    good = zkc.flatten_inputs(random_voter(random.Random(2), ol.poseidon, nLevels=nl, depth_c=4, depth_s=2), nl)
+    ni = ctx.n_inputs(nl)
+
+    def patched(i, value):
+        b = bytearray(good); b[32 * i:32 * i + 32] = value.to_bytes(32, 'little'); return bytes(b)
+    cases = [good, patched(4, ol.R), patched(4, 2**256 - 1), patched(4, ol.R - 1), patched(ni - 1, ol.R), good]      # voteHash[0] (unconstrained), last sikSibling
+    ws, st = ctx.witness(cases, nLevels=nl)
+    ost = [ol.witness(c, nl)[0] for c in cases]
+    assert st == ost == [0, 6, 6, 0, 6, 0]
+    assert ws[0] == ws[5] == ol.witness(good, nl)[1] and ws[3] == ol.witness(cases[3], nl)[1]
+
+
+def test_shallowest_and_deepest_voters(env):
+    """depth 0 (a census of one voter: every sibling zero, the root IS the leaf hash) and depth nLevels in both trees; witness and proof bytes equal the oracle's"""
+    zkc, ctx, pk, zk, vk, nl = env
+    from census_gen import random_voter
+    rng = random.Random(3)
+    voters = [random_voter(rng, ol.poseidon, nLevels=nl, depth_c=0, depth_s=0), random_voter(rng, ol.poseidon, nLevels=nl, depth_c=nl, depth_s=nl),
+              random_voter(rng, ol.poseidon, nLevels=nl, depth_c=0, depth_s=nl), random_voter(rng, ol.poseidon, nLevels=nl, depth_c=1, depth_s=1, zero_frac=0.0)]
+    assert all(s == '0' for s in voters[0]['censusSiblings'])
+    ws, st = ctx.witness(voters, nLevels=nl)
+    assert st == [0] * 4
+    for v, w in zip(voters, ws):
+        rc, ow = ol.witness(v, nl); assert rc == 0 and ow == w
+        p, u = pk.prove(w, 7, 9)
+        rc, op, ou = ol.prove(zk, w, 7, 9); assert rc == 0 and (p, u) == (op, ou)
+        assert ol.verify(vk, u, p)
+
+
+def test_extreme_blinding_scalars_and_bad_ones(env):
+    zkc, ctx, pk, zk, vk, nl = env
+    from census_gen import random_voter
+    v = random_voter(random.Random(4), ol.poseidon, nLevels=nl, depth_c=5, depth_s=6)
+    ws, st = ctx.witness([v], nLevels=nl)
+    for r, s in ((0, 0), (0, 1), (ol.R - 1, ol.R - 1), (1, ol.R - 1), (2**253, 2**128)):
+        p, u = pk.prove(ws[0], r, s)
+        rc, op, ou = ol.prove(zk, ws[0], r, s)
+        assert rc == 0 and (p, u) == (op, ou), (r, s)
+        assert ol.verify(vk, u, p)
+    with pytest.raises(zkc.ZkcError) as e:                                                    # r = the field order itself: refused, not reduced silently
+        pk.prove(ws[0], ol.R, 1)
+    assert e.value.code == 4
+    with pytest.raises(zkc.ZkcError) as e:
+        pk.prove(ws[0][:-32], 1, 2)                                                            # one wire short: rapidsnark's INVALID_WITNESS_LENGTH
+    assert e.value.code == 3 and 'Invalid witness length' in str(e.value)
+
+
+def test_ragged_sibling_lists_flatten_like_the_reference_pads_them(env):
+    """internal/inputs.go:52,72 appends zero siblings up to nLevels + 1; a caller may hand over the packed list.  Short, exact and over-long lists."""
+    zkc, ctx, pk, zk, vk, nl = env
+    from census_gen import random_voter
+    v = random_voter(random.Random(5), ol.poseidon, nLevels=nl, depth_c=3, depth_s=2)
+    packed = dict(v, censusSiblings=v['censusSiblings'][:3], sikSiblings=v['sikSiblings'][:2])
+    assert zkc.flatten_inputs(packed, nl) == zkc.flatten_inputs(v, nl) == ol.flat_inputs(packed, nl)
+    ws, st = ctx.witness([packed, v], nLevels=nl)
+    assert st == [0, 0] and ws[0] == ws[1]
+    with pytest.raises((ValueError, AssertionError)):
+        zkc.flatten_inputs(dict(v, censusSiblings=v['censusSiblings'] + ['0']), nl)

@@ -11,6 +11,8 @@
 #   verify_bench     tools/verify_bench.py 1024                                 node           node napi/example.js
 #   prof             rocprofv3 --kernel-trace --stats over a 2-step bench       pmc:<name>:<counters,comma>   one PMC pass over a one-pass bench
 #   calib            FETCH_SIZE calibration (tools/probe/gather_probe.hip)      py:<script,args>              python <script> <args>
+#   trace1           rocprofv3 --kernel-trace over tools/latency.py -> timeline of one proof (tools/single_proof_trace.py)
+#   env:NAME=VALUE   export NAME=VALUE for the steps that follow (A/B of a library switch on one box)
 set -o pipefail
 R="$GRAFT_REPO_ROOT"; [ -n "$R" ] || R="$(cd "$(dirname "$0")/../.." && pwd)"
 cd "$R"; RUN=${1:-run}; shift; O="$R/gpurun_out/$RUN"; mkdir -p "$O"
@@ -37,11 +39,11 @@ P
                   done; unset ZKCENSUS_LIB ;;
     rate_probe)   hipcc --offload-arch=gfx950 -O3 -Wno-unused-result tools/probe/rate_probe.hip -o /tmp/rate_probe > "$O/rate_probe_build.log" 2>&1 && timeout -k 10 300 /tmp/rate_probe > "$O/rate_probe.txt" 2>&1; rc=$?; head -8 "$O/rate_probe.txt" ;;
     fieldmul)     hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-result -I zk-franchise-proof-circuit_amd/csrc tools/probe/fieldmul_probe.hip -o /tmp/fieldmul_probe > "$O/fieldmul_build.log" 2>&1 && timeout -k 10 300 /tmp/fieldmul_probe > "$O/fieldmul_probe.txt" 2>&1; rc=$?; cat "$O/fieldmul_probe.txt" ;;
-    latency)      timeout -k 10 300 python tools/latency.py > "$O/latency.json" 2> "$O/latency.err"; rc=$?; tail -c 700 "$O/latency.json" ;;
+    latency)      f="latency${ZKC_AB_TAG:+_$ZKC_AB_TAG}"; timeout -k 10 300 python tools/latency.py > "$O/$f.json" 2> "$O/$f.err"; rc=$?; tail -c 900 "$O/$f.json" ;;
     stress)       timeout -k 10 400 python tools/stress.py 20 5 > "$O/stress.json" 2> "$O/stress.err"; rc=$?; tail -c 600 "$O/stress.json" ;;
     verify_bench) timeout -k 10 300 python tools/verify_bench.py 1024 > "$O/verify_bench.json" 2> "$O/verify_bench.err"; rc=$?; tail -c 400 "$O/verify_bench.json" ;;
     node)         timeout -k 10 300 node napi/example.js > "$O/node_example.json" 2> "$O/node_example.err"; rc=$?; tail -c 900 "$O/node_example.json" ;;
-    py)           f="py_$(echo "$arg" | tr -c 'A-Za-z0-9\n' '_')"; timeout -k 10 600 python ${arg//,/ } > "$O/$f.out" 2> "$O/$f.err"; rc=$?; tail -c 1200 "$O/$f.out" ;;
+    py)           f="py_$(echo "$arg" | tr -c 'A-Za-z0-9\n' '_')${ZKC_AB_TAG:+_$ZKC_AB_TAG}"; timeout -k 10 600 python ${arg//,/ } > "$O/$f.out" 2> "$O/$f.err"; rc=$?; tail -c 1200 "$O/$f.out" ;;
     prof)         cd /tmp && export TMPDIR=/tmp
                   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-verify > "$O/prof.log" 2>&1; rc=$?
                   find "$O/prof" -name "*kernel_trace.csv" -size +20M -delete ;;
@@ -49,6 +51,10 @@ P
                   timeout -k 10 300 rocprofv3 --pmc ${ctrs//,/ } --output-format csv -d "$O/pmc_$pn" -- $PMC_BENCH > "$O/pmc_$pn.log" 2>&1; rc=$?; tail -2 "$O/pmc_$pn.log" ;;
     calib)        cd /tmp && export TMPDIR=/tmp
                   hipcc --offload-arch=gfx950 -O3 -Wno-unused-result "$R/tools/probe/gather_probe.hip" -o /tmp/gather_probe > /dev/null 2>&1 && timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_calib" -- /tmp/gather_probe > "$O/gather_probe.txt" 2>&1; rc=$? ;;
+    trace1)       cd /tmp && export TMPDIR=/tmp
+                  timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$O/trace1" -- python3 "$R/tools/latency.py" > "$O/trace1.log" 2>&1; rc=$?
+                  f=$(find "$O/trace1" -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python3 "$R/tools/single_proof_trace.py" "$f" > "$O/single_proof_trace.txt" 2>&1; find "$O/trace1" -name "*.csv" -delete; tail -60 "$O/single_proof_trace.txt" ;;
+    env)          export "$arg"; rc=0 ;;                         # env:NAME=VALUE for the steps that follow (env:NAME= clears it)
     *)            log "unknown step $step"; exit 2 ;;
   esac
   log "$step rc=$rc"

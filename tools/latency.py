@@ -16,15 +16,22 @@ def main():
     nW = ctx.n_wires(160)
     d_w = torch.empty(nW * 32, dtype=torch.uint8, device='cuda'); d_s = torch.zeros(1, dtype=torch.int32, device='cuda')
     res = {}
-    for it in range(4):
+    best = {}
+    rs = lambda it: (11 + it).to_bytes(32, 'little') + (17 + it).to_bytes(32, 'little')
+    for it in range(12):                                   # minimum over 12 rounds (the first ones grow work space and caches)
         t0 = time.perf_counter()
         ws, st = ctx.witness([flat])                       # host buffers in and out (2.6 MB witness over PCIe)
         t1 = time.perf_counter()
         pk.prove(ws[0], 11 + it, 17 + it)                  # host witness in, 256-byte proof out
         t2 = time.perf_counter()
-        ctx.witness_dev(d_in.data_ptr(), 1, d_w.data_ptr(), d_s.data_ptr()); pk.prove_dev(d_w.data_ptr(), 11 + it, 17 + it)   # device-resident path
+        ctx.witness_dev(d_in.data_ptr(), 1, d_w.data_ptr(), d_s.data_ptr()); pk.prove_dev(d_w.data_ptr(), 11 + it, 17 + it)   # device-resident, two calls
         t3 = time.perf_counter()
-        res = {'witness_host_ms': round((t1 - t0) * 1e3, 2), 'prove_host_ms': round((t2 - t1) * 1e3, 2), 'fullprove_device_resident_ms': round((t3 - t2) * 1e3, 2), 'status': st[0]}
+        pk.fullprove_batch_dev(d_in.data_ptr(), 1, d_w.data_ptr(), d_s.data_ptr(), rs(it))                                  # device-resident, ONE call (inputs -> proof)
+        t4 = time.perf_counter()
+        for k, v in (('witness_host_ms', t1 - t0), ('prove_host_ms', t2 - t1), ('fullprove_device_resident_ms', t3 - t2), ('fullprove_one_call_ms', t4 - t3)):
+            best[k] = min(best.get(k, 1e9), v)
+    res = {k: round(v * 1e3, 2) for k, v in best.items()}; res['status'] = st[0]
+    res['blinding'] = 'plain 254-bit products (ZKC_NO_GLV)' if os.environ.get('ZKC_NO_GLV') is not None else 'GLV halves'
     # per-stage device time of ONE device-resident fullProve (HIP events around each kernel category on the stream it is launched on; the G2 pass,
     # the blinding and the G1 pass run on three streams, so the categories overlap and do not add up to the end-to-end figure)
     cats = {0: 'witness', 1: 'buildABC_matvec', 2: 'ntt_joinABC', 3: 'msm_bucketing', 4: 'msm_accumulate_g1', 5: 'msm_accumulate_g2', 6: 'msm_reduce'}
