@@ -217,9 +217,6 @@ void zkc_msm_g1_free(zkc_msm* m);
  *                  host_out = affine point in standard form (64 B, or 128 B for B2). */
 int zkc_debug_stage(zkc_zkey* zk, const void* d_wtns, int stage, void* host_out);
 int zkc_msm_debug(zkc_zkey* zk, int which, const void* d_scalars, uint32_t count, void* host_out);
-/* the host-side GLV split the blinding step uses for its two variable-base products: k (32 B LE, < r) -> out = k1[4 words], k2[4 words], flags (1: k1 negative,
- * 2: k2 negative, 4: valid), k = +-k1 +- k2 lambda (mod r), |k1|, |k2| < 2^127.  Host only. */
-int zkc_debug_glv_decompose(const uint8_t k[32], uint32_t out[12]);
 
 /* ---- f1 support: batched Poseidon over BN254 Fr (circomlib parameters), n_inputs in {2,3,4}; host buffers,
  * inputs B x n_inputs x 32 B, out B x 32 B.  The census builder hashes whole tree levels with it. ---- */

@@ -161,26 +161,3 @@ def test_zkey_fingerprint_identifies_keys(tmp_path):
     t0 = time.perf_counter()
     for _ in range(20): fp(a)
     assert (time.perf_counter() - t0) / 20 < 0.02
-
-
-def test_glv_split_of_blinding_scalars():
-    """The blinding's two variable-base products run over the GLV halves of r and s (csrc/zkc_finalize.hip).  The host-side split, against Python integers:
-    k = +-k1 +- k2 lambda (mod r) with |k1|, |k2| < 2^127 for edge and random scalars, lambda a primitive cube root of unity in Fr."""
-    import ctypes, random
-    from zkcensus_amd import _native
-    lib = _native.load()
-    lam = 4407920970296243842393367215006156084916469457145843978461
-    assert (lam * lam + lam + 1) % ol.R == 0
-    rng = random.Random(17)
-    ks = [0, 1, 2, ol.R - 1, ol.R - 2, lam, lam + 1, ol.R - lam, 1 << 127, (1 << 128) - 1, 1 << 253, ol.R // 2, ol.R // 3] + [rng.randrange(ol.R) for _ in range(3000)]
-    worst = 0
-    for k in ks:
-        out = (ctypes.c_uint32 * 12)()
-        assert lib.zkc_debug_glv_decompose(k.to_bytes(32, 'little'), out) == 0, k
-        k1 = sum(out[i] << (32 * i) for i in range(4)); k2 = sum(out[4 + i] << (32 * i) for i in range(4))
-        assert out[8] & 4 and k1 < 1 << 127 and k2 < 1 << 127
-        if out[8] & 1: k1 = -k1
-        if out[8] & 2: k2 = -k2
-        assert (k1 + k2 * lam - k) % ol.R == 0, k
-        worst = max(worst, abs(k1).bit_length(), abs(k2).bit_length())
-    assert worst <= 127

@@ -31,7 +31,6 @@ def main():
         for k, v in (('witness_host_ms', t1 - t0), ('prove_host_ms', t2 - t1), ('fullprove_device_resident_ms', t3 - t2), ('fullprove_one_call_ms', t4 - t3)):
             best[k] = min(best.get(k, 1e9), v)
     res = {k: round(v * 1e3, 2) for k, v in best.items()}; res['status'] = st[0]
-    res['blinding'] = 'plain 254-bit products (ZKC_NO_GLV)' if os.environ.get('ZKC_NO_GLV') is not None else 'GLV halves'
     # per-stage device time of ONE device-resident fullProve (HIP events around each kernel category on the stream it is launched on; the G2 pass,
     # the blinding and the G1 pass run on three streams, so the categories overlap and do not add up to the end-to-end figure)
     cats = {0: 'witness', 1: 'buildABC_matvec', 2: 'ntt_joinABC', 3: 'msm_bucketing', 4: 'msm_accumulate_g1', 5: 'msm_accumulate_g2', 6: 'msm_reduce'}

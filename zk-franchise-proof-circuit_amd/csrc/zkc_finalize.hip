@@ -6,8 +6,6 @@
 // Expanded so that nothing depends on piA / piB1:  s piA + r piB1 - rs delta = s A' + s alpha + r B1' + r beta1 + rs delta,
 // i.e. two variable-base products and five fixed-base ones in G1 plus one in G2, the fixed-base ones read from 8-bit window tables.
 // Runs on the lane's blinding stream so that it overlaps the next pipeline pass.
-#include <cstring>
-#include <string.h>
 #include "zkc_prover.h"
 #include "zkc_f29_g1.h"
 
@@ -65,43 +63,6 @@ __device__ G1XYZZ var_mul29_g(const G1XYZZ& P, const uint32_t k[8], Acc29* __res
     return f29_pt_is_inf(acc) ? G1XYZZ::inf() : f29_pt_to_xyzz(acc);
 }
 
-// ---- [r3] the same product with the curve's endomorphism (GLV): phi(x, y) = (beta x, y) equals lambda (x, y) on BN254 G1 for the cube roots of unity
-// beta in Fq and lambda in Fr below, and every k < r splits as k = k1 + k2 lambda (mod r) with |k1|, |k2| < 2^127 (glv_decompose, host).  k P = k1 P + k2 phi(P) then
-// shares its doublings between the two halves: 32 four-bit windows x (4 doublings + at most 2 additions) instead of 64 x (4 + 1) -- 128 doublings instead of
-// 256 on the longest chain of the blinding, which is the tail of a single proof's latency.  Group arithmetic is exact: same proof bytes either way.
-__device__ __constant__ uint32_t kGlvBetaMont[8] = {0xd782e155u, 0x71930c11u, 0xffbe3323u, 0xa6bb947cu, 0xd4741444u, 0xaa303344u, 0x26594943u, 0x2c3b3f0du};   // beta 2^256 mod q, beta = 2203960485148121921418603742825762020974279258880205651966
-__device__ __forceinline__ uint32_t glv_nibble(const uint32_t k[4], int w) {
-    uint32_t limb = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) limb = (q == (w >> 3)) ? k[q] : limb;
-    return (limb >> (4 * (w & 7))) & 15u;
-}
-__device__ __forceinline__ void glv_neg_y(Acc29& t) {            // (X, -Y, ZZ, ZZZ): D27 dominates a loose coordinate (< 32 p), the result is brought back below 3 p
-    uint32_t z[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    f29_sub(t.Y, z, t.Y, Dom29::D27); f29_carry(t.Y); f29_reduce_small<FqParams>(t.Y);
-}
-// g: GLV_WORDS words made by glv_decompose: k1[4], k2[4], flags (1: k1 negative, 2: k2 negative, 4: valid).  tab: 16 entries owned by the calling lane (LDS or global)
-__device__ G1XYZZ var_mul29_glv(const G1XYZZ& P, const uint32_t* __restrict__ g, Acc29* tab) {
-    if (P.is_inf()) return P;
-    uint32_t k1[4], k2[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) { k1[i] = g[i]; k2[i] = g[4 + i]; }
-    const bool n1 = g[8] & 1u, n2 = g[8] & 2u;
-    uint32_t beta[9]; f29_enter_fq(beta, kGlvBetaMont);
-    { Acc29 one = f29_pt_from_xyzz(P), t = one; tab[1] = one; for (int i = 2; i < 16; i++) { f29_pt_add(t, t, one); tab[i] = t; } }
-    Acc29 acc; f29_pt_set_inf(acc);
-    for (int w = 31; w >= 0; w--) {
-        if (!f29_pt_is_inf(acc)) for (int d = 0; d < 4; d++) f29_pt_dbl(acc, acc);
-        const uint32_t d1 = glv_nibble(k1, w), d2 = glv_nibble(k2, w);
-        if (d1) { Acc29 e = tab[d1]; if (n1) glv_neg_y(e); f29_pt_add(acc, acc, e); }
-        if (d2) { Acc29 e = tab[d2]; uint32_t bx[9]; f29_mul<FqParams>(bx, e.X, beta);
-#pragma unroll
-                  for (int i = 0; i < 9; i++) e.X[i] = bx[i];
-                  if (n2) glv_neg_y(e); f29_pt_add(acc, acc, e); }
-    }
-    return f29_pt_is_inf(acc) ? G1XYZZ::inf() : f29_pt_to_xyzz(acc);
-}
-
 // the voter-independent part of a section's MSM for proof q (constant folding, zkc_prove.hip): base + sum over the folded levels of both trees
 template <class P>
 __device__ P fold_const(const P* __restrict__ tab, const FinalizeArgs& a, int q) {
@@ -125,8 +86,7 @@ zkc_finalize(FinalizeArgs a) {
     uint8_t* out = a.out + 256 * (size_t)q;
     if (wave == 0 && lane < 2) {
         const G1XYZZ P = lane == 0 ? xyzz_add(a.r1[nq + 3 * q + 0], fold_const(a.foldA, a, q)) : xyzz_add(a.r1[nq + 3 * q + 1], fold_const(a.foldB1, a, q));
-        const uint32_t* g = a.glv ? a.glv + ((size_t)q * 2 + lane) * GLV_WORDS : nullptr;
-        sh[lane] = (g && (g[8] & 4u)) ? var_mul29_glv(P, g, tab[lane]) : var_mul29(P, lane == 0 ? s : r, tab[lane]);      // s A' , r B1'
+        sh[lane] = var_mul29(P, lane == 0 ? s : r, tab[lane]);                                 // s A' , r B1'
     } else if (wave == 1 && lane < 5) {
         uint32_t k[8];
         if (lane == 2) { Fr rs = fp_from_std<FrParams>(r) * fp_from_std<FrParams>(s); fp_to_std<FrParams>(k, rs); }
@@ -175,9 +135,7 @@ zkc_finalize_products(FinalizeArgs a, int nq) {
     Acc29* tabs = reinterpret_cast<Acc29*>(res2 + nq);
     if (task < 2) {
         const G1XYZZ P = task == 0 ? xyzz_add(a.r1[nq + 3 * q + 0], fold_const(a.foldA, a, q)) : xyzz_add(a.r1[nq + 3 * q + 1], fold_const(a.foldB1, a, q));
-        const uint32_t* g = a.glv ? a.glv + ((size_t)q * 2 + task) * GLV_WORDS : nullptr;
-        Acc29* tb = tabs + ((size_t)task * nq + q) * 16;
-        res1[(size_t)task * nq + q] = (g && (g[8] & 4u)) ? var_mul29_glv(P, g, tb) : var_mul29_g(P, task == 0 ? s : r, tb);                 // s A' , r B1'
+        res1[(size_t)task * nq + q] = var_mul29_g(P, task == 0 ? s : r, tabs + ((size_t)task * nq + q) * 16);                 // s A' , r B1'
     } else if (task == 3) {
         return;                                                            // s delta in G1 is not part of any proof element (slot kept so that the task numbers read like the formula)
     } else if (task < 7) {
@@ -215,63 +173,6 @@ zkc_finalize_combine(FinalizeArgs a, int nq) {
         store_fq_std(out + 64, p.x.c0); store_fq_std(out + 96, p.x.c1); store_fq_std(out + 128, p.y.c0); store_fq_std(out + 160, p.y.c1);
     }
 }
-
-// ---- host: k (8 x u32, standard form, < r) -> k1 + k2 lambda with |k1|, |k2| < 2^127 (out: k1[4], k2[4], flags; GLV_WORDS words).
-// Lattice basis of {(a, b) : a + b lambda = 0 mod r}: v1 = (a1, -nb1), v2 = (a2, b2), det = r; c1 = floor(k g1 / 2^256), c2 = floor(k g2 / 2^256) with
-// g1 = floor(2^256 b2 / r), g2 = floor(2^256 nb1 / r) approximate the coordinates of (k, 0) in that basis; k1 = k - c1 a1 - c2 a2, k2 = c1 nb1 - c2 b2.
-// Any integers c1, c2 give a valid split; these give short ones (127 bits over 200 000 random and edge scalars).  The result is CHECKED in Fr before it is
-// marked valid (flag 4): an invalid entry makes the kernel take the plain 254-bit product.
-namespace {
-typedef unsigned __int128 u128;
-struct Wide { uint64_t d[6]; };                                             // 384-bit two's complement
-Wide wide_mul(const uint64_t* a, int na, const uint64_t* b, int nb) {       // truncated to 384 bits
-    Wide r{};
-    for (int i = 0; i < na; i++) {
-        u128 c = 0;
-        for (int j = 0; i + j < 6; j++) { c += (u128)a[i] * (j < nb ? b[j] : 0) + r.d[i + j]; r.d[i + j] = (uint64_t)c; c >>= 64; }
-    }
-    return r;
-}
-Wide wide_sub(Wide a, const Wide& b) { u128 br = 0; for (int i = 0; i < 6; i++) { const u128 v = (u128)a.d[i] - b.d[i] - br; a.d[i] = (uint64_t)v; br = (v >> 64) & 1; } return a; }
-bool wide_abs128(Wide a, uint32_t out[4], bool& neg) {                      // |a| into 4 words; false when it does not fit 127 bits
-    neg = a.d[5] >> 63;
-    if (neg) { Wide z{}; a = wide_sub(z, a); }
-    if (a.d[2] | a.d[3] | a.d[4] | a.d[5] | (a.d[1] >> 63)) return false;
-    out[0] = (uint32_t)a.d[0]; out[1] = (uint32_t)(a.d[0] >> 32); out[2] = (uint32_t)a.d[1]; out[3] = (uint32_t)(a.d[1] >> 32);
-    return true;
-}
-}  // namespace
-void glv_decompose(const uint32_t k32[8], uint32_t out[GLV_WORDS]) {
-    static const uint64_t G1[2] = {0xd91d232ec7e0b3d7ull, 0x2ull}, G2[3] = {0x7a7bd9d4391eb18dull, 0x4ccef014a773d2cfull, 0x2ull};
-    static const uint64_t A1[1] = {0x89d3256894d213e3ull}, NB1[2] = {0x8211bbeb7d4f1128ull, 0x6f4d8248eeb859fcull}, A2[2] = {0x0be4e1541221250bull, 0x6f4d8248eeb859fdull}, B2[1] = {0x89d3256894d213e3ull};
-    static const uint32_t LAMBDA[8] = {0xb99c90ddu, 0x8b17ea66u, 0x8d8daaa7u, 0x5bfc4108u, 0x41a91758u, 0xb3c4d79du, 0u, 0u};      // 4407920970296243842393367215006156084916469457145843978461
-    for (int i = 0; i < GLV_WORDS; i++) out[i] = 0;
-    uint64_t k[4]; for (int i = 0; i < 4; i++) k[i] = (uint64_t)k32[2 * i] | ((uint64_t)k32[2 * i + 1] << 32);
-    // c = (k g) >> 256 needs the full 7-limb product: two halves of at most 6 limbs each
-    auto mulhi = [&](const uint64_t* g, int ng, uint64_t c[3]) {
-        uint64_t prod[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i = 0; i < 4; i++) { u128 cy = 0; for (int j = 0; i + j < 8; j++) { cy += (u128)k[i] * (j < ng ? g[j] : 0) + prod[i + j]; prod[i + j] = (uint64_t)cy; cy >>= 64; } }
-        c[0] = prod[4]; c[1] = prod[5]; c[2] = prod[6];
-    };
-    uint64_t c1[3], c2[3]; mulhi(G1, 2, c1); mulhi(G2, 3, c2);
-    Wide K{}; for (int i = 0; i < 4; i++) K.d[i] = k[i];
-    const Wide k1 = wide_sub(wide_sub(K, wide_mul(c1, 3, A1, 1)), wide_mul(c2, 3, A2, 2));
-    const Wide k2 = wide_sub(wide_mul(c1, 3, NB1, 2), wide_mul(c2, 3, B2, 1));
-    bool n1, n2;
-    if (!wide_abs128(k1, out, n1) || !wide_abs128(k2, out + 4, n2)) return;
-    // check in Fr: (+-k1) + (+-k2) lambda == k
-    uint32_t w[8] = {out[0], out[1], out[2], out[3], 0, 0, 0, 0}; Fr f1 = fp_from_std<FrParams>(w);
-    uint32_t v[8] = {out[4], out[5], out[6], out[7], 0, 0, 0, 0}; Fr f2 = fp_from_std<FrParams>(v) * fp_from_std<FrParams>(LAMBDA);
-    if (n1) f1 = Fr::zero() - f1;
-    if (n2) f2 = Fr::zero() - f2;
-    if (!(f1 + f2 == fp_from_std<FrParams>(k32))) return;
-    out[8] = (n1 ? 1u : 0u) | (n2 ? 2u : 0u) | 4u;
-}
-
-}  // namespace zkc
-// test hook (tests/test_host_abi_cpu.py): the host-side GLV split of a scalar, no GPU involved.  out: k1[4], k2[4], flags (1: k1 < 0, 2: k2 < 0, 4: valid)
-extern "C" int zkc_debug_glv_decompose(const uint8_t k[32], uint32_t out[12]) { uint32_t w[8]; memcpy(w, k, 32); zkc::glv_decompose(w, out); return (out[8] & 4u) ? ZKC_OK : ZKC_ERR_GENERIC; }
-namespace zkc {
 
 size_t finalize_scratch_bytes(int nproofs) { return (size_t)nproofs * (7 * sizeof(G1XYZZ) + sizeof(G2XYZZ) + 2 * 16 * sizeof(Acc29)); }
 

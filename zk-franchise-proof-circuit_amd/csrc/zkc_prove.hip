@@ -74,7 +74,7 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     for (auto& kv : zk->fold.vmaps) if (kv.second.d) (void)hipFree(kv.second.d);
     for (void* q : {(void*)zk->fold.d_foldA, (void*)zk->fold.d_foldB1, (void*)zk->fold.d_foldC, (void*)zk->fold.d_foldB2}) if (q) (void)hipFree(q);
     if (zk->h_flags) (void)hipHostFree(zk->h_flags);
-    for (auto& c : zk->call) { if (c.h_out) (void)hipHostFree(c.h_out); if (c.h_glv) (void)hipHostFree(c.h_glv); if (c.d_glv) (void)hipFree(c.d_glv); for (hipEvent_t e : c.ev_done) if (e) (void)hipEventDestroy(e); }
+    for (auto& c : zk->call) { if (c.h_out) (void)hipHostFree(c.h_out); for (hipEvent_t e : c.ev_done) if (e) (void)hipEventDestroy(e); }
     if (zk->ev_start) (void)hipEventDestroy(zk->ev_start);
     for (hipEvent_t e : zk->ev_chunk) (void)hipEventDestroy(e);
     for (auto& L : zk->lane) {
@@ -425,24 +425,14 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
     zkc_zkey::CallSlot& CS = zk->call[cs];
     if (CS.pending) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "prove_batch_begin: this call slot has a call in flight (finish it first)");
     if (CS.cap < (size_t)B) {                                    // the slot is idle (finished), so its buffers are nobody's
-        if (CS.d_rs) { ZKC_HIP_CHECK(ctx, hipFree(CS.d_rs)); ZKC_HIP_CHECK(ctx, hipFree(CS.d_proofs)); ZKC_HIP_CHECK(ctx, hipHostFree(CS.h_out)); ZKC_HIP_CHECK(ctx, hipFree(CS.d_glv)); ZKC_HIP_CHECK(ctx, hipHostFree(CS.h_glv)); CS.d_rs = CS.d_proofs = CS.h_out = nullptr; CS.d_glv = CS.h_glv = nullptr; CS.cap = 0; }
+        if (CS.d_rs) { ZKC_HIP_CHECK(ctx, hipFree(CS.d_rs)); ZKC_HIP_CHECK(ctx, hipFree(CS.d_proofs)); ZKC_HIP_CHECK(ctx, hipHostFree(CS.h_out)); CS.d_rs = CS.d_proofs = CS.h_out = nullptr; CS.cap = 0; }
         const size_t want = std::max<size_t>((size_t)B, std::min<size_t>(2 * CS.cap, 4096));
         ZKC_HIP_CHECK(ctx, hipMalloc((void**)&CS.d_rs, 64 * want)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&CS.d_proofs, 256 * want));
-        ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&CS.h_out, (256 + 32 * (size_t)zk->nPub) * want));
-        ZKC_HIP_CHECK(ctx, hipMalloc((void**)&CS.d_glv, 2 * GLV_WORDS * 4 * want)); ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&CS.h_glv, 2 * GLV_WORDS * 4 * want)); CS.cap = want;
+        ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&CS.h_out, (256 + 32 * (size_t)zk->nPub) * want)); CS.cap = want;
     }
     for (int l = 0; l < zk->nlanes; l++) if (!CS.ev_done[l]) ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&CS.ev_done[l], hipEventDisableTiming));
     uint8_t* const h_pub = CS.h_out + 256ull * CS.cap;      // results land in pinned memory so that no copy blocks the enqueueing thread
     ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.d_rs, rs, 64 * (size_t)B, hipMemcpyHostToDevice, st0));
-    // [r3] the blinding's two variable-base products run over the GLV halves of s and r (zkc_finalize.hip): split on the host, checked there, uploaded beside (r, s)
-    static const bool use_glv = getenv("ZKC_NO_GLV") == nullptr;
-    if (use_glv) {
-        for (int b = 0; b < B; b++) {
-            uint32_t r32[8], s32[8]; memcpy(r32, rs + 64 * (size_t)b, 32); memcpy(s32, rs + 64 * (size_t)b + 32, 32);
-            glv_decompose(s32, CS.h_glv + ((size_t)b * 2 + 0) * GLV_WORDS); glv_decompose(r32, CS.h_glv + ((size_t)b * 2 + 1) * GLV_WORDS);
-        }
-        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.d_glv, CS.h_glv, 2 * GLV_WORDS * 4 * (size_t)B, hipMemcpyHostToDevice, st0));
-    }
     // per pass (chunk of max_inflight proofs), all enqueued now on st0: [witness kernels] -> fold check (which levels of the witness differ
     // from the voter-independent template?) -> flags to the host -> event.  The pass loop below waits for a chunk's event only.
     uint32_t* tmpl = nullptr;
@@ -576,7 +566,7 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         fa.foldA = zk->fold.d_foldA; fa.foldB1 = zk->fold.d_foldB1; fa.foldC = zk->fold.d_foldC; fa.foldB2 = zk->fold.d_foldB2; fa.fold_n = can_fold ? L.n : 0;
         for (int q = 0; q < nb; q++) { fa.dc[q] = fold ? dcq[q] : (uint8_t)255; fa.ds[q] = fold ? dsq[q] : (uint8_t)255; }
         fa.tblDelta1 = zk->d_tblDelta1; fa.tblAlpha1 = zk->d_tblAlpha1; fa.tblBeta1 = zk->d_tblBeta1; fa.tblDelta2 = zk->d_tblDelta2;
-        fa.alpha1 = zk->alpha1; fa.beta2 = zk->beta2; fa.rs = CS.d_rs + 64 * (size_t)p0; fa.out = CS.d_proofs + 256 * (size_t)p0; fa.glv = use_glv ? CS.d_glv + 2 * GLV_WORDS * (size_t)p0 : nullptr; fa.scratch = LN.d_fin;
+        fa.alpha1 = zk->alpha1; fa.beta2 = zk->beta2; fa.rs = CS.d_rs + 64 * (size_t)p0; fa.out = CS.d_proofs + 256 * (size_t)p0; fa.scratch = LN.d_fin;
         ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm, 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm2, 0));
         if ((rc = finalize_launch(ctx, fin, fa, nb))) return rc;
         ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.h_out + 256ull * p0, CS.d_proofs + 256 * (size_t)p0, 256ull * nb, hipMemcpyDeviceToHost, fin));

@@ -36,7 +36,6 @@ struct MsmJob {
     // 2^hbits level-1 bins by the high bits of the bucket index (bins [bin0, bin0 + 2^hbits) of the pass), then each bin into 2^lbits buckets
     uint32_t bucket0, bin0, hbits, lbits, tile0, cnt0;   // tile0: first 1024-scalar tile of this job in the flattened tile list of the pass; cnt0: its (bin, tile) counters
 };
-constexpr int GLV_WORDS = 12;                           // k1[4], k2[4], flags, pad (zkc_finalize.hip glv_decompose)
 // arguments of the blinding kernel (zkc_finalize.hip); everything except r1/r2/rs/out is constant per proving key
 struct FinalizeArgs {
     const G1XYZZ* r1; const G2XYZZ* r2;                 // MSM results of this pass: r1[q] = H_q, r1[n + 3q + {0,1,2}] = A_q, B1_q, C_q ; r2[q]
@@ -47,7 +46,6 @@ struct FinalizeArgs {
     const G1Affine *tblDelta1, *tblAlpha1, *tblBeta1; const G2Affine* tblDelta2;   // 32 x 255 fixed-base tables
     G1Affine alpha1; G2Affine beta2;
     const uint8_t* rs; uint8_t* out;                    // device: nproofs x 64 (r || s) -> nproofs x 256 proof bytes
-    const uint32_t* glv;                                // device: nproofs x 2 x GLV_WORDS, the GLV halves of s (entry 0, times A') and r (entry 1, times B1'); nullptr: plain 254-bit products
     void* scratch;                                      // finalize_scratch_bytes(nproofs) of device memory: products and window tables of the lane-per-product kernels (nullptr: one wave per task)
 };
 // The (digit, point) entries of a pass are bucketed JOB BY JOB (an entry never leaves its job's region [ent_off, ent_off + count nw) of the
@@ -171,7 +169,6 @@ struct zkc_zkey {
     // call run while the previous one drains (its witness kernels beside the other call's MSMs, its transforms beside the other's bucket reduction and blinding)
     struct CallSlot {
         uint8_t *d_rs = nullptr, *d_proofs = nullptr; size_t cap = 0;       // [B][64], [B][256]
-        uint32_t *d_glv = nullptr, *h_glv = nullptr;                        // [B][2][GLV_WORDS]: GLV halves of s and r (h_glv pinned)
         uint8_t* h_out = nullptr;                                           // pinned: [B][256] proofs then [B][nPub][32] public signals (async D2H target)
         hipEvent_t ev_done[2] = {nullptr, nullptr};                         // per lane: recorded on its blinding stream behind the call's last copy
         int B = 0; bool pending = false;
@@ -217,7 +214,6 @@ int prove_batch_finish(zkc_zkey* zk, int cs, uint8_t* proofs, uint8_t* publics);
 // service begins the next call then: its witness kernels and transforms run beside that tail, and until then it keeps collecting requests.
 bool prove_tail_reached(zkc_zkey* zk);
 size_t finalize_scratch_bytes(int nproofs);
-void glv_decompose(const uint32_t k_std[8], uint32_t out[GLV_WORDS]);      // host: k -> k1 + k2 lambda, |k1|, |k2| < 2^127, checked in Fr
 int msm_precompute_g1(zkc_ctx* ctx, uint32_t count, G1Affine* d_table, int c);   // d_table[0..count) = base on entry
 int msm_precompute_g2(zkc_ctx* ctx, uint32_t count, G2Affine* d_table, int c);
 int msm_g2_table29(zkc_ctx* ctx, const G2Affine* d_table, uint32_t* d_out, size_t count);       // d_out: 60 words per point
