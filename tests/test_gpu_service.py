@@ -154,3 +154,43 @@ def test_failed_work_space_growth_leaves_the_key_usable(monkeypatch):
     p12, u12 = pk.fullprove_batch_dev(d_in.data_ptr(), 12, d_w.data_ptr(), d_st.data_ptr(), rs)
     assert p12[:512] == p2 and ol.verify(vk, u12[-256:], p12[-256:])
     pk.close(); ctx.close()
+
+
+def test_async_submit_and_destroy_with_requests_pending():
+    """zkc_service_submit_fullprove (what the N-API addon calls): completions arrive by callback on a service thread; destroying the service while requests are still
+    queued completes every one of them exactly once -- proved, or failed with 'shut down' -- and never crashes or leaks a caller waiting."""
+    import torch  # noqa: F401
+    import zkcensus_amd
+    from zkcensus_amd import setup, _native
+    nl, N = 10, 200
+    _, zkey_path, vkey_path = setup.ensure_test_artifacts(nl)
+    zk = open(zkey_path, 'rb').read(); vk = json.load(open(vkey_path))
+    voters = _voters(8, nl, 31)
+    flats = [zkcensus_amd.flatten_inputs(v, nl) for v in voters]
+    lib = _native.load()
+    svc = zkcensus_amd.ProvingService([0])
+    svc.fullprove(zk, flats[0], nLevels=nl)                             # key resident before the burst
+    DONE = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_char_p)
+    proofs = [ctypes.create_string_buffer(256) for _ in range(N)]; pubs = [ctypes.create_string_buffer(256) for _ in range(N)]
+    seen = []; lock = threading.Lock()
+
+    def done(user, rc, status, text):
+        with lock:
+            seen.append((int(user or 0), rc, status, (text or b'').decode()))
+    cb = DONE(done)
+    for i in range(N):
+        rc = lib.zkc_service_submit_fullprove(svc._h, zk, len(zk), nl, flats[i % 8], None, ctypes.cast(proofs[i], ctypes.c_char_p), ctypes.cast(pubs[i], ctypes.c_char_p),
+                                              ctypes.cast(cb, ctypes.c_void_p), ctypes.c_void_p(i + 1))
+        assert rc == 0
+    svc.close()                                                         # destroy with most of them still queued or in flight
+    assert sorted(u for u, *_ in seen) == list(range(1, N + 1))         # every request completed exactly once
+    ok = [u for u, rc, st, _ in seen if rc == 0]; down = [u for u, rc, st, t in seen if rc != 0]
+    assert all('shut down' in t for u, rc, st, t in seen if rc != 0)
+    assert len(ok) + len(down) == N and len(ok) >= 1
+    for u in ok[:20]:
+        assert ol.verify(vk, pubs[u - 1].raw, proofs[u - 1].raw)
+    # submitting to a bad key image fails at once, nothing is queued
+    svc2 = zkcensus_amd.ProvingService([0])
+    assert lib.zkc_service_submit_fullprove(svc2._h, b'zkeyXXXXXXXXXXXX', 16, nl, flats[0], None, ctypes.cast(proofs[0], ctypes.c_char_p), None, ctypes.cast(cb, ctypes.c_void_p), None) == 5
+    assert svc2.stats()['requests'] == 0
+    svc2.close()
