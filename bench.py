@@ -31,6 +31,7 @@ def parse_args():
     ap.add_argument('--nlevels', type=int, default=160)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-verify', action='store_true', help='skip the post-run verification of the timed proofs')
+    ap.add_argument('--no-step-pipelining', action='store_true', help='one synchronous call per step (rounds 1-2) instead of begin(k + 1) before finish(k)')
     ap.add_argument('--no-extras', action='store_true', help='skip the extra legs after the timed region (host-to-host rate, unfolded / worst-case rates, isolated per-stage times)')
     ap.add_argument('--dry-run-cpu', action='store_true',
                     help='launcher / rendezvous / gather rehearsal on the CPU (gloo, fabricated records, no prover): NOT a measurement')
@@ -285,22 +286,42 @@ def main():
     flat = b''.join(zkcensus_amd.flatten_inputs(v, args.nlevels) for v in voters)
     d_inputs = torch.from_numpy(np.frombuffer(flat, dtype=np.uint8).copy()).cuda(dev)
     nW = ctx.n_wires(args.nlevels)
-    d_wtns = torch.empty(B * nW * 32, dtype=torch.uint8, device='cuda')
-    d_status = torch.zeros(B, dtype=torch.int32, device='cuda')
+    # two sets of witness / status buffers: a step is begun (everything enqueued: zkc_batch_begin) before the previous one is finished (zkc_batch_finish), so that
+    # the tail of step k -- bucket reduction and blinding of its last pass, copies -- runs beside the head of step k + 1 (its first witness kernels and transforms):
+    # what a caller that keeps the GPU fed does (the proving service does the same for per-voter callers).  Every step is still begun AND finished inside the timed
+    # region; --no-step-pipelining makes each step one synchronous zkc_fullprove_batch_dev call as in rounds 1 and 2.
+    pipelined = not args.no_step_pipelining
+    d_wtns_s = [torch.empty(B * nW * 32, dtype=torch.uint8, device='cuda') for _ in range(2 if pipelined else 1)]
+    d_status_s = [torch.zeros(B, dtype=torch.int32, device='cuda') for _ in range(len(d_wtns_s))]
     out = {}
     rs = np.random.default_rng(0x5A4B43454E535553 + rank)
+    state = {'prev': None, 'i': 0}
 
-    def step():
-        rsb = draw_rs(rs, 2 * B).tobytes()                                    # (r, s) per proof, uniform in Fr
-        # inputs -> witness -> proof for the whole batch (groth16.fullProve per voter, ts_inputs/src/example.ts:358): one C-ABI call
-        p, pub = pk.fullprove_batch_dev(d_inputs.data_ptr(), B, d_wtns.data_ptr(), d_status.data_ptr(), rsb)
-        rec = parallel.pack_records(p, pub, d_status.cpu().tolist())      # 256 B proof + 8 x 32 B signals + status per voter
+    def collect(slot, rsb, p, pub):
+        rec = parallel.pack_records(p, pub, d_status_s[slot].cpu().tolist())      # 256 B proof + 8 x 32 B signals + status per voter
         # RCCL over xGMI: the only collective -- finished proofs to every rank (513 B per voter)
         if world > 1:
             out['records'] = parallel.gather_records(rec if share else rec.cuda(dev), world, dist, B * world)
         else:
             out['records'] = rec
-        out['rec'], out['proofs'], out['pubs'], out['rs'] = rec, p, pub, rsb
+        out['rec'], out['proofs'], out['pubs'], out['rs'], out['slot'] = rec, p, pub, rsb, slot
+
+    def step():
+        rsb = draw_rs(rs, 2 * B).tobytes()                                    # (r, s) per proof, uniform in Fr
+        # inputs -> witness -> proof for the whole batch (groth16.fullProve per voter, ts_inputs/src/example.ts:358) through the C ABI
+        if not pipelined:
+            p, pub = pk.fullprove_batch_dev(d_inputs.data_ptr(), B, d_wtns_s[0].data_ptr(), d_status_s[0].data_ptr(), rsb)
+            return collect(0, rsb, p, pub)
+        slot = state['i'] & 1; state['i'] += 1
+        pk.batch_begin(slot, d_inputs.data_ptr(), B, d_wtns_s[slot].data_ptr(), d_status_s[slot].data_ptr(), rsb)
+        drain()
+        state['prev'] = (slot, rsb)
+
+    def drain():
+        if state['prev'] is not None:
+            slot, rsb = state['prev']; state['prev'] = None
+            p, pub = pk.batch_finish(slot, B)
+            collect(slot, rsb, p, pub)
 
     def sync():
         torch.cuda.synchronize()
@@ -310,22 +331,25 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     if args.warmup:
-        assert int(d_status.abs().sum().item()) == 0, 'a synthetic voter failed a circuit assert'
+        assert all(int(t.abs().sum().item()) == 0 for t in d_status_s), 'a synthetic voter failed a circuit assert'
     ctx._lib.zkc_profile_enable(ctx._h, 0x7f)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     sync()
     dt = time.perf_counter() - t0
+    d_wtns, d_status = d_wtns_s[out['slot']], d_status_s[out['slot']]          # buffers of the LAST timed step: what the verification legs below look at
     tmax = torch.tensor([dt], dtype=torch.float64, device='cuda')
     if world > 1 and not share:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elif world > 1:
         t = tmax.cpu(); dist.all_reduce(t, op=dist.ReduceOp.MAX); tmax = t
     dt = float(tmax.item())
-    assert int(d_status.abs().sum().item()) == 0, 'a synthetic voter failed a circuit assert'
+    assert all(int(t.abs().sum().item()) == 0 for t in d_status_s), 'a synthetic voter failed a circuit assert'
 
     # ---- per-category device time from HIP events on the library's stream ----
     prof = read_prof(ctx)
@@ -440,7 +464,7 @@ def main():
             'data': 'synthetic',
             'config': {'workload': 'zkCensus nLevels=%d, batch of %d voter proofs per GPU per step (BASELINE configs[2]/[3] shape), '
                                    'own test zkey seed 0x5A4B43454E535553, synthetic %d-voter census' % (args.nlevels, B, max(8192, B * world)),
-                       'batch_per_gpu': B, 'nVars': pk.n_vars, 'domainSize': pk.domain_size, 'parallelism': 'independent proofs per GPU, RCCL all_gather of 513 B/proof'},
+                       'step_pipelining': pipelined, 'batch_per_gpu': B, 'nVars': pk.n_vars, 'domainSize': pk.domain_size, 'parallelism': 'independent proofs per GPU, RCCL all_gather of 513 B/proof'},
             'roofline': roofline, 'cpu_baseline': cpu, 'verified': verified,
             'host_to_host': (extras or {}).get('host_to_host'), 'folding': (extras or {}).get('folding'), 'stages_isolated': (extras or {}).get('stages_isolated'),
             'stage_ms_per_proof_overlapped_not_additive': {k: round(v['ms'] / (args.steps * B), 4) for k, v in prof.items() if k != 'msm_g1_streamed'},

@@ -108,6 +108,14 @@ int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, int
  * of one pass run underneath the MSMs of the previous one.  Needs a key of ZkFranchiseProofCircuit(nLevels) shape. */
 int zkc_fullprove_batch_dev(zkc_zkey* zk, const void* d_inputs, int B, void* d_wtns, int32_t* d_status, const uint8_t* rs, uint8_t* proofs, uint8_t* publics);
 
+/* The same batch calls in two halves, for a caller that keeps the GPU fed with batch after batch (bench.py does; the proving service below does it for per-voter callers):
+ * begin validates, enqueues every pipeline pass and returns without waiting for the GPU; finish waits for that call and copies its proofs (B x 256 B) and public
+ * signals (B x nPublic x 32 B, may be NULL) out.  slot = 0 or 1: two calls may be in flight on one key, and while call k drains (bucket reduction, blinding, copies)
+ * the witness kernels and transforms of call k + 1 already run.  A slot must be finished before it is begun again; d_inputs / d_wtns / d_status belong to the call
+ * until its finish returns (use two sets of buffers); rs is copied by begin.  d_inputs == NULL: the witnesses are given in d_wtns (zkc_prove_batch_dev's form). */
+int zkc_batch_begin(zkc_zkey* zk, int slot, const void* d_inputs, int B, void* d_wtns, int32_t* d_status, const uint8_t* rs);
+int zkc_batch_finish(zkc_zkey* zk, int slot, uint8_t* proofs, uint8_t* publics);
+
 /* ---- e: several GPUs from ONE host process (SURVEY.md 8b's zkc_ctx_create(device_ids[], n), 8e's "one host thread + one HIP stream set per
  * device").  The reference's hosts are single processes (the Go loop over prover.Prove, zk_census_test.go:89; Node's groth16.fullProve,
  * ts_inputs/src/example.ts:358-362): a pool owns one context and one resident key per listed device and splits a batch into contiguous blocks

@@ -105,3 +105,39 @@ def test_ragged_sibling_lists_flatten_like_the_reference_pads_them(env):
     assert st == [0, 0] and ws[0] == ws[1]
     with pytest.raises((ValueError, AssertionError)):
         zkc.flatten_inputs(dict(v, censusSiblings=v['censusSiblings'] + ['0']), nl)
+
+
+def test_split_batch_calls_overlap_and_match_the_synchronous_call(env):
+    """zkc_batch_begin / zkc_batch_finish: two calls in flight on one key (two slots, two sets of buffers) give the bytes of two synchronous calls; a slot that is busy
+    cannot be begun again and an idle one cannot be finished."""
+    zkc, ctx, pk, zk, vk, nl = env
+    import torch, numpy as np
+    from census_gen import random_voter
+    rng = random.Random(6)
+    nW = ctx.n_wires(nl)
+    batches = []
+    for B in (5, 9):
+        voters = [random_voter(rng, ol.poseidon, nLevels=nl, depth_c=rng.randrange(0, nl + 1), depth_s=rng.randrange(0, nl + 1)) for _ in range(B)]
+        flat = b''.join(zkc.flatten_inputs(v, nl) for v in voters)
+        rs = b''.join(rng.randrange(ol.R).to_bytes(32, 'little') for _ in range(2 * B))
+        d_in = torch.from_numpy(np.frombuffer(flat, dtype=np.uint8).copy()).cuda()
+        d_w = torch.empty(B * nW * 32, dtype=torch.uint8, device='cuda'); d_st = torch.zeros(B, dtype=torch.int32, device='cuda')
+        batches.append((B, voters, rs, d_in, d_w, d_st))
+    sync = [pk.fullprove_batch_dev(d_in.data_ptr(), B, d_w.data_ptr(), d_st.data_ptr(), rs) for B, _, rs, d_in, d_w, d_st in batches]
+    for (B, _, rs, d_in, d_w, d_st), slot in zip(batches, (0, 1)):
+        pk.batch_begin(slot, d_in.data_ptr(), B, d_w.data_ptr(), d_st.data_ptr(), rs)
+    with pytest.raises(zkc.ZkcError) as e:                              # slot 1 has a call in flight
+        B, _, rs, d_in, d_w, d_st = batches[0]
+        pk.batch_begin(1, d_in.data_ptr(), B, d_w.data_ptr(), d_st.data_ptr(), rs)
+    assert e.value.code == 4
+    got = [pk.batch_finish(0, batches[0][0]), pk.batch_finish(1, batches[1][0])]
+    assert got == sync
+    with pytest.raises(zkc.ZkcError):
+        pk.batch_finish(0, 5)                                           # nothing in flight on slot 0 any more
+    # witnesses given (d_inputs = NULL): the groth16.prove shape through the same two halves
+    B, voters, rs, d_in, d_w, d_st = batches[1]
+    pk.batch_begin(0, None, B, d_w.data_ptr(), None, rs)
+    assert pk.batch_finish(0, B) == sync[1]
+    rc, w = ol.witness(voters[3], nl)
+    rc2, op, ou = ol.prove(zk, w, int.from_bytes(rs[64 * 3:64 * 3 + 32], 'little'), int.from_bytes(rs[64 * 3 + 32:64 * 4], 'little'))
+    assert rc == 0 and rc2 == 0 and sync[1][0][256 * 3:256 * 4] == op

@@ -124,6 +124,16 @@ class ProvingKey:
         self.ctx._check(self._lib.zkc_fullprove_batch_dev(self._h, d_inputs_ptr, B, d_wtns_ptr, d_status_ptr, bytes(rs), proofs, pubs))
         return proofs.raw, pubs.raw
 
+    def batch_begin(self, slot, d_inputs_ptr, B, d_wtns_ptr, d_status_ptr, rs):
+        """First half of a batch call (zkc_batch_begin): everything is enqueued, nothing is waited for.  d_inputs_ptr None: the witnesses are given.  The device
+        buffers belong to the call until batch_finish(slot, B) returns; two slots may be in flight, so that one call's tail overlaps the next call's head."""
+        self.ctx._check(self._lib.zkc_batch_begin(self._h, slot, d_inputs_ptr, B, d_wtns_ptr, d_status_ptr, bytes(rs)))
+
+    def batch_finish(self, slot, B):
+        proofs = ctypes.create_string_buffer(256 * B); pubs = ctypes.create_string_buffer(32 * self.n_public * B)
+        self.ctx._check(self._lib.zkc_batch_finish(self._h, slot, proofs, pubs))
+        return proofs.raw, pubs.raw
+
     def debug_stage(self, d_wtns_ptr, stage):
         out = ctypes.create_string_buffer((96 if stage == 0 else 32) * self.domain_size)
         self.ctx._check(self._lib.zkc_debug_stage(self._h, d_wtns_ptr, stage, out))

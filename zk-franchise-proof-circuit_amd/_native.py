@@ -78,6 +78,8 @@ def load():
     L.zkc_pool_last_error.argtypes = [vp]; L.zkc_pool_last_error.restype = ctypes.c_char_p
     L.zkc_pool_zkey_load.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
     L.zkc_pool_fullprove_batch.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, i32p]
+    L.zkc_batch_begin.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, vp, vp, ctypes.c_char_p]
+    L.zkc_batch_finish.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p]
     L.zkc_service_create.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(vp)]
     L.zkc_service_destroy.argtypes = [vp]; L.zkc_service_destroy.restype = None
     L.zkc_service_default.argtypes = []; L.zkc_service_default.restype = vp

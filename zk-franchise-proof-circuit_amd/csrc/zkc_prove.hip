@@ -74,7 +74,7 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     for (auto& kv : zk->fold.vmaps) if (kv.second.d) (void)hipFree(kv.second.d);
     for (void* q : {(void*)zk->fold.d_foldA, (void*)zk->fold.d_foldB1, (void*)zk->fold.d_foldC, (void*)zk->fold.d_foldB2}) if (q) (void)hipFree(q);
     if (zk->h_flags) (void)hipHostFree(zk->h_flags);
-    for (auto& c : zk->call) { if (c.h_out) (void)hipHostFree(c.h_out); for (hipEvent_t e : c.ev_done) if (e) (void)hipEventDestroy(e); }
+    for (auto& c : zk->call) { if (c.h_out) (void)hipHostFree(c.h_out); if (c.h_rs) (void)hipHostFree(c.h_rs); for (hipEvent_t e : c.ev_done) if (e) (void)hipEventDestroy(e); }
     if (zk->ev_start) (void)hipEventDestroy(zk->ev_start);
     for (hipEvent_t e : zk->ev_chunk) (void)hipEventDestroy(e);
     for (auto& L : zk->lane) {
@@ -425,14 +425,15 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
     zkc_zkey::CallSlot& CS = zk->call[cs];
     if (CS.pending) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "prove_batch_begin: this call slot has a call in flight (finish it first)");
     if (CS.cap < (size_t)B) {                                    // the slot is idle (finished), so its buffers are nobody's
-        if (CS.d_rs) { ZKC_HIP_CHECK(ctx, hipFree(CS.d_rs)); ZKC_HIP_CHECK(ctx, hipFree(CS.d_proofs)); ZKC_HIP_CHECK(ctx, hipHostFree(CS.h_out)); CS.d_rs = CS.d_proofs = CS.h_out = nullptr; CS.cap = 0; }
+        if (CS.d_rs) { ZKC_HIP_CHECK(ctx, hipFree(CS.d_rs)); ZKC_HIP_CHECK(ctx, hipFree(CS.d_proofs)); ZKC_HIP_CHECK(ctx, hipHostFree(CS.h_out)); ZKC_HIP_CHECK(ctx, hipHostFree(CS.h_rs)); CS.d_rs = CS.d_proofs = CS.h_out = CS.h_rs = nullptr; CS.cap = 0; }
         const size_t want = std::max<size_t>((size_t)B, std::min<size_t>(2 * CS.cap, 4096));
         ZKC_HIP_CHECK(ctx, hipMalloc((void**)&CS.d_rs, 64 * want)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&CS.d_proofs, 256 * want));
-        ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&CS.h_out, (256 + 32 * (size_t)zk->nPub) * want)); CS.cap = want;
+        ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&CS.h_out, (256 + 32 * (size_t)zk->nPub) * want)); ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&CS.h_rs, 64 * want)); CS.cap = want;
     }
     for (int l = 0; l < zk->nlanes; l++) if (!CS.ev_done[l]) ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&CS.ev_done[l], hipEventDisableTiming));
     uint8_t* const h_pub = CS.h_out + 256ull * CS.cap;      // results land in pinned memory so that no copy blocks the enqueueing thread
-    ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.d_rs, rs, 64 * (size_t)B, hipMemcpyHostToDevice, st0));
+    memcpy(CS.h_rs, rs, 64 * (size_t)B);                                     // the caller's rs is its own again when begin returns
+    ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.d_rs, CS.h_rs, 64 * (size_t)B, hipMemcpyHostToDevice, st0));
     // per pass (chunk of max_inflight proofs), all enqueued now on st0: [witness kernels] -> fold check (which levels of the witness differ
     // from the voter-independent template?) -> flags to the host -> event.  The pass loop below waits for a chunk's event only.
     uint32_t* tmpl = nullptr;
@@ -611,6 +612,14 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
     if (rc) return rc;
     return prove_batch_finish(zk, 0, proofs, publics);
 }
+
+// the two halves as C entry points (include/zkcensus.h): what a caller that pipelines batch after batch uses
+extern "C" int zkc_batch_begin(zkc_zkey* zk, int slot, const void* d_inputs, int B, void* d_wtns, int32_t* d_status, const uint8_t* rs) {
+    if (!zk || !d_wtns || (d_inputs && !d_status)) return zkc_fail(zk ? zk->ctx : nullptr, ZKC_ERR_BAD_ARG, "zkc_batch_begin: bad argument");
+    if (d_inputs && zk->nLevels < 0) return zkc_fail(zk->ctx, ZKC_ERR_BAD_ARG, "zkc_batch_begin: the key is not a ZkFranchiseProofCircuit(nLevels) key; compute the witness elsewhere and pass d_inputs = NULL");
+    return prove_batch_begin(zk, slot, d_wtns, zk->nVars, B, rs, true, d_inputs, d_status);
+}
+extern "C" int zkc_batch_finish(zkc_zkey* zk, int slot, uint8_t* proofs, uint8_t* publics) { return prove_batch_finish(zk, slot, proofs, publics); }
 
 // B witnesses resident in HBM -> B proofs.  rs: B x 64 B (r || s).  proofs: B x 256 B, publics: B x nPublic x 32 B (host).
 extern "C" int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, int B, const uint8_t* rs, uint8_t* proofs, uint8_t* publics) {

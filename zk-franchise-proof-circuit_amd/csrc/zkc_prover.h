@@ -170,6 +170,7 @@ struct zkc_zkey {
     struct CallSlot {
         uint8_t *d_rs = nullptr, *d_proofs = nullptr; size_t cap = 0;       // [B][64], [B][256]
         uint8_t* h_out = nullptr;                                           // pinned: [B][256] proofs then [B][nPub][32] public signals (async D2H target)
+        uint8_t* h_rs = nullptr;                                            // pinned copy of the caller's (r, s): begin returns before the upload has executed
         hipEvent_t ev_done[2] = {nullptr, nullptr};                         // per lane: recorded on its blinding stream behind the call's last copy
         int B = 0; bool pending = false;
     } call[2];
