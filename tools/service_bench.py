@@ -10,19 +10,43 @@ node runs first, as a child started before this process touches the GPU."""
 import ctypes, json, os, random, shutil, subprocess, sys, tempfile, threading, time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, os.path.join(ROOT, 'tools'))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tools'))
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 PER = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 NL = 160
 
 
+def _le32(x):
+    return int(x).to_bytes(32, 'little')
+
+
+def _g1(p):
+    return _le32(p[0]) + _le32(p[1]) if int(p[2]) != 0 else bytes(64)
+
+
+def _g2(p):
+    return bytes(128) if int(p[2][0]) == 0 and int(p[2][1]) == 0 else _le32(p[0][0]) + _le32(p[0][1]) + _le32(p[1][0]) + _le32(p[1][1])
+
+
+def vk_bytes(vk):
+    return _g1(vk['vk_alpha_1']) + _g2(vk['vk_beta_2']) + _g2(vk['vk_gamma_2']) + _g2(vk['vk_delta_2']) + b''.join(_g1(p) for p in vk['IC'])
+
+
+def proof_bytes(pr):
+    return _g1(pr['pi_a']) + _g2(pr['pi_b']) + _g1(pr['pi_c'])
+
+
+def poseidon(xs):                                             # pure-Python Poseidon of tools/circuit_model.py: test data only, nothing timed goes through it
+    import synth_voter
+    return synth_voter.H(*xs)
+
+
 def main():
-    import oracle_lib as ol                                   # voter generation only (Poseidon on the CPU); nothing timed goes through it
     from census_gen import random_voter
     from zkcensus_amd import setup
     _, zkey_path, vkey_path = setup.ensure_test_artifacts(NL)
     rng = random.Random(2024)
-    voters = [random_voter(rng, ol.poseidon, nLevels=NL, depth_c=rng.randrange(12, 18), depth_s=rng.randrange(12, 18)) for _ in range(T)]
+    voters = [random_voter(rng, poseidon, nLevels=NL, depth_c=rng.randrange(12, 18), depth_s=rng.randrange(12, 18)) for _ in range(T)]
     out = {'threads': T, 'calls_per_thread': PER, 'nLevels': NL}
     node = shutil.which('node')
     if node and os.path.exists(os.path.join(ROOT, 'napi', 'zkcensus.node')):
@@ -37,7 +61,7 @@ def main():
     import zkcensus_amd
     from zkcensus_amd import _native
     lib = _native.load()
-    zk = open(zkey_path, 'rb').read(); vk = ol.vk_bytes(json.load(open(vkey_path)))
+    zk = open(zkey_path, 'rb').read(); vk = vk_bytes(json.load(open(vkey_path)))
     ctx = zkcensus_amd.Context(0)
     ws, st = ctx.witness(voters, nLevels=NL)
     assert st == [0] * T
@@ -68,7 +92,7 @@ def main():
         for x in th: x.join()
         dt = time.time() - t0; s1 = svc.stats(); tm1 = svc.timing()
         if kind == 'groth16_prover':
-            res = [[(ol.proof_bytes(json.loads(p)), b''.join(ol.le32(x) for x in json.loads(u))) for p, u in r] for r in res]
+            res = [[(proof_bytes(json.loads(p)), b''.join(_le32(x) for x in json.loads(u))) for p, u in r] for r in res]
         proofs = b''.join(p for r in res for p, _ in r); pubs = b''.join(u for r in res for _, u in r); n = T * PER
         ok = lib.zkc_verify_batch(ctx._h, vk, 8, pubs, proofs, n, None)
         return {'proofs': n, 'seconds': round(dt, 4), 'proofs_per_s': round(n / dt, 1), 'batches': s1['batches'] - s0['batches'], 'largest_batch': s1['largest_batch'],

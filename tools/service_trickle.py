@@ -5,15 +5,39 @@ spent their time (zkc_service_timing).  usage: service_trickle.py [requests] [ga
 import ctypes, json, os, random, sys, threading, time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, os.path.join(ROOT, 'tools'))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tools'))
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 GAP = float(sys.argv[2]) if len(sys.argv) > 2 else 600.0
 ROUNDS = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 NL = 160
 
 
+def _le32(x):
+    return int(x).to_bytes(32, 'little')
+
+
+def _g1(p):
+    return _le32(p[0]) + _le32(p[1]) if int(p[2]) != 0 else bytes(64)
+
+
+def _g2(p):
+    return bytes(128) if int(p[2][0]) == 0 and int(p[2][1]) == 0 else _le32(p[0][0]) + _le32(p[0][1]) + _le32(p[1][0]) + _le32(p[1][1])
+
+
+def vk_bytes(vk):
+    return _g1(vk['vk_alpha_1']) + _g2(vk['vk_beta_2']) + _g2(vk['vk_gamma_2']) + _g2(vk['vk_delta_2']) + b''.join(_g1(p) for p in vk['IC'])
+
+
+def proof_bytes(pr):
+    return _g1(pr['pi_a']) + _g2(pr['pi_b']) + _g1(pr['pi_c'])
+
+
+def poseidon(xs):                                             # pure-Python Poseidon of tools/circuit_model.py: test data only, nothing timed goes through it
+    import synth_voter
+    return synth_voter.H(*xs)
+
+
 def main():
-    import oracle_lib as ol
     from census_gen import random_voter
     from zkcensus_amd import setup
     import torch  # noqa: F401
@@ -21,9 +45,9 @@ def main():
     from zkcensus_amd import _native
     _, zkey_path, vkey_path = setup.ensure_test_artifacts(NL)
     rng = random.Random(7)
-    base = [random_voter(rng, ol.poseidon, nLevels=NL, depth_c=rng.randrange(12, 18), depth_s=rng.randrange(12, 18)) for _ in range(min(N, 64))]
+    base = [random_voter(rng, poseidon, nLevels=NL, depth_c=rng.randrange(12, 18), depth_s=rng.randrange(12, 18)) for _ in range(min(N, 64))]
     flats = [zkcensus_amd.flatten_inputs(v, NL) for v in base]
-    lib = _native.load(); zk = open(zkey_path, 'rb').read(); vk = ol.vk_bytes(json.load(open(vkey_path)))
+    lib = _native.load(); zk = open(zkey_path, 'rb').read(); vk = vk_bytes(json.load(open(vkey_path)))
     svc = zkcensus_amd.ProvingService(default=True)
     DONE = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_char_p)
     out = []
