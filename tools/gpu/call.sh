@@ -24,7 +24,7 @@ for step in "$@"; do
   cd "$R"
   case $name in
     tests)        if [ -n "$arg" ]; then timeout -k 10 1000 python -m pytest tests -m gpu -x -q -k "${arg//,/ }" > "$O/gpu_tests.log" 2>&1; else timeout -k 10 1100 python -m pytest tests -m gpu -x -q > "$O/gpu_tests.log" 2>&1; fi; rc=$?; tail -4 "$O/gpu_tests.log" ;;
-    bench)        if [ -n "$arg" ]; then f="bench_$(echo "$arg" | tr -c 'A-Za-z0-9\n' '_')"; timeout -k 10 600 python bench.py ${arg//,/ } > "$O/$f.json" 2> "$O/$f.err"; rc=$?; head -c 400 "$O/$f.json"; echo
+    bench)        if [ -n "$arg" ]; then f="bench_$(echo "$arg" | tr -c 'A-Za-z0-9\n' '_')${ZKC_AB_TAG:+_$ZKC_AB_TAG}"; timeout -k 10 600 python bench.py ${arg//,/ } > "$O/$f.json" 2> "$O/$f.err"; rc=$?; head -c 400 "$O/$f.json"; echo
                   else timeout -k 10 500 python bench.py > "$O/bench_default.json" 2> "$O/bench_default.err"; rc=$?; head -c 400 "$O/bench_default.json"; echo; fi ;;
     bench200)     timeout -k 10 300 python bench.py --steps 200 --warmup 2 --no-cpu-baseline --no-verify > "$O/bench_200.json" 2> "$O/bench_200.err"; rc=$?; head -c 260 "$O/bench_200.json"; echo ;;
     ab)           rc=0
@@ -54,7 +54,8 @@ P
     trace1)       cd /tmp && export TMPDIR=/tmp
                   timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$O/trace1" -- python3 "$R/tools/latency.py" > "$O/trace1.log" 2>&1; rc=$?
                   f=$(find "$O/trace1" -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python3 "$R/tools/single_proof_trace.py" "$f" > "$O/single_proof_trace.txt" 2>&1; find "$O/trace1" -name "*.csv" -delete; tail -60 "$O/single_proof_trace.txt" ;;
-    env)          export "$arg"; rc=0 ;;                         # env:NAME=VALUE for the steps that follow (env:NAME= clears it)
+    env)          export "$arg"; rc=0 ;;
+    unset)        unset "$arg"; rc=0 ;;                         # env:NAME=VALUE for the steps that follow (env:NAME= clears it)
     *)            log "unknown step $step"; exit 2 ;;
   esac
   log "$step rc=$rc"
