@@ -104,80 +104,6 @@ zkc_msm_accumulate29(const Affine<Fq>* __restrict__ table_all, const MsmJobList*
     partial[s] = out;
 }
 
-// ---- [r3 experiment, ZKC_ACC_SLICED=1] K5, G1 over a PRE-SLICED copy of the window tables: 32 words per point = x (nine 29-bit limbs of 32 x the coordinate: its R' form), y and
-// -y the same way, an infinity flag -- so that the loop neither slices two coordinates nor negates one through an eight-limb borrow chain per addition (about 90 of its 2337
-// instructions), for twice the table bytes (128-byte rows, five 16-byte loads per gather: x0..7 | x8 y0..2 | y3..6 | y7 y8 flag, and the same three chunks again with -y).
-constexpr int G1T29_WORDS = 32;
-__global__ void __launch_bounds__(128)
-zkc_g1_table29(const Affine<Fq>* __restrict__ tbl, uint32_t* __restrict__ out, size_t count) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const Affine<Fq> a = PointIO<Fq>::load(tbl + i);
-    uint32_t x[9], y[9], ny[9]; const Fq n = fp_neg(a.y);
-    f29_from_fp_shl5(x, a.x.v); f29_from_fp_shl5(y, a.y.v); f29_from_fp_shl5(ny, n.v);
-    const uint32_t flag = a.is_inf() ? 1u : 0u;
-    uint4* o = reinterpret_cast<uint4*>(out + i * G1T29_WORDS);
-    o[0] = make_uint4(x[0], x[1], x[2], x[3]); o[1] = make_uint4(x[4], x[5], x[6], x[7]);
-    o[2] = make_uint4(x[8], y[0], y[1], y[2]); o[3] = make_uint4(y[3], y[4], y[5], y[6]); o[4] = make_uint4(y[7], y[8], flag, 0);
-    o[5] = make_uint4(x[8], ny[0], ny[1], ny[2]); o[6] = make_uint4(ny[3], ny[4], ny[5], ny[6]); o[7] = make_uint4(ny[7], ny[8], flag, 0);
-}
-int msm_g1_table29(zkc_ctx* ctx, const G1Affine* d_table, uint32_t* d_out, size_t count) {
-    hipLaunchKernelGGL(zkc_g1_table29, dim3((unsigned)((count + 127) / 128)), dim3(128), 0, ctx->stream, d_table, d_out, count);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, std::string("zkc_g1_table29: ") + hipGetErrorString(e));
-    return ZKC_OK;
-}
-struct G1Row { uint4 a, b, c, d, e; };
-__device__ __forceinline__ G1Row g1row_load(const uint32_t* row, uint32_t neg) {
-    const uint4* q = reinterpret_cast<const uint4*>(row); const uint4* t = q + (neg ? 5 : 2);
-    G1Row r; r.a = q[0]; r.b = q[1]; r.c = t[0]; r.d = t[1]; r.e = t[2];
-    return r;
-}
-template <int MINW>
-__global__ void __launch_bounds__(128, MINW)
-zkc_msm_accumulate29s(const uint32_t* __restrict__ table29_all, const MsmJobList* __restrict__ jlp, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ off,
-                      const uint32_t* __restrict__ bcnt, const uint32_t* __restrict__ segoff, const uint32_t* __restrict__ seg2bucket, const uint32_t* __restrict__ perm, uint32_t nbuckets,
-                      XYZZ<Fq>* __restrict__ partial, uint32_t max_segments) {
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t nseg = segoff[nbuckets]; if (nseg > max_segments) nseg = max_segments;
-    if (gid >= nseg) return;
-    const uint32_t s = perm[gid];
-    const uint32_t b = seg2bucket[s];
-    uint32_t lo, hi; msm_seg_range(bcnt[b], segoff[b + 1] - segoff[b], s - segoff[b], lo, hi);
-    const uint32_t start = off[b] + lo, end = off[b] + hi;
-    uint32_t bd, bj; jlp->decode(b, bd, bj);
-    const uint32_t* __restrict__ table = table29_all + (size_t)jlp->job[bj].tbl_off * G1T29_WORDS;
-    constexpr uint32_t rowmask = 0x7fffffffu;
-    Acc29 acc; bool inf = true;
-    uint32_t v = vals[start];
-    G1Row p = g1row_load(table + (size_t)(v & rowmask) * G1T29_WORDS, v >> 31);
-    for (uint32_t j = start; j < end; j++) {
-        const uint32_t vn = (j + 1 < end) ? vals[j + 1] : v;
-        const G1Row pn = g1row_load(table + (size_t)(vn & rowmask) * G1T29_WORDS, vn >> 31);      // next gather in flight during this addition
-        if (!p.e.z) {
-            const uint32_t x2[9] = {p.a.x, p.a.y, p.a.z, p.a.w, p.b.x, p.b.y, p.b.z, p.b.w, p.c.x};
-            const uint32_t y2[9] = {p.c.y, p.c.z, p.c.w, p.d.x, p.d.y, p.d.z, p.d.w, p.e.x, p.e.y};      // the sign of the digit already chose y or -y
-            bool same_y = false;
-            if (inf) {
-                f29_mul<FqParams>(acc.X, x2, F29K<FqParams>::one.l); f29_mul<FqParams>(acc.Y, y2, F29K<FqParams>::one.l);
-#pragma unroll
-                for (int k = 0; k < 9; k++) acc.ZZ[k] = acc.ZZZ[k] = F29K<FqParams>::one.l[k];
-                inf = false;
-            } else if (!f29_madd(acc, x2, y2, same_y)) {
-                if (same_y) {                                               // the bucket holds this very point: double it (rare; generic code)
-                    Affine<Fq> a; a.x = f29_to_fp<FqParams>(x2); a.y = f29_to_fp<FqParams>(y2);
-                    const XYZZ<Fq> d = xyzz_dbl_affine(a);
-                    f29_enter_fq(acc.X, d.X.v); f29_enter_fq(acc.Y, d.Y.v); f29_enter_fq(acc.ZZ, d.ZZ.v); f29_enter_fq(acc.ZZZ, d.ZZZ.v);
-                } else inf = true;                                          // P + (-P)
-            }
-        }
-        v = vn; p = pn;
-    }
-    XYZZ<Fq> out = XYZZ<Fq>::inf();
-    if (!inf) { out.X = f29_to_fp<FqParams>(acc.X); out.Y = f29_to_fp<FqParams>(acc.Y); out.ZZ = f29_to_fp<FqParams>(acc.ZZ); out.ZZZ = f29_to_fp<FqParams>(acc.ZZZ); }
-    partial[s] = out;
-}
-
 // ---- K5, G2: radix-2^29 accumulator over Fq2 (zkc_f29_g2.h).  The table is a second copy of the pre-shifted G2 bases in R' form:
 // 60 words per point = x (9 + 9 limbs, word 18 = 1 for the point at infinity, word 19 pad), y, -y, so a signed digit only picks
 // which 80-byte chunk to load. ----
@@ -632,10 +558,6 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
         if constexpr (kG2)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate29_g2<1>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
                                zk->d_g2_29, (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.bcnt, w.segoff, w.seg2bucket, w.perm, nb, reinterpret_cast<XYZZ<Fq2>*>(partial), (uint32_t)w.max_segments);
-        else if (zk->d_g1_29 && reinterpret_cast<const void*>(table) == reinterpret_cast<const void*>(zk->d_g1))      // [r3 experiment] the pre-sliced copy of the key's G1 tables
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate29s<2>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
-                               zk->d_g1_29, (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.bcnt, w.segoff, w.seg2bucket, w.perm, nb,
-                               reinterpret_cast<XYZZ<Fq>*>(partial), (uint32_t)w.max_segments);
         else      // G1: same layout, field type with the inlined product.  160 VGPRs = 3 waves per SIMD; capped at 128 (4 waves) the accumulator spills and the kernel is 3.6x slower
             hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate29<2>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
                                reinterpret_cast<const Affine<Fq>*>(table), (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.bcnt, w.segoff, w.seg2bucket, w.perm, nb,

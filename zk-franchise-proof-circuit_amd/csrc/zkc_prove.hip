@@ -68,7 +68,7 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     ZKC_LOCK(zk->ctx);
     (void)hipSetDevice(zk->ctx->device);
     (void)hipStreamSynchronize(zk->ctx->stream);
-    void* ptrs[] = {zk->d_perm, zk->d_rowlen, zk->d_jdptr, zk->d_col, zk->d_val, zk->d_tw_fwd, zk->d_tw_inv, zk->d_tw_fwd29, zk->d_tw_inv29, zk->d_coset, zk->d_coset_br, zk->d_g1, zk->d_g2, zk->d_g1_29, zk->d_g2_29, zk->d_flags,
+    void* ptrs[] = {zk->d_perm, zk->d_rowlen, zk->d_jdptr, zk->d_col, zk->d_val, zk->d_tw_fwd, zk->d_tw_inv, zk->d_tw_fwd29, zk->d_tw_inv29, zk->d_coset, zk->d_coset_br, zk->d_g1, zk->d_g2, zk->d_g2_29, zk->d_flags,
                     zk->d_tblDelta1, zk->d_tblAlpha1, zk->d_tblBeta1, zk->d_tblDelta2, zk->call[0].d_rs, zk->call[0].d_proofs, zk->call[1].d_rs, zk->call[1].d_proofs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : zk->fold.vmaps) if (kv.second.d) (void)hipFree(kv.second.d);
@@ -222,7 +222,6 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
         (rc = msm_precompute_g1(ctx, nc, zk->d_g1 + zk->offC, MSM_C_SMALL)) || (rc = msm_precompute_g1(ctx, n, zk->d_g1 + zk->offH, MSM_C_BIG)) ||
         (rc = msm_precompute_g2(ctx, nv, zk->d_g2, MSM_C_SMALL))) return bail(rc);
     if ((rc = dmalloc(ctx, &zk->d_g2_29, 60 * (size_t)NWS * nv)) || (rc = msm_g2_table29(ctx, zk->d_g2, zk->d_g2_29, (size_t)NWS * nv))) return bail(rc);
-    if (getenv("ZKC_ACC_SLICED") && ((rc = dmalloc(ctx, &zk->d_g1_29, 32 * g1_points)) || (rc = msm_g1_table29(ctx, zk->d_g1, zk->d_g1_29, g1_points)))) return bail(rc);
     // ---- work buffers: up to `max_inflight` proofs share one MSM pipeline pass; the buffers themselves are sized by lanes_ensure() for
     //      the number of proofs a call actually puts in flight (a single-proof caller does not reserve the work space of 96) ----
     const char* e_inf = getenv("ZKC_INFLIGHT");

@@ -155,7 +155,6 @@ struct zkc_zkey {
     uint32_t *d_tw_fwd29 = nullptr, *d_tw_inv29 = nullptr;                  // the twiddles in radix 2^29 (what the NTT passes read)
     // pre-shifted base tables, one allocation per group: G1 = [A | B1 | C | H], G2 = [B2]; T[w][i] = 2^(c*w) * P_i
     zkc::G1Affine* d_g1 = nullptr; zkc::G2Affine* d_g2 = nullptr;
-    uint32_t* d_g1_29 = nullptr;                                            // [r3 experiment, ZKC_ACC_SLICED] the G1 tables again, pre-sliced: 32 words per point (x, y, -y in 29-bit limbs)
     uint32_t* d_g2_29 = nullptr;                                            // the G2 table again in radix 2^29 (60 words per point: x, y, -y), read by the accumulation
     uint32_t offA = 0, offB1 = 0, offC = 0, offH = 0;                       // table offsets inside d_g1 (points)
     // per-proof work buffers
@@ -218,8 +217,7 @@ bool prove_tail_reached(zkc_zkey* zk);
 size_t finalize_scratch_bytes(int nproofs);
 int msm_precompute_g1(zkc_ctx* ctx, uint32_t count, G1Affine* d_table, int c);   // d_table[0..count) = base on entry
 int msm_precompute_g2(zkc_ctx* ctx, uint32_t count, G2Affine* d_table, int c);
-int msm_g2_table29(zkc_ctx* ctx, const G2Affine* d_table, uint32_t* d_out, size_t count);
-int msm_g1_table29(zkc_ctx* ctx, const G1Affine* d_table, uint32_t* d_out, size_t count);       // d_out: 32 words per point       // d_out: 60 words per point
+int msm_g2_table29(zkc_ctx* ctx, const G2Affine* d_table, uint32_t* d_out, size_t count);       // d_out: 60 words per point
 // out[i] = scalar[wires[i]] * P[wires[i] - pt_shift] (window-0 table), then per-group sums: gsum[g] = sum out[gstart[g]..gstart[g+1])
 int fold_group_sums_g1(zkc_ctx* ctx, const G1Affine* tbl, const uint32_t* d_scalars, const uint32_t* d_wires, uint32_t nw, int32_t pt_shift,
                        const uint32_t* d_gstart, uint32_t ngroups, G1XYZZ* h_out);
