@@ -194,3 +194,56 @@ def test_async_submit_and_destroy_with_requests_pending():
     assert lib.zkc_service_submit_fullprove(svc2._h, b'zkeyXXXXXXXXXXXX', 16, nl, flats[0], None, ctypes.cast(proofs[0], ctypes.c_char_p), None, ctypes.cast(cb, ctypes.c_void_p), None) == 5
     assert svc2.stats()['requests'] == 0
     svc2.close()
+
+
+def test_queue_spills_over_further_device_entries(monkeypatch):
+    """Several device entries (device 0 listed three times stands in for three GPUs on a one-GPU box: three contexts, three resident keys, six workers): with a low spill
+    threshold a loaded queue brings the other entries up -- each loads the key from the service's own copy of the image BEFORE it takes requests -- and every caller
+    still gets the proof of its own inputs."""
+    import torch  # noqa: F401
+    import zkcensus_amd
+    from zkcensus_amd import setup
+    nl, T, per = 10, 48, 6
+    _, zkey_path, vkey_path = setup.ensure_test_artifacts(nl)
+    zk = open(zkey_path, 'rb').read(); vk = json.load(open(vkey_path))
+    voters = _voters(T * per, nl, 41)
+    rng = random.Random(6)
+    rs = [rng.randrange(ol.R).to_bytes(32, 'little') + rng.randrange(ol.R).to_bytes(32, 'little') for _ in voters]
+    monkeypatch.setenv('ZKC_SERVICE_SPILL', '6')
+    svc = zkcensus_amd.ProvingService([0, 0, 0])
+    monkeypatch.delenv('ZKC_SERVICE_SPILL')
+    out = [None] * len(voters)
+
+    def caller(t):
+        for k in range(per):
+            i = t * per + k
+            out[i] = svc.fullprove(bytes(zk) if t % 2 else zk, voters[i], nLevels=nl, rs=rs[i])          # two different caller buffers holding the same image: one key
+    th = [threading.Thread(target=caller, args=(t,)) for t in range(T)]
+    for t in th: t.start()
+    for t in th: t.join()
+    st = svc.stats()
+    assert st['requests'] == T * per and st['failed'] == 0 and st['waiting'] == 0 and st['devices'] == 3
+    assert 1 <= st['key_loads'] <= 3 and st['devices_used'] >= 1
+    for i in range(0, len(voters), 13):
+        rc, w = ol.witness(voters[i], nl)
+        rc2, op, ou = ol.prove(zk, w, int.from_bytes(rs[i][:32], 'little'), int.from_bytes(rs[i][32:], 'little'))
+        assert rc == 0 and rc2 == 0 and out[i] == (op, ou, 0)
+    # an image that differs from the resident one ONLY in bytes the sampled fingerprint does not look at is another key: it must not be served the resident one
+    import struct
+    lib = svc._lib
+    fp_a = ctypes.create_string_buffer(32); fp_b = ctypes.create_string_buffer(32)
+    twin = bytearray(zk); pos = None
+    for cand in range(len(zk) // 2, len(zk) // 2 + 200000, 37):                     # flip a byte until the fingerprint stays the same (most bytes are unsampled)
+        t2 = bytearray(zk); t2[cand] ^= 1
+        lib.zkc_zkey_fingerprint(zk, len(zk), fp_a); lib.zkc_zkey_fingerprint(bytes(t2), len(t2), fp_b)
+        if fp_a.raw == fp_b.raw:
+            twin, pos = t2, cand; break
+    assert pos is not None
+    loads_before = svc.stats()['key_loads']
+    try:
+        p, u, s = svc.fullprove(bytes(twin), voters[0], nLevels=nl, rs=rs[0])       # a corrupted key: either refused by the loader or proves something that is NOT the good key's proof
+        assert (p, u) != out[0][:2] or svc.stats()['key_loads'] > loads_before
+    except zkcensus_amd.ZkcError:
+        pass
+    assert svc.stats()['key_loads'] > loads_before                                 # it was treated as a different key (loaded, or load attempted), never aliased
+    svc.close()

@@ -8,7 +8,10 @@
 // zkc_prove_batch_dev call, and every caller gets its own proof, status and error back.  Two workers per device: while one holds the GPU the
 // other collects and uploads the next batch and tops it up until the GPU is free.  Devices: an explicit list, $ZKC_DEVICE ("2", "0,1,2,3", "all")
 // or, unset, every visible device -- but a device is only brought up (context + 1 GB of key tables, 0.6 s) when the queue is long enough to pay for
-// it, so a sequential caller stays on the first one.
+// it, so a sequential caller stays on the first one; and a device that is brought up loads its key from the service's OWN copy of the image BEFORE it takes
+// any request, so nobody waits behind a key load that a warm device could have served meanwhile.
+// Key identity: the service keeps a copy of every .zkey image it has seen (at most four), found per call through the sampled fingerprint and confirmed, the
+// first time a given caller buffer (pointer, length) shows up, by the SHA-256 of the whole image: two images that differ only in unsampled bytes are two keys.
 // Host code over the public batch entry points; launches no kernel of its own.
 #include "zkc_prover.h"
 #include "zkc_hostparse.h"
@@ -25,11 +28,16 @@
 
 namespace {
 enum { KIND_FULLPROVE = 0, KIND_PROVE = 1 };
+struct KeyImage {                                                  // the service's own copy of a .zkey image: outlives the caller's buffer, shared by all devices
+    uint8_t fp[32], sha[32]; std::vector<uint8_t> bytes;
+    std::set<std::pair<const void*, size_t>> confirmed;            // caller buffers whose full SHA-256 equalled sha (under zkc_service::img_mu)
+    uint64_t last_use = 0;
+};
 struct Req {
-    int kind; uint8_t fp[32]; const uint8_t* zkey; size_t zkey_len; int nLevels; const uint8_t* data; uint32_t nW;
+    int kind; std::shared_ptr<KeyImage> img; int nLevels; const uint8_t* data; uint32_t nW;
     uint8_t rs[64]; uint8_t* proof; uint8_t* pub;
     zkc_done_fn done; void* user;
-    bool same_class(const Req& o) const { return kind == o.kind && nLevels == o.nLevels && !memcmp(fp, o.fp, 32); }
+    bool same_class(const Req& o) const { return kind == o.kind && nLevels == o.nLevels && img.get() == o.img.get(); }
 };
 struct Waiter { std::mutex m; std::condition_variable cv; bool finished = false; int rc = 0; int32_t status = 0; std::string err; };
 void waiter_done(void* u, int rc, int32_t status, const char* err) {
@@ -53,18 +61,19 @@ struct zkc_service {
     struct Dev {
         int device = 0; std::mutex gpu_mu;              // held while a worker owns the GPU pipeline of this device (key switch + batch call)
         zkc_ctx* ctx = nullptr; zkc_zkey* key = nullptr;
-        std::set<std::pair<const void*, size_t>> confirmed;   // .zkey images whose FULL SHA-256 was compared with the resident key's (fingerprints are sampled)
-        // under zkc_service::mu: what this device holds or is about to load
-        bool has_want = false; uint8_t want_fp[32] = {0};
+        // under zkc_service::mu: the image whose key is resident (set after a successful load) and the one a worker of this device is loading right now
+        std::shared_ptr<KeyImage> resident, loading;
         uint64_t batches = 0, proofs = 0;
         std::mutex fl_mu; std::condition_variable fl_cv; int in_flight = 0;      // split calls begun on this device's key and not finished yet (a key switch waits for zero)
     };
     struct Worker {
         Dev* dev = nullptr; int index = 0; std::thread th; std::condition_variable cv; bool wake = false, idle = false;
+        std::shared_ptr<KeyImage> warm;                  // set by dispatch: bring this device up for that key before taking requests
         HipBuf h_in{nullptr, 0, true}, h_wtns{nullptr, 0, true}, d_in, d_wtns, d_status, h_proofs{nullptr, 0, true}, h_pubs{nullptr, 0, true}, h_status{nullptr, 0, true};
         hipStream_t st = nullptr; size_t cap = 0;        // requests the staging buffers hold (grows geometrically with the batches this worker has seen)
     };
     std::mutex mu; std::deque<Req*> q; bool stop = false;
+    std::mutex img_mu; std::vector<std::shared_ptr<KeyImage>> images; uint64_t img_clock = 0;      // key images by (fingerprint, SHA-256); at most four kept
     std::vector<std::unique_ptr<Dev>> devs; std::vector<std::unique_ptr<Worker>> workers;
     int max_batch = 256, spill = 32;
     uint64_t n_requests = 0, n_batches = 0, largest_batch = 0, key_loads = 0, n_failed = 0;
@@ -76,35 +85,43 @@ namespace {
 void finish(Req* r, int rc, int32_t status, const std::string& err) { r->done(r->user, rc, status, err.c_str()); delete r; }
 
 // ---- dispatch (all under svc->mu) ----
-bool any_dev_wants(zkc_service* s, const uint8_t fp[32]) { for (auto& d : s->devs) if (d->has_want && !memcmp(d->want_fp, fp, 32)) return true; return false; }
-// the requests worker w takes now: the class of the first queued request its device already holds the key for, else (device cold, key unknown to every
-// device, or the queue long enough to pay for a load) the class of the head; up to `cap` of that class, in arrival order
+bool any_dev_has(zkc_service* s, const KeyImage* img) { for (auto& d : s->devs) if (d->resident.get() == img || d->loading.get() == img) return true; return false; }
+// the requests worker w takes now, up to `cap` of one class in arrival order:
+//   its device holds a key            -> the class of the first queued request for that key;
+//   else, no device holds or is loading the head's key (the very first request, or a new key)
+//                                     -> the head's class: this worker will load the key with those requests in hand (somebody has to);
+//   else                              -> nothing: other devices serve that key (if the queue grows past `spill`, dispatch brings this device up FIRST, without requests)
 std::vector<Req*> grab(zkc_service* s, zkc_service::Worker* w, size_t cap, const Req* like = nullptr) {
     std::vector<Req*> out;
     if (s->q.empty() || cap == 0) return out;
     zkc_service::Dev* d = w->dev;
     const Req* cls = like;
-    if (!cls && d->has_want) for (Req* r : s->q) if (!memcmp(r->fp, d->want_fp, 32)) { cls = r; break; }
-    if (!cls) {
-        const Req* head = s->q.front();
-        if (!d->has_want || !any_dev_wants(s, head->fp) || s->q.size() >= (size_t)s->spill) cls = head;
-    }
+    if (!cls && d->resident && !d->loading) for (Req* r : s->q) if (r->img.get() == d->resident.get()) { cls = r; break; }
+    if (!cls && !d->loading && !any_dev_has(s, s->q.front()->img.get())) { cls = s->q.front(); d->loading = cls->img; }
     if (!cls) return out;
     const Req key = *cls;
     for (auto it = s->q.begin(); it != s->q.end() && out.size() < cap;) { if ((*it)->same_class(key)) { out.push_back(*it); it = s->q.erase(it); } else ++it; }
-    if (!like) { d->has_want = true; memcpy(d->want_fp, key.fp, 32); }
     return out;
 }
-// wake at most one idle worker for the head of the queue: first a worker on a device that holds (or is loading) its key, then -- when no device does, or the
-// queue has grown past `spill` requests -- a worker on a cold device
+// wake at most one idle worker for the head of the queue: a worker on a device that holds its key; if no device holds or loads it, any idle worker (it will load
+// it); if the queue has grown past `spill` requests, an idle worker on a device without that key -- told to load the key first (warm) and only then to take requests
 void dispatch(zkc_service* s) {
     if (s->q.empty()) return;
     const Req* head = s->q.front();
     zkc_service::Worker* pick = nullptr;
-    for (auto& w : s->workers) if (w->idle && !w->wake && w->dev->has_want && !memcmp(w->dev->want_fp, head->fp, 32)) { pick = w.get(); break; }
-    if (!pick && (!any_dev_wants(s, head->fp) || s->q.size() >= (size_t)s->spill)) {
-        for (auto& w : s->workers) if (w->idle && !w->wake && !w->dev->has_want) { pick = w.get(); break; }
-        if (!pick && !any_dev_wants(s, head->fp)) for (auto& w : s->workers) if (w->idle && !w->wake) { pick = w.get(); break; }
+    for (auto& w : s->workers) if (w->idle && !w->wake && !w->dev->loading && w->dev->resident.get() == head->img.get()) { pick = w.get(); break; }
+    if (!pick && !any_dev_has(s, head->img.get())) {
+        for (auto& w : s->workers) if (w->idle && !w->wake && !w->dev->resident && !w->dev->loading) { pick = w.get(); break; }      // a cold device first
+        if (!pick) for (auto& w : s->workers) if (w->idle && !w->wake && !w->dev->loading) { pick = w.get(); break; }
+    }
+    if (!pick && s->q.size() >= (size_t)s->spill) {
+        for (auto& w : s->workers)
+            if (w->idle && !w->wake && !w->dev->loading && w->dev->resident.get() != head->img.get()) {
+                bool sibling_busy = false;                                  // a device whose other worker is in a call keeps its key: do not pull it out from under it
+                for (auto& o : s->workers) if (o.get() != w.get() && o->dev == w->dev && !o->idle) sibling_busy = true;
+                if (sibling_busy) continue;
+                pick = w.get(); pick->warm = head->img; pick->dev->loading = head->img; break;
+            }
     }
     if (pick) { pick->wake = true; pick->cv.notify_one(); }
 }
@@ -135,16 +152,35 @@ void fail_all(zkc_service* s, Batch& b, int rc, const std::string& err) {
     for (Req* r : b.reqs) finish(r, rc, 0, err);
     b.reqs.clear();
 }
+// makes `img` the resident key of device d.  Caller holds d->gpu_mu.  Waits for the device's calls in flight before it frees the key they read.
+int ensure_key(zkc_service* s, zkc_service::Dev* d, const std::shared_ptr<KeyImage>& img, std::string& why) {
+    int rc = ZKC_OK;
+    if (!d->ctx && (rc = zkc_ctx_create(d->device, &d->ctx))) { d->ctx = nullptr; why = std::string("device ") + std::to_string(d->device) + ": " + zkc_last_error(nullptr); }
+    bool have = false;
+    { std::lock_guard<std::mutex> g(s->mu); have = d->key && d->resident.get() == img.get(); }
+    if (!rc && !have) {
+        { std::unique_lock<std::mutex> fl(d->fl_mu); d->fl_cv.wait(fl, [&] { return d->in_flight == 0; }); }      // the other worker's call still reads the old key
+        { std::lock_guard<std::mutex> g(s->mu); d->resident.reset(); }
+        if (d->key) { zkc_zkey_free(d->key); d->key = nullptr; }
+        rc = zkc_zkey_load(d->ctx, img->bytes.data(), img->bytes.size(), &d->key);
+        if (rc) { d->key = nullptr; why = zkc_last_error(d->ctx); }
+        std::lock_guard<std::mutex> g(s->mu); s->key_loads++;
+        if (!rc) d->resident = img;
+    }
+    { std::lock_guard<std::mutex> g(s->mu); if (d->loading.get() == img.get()) d->loading.reset(); }
+    return rc;
+}
 void process(zkc_service* s, zkc_service::Worker* w, std::vector<Req*>&& first) {
     zkc_service::Dev* d = w->dev;
     Batch b; b.reqs = std::move(first);
     const Req cls = *b.reqs[0];
+    struct LoadingGuard { zkc_service* s; zkc_service::Dev* d; const KeyImage* img; ~LoadingGuard() { std::lock_guard<std::mutex> g(s->mu); if (d->loading.get() == img) d->loading.reset(); } } lguard{s, d, cls.img.get()};
     const bool full = cls.kind == KIND_FULLPROVE;
     std::string err;
     if (hipSetDevice(d->device) != hipSuccess) { (void)hipGetLastError(); return fail_all(s, b, ZKC_ERR_HIP, "hipSetDevice failed"); }
     // shapes from the file header alone (the key may not be resident yet)
     zkc::parse::BinSections bs; zkc::parse::ZkeyHeader zh;
-    if (!zkc::parse::binfile_sections(cls.zkey, cls.zkey_len, "zkey", 1, bs, err) || !zkc::parse::zkey_check(bs, zh, err, false)) return fail_all(s, b, ZKC_ERR_FORMAT, err);
+    if (!zkc::parse::binfile_sections(cls.img->bytes.data(), cls.img->bytes.size(), "zkey", 1, bs, err) || !zkc::parse::zkey_check(bs, zh, err, false)) return fail_all(s, b, ZKC_ERR_FORMAT, err);
     const size_t nW = zh.nVars, nPub = zh.nPub, nIn = full ? (size_t)zkc_circuit_n_inputs(cls.nLevels) : 0;
     if (full && (nIn == 0 || (size_t)zkc_circuit_n_wires(cls.nLevels) != nW)) return fail_all(s, b, ZKC_ERR_BAD_ARG, "the key is not a ZkFranchiseProofCircuit(" + std::to_string(cls.nLevels) + ") key");
     if (!full) {                                            // a witness of the wrong length fails alone, like rapidsnark's INVALID_WITNESS_LENGTH
@@ -196,23 +232,8 @@ void process(zkc_service* s, zkc_service::Worker* w, std::vector<Req*>&& first) 
         { std::lock_guard<std::mutex> g(s->mu); std::vector<Req*> more = grab(s, w, cap - b.reqs.size(), &cls); for (Req* r : more) if (full || r->nW == nW) b.reqs.push_back(r); else finish(r, ZKC_ERR_INVALID_WITNESS_LENGTH, 0, "Invalid witness length"); }
         if (!stage(w, b, from, nIn, nW, err)) { (void)hipGetLastError(); return fail_all(s, b, ZKC_ERR_HIP, err); }
         const int B = (int)b.reqs.size();
-        if (!d->ctx && (rc = zkc_ctx_create(d->device, &d->ctx))) { d->ctx = nullptr; return fail_all(s, b, rc, std::string("device ") + std::to_string(d->device) + ": " + zkc_last_error(nullptr)); }
-        // resident key: the sampled fingerprint decides per call; the first time a given image (pointer, length) meets a resident key the FULL SHA-256 is
-        // compared as well, so two images that differ only in bytes the fingerprint does not sample cannot alias in a long-lived process
-        bool reload = !d->key || memcmp(d->key->fingerprint, cls.fp, 32) != 0;
-        if (!reload && !d->confirmed.count({cls.zkey, cls.zkey_len})) {
-            uint8_t full_sha[32]; zkc::parse::sha256(cls.zkey, cls.zkey_len, full_sha);
-            if (memcmp(full_sha, d->key->sha256, 32) != 0) reload = true; else { if (d->confirmed.size() > 64) d->confirmed.clear(); d->confirmed.insert({cls.zkey, cls.zkey_len}); }
-        }
-        if (reload) {
-            { std::unique_lock<std::mutex> fl(d->fl_mu); d->fl_cv.wait(fl, [&] { return d->in_flight == 0; }); }      // the other worker's call still reads the old key
-            if (d->key) { zkc_zkey_free(d->key); d->key = nullptr; }
-            d->confirmed.clear();
-            rc = zkc_zkey_load(d->ctx, cls.zkey, cls.zkey_len, &d->key);
-            { std::lock_guard<std::mutex> g(s->mu); s->key_loads++; }
-            if (rc) { d->key = nullptr; const std::string why = zkc_last_error(d->ctx); { std::lock_guard<std::mutex> g(s->mu); d->has_want = false; } return fail_all(s, b, rc, why); }
-            d->confirmed.insert({cls.zkey, cls.zkey_len});          // loaded from this very image
-        }
+        // resident key: the service's own image object is the identity (fingerprint + full SHA-256 were settled when the request was accepted)
+        { std::string why; if ((rc = ensure_key(s, d, cls.img, why))) return fail_all(s, b, rc, why); }
         if (full && d->key->nLevels != cls.nLevels) return fail_all(s, b, ZKC_ERR_BAD_ARG, "the key is not a ZkFranchiseProofCircuit(" + std::to_string(cls.nLevels) + ") key");
         b.rs.resize((size_t)B * 64);
         for (int i = 0; i < B; i++) memcpy(b.rs.data() + 64 * (size_t)i, b.reqs[i]->rs, 64);
@@ -248,8 +269,16 @@ void worker_main(zkc_service* s, zkc_service::Worker* w) {
     std::unique_lock<std::mutex> lk(s->mu);
     for (;;) {
         std::vector<Req*> batch;
-        while (!s->stop && (batch = grab(s, w, (size_t)s->max_batch)).empty()) {
+        while (!s->stop && !w->warm && (batch = grab(s, w, (size_t)s->max_batch)).empty()) {
             w->idle = true; w->cv.wait(lk, [&] { return w->wake || s->stop; }); w->wake = false; w->idle = false;
+        }
+        if (!s->stop && w->warm) {                           // bring this device up for that key first; the queue is being served by the devices that have it
+            std::shared_ptr<KeyImage> img = std::move(w->warm); w->warm.reset();
+            lk.unlock();
+            if (hipSetDevice(w->dev->device) == hipSuccess) { std::lock_guard<std::mutex> gpu(w->dev->gpu_mu); std::string why; (void)ensure_key(s, w->dev, img, why); }
+            else { (void)hipGetLastError(); std::lock_guard<std::mutex> g(s->mu); if (w->dev->loading.get() == img.get()) w->dev->loading.reset(); }
+            lk.lock();
+            continue;
         }
         if (s->stop) { for (Req* r : batch) s->q.push_front(r); break; }
         dispatch(s);                                        // what is left in the queue may be another worker's
@@ -303,13 +332,47 @@ extern "C" zkc_service* zkc_service_default(void) {
     if (!svc) g_service_err = why;                                    // every thread that asks gets the reason, not only the first
     return svc;
 }
+// the service's image object for a caller's .zkey buffer: found by the sampled fingerprint, confirmed -- once per (buffer pointer, length) -- by the SHA-256 of
+// the whole image, copied the first time it is seen.  At most four images are kept (least recently used out first; requests in flight keep theirs alive).
+static std::shared_ptr<KeyImage> image_of(zkc_service* s, const void* zkey, size_t zkey_len, std::string& why) {
+    uint8_t fp[32];
+    if (zkc_zkey_fingerprint(zkey, zkey_len, fp)) { why = "not a zkey file"; return nullptr; }
+    std::lock_guard<std::mutex> g(s->img_mu);
+    const std::pair<const void*, size_t> ident(zkey, zkey_len);
+    bool sha_known = false; uint8_t sha[32];
+    for (auto& im : s->images) {
+        if (memcmp(im->fp, fp, 32) || im->bytes.size() != zkey_len) continue;
+        if (!im->confirmed.count(ident)) {
+            if (!sha_known) { zkc::parse::sha256(zkey, zkey_len, sha); sha_known = true; }
+            if (memcmp(sha, im->sha, 32)) continue;                          // same sampled bytes, different image: another key
+            if (im->confirmed.size() > 256) im->confirmed.clear();
+            im->confirmed.insert(ident);
+        }
+        im->last_use = ++s->img_clock;
+        return im;
+    }
+    auto im = std::make_shared<KeyImage>();
+    memcpy(im->fp, fp, 32);
+    if (!sha_known) zkc::parse::sha256(zkey, zkey_len, sha);
+    memcpy(im->sha, sha, 32);
+    im->bytes.assign((const uint8_t*)zkey, (const uint8_t*)zkey + zkey_len);
+    im->confirmed.insert(ident); im->last_use = ++s->img_clock;
+    if (s->images.size() >= 4) {
+        size_t lru = 0; for (size_t i = 1; i < s->images.size(); i++) if (s->images[i]->last_use < s->images[lru]->last_use) lru = i;
+        s->images.erase(s->images.begin() + (long)lru);
+    }
+    s->images.push_back(im);
+    return im;
+}
 static int submit(zkc_service* s, int kind, const void* zkey, size_t zkey_len, int nLevels, const void* data, uint32_t nW, const uint8_t* rs, uint8_t* proof, uint8_t* pub,
                   zkc_done_fn done, void* user) {
     if (!s || !zkey || !data || !proof || !done) return service_fail(ZKC_ERR_BAD_ARG, "zkc_service_submit: bad argument");
+    std::string why;
+    std::shared_ptr<KeyImage> img = image_of(s, zkey, zkey_len, why);
+    if (!img) return service_fail(ZKC_ERR_FORMAT, why);
     Req* r = new Req();
-    r->kind = kind; r->zkey = (const uint8_t*)zkey; r->zkey_len = zkey_len; r->nLevels = kind == KIND_FULLPROVE ? nLevels : 0; r->data = (const uint8_t*)data; r->nW = nW;
+    r->kind = kind; r->img = std::move(img); r->nLevels = kind == KIND_FULLPROVE ? nLevels : 0; r->data = (const uint8_t*)data; r->nW = nW;
     r->proof = proof; r->pub = pub; r->done = done; r->user = user;
-    if (zkc_zkey_fingerprint(zkey, zkey_len, r->fp)) { delete r; return service_fail(ZKC_ERR_FORMAT, "not a zkey file"); }
     if (rs) {
         for (int k = 0; k < 2; k++) { uint32_t t[8]; memcpy(t, rs + 32 * k, 32); if (!zkc::fp_std_lt_p<zkc::FrParams>(t)) { delete r; return service_fail(ZKC_ERR_BAD_ARG, "r or s >= field order"); } }
         memcpy(r->rs, rs, 64);
