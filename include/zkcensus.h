@@ -140,12 +140,13 @@ int  zkc_pool_fullprove_batch(zkc_pool* pool, const void* inputs, int B, const u
  * whatever has accumulated in ONE pipeline pass sequence (zkc_fullprove_batch_dev / zkc_prove_batch_dev): a lone caller is served at once,
  * concurrent callers share passes (64 concurrent callers reach most of the batch rate instead of 64 x the single-proof latency).
  * Devices: hip_devices[n], or n = 0: $ZKC_DEVICE ("2", "0,1,2,3", "all"), unset = every visible device; a device is brought up (context, key
- * tables) only when the queue is long enough to pay for it.  The resident key of a device is identified per call by zkc_zkey_fingerprint
- * of the .zkey image (a SAMPLED hash); the first time an image (pointer, length) meets a resident key its full SHA-256 is compared too.
+ * tables) only when the queue is long enough to pay for it, and loads its key before it takes requests.  Key identity: the service keeps its own copy of
+ * every .zkey image it has seen (at most four); a request finds its image through zkc_zkey_fingerprint (a SAMPLED hash) and, the first time a given caller
+ * buffer (pointer, length) shows up, through the SHA-256 of the whole image -- so the caller's .zkey buffer need only stay valid during the call itself.
  * The blocking calls return the voter's own result: ZKC_OK, ZKC_ERR_WITNESS (status = ZKC_W_*: that voter failed a circuit assert; other
  * callers of the same pass are not affected), or an error with text in err.  rs = r || s (64 B) or NULL (drawn uniform in Fr).
  * The submit calls return at once; `done` runs on a service thread when the proof (or error) is in the caller's buffers, which -- like the
- * .zkey image, inputs / witness -- must stay valid until then.  zkc_service_default(): the process-wide instance groth16_prover uses. */
+ * inputs / witness, but not the .zkey image -- must stay valid until then.  zkc_service_default(): the process-wide instance groth16_prover uses. */
 typedef struct zkc_service zkc_service;
 typedef void (*zkc_done_fn)(void* user, int rc, int32_t witness_status, const char* error_text /* valid during the call */);
 int  zkc_service_create(const int* hip_devices, int n, zkc_service** out);
