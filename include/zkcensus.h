@@ -36,12 +36,21 @@ enum {
     ZKC_ERR_HIP = 6,
     ZKC_ERR_WITNESS = 7               /* at least one voter failed a circuit assert: see per-voter status */
 };
-/* per-voter witness status (the reference wasm raises "Assert Failed" naming these template lines) */
+/* per-voter witness status.  The reference's witness calculator stops at the first assert it reaches and throws "Assert Failed." with circom's trace
+ * of template lines (snarkjs witness_calculator.js exceptionHandler code 4); the values name those sites, and when a voter violates several the status
+ * is the one the wasm reaches first: it runs census.circom top to bottom (:72 weight, :79-90 sikVerifier, :92-103 censusVerifier, :114 nullifier) and, in an
+ * SMTVerifier, the SMTLevIns assert (smtverifier.circom:70 -> smtlevins.circom:93) before the root comparison (:134) -- i.e. 1, 7, 2, 5, 3, 4.
+ * tests/golden/witness_vectors.json holds the wasm's message for every single, pair and triple of violations. */
 enum {
-    ZKC_W_OK = 0, ZKC_W_ERR_WEIGHT = 1 /* census.circom:72 */, ZKC_W_ERR_SIK_ROOT = 2 /* :90 */,
-    ZKC_W_ERR_CENSUS_ROOT = 3 /* :103 */, ZKC_W_ERR_NULLIFIER = 4 /* :114 */, ZKC_W_ERR_LAST_SIBLING = 5 /* smtlevins */,
-    ZKC_W_ERR_INPUT_RANGE = 6
+    ZKC_W_OK = 0, ZKC_W_ERR_WEIGHT = 1 /* census.circom:72 */, ZKC_W_ERR_SIK_ROOT = 2 /* :90 via smtverifier.circom:134 */,
+    ZKC_W_ERR_CENSUS_ROOT = 3 /* :103 via :134 */, ZKC_W_ERR_NULLIFIER = 4 /* :114 */, ZKC_W_ERR_LAST_SIBLING = 5 /* :103 via smtlevins.circom:93: censusSiblings[nLevels] != 0 */,
+    ZKC_W_ERR_INPUT_RANGE = 6 /* a 32-byte input value >= r: this boundary's own check, made before any assert (snarkjs reduces decimal strings mod r first, and so do the hosts above it) */,
+    ZKC_W_ERR_SIK_LAST_SIBLING = 7 /* :90 via smtlevins.circom:93: sikSiblings[nLevels] != 0 */
 };
+/* The Error.message snarkjs throws for that status: "Assert Failed.\nError in template <T> line: <n>\n..." (innermost template first).  At nLevels 160 the
+ * template instance numbers of the committed dev/160 circuit.wasm are included (ForceEqualIfEnabled_159, SMTLevIns_80, SMTVerifier_160, ZkFranchiseProofCircuit_234)
+ * and the text is byte-equal to the reference's; other depths would need the circuit compiled to know them and get the names without numbers.  NULL for 0 / unknown. */
+const char* zkc_witness_status_text(int nLevels, int32_t status);
 
 /* ---- context ----
  * One context per (process, GPU).  SURVEY.md 8b sketched zkc_ctx_create(device_ids[], n); the build runs one process per GPU instead

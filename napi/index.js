@@ -70,8 +70,6 @@ function toJson(out) {
   for (let i = 0; i < out.publicSignals.length / 32; i++) publicSignals.push(fromLe(out.publicSignals, 32 * i).toString());
   return { proof, publicSignals };
 }
-const ASSERT_SITE = { 1: "ZkFranchiseProofCircuit line: 72", 2: "ZkFranchiseProofCircuit line: 90", 3: "ZkFranchiseProofCircuit line: 103",
-  4: "ZkFranchiseProofCircuit line: 114", 5: "SMTLevIns line: 93", 6: "input >= field order" };
 const blind = (opts, k) => (opts && opts[k] !== undefined ? le32(opts[k]) : null);      // null: drawn uniformly in Fr by the library
 
 const wtns = {
@@ -101,7 +99,7 @@ const groth16 = {
     const np = out.publicSignals.length / inputs.length;
     return inputs.map((_, i) => {
       const st = out.status.readInt32LE(4 * i);
-      if (st !== 0) return new Error(`Error: Assert Failed. Error in template ${ASSERT_SITE[st] || "?"}`);
+      if (st !== 0) return new Error(native.statusText(nLevels, st, LIB));
       return toJson({ proof: out.proofs.subarray(256 * i, 256 * i + 256), publicSignals: out.publicSignals.subarray(np * i, np * i + np) });
     });
   },

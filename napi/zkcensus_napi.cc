@@ -41,6 +41,7 @@ struct Api {
     int (*submit_fullprove)(void*, const void*, size_t, int, const void*, const uint8_t*, uint8_t*, uint8_t*, done_fn, void*) = nullptr;
     int (*submit_prove)(void*, const void*, size_t, const void*, uint32_t, const uint8_t*, uint8_t*, uint8_t*, done_fn, void*) = nullptr;
     int (*header_info)(const void*, size_t, uint32_t*, uint32_t*, uint32_t*) = nullptr;
+    const char* (*status_text)(int, int32_t) = nullptr;
     std::string err;
 } g;
 std::mutex g_mu;                       // guards everything below and every use of the shared context / key
@@ -61,7 +62,7 @@ bool load_api(const std::string& hint) {               // caller holds g_mu
     SYM(pool_create, "zkc_pool_create") SYM(pool_destroy, "zkc_pool_destroy") SYM(pool_err, "zkc_pool_last_error") SYM(pool_zkey_load, "zkc_pool_zkey_load")
     SYM(pool_zkey, "zkc_pool_zkey") SYM(pool_fullprove, "zkc_pool_fullprove_batch")
     SYM(service_default, "zkc_service_default") SYM(service_err, "zkc_service_last_error") SYM(submit_fullprove, "zkc_service_submit_fullprove")
-    SYM(submit_prove, "zkc_service_submit_prove") SYM(header_info, "zkc_zkey_header_info")
+    SYM(submit_prove, "zkc_service_submit_prove") SYM(header_info, "zkc_zkey_header_info") SYM(status_text, "zkc_witness_status_text")
 #undef SYM
     g.h = h;
     return true;
@@ -72,12 +73,10 @@ bool ensure_ctx(std::string& err) {                     // caller holds g_mu
     if (g.ctx_create(d ? atoi(d) : 0, &g_ctx)) { g_ctx = nullptr; err = g.last_error(nullptr); return false; }
     return true;
 }
-const char* assert_site(int status) {                   // census.circom line of each assert, as the wasm's "Assert Failed" message names it
-    switch (status) {
-        case 1: return "ZkFranchiseProofCircuit line: 72"; case 2: return "ZkFranchiseProofCircuit line: 90"; case 3: return "ZkFranchiseProofCircuit line: 103";
-        case 4: return "ZkFranchiseProofCircuit line: 114"; case 5: return "SMTLevIns line: 93"; case 6: return "input >= field order";
-    }
-    return "?";
+// the message snarkjs's Error carries for a failed assert ("Assert Failed.\nError in template ... line: N\n"), from the library (zkc_witness_status_text)
+std::string assert_text(int nLevels, int32_t status) {
+    const char* t = g.status_text(nLevels, status);
+    return t ? std::string(t) : "Assert Failed.\n(witness status " + std::to_string(status) + ")";
 }
 
 enum Kind { FULLPROVE, PROVE, WITNESS, BATCH };
@@ -95,7 +94,7 @@ bool run_witness(Work* w, std::vector<uint8_t>& wtns) {
     if (nw <= 0 || (int)w->inputs.size() != ni * 32) { w->err = "Not all inputs have been set"; return false; }
     wtns.resize((size_t)nw * 32); int32_t status = 0;
     const int rc = g.witness(g_ctx, w->nLevels, w->inputs.data(), 1, wtns.data(), &status);
-    if (rc) { w->err = status ? std::string("Error: Assert Failed. Error in template ") + assert_site(status) : std::string(g.last_error(g_ctx)); return false; }
+    if (rc) { w->err = status ? assert_text(w->nLevels, status) : std::string(g.last_error(g_ctx)); return false; }
     return true;
 }
 // B voters over the listed devices (zkc_pool_*): one context, resident key and host thread per device; caller holds g_mu
@@ -165,7 +164,7 @@ void complete(napi_env env, napi_status, void* data) { settle(env, (Work*)data);
 napi_threadsafe_function g_tsfn = nullptr; int g_inflight = 0;        // g_inflight: main thread only
 void on_done(void* user, int rc, int32_t status, const char* text) {  // service thread
     Work* w = (Work*)user;
-    if (rc == 7 /* ZKC_ERR_WITNESS */) w->err = std::string("Error: Assert Failed. Error in template ") + assert_site(status);
+    if (rc == 7 /* ZKC_ERR_WITNESS */) w->err = assert_text(w->nLevels, status);
     else if (rc) w->err = text && *text ? text : "proving failed";
     napi_call_threadsafe_function(g_tsfn, w, napi_tsfn_blocking);
 }
@@ -258,6 +257,15 @@ napi_value CircuitFromWasm(napi_env env, napi_callback_info info) {
     napi_set_named_property(env, obj, "nLevels", v); napi_set_named_property(env, obj, "sha256", s);
     return obj;
 }
+// statusText(nLevels, status, libPath) -> string: the Error.message of the reference for a per-voter witness status (fullProveBatch builds its Error objects from it)
+napi_value StatusText(napi_env env, napi_callback_info info) {
+    size_t argc = 3; napi_value a[3]; napi_get_cb_info(env, info, &argc, a, nullptr, nullptr);
+    std::lock_guard<std::mutex> guard(g_mu);
+    if (!load_api(str_arg(env, a[2]))) { napi_throw_error(env, nullptr, g.err.c_str()); return nullptr; }
+    int32_t nl = 0, st = 0; napi_get_value_int32(env, a[0], &nl); napi_get_value_int32(env, a[1], &st);
+    const std::string t = assert_text(nl, st);
+    napi_value out; napi_create_string_utf8(env, t.c_str(), t.size(), &out); return out;
+}
 // verifyJson(vkeyJson, publicJson, proofJson, libPath) -> boolean   (CPU pairing check, milliseconds)
 napi_value VerifyJson(napi_env env, napi_callback_info info) {
     size_t argc = 4; napi_value a[4]; napi_get_cb_info(env, info, &argc, a, nullptr, nullptr);
@@ -272,7 +280,7 @@ napi_value Init(napi_env env, napi_value exports) {
     napi_create_threadsafe_function(env, nullptr, nullptr, name, 0, 1, nullptr, nullptr, nullptr, settle_js, &g_tsfn);
     napi_unref_threadsafe_function(env, g_tsfn);
 #define EXPORT(name, fn) napi_create_function(env, name, NAPI_AUTO_LENGTH, fn, nullptr, &f); napi_set_named_property(env, exports, name, f);
-    EXPORT("fullProveRaw", FullProveRaw) EXPORT("fullProveBatchRaw", FullProveBatchRaw) EXPORT("proveRaw", ProveRaw) EXPORT("witnessRaw", WitnessRaw) EXPORT("circuitFromWasm", CircuitFromWasm) EXPORT("verifyJson", VerifyJson)
+    EXPORT("fullProveRaw", FullProveRaw) EXPORT("fullProveBatchRaw", FullProveBatchRaw) EXPORT("proveRaw", ProveRaw) EXPORT("witnessRaw", WitnessRaw) EXPORT("circuitFromWasm", CircuitFromWasm) EXPORT("verifyJson", VerifyJson) EXPORT("statusText", StatusText)
 #undef EXPORT
     return exports;
 }

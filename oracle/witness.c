@@ -212,23 +212,26 @@ int zko_witness(int nL, const uint64_t *inputs, uint64_t *wires) {
     ptrace_t *Tsik = malloc(sizeof *Tsik), *Tnul = malloc(sizeof *Tnul);
     fe_t sin[3] = {*address, *password, *signature}; poseidon_trace(Tsik, sin, 3);
     fe_t nin4[4] = {*signature, *password, eid[0], eid[1]}; poseidon_trace(Tnul, nin4, 4);
-    fe_t root; int bad;
+    /* The witness is emitted in wire order, but the status is the assert the reference's calculator reaches FIRST; it runs the main template top to
+     * bottom (weight :72, sikVerifier :79-90, censusVerifier :92-103, nullifier :114) and, inside an SMTVerifier, the SMTLevIns assert (smtverifier.circom:70)
+     * before the root comparison (:134).  tests/golden/witness_vectors.json holds the wasm's message for every pair and triple of violations. */
+    fe_t root; int bad, e_weight = 0, e_sik_last = 0, e_sik_root = 0, e_census_last = 0, e_census_root = 0, e_nullifier = 0;
     emit_smt_verifier(&W, n, address, avail, cs, &root, &bad);
-    if (bad && !rc) rc = ZKO_ERR_LAST_SIBLING;
-    if (!fe_eq(&root, censusRoot) && !rc) rc = ZKO_ERR_CENSUS_ROOT;
+    e_census_last = bad; e_census_root = !fe_eq(&root, censusRoot);
     { fe_t z; memset(&z, 0, sizeof z); put(&W, &z); }                       /* checkNullifier.isz.inv */
     /* checkWeight = LessEqThan(252)(voteWeight, availableWeight): bits 0..250 of voteWeight + 2^252 - (availableWeight+1) */
     { fe_t x, p252, one; uint64_t s[4] = {0, 0, 0, 1ULL << 60}; fe_from_u64x4(&p252, s, R); fe_set_u64(&one, 1, R);
       fe_add(&x, voteW, &p252, R); fe_sub(&x, &x, avail, R); fe_sub(&x, &x, &one, R);
       uint64_t xs[4]; fe_to_u64x4(xs, &x, R);
-      if ((bit_of(xs, 252) || bit_of(xs, 253)) && !rc) rc = ZKO_ERR_WEIGHT;
+      e_weight = bit_of(xs, 252) || bit_of(xs, 253);
       for (int i = 0; i <= 250; i++) put_u(&W, (uint64_t)bit_of(xs, i)); }
-    if (!fe_eq(&Tnul->out, nullifier) && !rc) rc = ZKO_ERR_NULLIFIER;
+    e_nullifier = !fe_eq(&Tnul->out, nullifier);
     emit_poseidon_t5(&W, Tnul);
     put(&W, &Tsik->out); emit_poseidon_std(&W, Tsik, 1u);
     emit_smt_verifier(&W, n, address, &Tsik->out, ss, &root, &bad);
-    if (bad && !rc) rc = ZKO_ERR_LAST_SIBLING;
-    if (!fe_eq(&root, sikRoot) && !rc) rc = ZKO_ERR_SIK_ROOT;
+    e_sik_last = bad; e_sik_root = !fe_eq(&root, sikRoot);
+    rc = e_weight ? ZKO_ERR_WEIGHT : e_sik_last ? ZKO_ERR_SIK_LAST_SIBLING : e_sik_root ? ZKO_ERR_SIK_ROOT : e_census_last ? ZKO_ERR_LAST_SIBLING
+       : e_census_root ? ZKO_ERR_CENSUS_ROOT : e_nullifier ? ZKO_ERR_NULLIFIER : ZKO_OK;
     if (W.k != nw) { rc = -100 - (W.k > nw); }
     else for (int i = 0; i < nw; i++) fe_to_u64x4(wires + 4 * i, &W.w[i], R);
     free(in); free(W.w); free(Tsik); free(Tnul);

@@ -17,8 +17,10 @@ enum { ZKO_OK = 0, ZKO_ERR_WEIGHT = 1,        /* census.circom:72  checkWeight.o
        ZKO_ERR_SIK_ROOT = 2,                  /* census.circom:79-90  sikVerifier root */
        ZKO_ERR_CENSUS_ROOT = 3,               /* census.circom:92-103 censusVerifier root */
        ZKO_ERR_NULLIFIER = 4,                 /* census.circom:111-114 */
-       ZKO_ERR_LAST_SIBLING = 5,              /* SMTLevIns: siblings[nLevels] must be 0 */
-       ZKO_ERR_INPUT_RANGE = 6 };             /* an input value >= r */
+       ZKO_ERR_LAST_SIBLING = 5,              /* SMTLevIns (smtlevins.circom:93 via smtverifier.circom:70): censusSiblings[nLevels] must be 0 */
+       ZKO_ERR_INPUT_RANGE = 6,               /* an input value >= r */
+       ZKO_ERR_SIK_LAST_SIBLING = 7 };        /* the same assert in sikVerifier: sikSiblings[nLevels] must be 0.  With several violations the status is the
+                                                 assert the reference's wasm reaches first: 1, 7, 2, 5, 3, 4 in that order */
 
 void zko_poseidon(uint64_t out[4], const uint64_t *in /* n x 4 */, int n);   /* n = 2,3,4 ; standard form in/out */
 int  zko_witness(int nLevels, const uint64_t *inputs, uint64_t *wires);      /* wires: zko_n_wires x 4 u64, standard form */

@@ -180,3 +180,14 @@ def golden(name):
 
 def load_json(name):
     return json.load(open(golden(name)))
+
+
+def status_of_wasm_message(msg):
+    """The per-voter status (include/zkcensus.h ZKC_W_*) that names the assert in a message of the reference's witness calculator: the outermost frame gives
+    the census.circom line, the innermost tells SMTLevIns (last sibling) from ForceEqualIfEnabled (root / nullifier)."""
+    import re
+    frames = re.findall(r'Error in template (\w+?)_\d+ line: (\d+)', msg)
+    assert frames and frames[-1][0] == 'ZkFranchiseProofCircuit', msg
+    line, inner = int(frames[-1][1]), frames[0][0]
+    return {(72, 'ZkFranchiseProofCircuit'): 1, (90, 'SMTLevIns'): 7, (90, 'ForceEqualIfEnabled'): 2, (103, 'SMTLevIns'): 5,
+            (103, 'ForceEqualIfEnabled'): 3, (114, 'ForceEqualIfEnabled'): 4}[(line, inner)]

@@ -31,8 +31,9 @@ def test_snarkjs_surface_and_rapidsnark_entry():
     assert a == b
     # a failing circuit assert surfaces like snarkjs' "Assert Failed"
     bad = dict(ex); bad['voteWeight'] = str(int(ex['availableWeight']) + 1)
-    with pytest.raises(RuntimeError, match='Assert Failed'):
+    with pytest.raises(RuntimeError) as e:
         groth16.fullProve(bad, None, zkey_path)
+    assert str(e.value) == 'Assert Failed.\nError in template ZkFranchiseProofCircuit_234 line: 72\n'      # the wasm's own text (tests/golden "weight_exceeds")
     # rapidsnark entry point: file images in, JSON text out
     lib = _native.load()
     zk = open(zkey_path, 'rb').read()

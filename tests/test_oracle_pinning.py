@@ -41,14 +41,34 @@ def test_witness_matches_reference_wasm(vec):
     assert [str(int.from_bytes(w[32 * i:32 * i + 32], 'little')) for i in range(1, 9)] == vec['public']
 
 
-EXPECT = {'weight_exceeds': 1, 'bad_sik_root': 2, 'bad_census_root': 3, 'bad_nullifier': 4, 'last_sibling_nonzero': 5}
+EXPECT = {'weight_exceeds': 1, 'bad_sik_root': 2, 'bad_census_root': 3, 'bad_nullifier': 4, 'last_sibling_nonzero': 5, 'lasts': 7}
 
 
 @pytest.mark.parametrize('vec', VEC['negative'], ids=[v['name'] for v in VEC['negative']])
 def test_witness_rejects_like_reference_wasm(vec):
-    assert vec['wasm_code'] == 4          # the reference raises "assert failed" for all five
+    """42 rejected voters: each assert alone, then every pair and triple of the six assert sites and all six at once.  The wasm stops at the first assert it
+    reaches; the oracle's status must name that one (not merely "some assert failed")."""
+    assert vec['wasm_code'] == 4          # the reference raises "assert failed" for every one
     rc, _ = ol.witness(vec['inputs'])
-    assert rc == EXPECT[vec['name']]
+    assert rc == ol.status_of_wasm_message(vec['wasm_msg'])
+    if vec['name'] in EXPECT:
+        assert rc == EXPECT[vec['name']]
+
+
+def test_status_text_is_the_reference_message():
+    """zkc_witness_status_text (host only, no GPU) returns snarkjs's Error.message for the status: "Assert Failed.\\n" + the wasm's lines, byte for byte at nLevels 160"""
+    from zkcensus_amd import _native
+    lib = _native.load()
+    seen = set()
+    for vec in VEC['negative']:
+        st = ol.status_of_wasm_message(vec['wasm_msg']); seen.add(st)
+        assert lib.zkc_witness_status_text(160, st).decode() == 'Assert Failed.\n' + vec['wasm_msg'] + '\n'
+    assert seen == {1, 2, 3, 4, 5, 7}
+    import re
+    for st in seen:                                                     # other depths: the same frames without the instance numbers of the dev/160 build
+        assert lib.zkc_witness_status_text(10, st).decode() == re.sub(r'_\d+ line', ' line', lib.zkc_witness_status_text(160, st).decode())
+    assert lib.zkc_witness_status_text(160, 0) is None and lib.zkc_witness_status_text(160, 8) is None and lib.zkc_witness_status_text(160, -1) is None
+    assert b'field order' in lib.zkc_witness_status_text(160, 6)
 
 
 def test_verifier_accepts_reference_triple_and_rejects_bitflips():

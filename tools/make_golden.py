@@ -56,6 +56,23 @@ def main():
             ('bad_sik_root', mut(sikRoot=str((int(base['sikRoot']) + 1) % cm.R))),
             ('bad_nullifier', mut(nullifier=str((int(base['nullifier']) + 1) % cm.R))),
             ('last_sibling_nonzero', bad_last)]
+    # several violations in one voter: the wasm stops at the FIRST assert it reaches, and a drop-in reports that one.  Every pair and triple of the six
+    # assert sites, and all six together.
+    import itertools
+    muts = {'weight': lambda v: v.update(voteWeight=str(int(v['availableWeight']) + 1)),
+            'sik': lambda v: v.update(sikRoot=str((int(v['sikRoot']) + 1) % cm.R)),
+            'census': lambda v: v.update(censusRoot=str((int(v['censusRoot']) + 1) % cm.R)),
+            'null': lambda v: v.update(nullifier=str((int(v['nullifier']) + 1) % cm.R)),
+            'lastc': lambda v: v['censusSiblings'].__setitem__(160, '5'),
+            'lasts': lambda v: v['sikSiblings'].__setitem__(160, '7')}
+    negs.append(('lasts', mut()))
+    muts['lasts'](negs[-1][1])
+    for r in (2, 3, 6):
+        for combo in itertools.combinations(muts, r):
+            v = copy.deepcopy(base)
+            for k in combo:
+                muts[k](v)
+            negs.append(('+'.join(combo), v))
     allv = [v for _, v in voters] + [v for _, v in negs]
     with tempfile.TemporaryDirectory() as td:
         json.dump(allv, open(td + '/in.json', 'w'))

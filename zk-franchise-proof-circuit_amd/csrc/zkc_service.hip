@@ -261,7 +261,8 @@ void process(zkc_service* s, zkc_service::Worker* w, std::vector<Req*>&& first) 
         Req* r = b.reqs[i];
         const int32_t st = full ? ((const int32_t*)w->h_status.p)[i] : 0;
         if (st == ZKC_W_OK) { memcpy(r->proof, (const uint8_t*)w->h_proofs.p + 256 * i, 256); if (r->pub) memcpy(r->pub, (const uint8_t*)w->h_pubs.p + nPub * 32 * i, nPub * 32); }
-        finish(r, st == ZKC_W_OK ? ZKC_OK : ZKC_ERR_WITNESS, st, st == ZKC_W_OK ? "" : "a circuit assert failed (see status)");
+        const char* why = st == ZKC_W_OK ? "" : zkc_witness_status_text(r->nLevels, st);
+        finish(r, st == ZKC_W_OK ? ZKC_OK : ZKC_ERR_WITNESS, st, why ? why : "a circuit assert failed (see status)");
     }
     { std::lock_guard<std::mutex> g(s->mu); s->us_finish += now_us() - t_e; }
 }

@@ -174,6 +174,39 @@ extern "C" int zkc_zkey_fingerprint(const void* zkey_bytes, size_t len, uint8_t 
     parse::zkey_fingerprint((const uint8_t*)zkey_bytes, len, bs, out);
     return ZKC_OK;
 }
+// The message of the Error snarkjs throws when the witness calculator hits an assert (witness_calculator.js exceptionHandler: "Assert Failed.\n" + the lines
+// circom's runtime printed, innermost template first).  Pinned against the wasm's own output in tests/golden/witness_vectors.json.
+extern "C" const char* zkc_witness_status_text(int nLevels, int32_t status) {
+    struct Site { int32_t st; const char* frames[3][2]; };                        // {template, line}, innermost first
+    static const Site sites[] = {
+        {ZKC_W_ERR_WEIGHT,           {{"ZkFranchiseProofCircuit", "72"}}},
+        {ZKC_W_ERR_SIK_LAST_SIBLING, {{"SMTLevIns", "93"}, {"SMTVerifier", "70"}, {"ZkFranchiseProofCircuit", "90"}}},
+        {ZKC_W_ERR_SIK_ROOT,         {{"ForceEqualIfEnabled", "56"}, {"SMTVerifier", "134"}, {"ZkFranchiseProofCircuit", "90"}}},
+        {ZKC_W_ERR_LAST_SIBLING,     {{"SMTLevIns", "93"}, {"SMTVerifier", "70"}, {"ZkFranchiseProofCircuit", "103"}}},
+        {ZKC_W_ERR_CENSUS_ROOT,      {{"ForceEqualIfEnabled", "56"}, {"SMTVerifier", "134"}, {"ZkFranchiseProofCircuit", "103"}}},
+        {ZKC_W_ERR_NULLIFIER,        {{"ForceEqualIfEnabled", "56"}, {"ZkFranchiseProofCircuit", "114"}}},
+    };
+    static const struct { const char* tmpl; const char* id; } ids160[] = {{"ForceEqualIfEnabled", "_159"}, {"SMTLevIns", "_80"}, {"SMTVerifier", "_160"}, {"ZkFranchiseProofCircuit", "_234"}};
+    static const std::vector<std::string> text = [] {
+        std::vector<std::string> t(2 * 8);
+        for (int with_ids = 0; with_ids < 2; with_ids++) {
+            for (const Site& s : sites) {
+                std::string m = "Assert Failed.\n";
+                for (const auto& f : s.frames) {
+                    if (!f[0]) break;
+                    m += std::string("Error in template ") + f[0];
+                    if (with_ids) for (const auto& k : ids160) if (!strcmp(k.tmpl, f[0])) m += k.id;
+                    m += std::string(" line: ") + f[1] + "\n";
+                }
+                t[with_ids * 8 + s.st] = m;
+            }
+            t[with_ids * 8 + ZKC_W_ERR_INPUT_RANGE] = "Input value is not below the field order r\n";
+        }
+        return t;
+    }();
+    if (status <= 0 || status >= 8) return nullptr;
+    return text[(nLevels == 160 ? 8 : 0) + status].c_str();
+}
 // circuits this build has a native witness generator for, by the sha256 of their circom witness-calculator wasm
 // the shape of a key straight from the file image (no GPU, no load): what a host needs to size its buffers before it submits a request
 extern "C" int zkc_zkey_header_info(const void* zkey_bytes, size_t len, uint32_t* nVars, uint32_t* nPublic, uint32_t* domainSize) {

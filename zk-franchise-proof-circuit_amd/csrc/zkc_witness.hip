@@ -481,7 +481,7 @@ zkc_witness_chains(WitnessLayout L, PoseidonTable tab, const uint32_t* __restric
         }
         bool bad_last;
         Fr r = smt_verifier_chain<false>(L, tab, e, blk, key_s, key, value, sib, &bad_last, tmpl_mode != 0);
-        if (bad_last) st = ZKC_W_ERR_LAST_SIBLING;
+        if (bad_last) st = kind == 0 ? ZKC_W_ERR_LAST_SIBLING : ZKC_W_ERR_SIK_LAST_SIBLING;
         else if (r != load_std(root)) st = kind == 0 ? ZKC_W_ERR_CENSUS_ROOT : ZKC_W_ERR_SIK_ROOT;
     }
     status[(size_t)b * 3 + kind] = st;
@@ -542,7 +542,7 @@ zkc_witness_chains_wave(WitnessLayout L, PoseidonTable tab, const uint32_t* __re
     }
     bool bad_last;
     Fr r = smt_verifier_chain<true>(L, tab, e, blk, key_s, key, value, sib, &bad_last, tmpl_mode != 0);
-    if (bad_last) st = ZKC_W_ERR_LAST_SIBLING;
+    if (bad_last) st = kind == 0 ? ZKC_W_ERR_LAST_SIBLING : ZKC_W_ERR_SIK_LAST_SIBLING;
     else if (r != load_std(root)) st = kind == 0 ? ZKC_W_ERR_CENSUS_ROOT : ZKC_W_ERR_SIK_ROOT;
     if (lane == 0) status[(size_t)b * 3 + kind] = st;
 }

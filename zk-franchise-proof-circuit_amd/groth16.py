@@ -96,6 +96,12 @@ def proof_to_json(proof, pub):
     return json.loads(pb.value.decode()), json.loads(ub.value.decode())
 
 
+def status_text(nLevels, status):
+    """The Error.message snarkjs carries for a per-voter witness status ("Assert Failed.\\nError in template ... line: N\\n"): zkc_witness_status_text"""
+    t = _native.load().zkc_witness_status_text(int(nLevels), int(status))
+    return t.decode() if t else 'Assert Failed.\n(witness status %d)' % status
+
+
 class wtns:
     @staticmethod
     def calculate(inputs, wasm_file=None, nLevels=None):
@@ -104,9 +110,7 @@ class wtns:
         ctx = _context()
         ws, st = ctx.witness([inputs], nLevels)
         if st[0] != 0:
-            sites = {1: 'ZkFranchiseProofCircuit line: 72', 2: 'ZkFranchiseProofCircuit line: 90', 3: 'ZkFranchiseProofCircuit line: 103',
-                     4: 'ZkFranchiseProofCircuit line: 114', 5: 'SMTLevIns line: 93', 6: 'input >= field order'}
-            raise RuntimeError('Error: Assert Failed. Error in template ' + sites.get(st[0], str(st[0])))
+            raise RuntimeError(status_text(nLevels, st[0]))
         lib = _native.load()
         n = len(ws[0]) // 32
         need = lib.zkc_wtns_write(ws[0], n, None, 0)
