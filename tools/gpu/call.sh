@@ -8,7 +8,7 @@
 #   bench:<args>     python bench.py <args with , for spaces>                   ab:<lib.so>    default / variant / default / variant bench A/B on this box
 #   rate_probe       tools/probe/rate_probe.hip                                 fieldmul       tools/probe/fieldmul_probe.hip (f29 / FP64 / MFMA products)
 #   latency          tools/latency.py                                           stress         tools/stress.py 20 5
-#   verify_bench     tools/verify_bench.py 1024                                 node           node napi/example.js
+#   verify_bench     tools/verify_bench.py 1024                                 node           napi/example.js on the test key (tests/test_00_gpu_node_addon.py)
 #   prof             rocprofv3 --kernel-trace --stats over a 2-step bench       pmc:<name>:<counters,comma>   one PMC pass over a one-pass bench
 #   calib            FETCH_SIZE calibration (tools/probe/gather_probe.hip)      py:<script,args>              python <script> <args>
 #   trace1           rocprofv3 --kernel-trace over tools/latency.py -> timeline of one proof (tools/single_proof_trace.py)
@@ -42,7 +42,7 @@ P
     latency)      f="latency${ZKC_AB_TAG:+_$ZKC_AB_TAG}"; timeout -k 10 300 python tools/latency.py > "$O/$f.json" 2> "$O/$f.err"; rc=$?; tail -c 900 "$O/$f.json" ;;
     stress)       timeout -k 10 400 python tools/stress.py 20 5 > "$O/stress.json" 2> "$O/stress.err"; rc=$?; tail -c 600 "$O/stress.json" ;;
     verify_bench) timeout -k 10 300 python tools/verify_bench.py 1024 > "$O/verify_bench.json" 2> "$O/verify_bench.err"; rc=$?; tail -c 400 "$O/verify_bench.json" ;;
-    node)         timeout -k 10 300 node napi/example.js > "$O/node_example.json" 2> "$O/node_example.err"; rc=$?; tail -c 900 "$O/node_example.json" ;;
+    node)         timeout -k 10 600 python -m pytest tests/test_00_gpu_node_addon.py -m gpu -x -q -s > "$O/node_example.log" 2>&1; rc=$?; tail -c 900 "$O/node_example.log" ;;
     py)           f="py_$(echo "$arg" | tr -c 'A-Za-z0-9\n' '_')${ZKC_AB_TAG:+_$ZKC_AB_TAG}"; timeout -k 10 600 python ${arg//,/ } > "$O/$f.out" 2> "$O/$f.err"; rc=$?; tail -c 1200 "$O/$f.out" ;;
     prof)         cd /tmp && export TMPDIR=/tmp
                   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-verify > "$O/prof.log" 2>&1; rc=$?
