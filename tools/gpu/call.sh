@@ -7,6 +7,7 @@
 #   bench            python bench.py (default contract run)                     bench200       200 steps, no CPU leg, no verification
 #   bench:<args>     python bench.py <args with , for spaces>                   ab:<lib.so>    default / variant / default / variant bench A/B on this box
 #   rate_probe       tools/probe/rate_probe.hip                                 fieldmul       tools/probe/fieldmul_probe.hip (f29 / FP64 / MFMA products)
+#   latprobe         tools/probe/latency_probe.hip (one wave, dependent chains)
 #   latency          tools/latency.py                                           stress         tools/stress.py 20 5
 #   verify_bench     tools/verify_bench.py 1024                                 node           napi/example.js on the test key (tests/test_00_gpu_node_addon.py)
 #   prof             rocprofv3 --kernel-trace --stats over a 2-step bench       pmc:<name>:<counters,comma>   one PMC pass over a one-pass bench
@@ -39,6 +40,7 @@ P
                   done; unset ZKCENSUS_LIB ;;
     rate_probe)   hipcc --offload-arch=gfx950 -O3 -Wno-unused-result tools/probe/rate_probe.hip -o /tmp/rate_probe > "$O/rate_probe_build.log" 2>&1 && timeout -k 10 300 /tmp/rate_probe > "$O/rate_probe.txt" 2>&1; rc=$?; head -8 "$O/rate_probe.txt" ;;
     fieldmul)     hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-result -I zk-franchise-proof-circuit_amd/csrc tools/probe/fieldmul_probe.hip -o /tmp/fieldmul_probe > "$O/fieldmul_build.log" 2>&1 && timeout -k 10 300 /tmp/fieldmul_probe > "$O/fieldmul_probe.txt" 2>&1; rc=$?; cat "$O/fieldmul_probe.txt" ;;
+    latprobe)     hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-result -Wno-unused-value -I zk-franchise-proof-circuit_amd/csrc tools/probe/latency_probe.hip -o /tmp/latency_probe > "$O/latprobe_build.log" 2>&1 && timeout -k 10 120 /tmp/latency_probe > "$O/latency_probe.txt" 2>&1; rc=$?; cat "$O/latency_probe.txt" ;;
     latency)      f="latency${ZKC_AB_TAG:+_$ZKC_AB_TAG}"; timeout -k 10 300 python tools/latency.py > "$O/$f.json" 2> "$O/$f.err"; rc=$?; tail -c 900 "$O/$f.json" ;;
     stress)       timeout -k 10 400 python tools/stress.py 20 5 > "$O/stress.json" 2> "$O/stress.err"; rc=$?; tail -c 600 "$O/stress.json" ;;
     verify_bench) timeout -k 10 300 python tools/verify_bench.py 1024 > "$O/verify_bench.json" 2> "$O/verify_bench.err"; rc=$?; tail -c 400 "$O/verify_bench.json" ;;

@@ -8,7 +8,7 @@ rows = []
 for r in csv.DictReader(open(sys.argv[1])):
     rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].replace('void ', '').replace('zkc::', '')[:46], r.get('Stream_Id', r.get('Queue_Id', '?'))))
 rows.sort()
-fin = [i for i, r in enumerate(rows) if r[2].startswith('zkc_finalize')]
+fin = [i for i, r in enumerate(rows) if r[2].startswith(('zkc_finalize', 'zkc_blind_tree_g1_out'))]      # the kernel that writes piA / piC: the last one of a proof
 # the profiled call of latency.py comes after the 12 timing rounds (each round: host witness + prove, two device-resident forms); take the LAST one-call fullprove of the rounds:
 # walk back from the last blinding kernel that is preceded by a witness kernel within 6 ms
 pick = None

@@ -35,6 +35,10 @@ template <class B> ZKC_HD Fq2T<B> fp_inv(const Fq2T<B>& a) {
     B n = fp_inv(a.c0 * a.c0 + a.c1 * a.c1);
     return {a.c0 * n, fp_neg(a.c1 * n)};
 }
+template <class B> ZKC_HD Fq2T<B> fp_inv_gcd(const Fq2T<B>& a) {                      // binary-Euclid inversion of the norm (zkc_field.h): single-lane tails only
+    B n = fp_inv_gcd(a.c0 * a.c0 + a.c1 * a.c1);
+    return {a.c0 * n, fp_neg(a.c1 * n)};
+}
 using Fq2 = Fq2T<Fq>;
 
 template <class F>
@@ -106,6 +110,14 @@ ZKC_HD Affine<F> xyzz_to_affine(const XYZZ<F>& p) {
     if (p.is_inf()) return Affine<F>::inf();
     F zi3 = fp_inv(p.ZZZ);              // 1/ZZZ ; 1/ZZ = ZZZ^-1 * ZZZ / ZZ ... use zi2 = (zi3 * ZZ)^2 since ZZ^3 = ZZZ^2
     F zi = zi3 * p.ZZ;                  // Z^-1  (ZZ = Z^2, ZZZ = Z^3)
+    F zi2 = fp_sqr(zi);
+    return {p.X * zi2, p.Y * zi3};
+}
+template <class F>
+ZKC_HD Affine<F> xyzz_to_affine_gcd(const XYZZ<F>& p) {       // xyzz_to_affine with fp_inv_gcd: same element, a quarter of the instructions, data-dependent loops
+    if (p.is_inf()) return Affine<F>::inf();
+    F zi3 = fp_inv_gcd(p.ZZZ);
+    F zi = zi3 * p.ZZ;
     F zi2 = fp_sqr(zi);
     return {p.X * zi2, p.Y * zi3};
 }

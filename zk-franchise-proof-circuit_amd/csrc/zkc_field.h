@@ -232,6 +232,51 @@ ZKC_HD Fp<P> fp_inv(const Fp<P>& a) {
     }
     return r;
 }
+// 1 / a by the binary extended Euclid algorithm (0 -> 0): about 760 rounds of 8-limb shifts, additions and subtractions -- a quarter of the instructions of
+// the 254 squarings + ~127 products of fp_inv.  Data-dependent control flow: for ONE lane (or a few) at the end of a latency chain (the blinding of a lone
+// proof, zkc_finalize.hip), not for a full wave of different values.  Works on the stored residue A = a R: A^-1 = a^-1 R^-1, and a^-1 R = A^-1 R^3 / R.
+template <class P>
+ZKC_HD Fp<P> fp_inv_gcd(const Fp<P>& a) {
+    if (a.is_zero()) return a;
+    uint32_t u[8], v[8], x1[8], x2[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { u[i] = a.v[i]; v[i] = P::p[i]; x1[i] = i == 0 ? 1u : 0u; x2[i] = 0; }
+    auto is_one = [](const uint32_t* t) { uint32_t o = t[0] ^ 1u;
+#pragma unroll
+        for (int i = 1; i < 8; i++) o |= t[i]; return o == 0; };
+    auto halve = [](uint32_t* t, uint32_t* x) {                      // t even: t /= 2, x /= 2 mod p
+        for (int i = 0; i < 7; i++) t[i] = (t[i] >> 1) | (t[i + 1] << 31);
+        t[7] >>= 1;
+        uint64_t c = 0; const uint32_t odd = 0u - (x[0] & 1u);       // x odd: x + p is even and below 2^255
+#pragma unroll
+        for (int i = 0; i < 8; i++) { c += (uint64_t)x[i] + (P::p[i] & odd); x[i] = (uint32_t)c; c >>= 32; }
+#pragma unroll
+        for (int i = 0; i < 7; i++) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
+        x[7] >>= 1;
+    };
+    auto sub_from = [](uint32_t* t, const uint32_t* w, uint32_t* x, const uint32_t* y) {      // t -= w (t >= w), x = x - y mod p
+        uint64_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const uint64_t d = (uint64_t)t[i] - w[i] - br; t[i] = (uint32_t)d; br = (d >> 63) & 1; }
+        br = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const uint64_t d = (uint64_t)x[i] - y[i] - br; x[i] = (uint32_t)d; br = (d >> 63) & 1; }
+        const uint32_t neg = 0u - (uint32_t)br; uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { c += (uint64_t)x[i] + (P::p[i] & neg); x[i] = (uint32_t)c; c >>= 32; }
+    };
+    while (!is_one(u) && !is_one(v)) {
+        while (!(u[0] & 1u)) halve(u, x1);
+        while (!(v[0] & 1u)) halve(v, x2);
+        bool ge = true;                                              // u >= v ?
+        for (int i = 7; i >= 0; i--) if (u[i] != v[i]) { ge = u[i] > v[i]; break; }
+        if (ge) sub_from(u, v, x1, x2); else sub_from(v, u, x2, x1);
+    }
+    Fp<P> w, r2;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { w.v[i] = is_one(u) ? x1[i] : x2[i]; r2.v[i] = P::r2[i]; }
+    return w * (r2 * r2);
+}
 template <class P>
 ZKC_HD bool fp_std_lt_p(const uint32_t s[8]) {       // s < p ?
     uint64_t br = 0;

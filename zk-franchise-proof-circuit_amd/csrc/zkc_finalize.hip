@@ -8,6 +8,7 @@
 // Runs on the lane's blinding stream so that it overlaps the next pipeline pass.
 #include "zkc_prover.h"
 #include "zkc_f29_g1.h"
+#include "zkc_f29_g2.h"
 
 namespace zkc {
 
@@ -174,11 +175,222 @@ zkc_finalize_combine(FinalizeArgs a, int nq) {
     }
 }
 
+// ---- [r3] passes of one or two proofs: no variable-base product at all ----
+// A lone proof pays for the LENGTH of the blinding's chains, not for their work: s A' and r B1' were 252 doublings and 78 additions in a row on one lane (0.87 ms of
+// a 4.7 ms proof, profiles/r03_single_proof_timeline.txt), beside 32 G2 additions and three square-and-multiply inversions in 8 x u32 code.  Here
+//   s A' = s K_A + sum_i (s w_i) A_i ,  r B1' = r K_B1 + sum_i (r w_i) B1_i     (K: the proof's folded constant, i: the wires that stay in its MSMs)
+// the two sums are two more jobs of the pass' G1 MSM (zkc_blind_scalars writes s w_i and r w_i; a lone proof leaves the chip idle anyway), and every other
+// product has a fixed base: delta, alpha (+ base constant), beta1 (+ base constant), the per-depth suffix constants of both trees, delta2.  A fixed-base product
+// is read from a 4-bit window table -- T[base][w][d-1] = d 16^w base, built on the device when the key is loaded (zkc_fb4_build) -- one window per LANE, and summed
+// by a six-step butterfly over the wave: six additions deep instead of 32 (or 330).  The inversions run in radix 2^29.
+// Table order (G1): 0 delta1, 1 alpha1, 2 beta1, 3 alpha1 + foldA[0], 4 beta1 + foldB1[0], 5 + i: foldA[1 + i] (i < 2 n), 5 + 2 n + i: foldB1[1 + i].
+extern "C" __global__ void __launch_bounds__(64) zkc_fb4_build_g1(const G1XYZZ* __restrict__ bases, int nbases, G1XYZZ* __restrict__ out) {
+    const int t = blockIdx.x * 64 + threadIdx.x, b = t >> 6, w = t & 63;
+    if (b >= nbases) return;
+    G1XYZZ* o = out + (size_t)t * FB4_ROW;
+    const G1XYZZ B = bases[b];
+    if (B.is_inf()) { for (int d = 0; d < FB4_ROW; d++) o[d] = G1XYZZ::inf(); return; }
+    Acc29 P = f29_pt_from_xyzz(B);
+    for (int i = 0; i < 4 * w; i++) f29_pt_dbl(P, P);
+    Acc29 acc = P; o[0] = f29_pt_to_xyzz(acc);
+    for (int d = 1; d < FB4_ROW; d++) { f29_pt_add(acc, acc, P); o[d] = f29_pt_to_xyzz(acc); }
+}
+extern "C" __global__ void __launch_bounds__(64) zkc_fb4_build_g2(G2XYZZ B, G2XYZZ beta2, G2XYZZ beta2_base, G2XYZZ* __restrict__ out) {
+    const int w = threadIdx.x;
+    if (w == 0) { out[(size_t)FB4_WIN * FB4_ROW] = beta2; out[(size_t)FB4_WIN * FB4_ROW + 1] = beta2_base; }       // what piB adds besides s delta2 and the MSM result
+    G2XYZZ* o = out + (size_t)w * FB4_ROW;
+    Acc29G2 P = f29g2_pt_from_xyzz(B);
+    for (int i = 0; i < 4 * w; i++) f29g2_pt_dbl(P, P);
+    Acc29G2 acc = P; o[0] = f29g2_pt_to_xyzz(acc);
+    for (int d = 1; d < FB4_ROW; d++) { f29g2_pt_add(acc, acc, P); o[d] = f29g2_pt_to_xyzz(acc); }
+}
+int fb4_build(zkc_ctx* ctx, hipStream_t st, const G1XYZZ* d_bases, int nbases, G1XYZZ* d_out, const G2XYZZ& delta2, const G2XYZZ& beta2, const G2XYZZ& beta2_base, G2XYZZ* d_out2) {
+    hipLaunchKernelGGL(zkc_fb4_build_g1, dim3(nbases), dim3(64), 0, st, d_bases, nbases, d_out);
+    hipLaunchKernelGGL(zkc_fb4_build_g2, dim3(1), dim3(64), 0, st, delta2, beta2, beta2_base, d_out2);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, std::string("zkc_fb4_build: ") + hipGetErrorString(e));
+    return ZKC_OK;
+}
+// out[sec][idx] = k_sec * w[idx] for the wires idx of the section's list (sec 0: the A list with k = s, sec 1: the B list with k = r), standard form in and out
+extern "C" __global__ void __launch_bounds__(256) zkc_blind_scalars(BlindArgs a) {
+    const int q = blockIdx.y >> 1, sec = blockIdx.y & 1;
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x, cnt = sec ? a.nB[q] : a.nA[q];
+    if (j >= cnt) return;
+    const uint32_t* map = sec ? a.mapB[q] : a.mapA[q];
+    const uint32_t idx = map ? map[j] : j;
+    const uint4* kp = reinterpret_cast<const uint4*>(a.rs + 64 * (size_t)q + (sec ? 0 : 32)); const uint4 k0 = kp[0], k1 = kp[1];
+    const uint32_t ks[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+    const uint4* wp = reinterpret_cast<const uint4*>(a.w[q] + 8 * (size_t)idx); const uint4 w0 = wp[0], w1 = wp[1];
+    const uint32_t ws[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    uint4* o = reinterpret_cast<uint4*>(a.out[q] + ((size_t)sec * a.nv + idx) * 8);
+    if ((ws[0] | ws[1] | ws[2] | ws[3] | ws[4] | ws[5] | ws[6] | ws[7]) == 0) { o[0] = make_uint4(0, 0, 0, 0); o[1] = make_uint4(0, 0, 0, 0); return; }
+    uint32_t pr[8]; fp_to_std<FrParams>(pr, fp_from_std<FrParams>(ws) * fp_from_std<FrParams>(ks));
+    o[0] = make_uint4(pr[0], pr[1], pr[2], pr[3]); o[1] = make_uint4(pr[4], pr[5], pr[6], pr[7]);
+}
+int blind_scalars_launch(zkc_ctx* ctx, hipStream_t st, const BlindArgs& a, int nproofs) {
+    uint32_t mx = 1; for (int q = 0; q < nproofs; q++) mx = std::max(mx, std::max(a.nA[q], a.nB[q]));
+    hipLaunchKernelGGL(zkc_blind_scalars, dim3((mx + 255) / 256, 2 * nproofs), dim3(256), 0, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, std::string("zkc_blind_scalars: ") + hipGetErrorString(e));
+    return ZKC_OK;
+}
+
+__device__ __forceinline__ uint32_t nibble_of(const uint32_t k[8], int i) {
+    uint32_t limb = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) limb = (q == (i >> 3)) ? k[q] : limb;
+    return (limb >> (4 * (i & 7))) & 15u;
+}
+__device__ __forceinline__ void shfl_xor_words(uint32_t* dst, const uint32_t* src, int nwords, int mask) {
+    for (int k = 0; k < nwords; k++) dst[k] = (uint32_t)__shfl_xor((int)src[k], mask, 64);
+}
+// sum over the lanes of a wave (every lane ends up with a representative of the sum)
+__device__ Acc29 wave_sum_g1(Acc29 p, int top = 32) {
+    for (int m = top; m >= 1; m >>= 1) {
+        Acc29 o;
+#pragma unroll
+        for (int k = 0; k < 9; k++) { o.X[k] = (uint32_t)__shfl_xor((int)p.X[k], m, 64); o.Y[k] = (uint32_t)__shfl_xor((int)p.Y[k], m, 64);
+                                      o.ZZ[k] = (uint32_t)__shfl_xor((int)p.ZZ[k], m, 64); o.ZZZ[k] = (uint32_t)__shfl_xor((int)p.ZZZ[k], m, 64); }
+        Acc29 r; f29_pt_add(r, p, o); p = r;
+    }
+    return p;
+}
+__device__ Acc29G2 wave_sum_g2(Acc29G2 p, int top) {
+    for (int m = top; m >= 1; m >>= 1) {
+        Acc29G2 o;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            o.X.c0[k] = (uint32_t)__shfl_xor((int)p.X.c0[k], m, 64); o.X.c1[k] = (uint32_t)__shfl_xor((int)p.X.c1[k], m, 64);
+            o.Y.c0[k] = (uint32_t)__shfl_xor((int)p.Y.c0[k], m, 64); o.Y.c1[k] = (uint32_t)__shfl_xor((int)p.Y.c1[k], m, 64);
+            o.ZZ.c0[k] = (uint32_t)__shfl_xor((int)p.ZZ.c0[k], m, 64); o.ZZ.c1[k] = (uint32_t)__shfl_xor((int)p.ZZ.c1[k], m, 64);
+            o.ZZZ.c0[k] = (uint32_t)__shfl_xor((int)p.ZZZ.c0[k], m, 64); o.ZZZ.c1[k] = (uint32_t)__shfl_xor((int)p.ZZZ.c1[k], m, 64);
+        }
+        Acc29G2 r; f29g2_pt_add(r, p, o); p = r;
+    }
+    return p;
+}
+__device__ __forceinline__ Acc29 load_pt29(const G1XYZZ& p) { Acc29 a; if (p.is_inf()) f29_pt_set_inf(a); else a = f29_pt_from_xyzz(p); return a; }
+__device__ __forceinline__ Acc29G2 load_pt29(const G2XYZZ& p) { Acc29G2 a; if (p.is_inf()) f29g2_pt_set_inf(a); else a = f29g2_pt_from_xyzz(p); return a; }
+// The three points of a small pass' proof leave the device as XYZZ (512 bytes: piA | piB | piC) and the host divides (prove_batch_finish): one field inversion is
+// ~0.15 ms as a chain of 254 dependent squarings on one lane, whatever the arithmetic, and ~10 us on a CPU core.  (The passes of many proofs keep the inversions on the device, one
+// per lane: there they cost no latency and the host would pay them serially.)
+__device__ __forceinline__ void store_xyzz(uint8_t* out, const Acc29& p) {
+    G1XYZZ* o = reinterpret_cast<G1XYZZ*>(out);
+    if (f29_pt_is_inf(p)) *o = G1XYZZ::inf(); else *o = f29_pt_to_xyzz(p);
+}
+__device__ __forceinline__ void store_xyzz(uint8_t* out, const Acc29G2& p) {
+    G2XYZZ* o = reinterpret_cast<G2XYZZ*>(out);
+    if (f29g2_pt_is_inf(p)) *o = G2XYZZ::inf(); else *o = f29g2_pt_to_xyzz(p);
+}
+// Three kernels, one wave per workgroup (the additions want more registers than a twelve-wave workgroup leaves them):
+//   zkc_blind_tree_g1      grid (10, proofs): tasks 0..7 a fixed-base product each; 8, 9: what does not depend on them (the MSM results and the constants of
+//                          piA and piC) summed meanwhile.  Results (radix 2^29) to scratch[proof][task].
+//   zkc_blind_tree_g1_out  grid (proofs), two waves: piC = eight operands over eight lanes of wave 0, piA = two over two lanes of wave 1; XYZZ out.
+//   zkc_blind_tree_g2      grid (proofs): piB = B2' + beta2 + s delta2.  Depends on nothing in G1: it runs on the G2 stream right behind the G2 MSM.
+// MSM results of the pass: r1[q] = H_q, r1[nq + 5 q + {0..4}] = A_q, B1_q, C_q, sum (s w) A, sum (r w) B1 ; r2[q] = B2_q.
+extern "C" __global__ void __launch_bounds__(64)
+zkc_blind_tree_g1(FinalizeArgs a) {
+    const int task = blockIdx.x, q = blockIdx.y, nq = gridDim.y, lane = threadIdx.x;
+    uint32_t r[8], s[8]; load_rs(a, q, r, s);
+    const bool folded = a.dc[q] != 255; const int n = a.fold_n, dc = a.dc[q], ds = a.ds[q];
+    const G1XYZZ* res = a.r1 + nq + 5 * (size_t)q;
+    Acc29* outv = reinterpret_cast<Acc29*>(a.scratch) + (size_t)q * 10 + task;
+    Acc29 v; f29_pt_set_inf(v);
+    if (task < 8) {
+        int base; bool use_r;
+        switch (task) {
+            case 0: base = 0; use_r = true; break;                                   // r delta
+            case 1: base = 0; use_r = true; break;                                   // rs delta (scalar replaced below)
+            case 2: base = folded ? 3 : 1; use_r = false; break;                     // s (alpha + base constant of A)
+            case 3: base = folded ? 5 + dc : -1; use_r = false; break;               // s (census-tree constant of A)
+            case 4: base = folded ? 5 + n + ds : -1; use_r = false; break;           // s (sik-tree constant of A)
+            case 5: base = folded ? 4 : 2; use_r = true; break;                      // r (beta1 + base constant of B1)
+            case 6: base = folded ? 5 + 2 * n + dc : -1; use_r = true; break;
+            default: base = folded ? 5 + 3 * n + ds : -1; use_r = true; break;
+        }
+        uint32_t k[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) k[i] = use_r ? r[i] : s[i];
+        if (task == 1) { const Fr rs = fp_from_std<FrParams>(r) * fp_from_std<FrParams>(s); fp_to_std<FrParams>(k, rs); }
+        if (base >= 0) {
+            const uint32_t d = nibble_of(k, lane);
+            if (d) v = load_pt29(a.fb4[((size_t)base * FB4_WIN + lane) * FB4_ROW + d - 1]);
+            v = wave_sum_g1(v);
+        }
+    } else if (task == 8) {             // piA without r delta: A + alpha + [foldA constants], four operands over four lanes
+        if (lane == 0) v = load_pt29(res[0]);
+        else if (lane == 1) v = load_pt29(a.fb4[((size_t)(folded ? 3 : 1) * FB4_WIN) * FB4_ROW]);     // 1 x (alpha + foldA[0]) or 1 x alpha
+        else if (lane == 2 && folded) v = load_pt29(a.foldA[1 + dc]);
+        else if (lane == 3 && folded) v = load_pt29(a.foldA[1 + n + ds]);
+        v = wave_sum_g1(v, 2);
+    } else {                            // piC without the fixed-base products: C + [foldC constants] + H + sum (s w) A + sum (r w) B1, seven operands over eight lanes
+        if (lane == 0) v = load_pt29(res[2]);
+        else if (lane == 1 && folded) v = load_pt29(a.foldC[0]);
+        else if (lane == 2 && folded) v = load_pt29(a.foldC[1 + dc]);
+        else if (lane == 3 && folded) v = load_pt29(a.foldC[1 + n + ds]);
+        else if (lane == 4) v = load_pt29(a.r1[q]);
+        else if (lane == 5) v = load_pt29(res[3]);
+        else if (lane == 6) v = load_pt29(res[4]);
+        v = wave_sum_g1(v, 4);
+    }
+    if (lane == 0) *outv = v;
+}
+extern "C" __global__ void __launch_bounds__(128)
+zkc_blind_tree_g1_out(FinalizeArgs a) {
+    const int q = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const Acc29* sv = reinterpret_cast<const Acc29*>(a.scratch) + (size_t)q * 10;
+    uint8_t* out = a.out_xyzz + 512 * (size_t)q;
+    Acc29 v; f29_pt_set_inf(v);
+    if (wave == 0) {            // piC = [task 9] + rs delta + s (alpha + K_A) (tasks 2, 3, 4) + r (beta1 + K_B1) (5, 6, 7): eight operands over eight lanes
+        if (lane == 0) v = sv[9]; else if (lane < 8) v = sv[lane];
+        v = wave_sum_g1(v, 4);
+        if (lane == 0) store_xyzz(out + 384, v);
+    } else {                    // piA = [task 8] + r delta
+        if (lane == 0) v = sv[8]; else if (lane == 1) v = sv[0];
+        v = wave_sum_g1(v, 1);
+        if (lane == 0) store_xyzz(out, v);
+    }
+}
+// piB = B2' + beta2 + s delta2: wave 0 the 64 windows of s delta2, wave 1 the four operands that do not depend on s (the MSM result, beta2 + the base constant,
+// the two per-depth constants); one more addition joins them
+extern "C" __global__ void __launch_bounds__(128)
+zkc_blind_tree_g2(FinalizeArgs a) {
+    __shared__ Acc29G2 pre;
+    const int q = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool folded = a.dc[q] != 255;
+    Acc29G2 v; f29g2_pt_set_inf(v);
+    if (wave == 0) {
+        uint32_t r[8], s[8]; load_rs(a, q, r, s);
+        const uint32_t d = nibble_of(s, lane);
+        if (d) v = load_pt29(a.fb4g2[(size_t)lane * FB4_ROW + d - 1]);
+        v = wave_sum_g2(v, 32);
+    } else {
+        if (lane == 0) v = load_pt29(a.r2[q]);
+        else if (lane == 1) v = load_pt29(a.fb4g2[(size_t)FB4_WIN * FB4_ROW + (folded ? 1 : 0)]);      // beta2, beta2 + foldB2[0]: two points behind the table
+        else if (lane == 2 && folded) v = load_pt29(a.foldB2[1 + a.dc[q]]);
+        else if (lane == 3 && folded) v = load_pt29(a.foldB2[1 + a.fold_n + a.ds[q]]);
+        v = wave_sum_g2(v, 2);
+        if (lane == 0) pre = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { Acc29G2 t; f29g2_pt_add(t, v, pre); store_xyzz(a.out_xyzz + 512 * (size_t)q + 128, t); }
+}
+int finalize_tree_g2_launch(zkc_ctx* ctx, hipStream_t st, const FinalizeArgs& a, int nproofs) {
+    hipLaunchKernelGGL(zkc_blind_tree_g2, dim3(nproofs), dim3(128), 0, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, std::string("zkc_blind_tree_g2: ") + hipGetErrorString(e));
+    return ZKC_OK;
+}
+
 size_t finalize_scratch_bytes(int nproofs) { return (size_t)nproofs * (7 * sizeof(G1XYZZ) + sizeof(G2XYZZ) + 2 * 16 * sizeof(Acc29)); }
 
 int finalize_launch(zkc_ctx* ctx, hipStream_t st, const FinalizeArgs& a, int nproofs) {
-    static const bool v1 = getenv("ZKC_FINALIZE_WAVES") != nullptr;          // the one-wave-per-task kernel (lowest latency for a single proof's own three chains)
-    if (v1 || !a.scratch || nproofs <= 2) hipLaunchKernelGGL(zkc_finalize, dim3(nproofs), dim3(256), 0, st, a);
+    static const bool v1 = getenv("ZKC_FINALIZE_WAVES") != nullptr;          // the one-wave-per-task kernel (variable-base products on one lane each)
+    if (a.per == 5) {           // the pass carries the two blinding sums as MSM jobs and piB has been written on the G2 stream (zkc_prove.hip)
+        hipLaunchKernelGGL(zkc_blind_tree_g1, dim3(10, nproofs), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(zkc_blind_tree_g1_out, dim3(nproofs), dim3(128), 0, st, a);
+    }
+    else if (v1 || !a.scratch || nproofs <= 2) hipLaunchKernelGGL(zkc_finalize, dim3(nproofs), dim3(256), 0, st, a);
     else {
         hipLaunchKernelGGL(zkc_finalize_products, dim3((nproofs + 63) / 64, 8), dim3(64), 0, st, a, nproofs);
         hipLaunchKernelGGL(zkc_finalize_combine, dim3((nproofs + 63) / 64, 3), dim3(64), 0, st, a, nproofs);

@@ -509,7 +509,11 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     if (nj <= 0 || nj > w.max_jobs) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: job count");
     static thread_local MsmJobList jl;                  // the caller's list plus the bucket-id layout of this pass
     jl = jl_in;
-    if (!jl.finish()) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: jobs need at most two window sizes (the larger first) and tables that fit the entry word");
+    if (!jl.finish()) {
+        std::string d = "msm_pass: jobs need at most two window sizes (the larger first) and tables that fit the entry word [" + std::to_string(nj) + " jobs:";
+        for (int j = 0; j < nj && j < 16; j++) d += " c" + std::to_string(jl.job[j].c) + "/" + std::to_string(jl.job[j].count) + "/" + std::to_string(jl.job[j].tbl_count);
+        return zkc_fail(ctx, ZKC_ERR_BAD_ARG, d + "]");
+    }
     const size_t total = jl.total_entries;
     const uint32_t nb = jl.total_buckets;
     if (total > w.max_entries || nb > w.max_buckets) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: too many entries for the work space");

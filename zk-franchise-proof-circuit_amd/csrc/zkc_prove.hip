@@ -69,17 +69,17 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     (void)hipSetDevice(zk->ctx->device);
     (void)hipStreamSynchronize(zk->ctx->stream);
     void* ptrs[] = {zk->d_perm, zk->d_rowlen, zk->d_jdptr, zk->d_col, zk->d_val, zk->d_tw_fwd, zk->d_tw_inv, zk->d_tw_fwd29, zk->d_tw_inv29, zk->d_coset, zk->d_coset_br, zk->d_g1, zk->d_g2, zk->d_g2_29, zk->d_flags,
-                    zk->d_tblDelta1, zk->d_tblAlpha1, zk->d_tblBeta1, zk->d_tblDelta2, zk->call[0].d_rs, zk->call[0].d_proofs, zk->call[1].d_rs, zk->call[1].d_proofs};
+                    zk->d_tblDelta1, zk->d_tblAlpha1, zk->d_tblBeta1, zk->d_tblDelta2, zk->d_fb4, zk->d_fb4g2, zk->call[0].d_rs, zk->call[0].d_proofs, zk->call[1].d_rs, zk->call[1].d_proofs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : zk->fold.vmaps) if (kv.second.d) (void)hipFree(kv.second.d);
     for (void* q : {(void*)zk->fold.d_foldA, (void*)zk->fold.d_foldB1, (void*)zk->fold.d_foldC, (void*)zk->fold.d_foldB2}) if (q) (void)hipFree(q);
     if (zk->h_flags) (void)hipHostFree(zk->h_flags);
-    for (auto& c : zk->call) { if (c.h_out) (void)hipHostFree(c.h_out); if (c.h_rs) (void)hipHostFree(c.h_rs); for (hipEvent_t e : c.ev_done) if (e) (void)hipEventDestroy(e); }
+    for (auto& c : zk->call) { if (c.h_out) (void)hipHostFree(c.h_out); if (c.h_rs) (void)hipHostFree(c.h_rs); if (c.h_xyzz) (void)hipHostFree(c.h_xyzz); if (c.d_xyzz) (void)hipFree(c.d_xyzz); for (hipEvent_t e : c.ev_done) if (e) (void)hipEventDestroy(e); }
     if (zk->ev_start) (void)hipEventDestroy(zk->ev_start);
     for (hipEvent_t e : zk->ev_chunk) (void)hipEventDestroy(e);
     for (auto& L : zk->lane) {
         for (hipStream_t q : {L.st, L.st2, L.fin}) if (q) { (void)hipStreamSynchronize(q); if (!zk->serial_streams) (void)hipStreamDestroy(q); }
-        for (void* q : {(void*)L.d_abc, (void*)L.d_t, (void*)L.d_p, L.d_fin}) if (q) (void)hipFree(q);
+        for (void* q : {(void*)L.d_abc, (void*)L.d_t, (void*)L.d_p, L.d_fin, (void*)L.d_bs}) if (q) (void)hipFree(q);
         for (hipEvent_t e : {L.ev_msm, L.ev_msm2, L.ev_sorted, L.ev_ntt, L.ev_mv, L.ev_acc, L.ev_fin[0], L.ev_fin[1]}) if (e) (void)hipEventDestroy(e);
         msm_work_free(L.w1); msm_work_free(L.w2);
     }
@@ -87,6 +87,7 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
 }
 
 static int fold_prepare(zkc_zkey* zk);
+static int fb4_prepare(zkc_zkey* zk);
 // (Re)allocates the per-pass work space of every lane for `inflight` proofs per pass (grow only).  The caller holds the context lock and no
 // pass is in flight.  Footprint per proof in flight at nLevels = 160: abc + NTT scratch 2 x 12 MiB, p 4 MiB, MSM entries ~25 MB, partial sums.
 static int lanes_ensure(zkc_zkey* zk, int inflight) {
@@ -107,7 +108,7 @@ static int lanes_ensure(zkc_zkey* zk, int inflight) {
     auto release = [&]() {
         for (int l = 0; l < zk->nlanes; l++) {
             zkc_lane& L = zk->lane[l];
-            for (void** q : {(void**)&L.d_abc, (void**)&L.d_t, (void**)&L.d_p, &L.d_fin}) if (*q) { (void)hipFree(*q); *q = nullptr; }
+            for (void** q : {(void**)&L.d_abc, (void**)&L.d_t, (void**)&L.d_p, &L.d_fin, (void**)&L.d_bs}) if (*q) { (void)hipFree(*q); *q = nullptr; }
             msm_work_free(L.w1); msm_work_free(L.w2);
         }
     };
@@ -121,6 +122,7 @@ static int lanes_ensure(zkc_zkey* zk, int inflight) {
         if (!rc) rc = dmalloc(ctx, &L.d_t, 3 * (size_t)n * inflight);
         if (!rc) rc = dmalloc(ctx, &L.d_p, 8 * (size_t)n * inflight);
         if (!rc && hipMalloc(&L.d_fin, finalize_scratch_bytes(inflight)) != hipSuccess) rc = zkc_fail(ctx, ZKC_ERR_HIP, "lanes_ensure: hipMalloc failed (blinding scratch)");
+        if (!rc) rc = dmalloc(ctx, &L.d_bs, 2 * 2 * 8 * (size_t)nv);
         if (!rc) rc = msm_work_alloc(ctx, L.w1, per_proof_entries * inflight, per_proof_buckets * inflight, 4 * inflight, false);
         if (!rc) rc = msm_work_alloc(ctx, L.w2, (size_t)NWS * nv * inflight, (size_t)msm_half(MSM_C_SMALL) * inflight, inflight, true);
         if (rc) { (void)hipGetLastError(); release(); return rc; }
@@ -254,6 +256,7 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
     ZKC_HIP_BAIL(hipStreamSynchronize(ctx->stream));
     // the folding tables of the voter-independent witness part are part of the key's one-time cost, not of the first proof
     if (zk->nLevels >= 0 && (rc = fold_prepare(zk))) return bail(rc);
+    if ((rc = fb4_prepare(zk))) return bail(rc);
     *out = zk;
     return ZKC_OK;
 #undef ZKC_UP
@@ -316,6 +319,33 @@ static int fold_prepare(zkc_zkey* zk) {
     if ((rc = fold_upload(ctx, &f.d_foldA, f.baseA, f.sufA)) || (rc = fold_upload(ctx, &f.d_foldB1, f.baseB1, f.sufB1)) || (rc = fold_upload(ctx, &f.d_foldC, f.baseC, f.sufC)) ||
         (rc = fold_upload(ctx, &f.d_foldB2, f.baseB2, f.sufB2))) return rc;
     f.ready = true;
+    return ZKC_OK;
+}
+// 4-bit fixed-base tables of everything the blinding of a small pass multiplies by r or s (zkc_finalize.hip): delta1, alpha1, beta1, and -- with folding -- alpha1 and beta1
+// plus the base constants of A and B1 and the per-depth suffix constants of both trees.  960 points per base: 80 MB at nLevels = 160, built on the device in about a millisecond.
+static int fb4_prepare(zkc_zkey* zk) {
+    static const bool off = [] { const char* e = getenv("ZKC_BLIND_TREE"); return e && atoi(e) == 0; }();
+    if (off || zk->d_fb4) return ZKC_OK;
+    zkc_ctx* ctx = zk->ctx;
+    std::vector<G1XYZZ> bases = {G1XYZZ::from_affine(zk->delta1), G1XYZZ::from_affine(zk->alpha1), G1XYZZ::from_affine(zk->beta1)};
+    const auto& f = zk->fold;
+    if (f.ready) {
+        bases.push_back(xyzz_add_affine(f.baseA[0], zk->alpha1)); bases.push_back(xyzz_add_affine(f.baseB1[0], zk->beta1));
+        for (int t = 0; t < 2; t++) bases.insert(bases.end(), f.sufA[t].begin(), f.sufA[t].end());
+        for (int t = 0; t < 2; t++) bases.insert(bases.end(), f.sufB1[t].begin(), f.sufB1[t].end());
+    }
+    G1XYZZ* d_bases = nullptr; int rc;
+    if ((rc = dmalloc(ctx, &d_bases, bases.size()))) return rc;
+    if ((rc = dmalloc(ctx, &zk->d_fb4, bases.size() * FB4_WIN * FB4_ROW)) || (rc = dmalloc(ctx, &zk->d_fb4g2, (size_t)FB4_WIN * FB4_ROW + 2))) { (void)hipFree(d_bases); return rc; }
+    hipError_t e = hipMemcpyAsync(d_bases, bases.data(), bases.size() * sizeof(G1XYZZ), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) { rc = fb4_build(ctx, ctx->stream, d_bases, (int)bases.size(), zk->d_fb4, G2XYZZ::from_affine(zk->delta2), G2XYZZ::from_affine(zk->beta2),
+                                             f.ready ? xyzz_add_affine(f.baseB2[0], zk->beta2) : G2XYZZ::from_affine(zk->beta2), zk->d_fb4g2); if (!rc) e = hipStreamSynchronize(ctx->stream); }
+    (void)hipFree(d_bases);
+    if (rc || e != hipSuccess) {
+        (void)hipFree(zk->d_fb4); (void)hipFree(zk->d_fb4g2); zk->d_fb4 = nullptr; zk->d_fb4g2 = nullptr;
+        return rc ? rc : zkc_fail(ctx, ZKC_ERR_HIP, std::string("fb4_prepare: ") + hipGetErrorString(e));
+    }
+    zk->fb4_bases = (int)bases.size();
     return ZKC_OK;
 }
 // device lists of the wires that stay in the MSMs of each section when levels >= Dc (census) / >= Ds (sik) and the n2bOld
@@ -425,12 +455,15 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
     zkc_zkey::CallSlot& CS = zk->call[cs];
     if (CS.pending) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "prove_batch_begin: this call slot has a call in flight (finish it first)");
     if (CS.cap < (size_t)B) {                                    // the slot is idle (finished), so its buffers are nobody's
-        if (CS.d_rs) { ZKC_HIP_CHECK(ctx, hipFree(CS.d_rs)); ZKC_HIP_CHECK(ctx, hipFree(CS.d_proofs)); ZKC_HIP_CHECK(ctx, hipHostFree(CS.h_out)); ZKC_HIP_CHECK(ctx, hipHostFree(CS.h_rs)); CS.d_rs = CS.d_proofs = CS.h_out = CS.h_rs = nullptr; CS.cap = 0; }
+        if (CS.d_rs) { ZKC_HIP_CHECK(ctx, hipFree(CS.d_rs)); ZKC_HIP_CHECK(ctx, hipFree(CS.d_proofs)); ZKC_HIP_CHECK(ctx, hipHostFree(CS.h_out)); ZKC_HIP_CHECK(ctx, hipHostFree(CS.h_rs)); ZKC_HIP_CHECK(ctx, hipFree(CS.d_xyzz)); ZKC_HIP_CHECK(ctx, hipHostFree(CS.h_xyzz));
+                       CS.d_rs = CS.d_proofs = CS.h_out = CS.h_rs = CS.d_xyzz = CS.h_xyzz = nullptr; CS.cap = 0; }
         const size_t want = std::max<size_t>((size_t)B, std::min<size_t>(2 * CS.cap, 4096));
         ZKC_HIP_CHECK(ctx, hipMalloc((void**)&CS.d_rs, 64 * want)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&CS.d_proofs, 256 * want));
-        ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&CS.h_out, (256 + 32 * (size_t)zk->nPub) * want)); ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&CS.h_rs, 64 * want)); CS.cap = want;
+        ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&CS.h_out, (256 + 32 * (size_t)zk->nPub) * want)); ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&CS.h_rs, 64 * want));
+        ZKC_HIP_CHECK(ctx, hipMalloc((void**)&CS.d_xyzz, 512 * want)); ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&CS.h_xyzz, 512 * want)); CS.cap = want;
     }
     for (int l = 0; l < zk->nlanes; l++) if (!CS.ev_done[l]) ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&CS.ev_done[l], hipEventDisableTiming));
+    CS.as_xyzz.assign((size_t)B, 0);
     uint8_t* const h_pub = CS.h_out + 256ull * CS.cap;      // results land in pinned memory so that no copy blocks the enqueueing thread
     memcpy(CS.h_rs, rs, 64 * (size_t)B);                                     // the caller's rs is its own again when begin returns
     ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.d_rs, CS.h_rs, 64 * (size_t)B, hipMemcpyHostToDevice, st0));
@@ -519,21 +552,40 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         // job order of the G1 pass: the nb H jobs first (the 16-bit bucket sort wants the jobs with the larger bucket count in front), then
         // A, B1, C per proof.  zkc_finalize reads results[q] = H_q and results[nb + 3 q + {0, 1, 2}] = A_q, B1_q, C_q.
         for (int q = 0; q < nb; q++) j1.add(LN.d_p + 8 * (size_t)n * q, nullptr, n, zk->offH, n, 0, MSM_C_BIG);
+        // [r3] a pass of one or two proofs carries its blinding's two variable-base products as two more MSM jobs each -- sum (s w_i) A_i and sum (r w_i) B1_i over the
+        // wires that stay in the proof's MSMs -- so that the blinding kernel is left with fixed-base products only (zkc_finalize.hip)
+        const bool tree = zk->d_fb4 != nullptr && nb <= 2;
+        BlindArgs ba{}; ba.rs = CS.d_rs + 64 * (size_t)p0; ba.nv = nv;
         for (int q = 0; q < nb; q++) {
             const uint32_t* w = w0 + (size_t)q * nv * 8;
+            uint32_t* bs = tree ? LN.d_bs + (size_t)q * 2 * nv * 8 : nullptr;
+            if (tree) { ba.w[q] = w; ba.out[q] = bs; }
             if (fold) {
                 const zkc_zkey::Fold::VMap& vm = vms[q];
                 j1.add(w, vm.d + vm.offA, vm.nA, zk->offA, nv, 0, MSM_C_SMALL);
                 j1.add(w, vm.d + vm.offB, vm.nB, zk->offB1, nv, 0, MSM_C_SMALL);
                 j1.add(w, vm.d + vm.offC, vm.nC, zk->offC, nc, (int32_t)np + 1, MSM_C_SMALL);
+                if (tree) { j1.add(bs, vm.d + vm.offA, vm.nA, zk->offA, nv, 0, MSM_C_SMALL); j1.add(bs + 8ull * nv, vm.d + vm.offB, vm.nB, zk->offB1, nv, 0, MSM_C_SMALL); }
                 j2.add(w, vm.d + vm.offB, vm.nB, 0, nv, 0, MSM_C_SMALL);
+                if (tree) { ba.mapA[q] = vm.d + vm.offA; ba.nA[q] = vm.nA; ba.mapB[q] = vm.d + vm.offB; ba.nB[q] = vm.nB; }
             } else {
                 j1.add(w, nullptr, nv, zk->offA, nv, 0, MSM_C_SMALL);
                 j1.add(w, nullptr, nv, zk->offB1, nv, 0, MSM_C_SMALL);
                 j1.add(w + 8ull * (np + 1), nullptr, nc, zk->offC, nc, 0, MSM_C_SMALL);
+                if (tree) { j1.add(bs, nullptr, nv, zk->offA, nv, 0, MSM_C_SMALL); j1.add(bs + 8ull * nv, nullptr, nv, zk->offB1, nv, 0, MSM_C_SMALL); }
                 j2.add(w, nullptr, nv, 0, nv, 0, MSM_C_SMALL);
+                if (tree) { ba.mapA[q] = ba.mapB[q] = nullptr; ba.nA[q] = ba.nB[q] = nv; }
             }
         }
+        if (tree && (rc = blind_scalars_launch(ctx, st, ba, nb))) return rc;                  // on the G1 stream, ahead of its bucketing (the witness and (r, s) are there: ev_chunk)
+        // the blinding's arguments: piB of a small pass is written on the G2 stream right behind the G2 MSM, everything else on the blinding stream below
+        FinalizeArgs fa{};
+        fa.r1 = (const G1XYZZ*)LN.w1.results + (size_t)slot * LN.w1.max_jobs; fa.r2 = (const G2XYZZ*)LN.w2.results + (size_t)slot * LN.w2.max_jobs;
+        fa.foldA = zk->fold.d_foldA; fa.foldB1 = zk->fold.d_foldB1; fa.foldC = zk->fold.d_foldC; fa.foldB2 = zk->fold.d_foldB2; fa.fold_n = can_fold ? L.n : 0;
+        for (int q = 0; q < nb; q++) { fa.dc[q] = fold ? dcq[q] : (uint8_t)255; fa.ds[q] = fold ? dsq[q] : (uint8_t)255; }
+        fa.tblDelta1 = zk->d_tblDelta1; fa.tblAlpha1 = zk->d_tblAlpha1; fa.tblBeta1 = zk->d_tblBeta1; fa.tblDelta2 = zk->d_tblDelta2;
+        fa.alpha1 = zk->alpha1; fa.beta2 = zk->beta2; fa.rs = CS.d_rs + 64 * (size_t)p0; fa.out = CS.d_proofs + 256 * (size_t)p0; fa.scratch = LN.d_fin;
+        fa.per = tree ? 5 : 3; fa.fb4 = zk->d_fb4; fa.fb4g2 = zk->d_fb4g2; fa.out_xyzz = CS.d_xyzz + 512 * (size_t)p0;
         // The G2 MSM needs only the witness: by default it starts with the pass and runs beside buildABC/NTT/G1 sort.  ZKC_G2_LATE holds it back
         // until the G1 stream has finished its short kernels (they were seen to stall next to the G2 chain's low-occupancy kernels); the G2
         // kernels then starve behind the 13 ms G1 accumulation instead and spill into the next pass -- measured equal within noise.
@@ -541,7 +593,11 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         // [r2] its bucketing starts with the pass, but its accumulation (VALU-bound, 3.3 ms alone) is held until the G1 stream leaves the NTT: it then
         // runs beside the G1 bucketing and segment kernels, which wait on memory and LDS atomics, instead of beside the NTT, which is VALU-bound too
         static const bool g2_acc_with_sort = getenv("ZKC_G2_ACC_EARLY") == nullptr;
-        if (g2_early) { if ((rc = msm_pass_g2(zk, LN.w2, j2, slot, false, st2, g2_acc_with_sort ? LN.ev_ntt : nullptr))) return rc; ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_msm2, st2)); }
+        if (g2_early) {
+            if ((rc = msm_pass_g2(zk, LN.w2, j2, slot, false, st2, g2_acc_with_sort ? LN.ev_ntt : nullptr))) return rc;
+            if (tree && (rc = finalize_tree_g2_launch(ctx, st2, fa, nb))) return rc;
+            ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_msm2, st2));
+        }
         tr[3] = now_ms();
         if ((rc = msm_pass_g1(zk, LN.w1, j1, slot, false, st, LN.ev_sorted, LN.ev_acc))) return rc;
         zk->last_lane = pass % zk->nlanes;
@@ -549,6 +605,7 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         if (!g2_early) {
             ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st2, LN.ev_sorted, 0));
             if ((rc = msm_pass_g2(zk, LN.w2, j2, slot, false, st2))) return rc;
+            if (tree && (rc = finalize_tree_g2_launch(ctx, st2, fa, nb))) return rc;
             ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_msm2, st2));
         }
         if (want_publics)       // wires 1..nPublic of every witness, one strided copy
@@ -562,15 +619,12 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
             ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_mv, fin));
         }
         // a7 on the second stream: overlaps the next pass
-        FinalizeArgs fa{};
-        fa.r1 = (const G1XYZZ*)LN.w1.results + (size_t)slot * LN.w1.max_jobs; fa.r2 = (const G2XYZZ*)LN.w2.results + (size_t)slot * LN.w2.max_jobs;
-        fa.foldA = zk->fold.d_foldA; fa.foldB1 = zk->fold.d_foldB1; fa.foldC = zk->fold.d_foldC; fa.foldB2 = zk->fold.d_foldB2; fa.fold_n = can_fold ? L.n : 0;
-        for (int q = 0; q < nb; q++) { fa.dc[q] = fold ? dcq[q] : (uint8_t)255; fa.ds[q] = fold ? dsq[q] : (uint8_t)255; }
-        fa.tblDelta1 = zk->d_tblDelta1; fa.tblAlpha1 = zk->d_tblAlpha1; fa.tblBeta1 = zk->d_tblBeta1; fa.tblDelta2 = zk->d_tblDelta2;
-        fa.alpha1 = zk->alpha1; fa.beta2 = zk->beta2; fa.rs = CS.d_rs + 64 * (size_t)p0; fa.out = CS.d_proofs + 256 * (size_t)p0; fa.scratch = LN.d_fin;
-        ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm, 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm2, 0));
+        ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm, 0));
+        if (!tree) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm2, 0));      // a small pass' piB is written on the G2 stream: piA and piC need not wait for it ...
         if ((rc = finalize_launch(ctx, fin, fa, nb))) return rc;
-        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.h_out + 256ull * p0, CS.d_proofs + 256 * (size_t)p0, 256ull * nb, hipMemcpyDeviceToHost, fin));
+        if (tree) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm2, 0));       // ... only the copy of the finished proof does
+        if (tree) { ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.h_xyzz + 512ull * p0, CS.d_xyzz + 512 * (size_t)p0, 512ull * nb, hipMemcpyDeviceToHost, fin)); for (int q = 0; q < nb; q++) CS.as_xyzz[p0 + q] = 1; }
+        else ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.h_out + 256ull * p0, CS.d_proofs + 256 * (size_t)p0, 256ull * nb, hipMemcpyDeviceToHost, fin));
         ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_fin[slot], fin));
         tr[5] = now_ms();
         if (trace_host) fprintf(stderr, "[zkc host] pass %2d: start %8.2f | chunk wait %6.2f | h_evals %6.2f | g2 pass %6.2f | g1 pass %6.2f | blinding %6.2f ms\n", pass, tr[0] - t_begin,
@@ -592,6 +646,13 @@ int zkc::prove_batch_finish(zkc_zkey* zk, int cs, uint8_t* proofs, uint8_t* publ
     CS.pending = false;
     if (e != hipSuccess) { ZKC_LOCK(zk->ctx); return zkc_fail(zk->ctx, ZKC_ERR_HIP, std::string("prove_batch_finish: ") + hipGetErrorString(e)); }
     memcpy(proofs, CS.h_out, 256ull * CS.B);
+    // the proofs of a small pass (one or two proofs: a call of that size, or the stub at the end of a larger one) arrive as XYZZ and are divided here: three inversions,
+    // microseconds on a core, ~0.2 ms at the end of the device's chain
+    for (int q = 0; q < CS.B; q++) if (CS.as_xyzz[q]) {
+        const uint8_t* x = CS.h_xyzz + 512 * (size_t)q; uint8_t* o = proofs + 256 * (size_t)q;
+        G1XYZZ a, c; G2XYZZ b; memcpy(&a, x, 128); memcpy(&b, x + 128, 256); memcpy(&c, x + 384, 128);
+        g1_to_std(o, xyzz_to_affine_gcd(a)); g2_to_std(o + 64, xyzz_to_affine_gcd(b)); g1_to_std(o + 192, xyzz_to_affine_gcd(c));
+    }
     if (publics) memcpy(publics, CS.h_out + 256ull * CS.cap, 32ull * zk->nPub * CS.B);
     return ZKC_OK;
 }

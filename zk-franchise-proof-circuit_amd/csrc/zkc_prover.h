@@ -47,7 +47,14 @@ struct FinalizeArgs {
     G1Affine alpha1; G2Affine beta2;
     const uint8_t* rs; uint8_t* out;                    // device: nproofs x 64 (r || s) -> nproofs x 256 proof bytes
     void* scratch;                                      // finalize_scratch_bytes(nproofs) of device memory: products and window tables of the lane-per-product kernels (nullptr: one wave per task)
+    // [r3] passes of one or two proofs (zkc_finalize.hip, "no variable-base product at all"): per = 5 MSM results per proof instead of 3 (A, B1, C, sum (s w) A, sum (r w) B1)
+    // and 4-bit fixed-base tables of delta1, alpha1, beta1 and every folding constant of A and B1 (fb4), of delta2 (fb4g2)
+    int per; const G1XYZZ* fb4; const G2XYZZ* fb4g2;
+    uint8_t* out_xyzz;                                  // device: nproofs x 512 bytes, piA (G1XYZZ) | piB (G2XYZZ) | piC (G1XYZZ): the host makes them affine (prove_batch_finish)
 };
+constexpr int FB4_WIN = 64, FB4_ROW = 15;              // windows per base, multiples per window: T[base][w][d - 1] = d 16^w base
+// zkc_blind_scalars: per proof q of a small pass, out[q][0][idx] = s w[idx] over the A list and out[q][1][idx] = r w[idx] over the B list (nullptr list: every wire)
+struct BlindArgs { const uint32_t* w[2]; const uint32_t* mapA[2]; const uint32_t* mapB[2]; uint32_t nA[2], nB[2]; uint32_t* out[2]; const uint8_t* rs; uint32_t nv; };
 // The (digit, point) entries of a pass are bucketed JOB BY JOB (an entry never leaves its job's region [ent_off, ent_off + count nw) of the
 // value arrays), in two counting passes instead of a device-wide key sort: the job is implicit in the position, the key is never stored.
 //   entry word after level 1 :  sign(1) | low bucket bits (lbits) | table row relative to the job's table (31 - lbits bits)
@@ -137,6 +144,7 @@ struct zkc_lane {
     hipStream_t st = nullptr, st2 = nullptr, fin = nullptr;               // buildABC/NTT/G1 MSM ; G2 MSM ; blinding + D2H
     zkc::Fr *d_abc = nullptr, *d_t = nullptr; uint32_t* d_p = nullptr;   // [inflight][3n] x2 (d_t = NTT scratch), [inflight][n x 8]
     void* d_fin = nullptr;                                                // blinding scratch, finalize_scratch_bytes(inflight)
+    uint32_t* d_bs = nullptr;                                             // [2 proofs][2 sections][nVars x 8]: the blinded scalars of a small pass (zkc_blind_scalars)
     zkc::MsmWork w1, w2;                                                  // G1 and G2 pipelines
     hipEvent_t ev_msm = nullptr, ev_msm2 = nullptr, ev_sorted = nullptr, ev_ntt = nullptr, ev_mv = nullptr, ev_acc = nullptr, ev_fin[2] = {nullptr, nullptr}; int npass = 0;      // ev_acc: the G1 accumulation of the lane's latest pass is through      // ev_ntt: buildABC/NTT/joinABC of the pass are through      // ev_fin[slot]: blinding of the pass that used result slot `slot`
 };
@@ -165,12 +173,14 @@ struct zkc_zkey {
     zkc_lane lane[2]; int nlanes = 2; bool serial_streams = false;          // serial_streams: the lanes borrow ctx->stream (ZKC_SERIAL_STREAMS, measurement only)
     uint32_t *d_flags = nullptr, *h_flags = nullptr; size_t flags_cap = 0;  // fold check: [B][2][n]
     zkc::G1Affine *d_tblDelta1 = nullptr, *d_tblAlpha1 = nullptr, *d_tblBeta1 = nullptr; zkc::G2Affine* d_tblDelta2 = nullptr;
+    zkc::G1XYZZ* d_fb4 = nullptr; zkc::G2XYZZ* d_fb4g2 = nullptr; int fb4_bases = 0;   // 4-bit fixed-base tables of the small-pass blinding (FinalizeArgs::fb4)
     // per CALL state, two slots: a call is begin (everything enqueued, returns) + finish (wait, copy out), and the proving service lets the begin of the next
     // call run while the previous one drains (its witness kernels beside the other call's MSMs, its transforms beside the other's bucket reduction and blinding)
     struct CallSlot {
         uint8_t *d_rs = nullptr, *d_proofs = nullptr; size_t cap = 0;       // [B][64], [B][256]
         uint8_t* h_out = nullptr;                                           // pinned: [B][256] proofs then [B][nPub][32] public signals (async D2H target)
         uint8_t* h_rs = nullptr;                                            // pinned copy of the caller's (r, s): begin returns before the upload has executed
+        uint8_t *d_xyzz = nullptr, *h_xyzz = nullptr; std::vector<uint8_t> as_xyzz;     // [B][512]: a small pass (one or two proofs) hands its three points over as XYZZ; as_xyzz[q]: proof q is to be made affine by finish
         hipEvent_t ev_done[2] = {nullptr, nullptr};                         // per lane: recorded on its blinding stream behind the call's last copy
         int B = 0; bool pending = false;
     } call[2];
@@ -206,6 +216,9 @@ int msm_pass_g2(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool t
 int msm_bucket_entries(zkc_ctx* ctx, MsmWork& w, const MsmJobList& jl, hipStream_t st, unsigned long long* d_entry_counter = nullptr);
 int msm_build_segments(zkc_ctx* ctx, MsmWork& w, const MsmJobList& jl, uint32_t seg, size_t seg_bound, hipStream_t st);
 int finalize_launch(zkc_ctx* ctx, hipStream_t st, const FinalizeArgs& a, int nproofs);
+int finalize_tree_g2_launch(zkc_ctx* ctx, hipStream_t st, const FinalizeArgs& a, int nproofs);           // piB of a small pass, on the G2 stream
+int fb4_build(zkc_ctx* ctx, hipStream_t st, const G1XYZZ* d_bases, int nbases, G1XYZZ* d_out, const G2XYZZ& delta2, const G2XYZZ& beta2, const G2XYZZ& beta2_base, G2XYZZ* d_out2);   // d_out2: 64 x 15 + 2 points
+int blind_scalars_launch(zkc_ctx* ctx, hipStream_t st, const BlindArgs& a, int nproofs);
 // a batch call in two halves (zkc_prove.hip; the public zkc_[full]prove_batch_dev are begin + finish on slot 0): begin validates, enqueues every pass and returns
 // without waiting for the GPU; finish waits for that call and copies proofs / public signals out.  cs = call slot 0 / 1; a slot must be finished before it is
 // begun again; d_wtns (and d_inputs, d_status) stay the caller's until finish returns.  d_inputs == nullptr: the witnesses are given.
