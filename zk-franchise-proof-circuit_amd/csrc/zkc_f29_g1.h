@@ -116,4 +116,16 @@ ZKC_HD void f29_pt_add(Acc29& r, const Acc29& a, const Acc29& b) {
     for (int k = 0; k < 9; k++) { r.X[k] = X3[k]; r.Y[k] = Y3[k]; r.ZZ[k] = V[k]; r.ZZZ[k] = Q[k]; }
 }
 
+// sum over the lanes of a wave (every lane ends up with a representative of the sum)
+__device__ inline Acc29 wave_sum_g1(Acc29 p, int top = 32) {
+    for (int m = top; m >= 1; m >>= 1) {
+        Acc29 o;
+#pragma unroll
+        for (int k = 0; k < 9; k++) { o.X[k] = (uint32_t)__shfl_xor((int)p.X[k], m, 64); o.Y[k] = (uint32_t)__shfl_xor((int)p.Y[k], m, 64);
+                                      o.ZZ[k] = (uint32_t)__shfl_xor((int)p.ZZ[k], m, 64); o.ZZZ[k] = (uint32_t)__shfl_xor((int)p.ZZZ[k], m, 64); }
+        Acc29 r; f29_pt_add(r, p, o); p = r;
+    }
+    return p;
+}
+
 }  // namespace zkc

@@ -173,4 +173,20 @@ ZKC_HD void f29g2_pt_add(Acc29G2& r, const Acc29G2& a, const Acc29G2& b) {
     r.X = X3; r.Y = Y3; r.ZZ = W; r.ZZZ = Q;
 }
 
+// sum over the lanes of a wave by a butterfly of full additions, `top` = half the group width (32: the whole wave); every lane of a group ends up with a representative of the sum
+__device__ inline Acc29G2 wave_sum_g2(Acc29G2 p, int top) {
+    for (int m = top; m >= 1; m >>= 1) {
+        Acc29G2 o;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            o.X.c0[k] = (uint32_t)__shfl_xor((int)p.X.c0[k], m, 64); o.X.c1[k] = (uint32_t)__shfl_xor((int)p.X.c1[k], m, 64);
+            o.Y.c0[k] = (uint32_t)__shfl_xor((int)p.Y.c0[k], m, 64); o.Y.c1[k] = (uint32_t)__shfl_xor((int)p.Y.c1[k], m, 64);
+            o.ZZ.c0[k] = (uint32_t)__shfl_xor((int)p.ZZ.c0[k], m, 64); o.ZZ.c1[k] = (uint32_t)__shfl_xor((int)p.ZZ.c1[k], m, 64);
+            o.ZZZ.c0[k] = (uint32_t)__shfl_xor((int)p.ZZZ.c0[k], m, 64); o.ZZZ.c1[k] = (uint32_t)__shfl_xor((int)p.ZZZ.c1[k], m, 64);
+        }
+        Acc29G2 r; f29g2_pt_add(r, p, o); p = r;
+    }
+    return p;
+}
+
 }  // namespace zkc

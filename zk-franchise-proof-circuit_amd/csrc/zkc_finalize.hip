@@ -244,31 +244,6 @@ __device__ __forceinline__ uint32_t nibble_of(const uint32_t k[8], int i) {
 __device__ __forceinline__ void shfl_xor_words(uint32_t* dst, const uint32_t* src, int nwords, int mask) {
     for (int k = 0; k < nwords; k++) dst[k] = (uint32_t)__shfl_xor((int)src[k], mask, 64);
 }
-// sum over the lanes of a wave (every lane ends up with a representative of the sum)
-__device__ Acc29 wave_sum_g1(Acc29 p, int top = 32) {
-    for (int m = top; m >= 1; m >>= 1) {
-        Acc29 o;
-#pragma unroll
-        for (int k = 0; k < 9; k++) { o.X[k] = (uint32_t)__shfl_xor((int)p.X[k], m, 64); o.Y[k] = (uint32_t)__shfl_xor((int)p.Y[k], m, 64);
-                                      o.ZZ[k] = (uint32_t)__shfl_xor((int)p.ZZ[k], m, 64); o.ZZZ[k] = (uint32_t)__shfl_xor((int)p.ZZZ[k], m, 64); }
-        Acc29 r; f29_pt_add(r, p, o); p = r;
-    }
-    return p;
-}
-__device__ Acc29G2 wave_sum_g2(Acc29G2 p, int top) {
-    for (int m = top; m >= 1; m >>= 1) {
-        Acc29G2 o;
-#pragma unroll
-        for (int k = 0; k < 9; k++) {
-            o.X.c0[k] = (uint32_t)__shfl_xor((int)p.X.c0[k], m, 64); o.X.c1[k] = (uint32_t)__shfl_xor((int)p.X.c1[k], m, 64);
-            o.Y.c0[k] = (uint32_t)__shfl_xor((int)p.Y.c0[k], m, 64); o.Y.c1[k] = (uint32_t)__shfl_xor((int)p.Y.c1[k], m, 64);
-            o.ZZ.c0[k] = (uint32_t)__shfl_xor((int)p.ZZ.c0[k], m, 64); o.ZZ.c1[k] = (uint32_t)__shfl_xor((int)p.ZZ.c1[k], m, 64);
-            o.ZZZ.c0[k] = (uint32_t)__shfl_xor((int)p.ZZZ.c0[k], m, 64); o.ZZZ.c1[k] = (uint32_t)__shfl_xor((int)p.ZZZ.c1[k], m, 64);
-        }
-        Acc29G2 r; f29g2_pt_add(r, p, o); p = r;
-    }
-    return p;
-}
 __device__ __forceinline__ Acc29 load_pt29(const G1XYZZ& p) { Acc29 a; if (p.is_inf()) f29_pt_set_inf(a); else a = f29_pt_from_xyzz(p); return a; }
 __device__ __forceinline__ Acc29G2 load_pt29(const G2XYZZ& p) { Acc29G2 a; if (p.is_inf()) f29g2_pt_set_inf(a); else a = f29g2_pt_from_xyzz(p); return a; }
 // The three points of a small pass' proof leave the device as XYZZ (512 bytes: piA | piB | piC) and the host divides (prove_batch_finish): one field inversion is

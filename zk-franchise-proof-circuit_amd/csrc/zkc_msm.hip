@@ -184,6 +184,58 @@ zkc_msm_accumulate29_g2(const uint32_t* __restrict__ table29_all, const MsmJobLi
     partial[s] = out;
 }
 
+// ---- [r3] K5 for a SMALL G2 pass (one to four proofs): half a WAVE per bucket.  With a lane per segment of 16 entries a bucket of ~100 entries is 16 mixed additions in a row,
+// up to eight full ones in the window walk and a merge pass for the heavier buckets -- the longest link of a lone proof's G2 chain (0.9 of 1.7 ms).  Here 32 lanes stride over
+// the bucket's entries (three or four additions in a row for 100 entries) and a five-step butterfly sums them; 2048 buckets are 1024 waves, one per SIMD, one round.  No segment
+// lists.  A bucket of more than 128 entries (the wires that are 1: thousands of entries in digit 1 of the lowest window) is cut into up to `nslice` slices, a half-wave each
+// (grid.y), whose sums are the bucket's "segments": the merge kernel adds them when there are more than two.  What the window kernel reads: partial[b nslice + y], segoff[b] = b nslice,
+// segcnt[b] = slices in use.  A full pass (192 k buckets) keeps the lane-per-segment kernel: there every lane has work for the whole walk.
+__global__ void __launch_bounds__(64)
+zkc_msm_bucketwave_g2(const uint32_t* __restrict__ table29_all, const MsmJobList* __restrict__ jlp, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ off,
+                      const uint32_t* __restrict__ bcnt, uint32_t* __restrict__ segoff, uint32_t* __restrict__ segcnt, uint32_t* __restrict__ heavy, uint32_t* __restrict__ heavy_count,
+                      XYZZ<Fq2>* __restrict__ partial, uint32_t nbuckets, uint32_t nslice) {
+    const uint32_t half = threadIdx.x >> 5, lane = threadIdx.x & 31, y = blockIdx.y;
+    const uint32_t b = 2 * blockIdx.x + half;
+    const uint32_t cnt = b < nbuckets ? bcnt[b] : 0u;
+    uint32_t m = (cnt + 127) / 128; if (m > nslice) m = nslice;               // slices in use
+    if (b < nbuckets && y == 0 && lane == 0) {
+        segoff[b] = b * nslice; segcnt[b] = m;
+        if (m > 2) { const uint32_t h = atomicAdd(heavy_count, 1u); if (h < (uint32_t)MSM_MAX_HEAVY) heavy[h] = b; }
+    }
+    const uint32_t lo = y < m ? (uint32_t)(((uint64_t)cnt * y) / m) : 0u, hi = y < m ? (uint32_t)(((uint64_t)cnt * (y + 1)) / m) : 0u;
+    Acc29G2 acc; f29g2_pt_set_inf(acc); bool inf = true;
+    if (__ballot(hi > lo) == 0) return;                                      // neither bucket of this wave has a slice y
+    if (hi > lo) {
+        uint32_t bd, bj; jlp->decode(b, bd, bj);
+        const uint32_t* __restrict__ table29 = table29_all + (size_t)jlp->job[bj].tbl_off * G2T29_WORDS;
+        constexpr uint32_t rowmask = 0x7fffffffu;
+        const uint32_t start = off[b];
+        for (uint32_t e = lo + lane; e < hi; e += 32) {
+            const uint32_t v = vals[start + e];
+            const uint32_t* pp = table29 + (size_t)(v & rowmask) * G2T29_WORDS;
+            const G2Chunk cx = g2_chunk_load(pp), cy = g2_chunk_load(pp + ((v >> 31) ? 40 : 20));
+            if (cx.w[18]) continue;                        // base at infinity
+            F2x29 x2, y2;
+#pragma unroll
+            for (int k = 0; k < 9; k++) { x2.c0[k] = cx.w[k]; x2.c1[k] = cx.w[9 + k]; y2.c0[k] = cy.w[k]; y2.c1[k] = cy.w[9 + k]; }
+            bool same_y = false;
+            if (inf) {
+                acc.X = x2; acc.Y = y2;
+#pragma unroll
+                for (int k = 0; k < 9; k++) { acc.ZZ.c0[k] = acc.ZZZ.c0[k] = F29K<FqParams>::one.l[k]; acc.ZZ.c1[k] = acc.ZZZ.c1[k] = 0; }
+                inf = false;
+            } else if (!f29g2_madd(acc, x2, y2, same_y)) {
+                if (same_y) {                              // the lane holds this very point: double it (rare; generic code)
+                    Affine<Fq2> a; a.x = {f29_to_fp<FqParams>(x2.c0), f29_to_fp<FqParams>(x2.c1)}; a.y = {f29_to_fp<FqParams>(y2.c0), f29_to_fp<FqParams>(y2.c1)};
+                    acc = f29g2_pt_from_xyzz(xyzz_dbl_affine(a));
+                } else { f29g2_pt_set_inf(acc); inf = true; }  // P + (-P)
+            }
+        }
+    }
+    acc = wave_sum_g2(acc, 16);                            // over the 32 lanes of each half
+    if (lane == 0 && hi > lo) partial[(size_t)b * nslice + y] = f29g2_pt_is_inf(acc) ? XYZZ<Fq2>::inf() : f29g2_pt_to_xyzz(acc);
+}
+
 // buckets with many segments (repeated witness values; every bucket of a 2^20-point job) are summed by one wave each: lanes stride over
 // the segments, then a tree over the lanes in LDS; the result replaces the bucket's first segment.  Radix-2^29 coordinates, one traits
 // struct per group.
@@ -303,42 +355,46 @@ zkc_msm_window29_g2(const XYZZ<Fq2>* __restrict__ partial, const uint32_t* __res
     if (threadIdx.x == 0) wres[2 * win.out] = f29g2_pt_is_inf(sh[0]) ? XYZZ<Fq2>::inf() : f29g2_pt_to_xyzz(sh[0]);
 }
 // one workgroup per job: result = sum_k W_k + vw * sum_k k * S_k over the job's virtual windows k (digit = vw k + local index)
-template <class F, int NT>
-__global__ void __launch_bounds__(NT)
-zkc_msm_final(const XYZZ<F>* __restrict__ wres, const MsmJobList* __restrict__ jl, XYZZ<F>* __restrict__ results) {
-    extern __shared__ uint4 lds4[];
-    XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(lds4);
-    const int j = blockIdx.x; constexpr int nt = NT;                          // NT >= virtual windows of the largest job
+// the per-job sum for G1 in radix 2^29, up to MSM_MAX_VW_G1 virtual windows per job; the scans run over the job's own window count (rounded up to a power of two)
+__global__ void __launch_bounds__(MSM_MAX_VW_G1)
+zkc_msm_final29(const XYZZ<Fq>* __restrict__ wres, const MsmJobList* __restrict__ jl, XYZZ<Fq>* __restrict__ results) {
+    __shared__ Acc29 sh[MSM_MAX_VW_G1];
+    const int j = blockIdx.x;
     const uint32_t vw = jl->job[j].vw, nvw = (1u << (jl->job[j].c - 1)) / vw, w0 = jl->job[j].win_off;
-    XYZZ<F> Wk = XYZZ<F>::inf(), Sk = XYZZ<F>::inf();
-    if (threadIdx.x < nvw) { Wk = wres[2 * (w0 + threadIdx.x)]; Sk = wres[2 * (w0 + threadIdx.x) + 1]; }
+    int nt = 1; while ((uint32_t)nt < nvw) nt <<= 1;                       // uniform over the workgroup
+    Acc29 Wk, Sk; f29_pt_set_inf(Wk); f29_pt_set_inf(Sk);
+    if (threadIdx.x < nvw) {
+        const XYZZ<Fq> a = wres[2 * (w0 + threadIdx.x)], b = wres[2 * (w0 + threadIdx.x) + 1];
+        if (!a.is_inf()) Wk = f29_pt_from_xyzz(a);
+        if (!b.is_inf()) Sk = f29_pt_from_xyzz(b);
+    }
     sh[threadIdx.x] = Sk; __syncthreads();
     for (int o = 1; o < nt; o <<= 1) {                                     // suffix sums of S over k
-        XYZZ<F> v = XYZZ<F>::inf();
+        Acc29 v; f29_pt_set_inf(v);
         if ((int)threadIdx.x + o < nt) v = sh[threadIdx.x + o];
         __syncthreads();
-        if ((int)threadIdx.x + o < nt) sh[threadIdx.x] = xyzz_add(sh[threadIdx.x], v);
+        if ((int)threadIdx.x + o < nt) { Acc29 t = sh[threadIdx.x]; f29_pt_add(t, t, v); sh[threadIdx.x] = t; }
         __syncthreads();
     }
-    XYZZ<F> y = XYZZ<F>::inf();
-    if (threadIdx.x >= 1) { y = sh[threadIdx.x]; for (uint32_t k = vw; k > 1; k >>= 1) y = xyzz_dbl(y); }   // sum_{k>=1} R_k = sum_k k S_k, times vw
-    y = xyzz_add(y, Wk);
+    Acc29 y; f29_pt_set_inf(y);
+    if (threadIdx.x >= 1 && (int)threadIdx.x < nt) { y = sh[threadIdx.x]; if (!f29_pt_is_inf(y)) for (uint32_t k = vw; k > 1; k >>= 1) f29_pt_dbl(y, y); }   // sum_{k>=1} R_k = sum_k k S_k, times vw
+    f29_pt_add(y, y, Wk);
     __syncthreads();
     sh[threadIdx.x] = y; __syncthreads();
     for (int st = nt / 2; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) sh[threadIdx.x] = xyzz_add(sh[threadIdx.x], sh[threadIdx.x + st]);
+        if ((int)threadIdx.x < st) { Acc29 t = sh[threadIdx.x]; f29_pt_add(t, t, sh[threadIdx.x + st]); sh[threadIdx.x] = t; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) results[j] = sh[0];
+    if (threadIdx.x == 0) results[j] = f29_pt_is_inf(sh[0]) ? XYZZ<Fq>::inf() : f29_pt_to_xyzz(sh[0]);
 }
 
 // the per-job sum for G2 in radix 2^29 (same scheme as zkc_msm_final)
 __global__ void __launch_bounds__(MSM_MAX_VW_PER_JOB)
 zkc_msm_final29_g2(const XYZZ<Fq2>* __restrict__ wres, const MsmJobList* __restrict__ jl, XYZZ<Fq2>* __restrict__ results) {
     __shared__ Acc29G2 sh[MSM_MAX_VW_PER_JOB];
-    constexpr int nt = MSM_MAX_VW_PER_JOB;
     const int j = blockIdx.x;
     const uint32_t vw = jl->job[j].vw, nvw = (1u << (jl->job[j].c - 1)) / vw, w0 = jl->job[j].win_off;
+    int nt = 1; while ((uint32_t)nt < nvw) nt <<= 1;                       // uniform over the workgroup: the scans run over the job's own window count
     Acc29G2 Wk, Sk; f29g2_pt_set_inf(Wk); f29g2_pt_set_inf(Sk);
     if (threadIdx.x < nvw) {
         const XYZZ<Fq2> a = wres[2 * (w0 + threadIdx.x)], b = wres[2 * (w0 + threadIdx.x) + 1];
@@ -354,7 +410,7 @@ zkc_msm_final29_g2(const XYZZ<Fq2>* __restrict__ wres, const MsmJobList* __restr
         __syncthreads();
     }
     Acc29G2 y; f29g2_pt_set_inf(y);
-    if (threadIdx.x >= 1) { y = sh[threadIdx.x]; if (!f29g2_pt_is_inf(y)) for (uint32_t k = vw; k > 1; k >>= 1) f29g2_pt_dbl(y, y); }
+    if (threadIdx.x >= 1 && (int)threadIdx.x < nt) { y = sh[threadIdx.x]; if (!f29g2_pt_is_inf(y)) for (uint32_t k = vw; k > 1; k >>= 1) f29g2_pt_dbl(y, y); }
     f29g2_pt_add(y, y, Wk);
     __syncthreads();
     sh[threadIdx.x] = y; __syncthreads();
@@ -521,6 +577,9 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     // serially, so a small pass (one proof) wants short ones: aim at ~2 waves per SIMD
     const uint32_t seg = (uint32_t)std::min<size_t>(MSM_SEG, std::max<size_t>(MSM_SEG_MIN, total / 131072));
     constexpr bool kG2 = sizeof(F) == sizeof(Fq2);
+    static const bool bw_off = [] { const char* e = getenv("ZKC_G2_BUCKET_WAVE"); return e && atoi(e) == 0; }();
+    const uint32_t bw_slices = (uint32_t)std::min<size_t>(32, w.max_segments / std::max<uint32_t>(nb, 1u));      // slices a heavy bucket may be cut into: nb x slices partial sums must fit
+    const bool bucket_wave = kG2 && !bw_off && nb <= 8192 && bw_slices >= 1;         // a small G2 pass: half a wave per bucket (zkc_msm_bucketwave_g2), no segment lists
     uint64_t alg_bytes = 0; uint32_t maxcount = 0;
     uint64_t streamed_bytes = 0;
     for (int j = 0; j < nj; j++) {
@@ -548,7 +607,7 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
         unsigned long long* ectr = (!kG2 && ((ctx->prof.mask >> ZKC_PROF_MSM_ACC_G1) & 1)) ? ctx->d_prof_entries : nullptr;      // profiling: real G1 additions of the pass
         int rc = msm_bucket_entries(ctx, w, jl, st, ectr); if (rc) return rc;                  // K4: digits -> entries grouped by bucket (vals2, off, bcnt)
         if (g_debug_sync) { hipError_t _e = hipStreamSynchronize(st); fprintf(stderr, "[zkc] bucket entries: %s\n", hipGetErrorString(_e)); }
-        rc = msm_build_segments(ctx, w, jl, seg, seg_bound, st); if (rc) return rc;      // segments of <= seg entries, longest first
+        if (!bucket_wave) { rc = msm_build_segments(ctx, w, jl, seg, seg_bound, st); if (rc) return rc; }      // segments of <= seg entries, longest first
         if (g_debug_sync) { hipError_t _e = hipStreamSynchronize(st); fprintf(stderr, "[zkc] segments: %s\n", hipGetErrorString(_e)); }
         if (ev_sorted) ZKC_HIP_CHECK(ctx, hipEventRecord(ev_sorted, st));          // the short kernels of this pass are through: what follows is long-running
     }
@@ -559,10 +618,16 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     {
         zkc_prof_scope _ps(ctx, kG2 ? ZKC_PROF_MSM_ACC_G2 : ZKC_PROF_MSM_ACC_G1, alg_bytes, st);
         if (!kG2 && ((ctx->prof.mask >> ZKC_PROF_MSM_ACC_G1) & 1)) ctx->prof.bytes[ZKC_PROF_MSM_G1_STREAMED] += streamed_bytes;
-        if constexpr (kG2)
+        if constexpr (kG2) {
+          if (bucket_wave) {
+            ZKC_HIP_CHECK(ctx, hipMemsetAsync(w.heavy + MSM_MAX_HEAVY, 0, 4, st));
+            hipLaunchKernelGGL(zkc_msm_bucketwave_g2, dim3((nb + 1) / 2, bw_slices), dim3(64), 0, st, zk->d_g2_29, (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.bcnt, w.segoff, w.segcnt, w.heavy,
+                               w.heavy + MSM_MAX_HEAVY, reinterpret_cast<XYZZ<Fq2>*>(partial), nb, bw_slices);
+          }
+          else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate29_g2<1>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
                                zk->d_g2_29, (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.bcnt, w.segoff, w.seg2bucket, w.perm, nb, reinterpret_cast<XYZZ<Fq2>*>(partial), (uint32_t)w.max_segments);
-        else      // G1: same layout, field type with the inlined product.  160 VGPRs = 3 waves per SIMD; capped at 128 (4 waves) the accumulator spills and the kernel is 3.6x slower
+        } else    // G1: same layout, field type with the inlined product.  160 VGPRs = 3 waves per SIMD; capped at 128 (4 waves) the accumulator spills and the kernel is 3.6x slower
             hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate29<2>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
                                reinterpret_cast<const Affine<Fq>*>(table), (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.bcnt, w.segoff, w.seg2bucket, w.perm, nb,
                                reinterpret_cast<XYZZ<Fq>*>(partial), (uint32_t)w.max_segments);
@@ -571,10 +636,10 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     }
     {
         zkc_prof_scope _pr(ctx, ZKC_PROF_MSM_REDUCE, 0, st);
-        if constexpr (kG2)
+        if constexpr (kG2) {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_merge29<Merge29G2>), dim3(1024), dim3(64), 0, st, reinterpret_cast<XYZZ<Fq2>*>(partial), w.segoff, w.segcnt, w.heavy,
                                w.heavy + MSM_MAX_HEAVY, (uint32_t)w.max_segments);
-        else
+        } else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_merge29<Merge29G1>), dim3(1024), dim3(64), 0, st, reinterpret_cast<XYZZ<Fq>*>(partial), w.segoff, w.segcnt, w.heavy,
                                w.heavy + MSM_MAX_HEAVY, (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_merge");
@@ -585,13 +650,13 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
             hipLaunchKernelGGL(zkc_msm_window29, dim3(jl.total_windows), dim3(64), 0, st, reinterpret_cast<const XYZZ<Fq>*>(partial), w.segoff, w.segcnt,
                                (const MsmWindow*)w.d_windows, reinterpret_cast<XYZZ<Fq>*>(wres), (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_window");
-        static_assert(msm_half(MSM_C_BIG) / msm_vw(MSM_C_BIG) <= MSM_MAX_VW_PER_JOB && msm_half(MSM_C_SMALL) / msm_vw(MSM_C_SMALL) <= MSM_MAX_VW_PER_JOB, "final kernel: one lane per virtual window");
+        static_assert(msm_half(MSM_C_SMALL) / MSM_VW_MIN <= MSM_MAX_VW_PER_JOB, "G2 per-job sum: one lane per virtual window");
+        for (int j = 0; j < nj; j++) if ((1u << (jl.job[j].c - 1)) / jl.job[j].vw > (uint32_t)(kG2 ? MSM_MAX_VW_PER_JOB : MSM_MAX_VW_G1)) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: too many virtual windows in a job for the per-job sum");
         if constexpr (kG2)
             hipLaunchKernelGGL(zkc_msm_final29_g2, dim3(nj), dim3(MSM_MAX_VW_PER_JOB), 0, st, reinterpret_cast<const XYZZ<Fq2>*>(wres), (const MsmJobList*)w.d_jobs,
                                reinterpret_cast<XYZZ<Fq2>*>(results));
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_final<F, MSM_MAX_VW_PER_JOB>), dim3(nj), dim3(MSM_MAX_VW_PER_JOB), MSM_MAX_VW_PER_JOB * sizeof(XYZZ<F>), st, wres,
-                               (const MsmJobList*)w.d_jobs, results);
+            hipLaunchKernelGGL(zkc_msm_final29, dim3(nj), dim3(MSM_MAX_VW_G1), 0, st, reinterpret_cast<const XYZZ<Fq>*>(wres), (const MsmJobList*)w.d_jobs, reinterpret_cast<XYZZ<Fq>*>(results));
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_final");
     }
     if (to_host) ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.h_results, results, (size_t)nj * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));

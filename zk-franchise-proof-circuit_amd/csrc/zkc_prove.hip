@@ -547,8 +547,8 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_ntt, st));
         tr[2] = now_ms();
         static thread_local MsmJobList j1, j2;     // 6 KB each: kept off the stack frame of a C-ABI entry point
-        const uint32_t vws = nb <= 4 ? 64u : 256u;          // few proofs in the pass: favour latency in the bucket reduction
-        j1.clear(vws); j2.clear(vws);
+        const uint32_t vws = nb <= 4 ? 64u : 256u, vwb = nb <= 4 ? 256u : 1024u;          // few proofs in the pass: favour latency in the bucket reduction
+        j1.clear(vws, vwb); j2.clear(vws);
         // job order of the G1 pass: the nb H jobs first (the 16-bit bucket sort wants the jobs with the larger bucket count in front), then
         // A, B1, C per proof.  zkc_finalize reads results[q] = H_q and results[nb + 3 q + {0, 1, 2}] = A_q, B1_q, C_q.
         for (int q = 0; q < nb; q++) j1.add(LN.d_p + 8 * (size_t)n * q, nullptr, n, zk->offH, n, 0, MSM_C_BIG);

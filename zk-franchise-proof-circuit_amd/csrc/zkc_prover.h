@@ -13,9 +13,10 @@ constexpr int MSM_C_BIG = 17, MSM_C_SMALL = 12;
 constexpr int msm_nw(int c) { return (254 + c) / c; }          // 17 -> 15 windows (255 bits), 12 -> 22 windows (264 bits)
 constexpr int msm_half(int c) { return 1 << (c - 1); }         // buckets per job
 // buckets per workgroup of the reduction ("virtual window"): 1024 for H (64 waves per job; 512: 1496, 1024: 1548, 2048: 1505 proofs/s),
-// 256 for the witness sections (16 waves per job instead of 4: their reduction is a latency chain, not a throughput problem)
-constexpr int msm_vw(int c) { return c >= 16 ? 1024 : 256; }
+// 256 for the witness sections (16 waves per job instead of 4: their reduction is a latency chain, not a throughput problem); passes of a few proofs take 256 and 64
+// (MsmJobList::vw_big / vw_small)
 constexpr int MSM_VW_MIN = 64, MSM_MAX_VW_PER_JOB = 64;
+constexpr int MSM_MAX_VW_G1 = 256;                 // virtual windows per G1 job the per-job sum takes (zkc_msm_final29): H with windows of 256 buckets in a small pass
 constexpr int MSM_SEG_MIN = 16;                    // ... down to this for small passes (latency of a single proof)
 constexpr int MSM_SEG = 128;                       // sorted entries per accumulation lane; with length-sorted waves (same box): 32 -> 2200, 40 -> 2222, 64 -> 2270, 128 -> 2297, 256 -> 2274, 512 -> 2220 proofs/s
 constexpr int MSM_MERGE_T = 8;                     // buckets with more segments get a wave of their own before the window pass
@@ -66,14 +67,15 @@ struct MsmJobList {
     MsmJob job[MSM_MAX_JOBS]; int njobs; uint32_t total_buckets, total_entries, total_windows, total_bins, total_tiles, total_tilecnt;
     uint32_t hs, hb, nbig;                              // set by finish(): bucket counts of the small / big jobs, number of big jobs (they come first)
     uint32_t hbits_big, hbits_small;                    // level-1 bin bits of the two job classes when uniform inside each class (else 0xff: search)
+    uint32_t vw_big = 1024;                             // virtual window of the c >= 16 jobs (H): 1024 for throughput, 256 for a pass of a few proofs -- a lane then walks 4 buckets in a row instead of 16 (zkc_msm_window29), for four times the windows in the per-job sum
     uint32_t vw_small = 256;                            // virtual window of the c < 16 jobs: 256 for throughput, 64 for the latency of a small pass (same box: 256 -> 2431 proofs/s, 4.9 ms ; 128 -> 2375, 4.0 ms ; 64 -> 2304, 3.9 ms single prove)
     void add(const uint32_t* scalars, const uint32_t* vmap, uint32_t count, uint32_t tbl_off, uint32_t tbl_count, int32_t pt_shift, int c) {
         MsmJob& j = job[njobs++];
-        const uint32_t vw = c >= 16 ? (uint32_t)msm_vw(c) : vw_small;
+        const uint32_t vw = c >= 16 ? vw_big : vw_small;
         j = MsmJob{scalars, vmap, count, tbl_off, tbl_count, pt_shift, (uint32_t)c, (uint32_t)msm_nw(c), vw, total_entries, total_windows, 0, 0, 0, 0, 0, 0};
         total_entries += count * (uint32_t)msm_nw(c); total_windows += (uint32_t)msm_half(c) / vw;
     }
-    void clear(uint32_t vw_small_jobs = 256) { vw_small = vw_small_jobs; njobs = 0; total_buckets = total_entries = total_windows = total_bins = total_tiles = total_tilecnt = 0; hs = hb = nbig = 0; }
+    void clear(uint32_t vw_small_jobs = 256, uint32_t vw_big_jobs = 1024) { vw_small = vw_small_jobs; vw_big = vw_big_jobs; njobs = 0; total_buckets = total_entries = total_windows = total_bins = total_tiles = total_tilecnt = 0; hs = hb = nbig = 0; }
     // false: more than two distinct window sizes, big jobs not in front, or a table too large for the row field of the level-1 entry word
     bool finish() {
         hs = 0xffffffffu; hb = 0;
