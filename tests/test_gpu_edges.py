@@ -141,3 +141,41 @@ def test_split_batch_calls_overlap_and_match_the_synchronous_call(env):
     rc, w = ol.witness(voters[3], nl)
     rc2, op, ou = ol.prove(zk, w, int.from_bytes(rs[64 * 3:64 * 3 + 32], 'little'), int.from_bytes(rs[64 * 3 + 32:64 * 4], 'little'))
     assert rc == 0 and rc2 == 0 and sync[1][0][256 * 3:256 * 4] == op
+
+
+def test_small_pass_blinding_without_variable_base_products_matches_the_general_one(env):
+    """Passes of one or two proofs take their own blinding (zkc_finalize.hip: two more MSM jobs, 4-bit fixed-base tables summed by a butterfly over the lanes, division on the
+    host); ZKC_BLIND_TREE=0 at key load selects the general kernels.  Same bytes for one and two proofs, for this
+    build's witnesses (folded) and a foreign one (not folded), for (r, s) = (0, 0), small and full-size, and for the stub pass at the end of a larger call."""
+    zkc, ctx, pk, zk, vk, nl = env
+    import torch, numpy as np
+    from census_gen import random_voter
+    rng = random.Random(8)
+    nW = ctx.n_wires(nl)
+    voters = [random_voter(rng, ol.poseidon, nLevels=nl, depth_c=rng.randrange(0, nl + 1), depth_s=rng.randrange(0, nl + 1)) for _ in range(5)]
+    ws, st = ctx.witness(voters, nLevels=nl)
+    assert st == [0] * 5
+    foreign = b''.join([(1).to_bytes(32, 'little')] + [rng.randrange(ol.R).to_bytes(32, 'little') for _ in range(nW - 1)])      # not a witness of the circuit: proved all the same, nothing folded
+    cases = [([ws[0]], [(0, 0)]), ([ws[0], ws[1]], [(1, 2), (ol.R - 1, ol.R - 2)]), ([bytes(foreign)], [(rng.randrange(ol.R), rng.randrange(ol.R))]),
+             ([bytes(foreign), ws[2]], [(5, 0), (0, 7)]), (list(ws), [(rng.randrange(ol.R), rng.randrange(ol.R)) for _ in range(5)])]
+    old = {k: os.environ.get(k) for k in ('ZKC_BLIND_TREE', 'ZKC_INFLIGHT')}
+    try:
+        os.environ['ZKC_BLIND_TREE'] = '0'
+        pk_general = zkc.ProvingKey(ctx, zk)
+        os.environ.pop('ZKC_BLIND_TREE'); os.environ['ZKC_INFLIGHT'] = '2'          # five proofs = passes of 2, 2 and a stub of 1, every one of them a small pass
+        pk_stub = zkc.ProvingKey(ctx, zk)
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    try:
+        for wl, rsl in cases:
+            rs = b''.join(r.to_bytes(32, 'little') + s.to_bytes(32, 'little') for r, s in rsl)
+            d_w = torch.from_numpy(np.frombuffer(b''.join(wl), dtype=np.uint8).copy()).cuda()
+            got = pk.prove_batch_dev(d_w.data_ptr(), len(wl), rs)
+            assert got == pk_general.prove_batch_dev(d_w.data_ptr(), len(wl), rs) == pk_stub.prove_batch_dev(d_w.data_ptr(), len(wl), rs), (len(wl), rsl)
+        rc, op, ou = ol.prove(zk, ws[0], 0, 0)
+        d_w = torch.from_numpy(np.frombuffer(ws[0], dtype=np.uint8).copy()).cuda()
+        assert rc == 0 and pk.prove_batch_dev(d_w.data_ptr(), 1, bytes(64))[0] == op
+    finally:
+        pk_general.close(); pk_stub.close()

@@ -1,0 +1,18 @@
+"""Host arithmetic that finishes a proof: the binary-Euclid inversion (csrc/zkc_field.h fp_inv_gcd, csrc/zkc_curve.h xyzz_to_affine_gcd) with which prove_batch_finish makes the
+three points of a small pass affine, against the square-and-multiply inversion everything else uses.  Built with hipcc (the headers are HIP host + device code), run on the CPU."""
+import os, shutil, subprocess
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_gcd_inversion_equals_fermat_inversion(tmp_path):
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc on this box')
+    exe = str(tmp_path / 'field_inv')
+    b = subprocess.run([hipcc, '--offload-arch=gfx950', '-std=c++17', '-O2', '-Wno-unused-result', '-I', os.path.join(ROOT, 'zk-franchise-proof-circuit_amd', 'csrc'), '-I', os.path.join(ROOT, 'include'),
+                        os.path.join(ROOT, 'tests', 'host', 'field_inv.hip'), '-o', exe], capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'field inversions: ok' in r.stdout, (r.stdout + r.stderr)[-2000:]

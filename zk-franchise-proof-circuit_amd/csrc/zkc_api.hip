@@ -145,6 +145,21 @@ extern "C" int zkc_ctx_create(int device, zkc_ctx** out) {
         if ((e = hipMalloc(&ctx->d_ptab29_mem, l29.size() * 4)) != hipSuccess) return fail(e, "hipMalloc(poseidon29)");
         if ((e = hipMemcpy(ctx->d_ptab29_mem, l29.data(), l29.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(poseidon29)");
         ctx->ptab.base = base; ctx->ptab.base29 = (const uint32_t*)ctx->d_ptab29_mem;
+        // K29 (PoseidonTable): per partial round of t = 3, 4 the products S_r[.] * C[5 t + r], canonical
+        std::vector<uint32_t> k29; size_t koff[2];
+        for (int t = 3; t <= 4; t++) {
+            koff[t - 3] = k29.size();
+            const int RP = t == 3 ? 57 : 56; const size_t oC = off[(t - 3) * 4 + 0], oS = off[(t - 3) * 4 + 1];
+            for (int r = 0; r < RP; r++) for (int k = 0; k < t; k++) {
+                const size_t si = oS + (size_t)(2 * t - 1) * r + (k ? t + k - 1 : 0), ci = oC + 5 * t + r;
+                const Fr prod = all[si] * all[ci];
+                uint32_t t9[9], o9[12] = {0}; f29_from_fp_shl5(t9, prod.v); f29_mul<FrParams>(o9, t9, F29K<FrParams>::one.l); f29_reduce_small<FrParams>(o9);
+                k29.insert(k29.end(), o9, o9 + 12);
+            }
+        }
+        if ((e = hipMalloc(&ctx->d_pk29_mem, k29.size() * 4)) != hipSuccess) return fail(e, "hipMalloc(poseidon K29)");
+        if ((e = hipMemcpy(ctx->d_pk29_mem, k29.data(), k29.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(poseidon K29)");
+        for (int t = 3; t <= 4; t++) ctx->ptab.K29[t] = (const uint32_t*)ctx->d_pk29_mem + koff[t - 3];
     }
     for (int t = 3; t <= 5; t++) {
         ctx->ptab.C[t] = base + off[(t - 3) * 4 + 0]; ctx->ptab.S[t] = base + off[(t - 3) * 4 + 1];
@@ -163,6 +178,7 @@ extern "C" void zkc_ctx_destroy(zkc_ctx* ctx) {
     for (auto& kv : ctx->ntt_tw) { if (kv.second.fwd) (void)hipFree(kv.second.fwd); if (kv.second.inv) (void)hipFree(kv.second.inv); if (kv.second.ninv) (void)hipFree(kv.second.ninv); }
     if (ctx->d_ptab_mem) (void)hipFree(ctx->d_ptab_mem);
     if (ctx->d_ptab29_mem) (void)hipFree(ctx->d_ptab29_mem);
+    if (ctx->d_pk29_mem) (void)hipFree(ctx->d_pk29_mem);
     if (ctx->d_scratch_in) (void)hipFree(ctx->d_scratch_in);
     if (ctx->d_scratch_out) (void)hipFree(ctx->d_scratch_out);
     if (ctx->d_status3) (void)hipFree(ctx->d_status3);

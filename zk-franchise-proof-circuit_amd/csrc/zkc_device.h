@@ -8,6 +8,7 @@ namespace zkc {
 struct PoseidonTable {           // device pointers, Montgomery form; index = t (3,4,5)
     const Fr* C[6]; const Fr* S[6]; const Fr* M[6]; const Fr* P[6];
     const Fr* base; const uint32_t* base29;      // the same constants as 12-word entries (nine 29-bit limbs, R' form, below 1.2 p): entry k <-> base[k]
+    const uint32_t* K29[6];                      // t = 3, 4: K29[t][r t + k] = S_r[k ? t + k - 1 : 0] * C[5 t + r], 12-word entries below p: the round constant of word 0 already multiplied into the sparse-mix row and column of partial round r (zkc_witness.hip, poseidon_wave29)
 };
 
 // Wire layout of ZkFranchiseProofCircuit(nL) as circom 2.1.5 -O2 numbered it (DESIGN.md "witness layout").

@@ -34,6 +34,7 @@ struct zkc_ctx {
     zkc::PoseidonTable ptab{};            // device pointers
     void* d_ptab_mem = nullptr;
     void* d_ptab29_mem = nullptr;         // the Poseidon constants again as radix-2^29 limbs (witness chains)
+    void* d_pk29_mem = nullptr;           // PoseidonTable::K29
     std::map<int, uint32_t*> tmpl;        // nLevels -> device template witness (nWires x 8 u32)
     struct TwiddleSet { uint32_t *fwd = nullptr, *inv = nullptr; void* ninv = nullptr; };
     std::map<int, TwiddleSet> ntt_tw;     // log n -> twiddles of the stand-alone NTT entry point (zkc_ntt_dev); freed with the context

@@ -324,8 +324,8 @@ static int fold_prepare(zkc_zkey* zk) {
 // 4-bit fixed-base tables of everything the blinding of a small pass multiplies by r or s (zkc_finalize.hip): delta1, alpha1, beta1, and -- with folding -- alpha1 and beta1
 // plus the base constants of A and B1 and the per-depth suffix constants of both trees.  960 points per base: 80 MB at nLevels = 160, built on the device in about a millisecond.
 static int fb4_prepare(zkc_zkey* zk) {
-    static const bool off = [] { const char* e = getenv("ZKC_BLIND_TREE"); return e && atoi(e) == 0; }();
-    if (off || zk->d_fb4) return ZKC_OK;
+    const char* e_off = getenv("ZKC_BLIND_TREE");                      // = 0 at key load: this key's small passes take the general blinding kernels (A/B, tests)
+    if ((e_off && atoi(e_off) == 0) || zk->d_fb4) return ZKC_OK;
     zkc_ctx* ctx = zk->ctx;
     std::vector<G1XYZZ> bases = {G1XYZZ::from_affine(zk->delta1), G1XYZZ::from_affine(zk->alpha1), G1XYZZ::from_affine(zk->beta1)};
     const auto& f = zk->fold;
@@ -543,8 +543,13 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         const bool mv_prefetch = mv_prefetch_env && zk->nlanes == 1;
         const bool mv_done = mv_prefetch && pass > 0;
         if (mv_done) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, LN.ev_mv, 0));
-        if ((rc = h_evals_dev(zk, LN, w0, nb, !mv_done))) return rc;
-        ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_ntt, st));
+        // a pass of a few proofs is a latency chain and its G2 side is the longer one: its kernels are enqueued FIRST (ahead of the dozen launches of buildABC and the
+        // transforms, ~5 us of host time each) and its accumulation does not wait for the transforms
+        const bool small = nb <= 4;
+        if (!small) {
+            if ((rc = h_evals_dev(zk, LN, w0, nb, !mv_done))) return rc;
+            ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_ntt, st));
+        }
         tr[2] = now_ms();
         static thread_local MsmJobList j1, j2;     // 6 KB each: kept off the stack frame of a C-ABI entry point
         const uint32_t vws = nb <= 4 ? 64u : 256u, vwb = nb <= 4 ? 256u : 1024u;          // few proofs in the pass: favour latency in the bucket reduction
@@ -594,9 +599,13 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         // runs beside the G1 bucketing and segment kernels, which wait on memory and LDS atomics, instead of beside the NTT, which is VALU-bound too
         static const bool g2_acc_with_sort = getenv("ZKC_G2_ACC_EARLY") == nullptr;
         if (g2_early) {
-            if ((rc = msm_pass_g2(zk, LN.w2, j2, slot, false, st2, g2_acc_with_sort ? LN.ev_ntt : nullptr))) return rc;
+            if ((rc = msm_pass_g2(zk, LN.w2, j2, slot, false, st2, g2_acc_with_sort && !small ? LN.ev_ntt : nullptr))) return rc;
             if (tree && (rc = finalize_tree_g2_launch(ctx, st2, fa, nb))) return rc;
             ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_msm2, st2));
+        }
+        if (small) {
+            if ((rc = h_evals_dev(zk, LN, w0, nb, !mv_done))) return rc;
+            ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_ntt, st));
         }
         tr[3] = now_ms();
         if ((rc = msm_pass_g1(zk, LN.w1, j1, slot, false, st, LN.ev_sorted, LN.ev_acc))) return rc;

@@ -257,31 +257,48 @@ __device__ Fr poseidon_wave29(const Fr* in, unsigned cmask, const PoseidonTable&
     W29 E1, E2, E3;
 #pragma unroll
     for (int k = 0; k < 9; k++) E1.l[k] = E2.l[k] = E3.l[k] = 0;
-    const int role = lane < 2 * T - 1 ? lane : 0;          // which product of the sparse mix this lane computes
+    // [r3] partial rounds, three products per round instead of four.  With x = word 0 and c its round constant the round needs
+    //   new word 0 = S[0] (x^5 + c) + sum_j S[j] word_j ,   new word i = word_i + S[T + i - 1] (x^5 + c)
+    // and every lane runs the same three products on its own operands (a wave has ONE instruction stream, so what counts is the number of products in a row):
+    //   A: lanes >= 2T-1: x x (= in2) | lane 0: S[0] x | lanes 1..T-1: S[j] word_j | lanes T..2T-2: S[T+i-1] x
+    //   B: the square of A: in4 in the lanes >= 2T-1, gathered from lane 63
+    //   C: A in4 + h with h = S[.] c (table K29) in lane 0 and S[.] c + word_i in lanes T..2T-2: the new word-0 term and the new words 1..T-1
+    // instead of x^2, x^4, x^5 and then one product per lane: 162 + 126 + 162 multiply-adds instead of 126 + 126 + 162 + 162.  The three trace values of
+    // round r are parked in lane 2T-1+r (in2 only exists in those lanes) and stored once after the last round.
+    constexpr int CH0 = 2 * T - 1;                          // first lane that walks the S-box chain
+    const bool chain = lane >= CH0;
+    const uint32_t* __restrict__ K29 = tab.K29[T];
     for (int r = 0; r < RP; r++) {
         const Fr* __restrict__ Sr = S + (2 * T - 1) * r;
-        const W29 c = ld_c29(tab, Sr + role);               // Sr[0..T-1]: the row for word 0; Sr[T+i-1]: the column entry for word i
-        W29 i2, i4; const W29 o = sbox29(st[0], i2, i4);
-        const W29 s0 = add29(o, ld_c29(tab, C + 5 * T + r));
-        if (lane == r) { E1 = i2; E2 = i4; }
-        W29 X = s0, H;
+        const W29 c = ld_c29(tab, Sr + (chain ? 0 : lane));
+        W29 Xa = st[0], Ya = chain ? st[0] : c;
 #pragma unroll
-        for (int k = 0; k < 9; k++) H.l[k] = 0;
+        for (int j = 1; j < T; j++) if (lane == j) Xa = st[j];
+        W29 A; f29_mul<FrParams>(A.l, Xa.l, Ya.l);
+        W29 B; f29_sqr<FrParams>(B.l, A.l);
+        const W29 x4 = bcast29(B, 63);
+        W29 H;
+        { const int ki = lane == 0 ? 0 : (lane >= T && lane < CH0 ? lane - T + 1 : 0);
+          const uint4* q = reinterpret_cast<const uint4*>(K29 + 12 * (size_t)(r * T + ki)); const uint4 a = q[0], b = q[1], d = q[2];
+          H = W29{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x}}; }
 #pragma unroll
-        for (int j = 1; j < T; j++) { if (role == j) X = st[j]; if (role == T + j - 1) H = st[j]; }
-        W29 Pd; f29_mul_addhi<FrParams>(Pd.l, X.l, c.l, H.l);
+        for (int i2 = 1; i2 < T; i2++) if (lane == T + i2 - 1) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) H.l[k] += st[i2].l[k];
+        }
+        W29 Pd; f29_mul_addhi<FrParams>(Pd.l, A.l, x4.l, H.l);
         W29 n0 = bcast29(Pd, 0);
 #pragma unroll
-        for (int j = 1; j < T; j++) { const W29 t = bcast29(Pd, j);
+        for (int j = 1; j < T; j++) { const W29 t = bcast29(A, j);
 #pragma unroll
             for (int k = 0; k < 9; k++) n0.l[k] += t.l[k]; }
         f29_carry(n0.l);
 #pragma unroll
-        for (int i = 1; i < T; i++) st[i] = bcast29(Pd, T + i - 1);
+        for (int i2 = 1; i2 < T; i2++) st[i2] = bcast29(Pd, T + i2 - 1);
         st[0] = n0;
-        if (lane == r) E3 = n0;
+        if (lane == CH0 + r) { E1 = A; E2 = x4; E3 = n0; }
     }
-    if (on && lane < RP) { emit29_any(e, blk + oP + 2 * lane, E1); emit29_any(e, blk + oP + 2 * lane + 1, E2); emit29_any(e, blk + oMS + lane, E3); }
+    if (on && lane >= CH0 && lane < CH0 + RP) { const int r = lane - CH0; emit29_any(e, blk + oP + 2 * r, E1); emit29_any(e, blk + oP + 2 * r + 1, E2); emit29_any(e, blk + oMS + r, E3); }
     for (int r = 0; r < 3; r++) full_round(4 + r, 5 + r, C + 5 * T + RP + r * T, M);
     W29 i2, i4; const W29 osl = sbox29(sel(st, jl), i2, i4);                       // sigmaF[7] and mixLast
     {
