@@ -559,7 +559,9 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         for (int q = 0; q < nb; q++) j1.add(LN.d_p + 8 * (size_t)n * q, nullptr, n, zk->offH, n, 0, MSM_C_BIG);
         // [r3] a pass of one or two proofs carries its blinding's two variable-base products as two more MSM jobs each -- sum (s w_i) A_i and sum (r w_i) B1_i over the
         // wires that stay in the proof's MSMs -- so that the blinding kernel is left with fixed-base products only (zkc_finalize.hip)
-        const bool tree = zk->d_fb4 != nullptr && nb <= 2;
+        // (the lanes' work space is sized for max(4, passes of this key) proofs of 3 + 1 jobs each: two proofs of 5 + 1 fit unless ZKC_INFLIGHT made the passes smaller than that)
+        size_t tree_entries = 0; for (int q = 0; q < nb; q++) tree_entries += (size_t)msm_nw(MSM_C_BIG) * n + (size_t)msm_nw(MSM_C_SMALL) * (fold ? 2 * (size_t)vms[q].nA + 2 * (size_t)vms[q].nB + vms[q].nC : 4 * (size_t)nv + nc);
+        const bool tree = zk->d_fb4 != nullptr && nb <= 2 && 6 * nb <= LN.w1.max_jobs && tree_entries <= LN.w1.max_entries && (size_t)nb * (5 * msm_half(MSM_C_SMALL) + msm_half(MSM_C_BIG)) <= LN.w1.max_buckets;
         BlindArgs ba{}; ba.rs = CS.d_rs + 64 * (size_t)p0; ba.nv = nv;
         for (int q = 0; q < nb; q++) {
             const uint32_t* w = w0 + (size_t)q * nv * 8;
