@@ -147,6 +147,7 @@ def extra_legs(args, ctx, pk, zkey_bytes, vk, B, d_inputs, d_wtns, d_status, fla
                        empty-subtree trace).  (a) voters whose leaves sit at the very bottom of both trees, through the same key: nothing folds; (b) the same
                        witnesses through a key loaded with ZKC_NO_FOLD=1, witness given -- the groth16.prove(zkey, wtns) path for a foreign witness -- with
                        bytes compared against the folded proofs of the timed step
+      single_proof     the first voter of the batch alone: inputs -> proof latency of one call (BASELINE configs[1]), and that its bytes equal the batch's
       stages_isolated  one pass with every stage on ONE stream (ZKC_SERIAL_STREAMS=1): the HIP-event brackets per kernel category are then isolated kernel
                        times, priced against their algorithmic bytes and the 8 TB/s roof"""
     import numpy as np, torch
@@ -163,6 +164,17 @@ def extra_legs(args, ctx, pk, zkey_bytes, vk, B, d_inputs, d_wtns, d_status, fla
     h2h(); torch.cuda.synchronize(); t0 = time.perf_counter(); h2h(); h2h(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     res['host_to_host'] = {'value': round(2 * B / dt, 1), 'unit': 'proofs/s', 'note': 'input blocks (334 x 32 B per voter) in pinned host memory when the clock starts, proofs and public '
                            'signals in host memory when it stops; 2 steps of %d' % B}
+    # ---- one proof (BASELINE configs[1]): the first voter of the batch alone, inputs -> proof in one call, inputs and outputs' device buffers as in the headline ----
+    one = []
+    for _ in range(14):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        p1, u1 = pk.fullprove_batch_dev(d_inputs.data_ptr(), 1, d_wtns.data_ptr(), d_status.data_ptr(), out['rs'][:64])
+        one.append((time.perf_counter() - t0) * 1e3)
+    one = sorted(one[2:])
+    res['single_proof'] = {'ms_min': round(one[0], 3), 'ms_median': round(one[len(one) // 2], 3), 'bytes_equal_proof_of_the_timed_batch': bool(p1 == out['proofs'][:256] and u1 == out['pubs'][:len(u1)]),
+                           'note': 'voter 0 of the timed batch alone, same (r, s): a pass of one proof takes the latency-shaped path (blinding without variable-base products, small virtual '
+                                   'windows, half a wave per G2 bucket; DESIGN.md section 7) and gives the bytes the batch gave; 12 calls after 2 warm-ups.  The witness chain grows with the depth of the voter\'s leaf: this census puts it 13-14 levels down '
+                                   '(the reference\'s inputs_example.json, shallower, takes 3.5 ms: profiles/r03_single_proof_latency.json)'}
     # ---- folding: worst cases ----
     Bd = min(B, 188)
     deep = census.deep_voters(ctx, Bd, nl)
@@ -466,7 +478,7 @@ def main():
                                    'own test zkey seed 0x5A4B43454E535553, synthetic %d-voter census' % (args.nlevels, B, max(8192, B * world)),
                        'step_pipelining': pipelined, 'batch_per_gpu': B, 'nVars': pk.n_vars, 'domainSize': pk.domain_size, 'parallelism': 'independent proofs per GPU, RCCL all_gather of 513 B/proof'},
             'roofline': roofline, 'cpu_baseline': cpu, 'verified': verified,
-            'host_to_host': (extras or {}).get('host_to_host'), 'folding': (extras or {}).get('folding'), 'stages_isolated': (extras or {}).get('stages_isolated'),
+            'host_to_host': (extras or {}).get('host_to_host'), 'single_proof': (extras or {}).get('single_proof'), 'folding': (extras or {}).get('folding'), 'stages_isolated': (extras or {}).get('stages_isolated'),
             'stage_ms_per_proof_overlapped_not_additive': {k: round(v['ms'] / (args.steps * B), 4) for k, v in prof.items() if k != 'msm_g1_streamed'},
         }
         if share:
