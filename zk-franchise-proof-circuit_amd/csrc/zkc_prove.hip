@@ -63,18 +63,35 @@ zkc_fold_check(WitnessLayout L, const uint32_t* __restrict__ wtns, const uint32_
     if (threadIdx.x == 0) flags[((size_t)b * 2 + tree) * n + g] = any ? 1u : 0u;
 }
 
+// ---- [r3] the folding depths of a voter straight from its inputs: 1 + the index of its last non-zero sibling, per tree.  That is where SMTLevIns puts the leaf, and every level
+// from there down carries the voter-independent trace.  A call of one or two voters reads these BEFORE its witness kernel has run, so that everything behind the witness can be
+// enqueued while it runs; zkc_fold_check still compares the finished witness with the template, and prove_batch_finish refuses the call if the two disagree for an accepted voter. ----
+extern "C" __global__ void __launch_bounds__(64)
+zkc_input_depths(const uint32_t* __restrict__ inputs, int nInputs, int n, uint32_t* __restrict__ out) {
+    const int b = blockIdx.x, tree = blockIdx.y;
+    const uint32_t* sib = inputs + ((size_t)b * nInputs + 12 + (size_t)tree * n) * 8;
+    int d = 0;
+    for (int i = threadIdx.x; i < n; i += 64) {
+        const uint4* q = reinterpret_cast<const uint4*>(sib + 8 * (size_t)i); const uint4 x = q[0], y = q[1];
+        if (x.x | x.y | x.z | x.w | y.x | y.y | y.z | y.w) d = i + 1;
+    }
+    for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(d, m, 64); d = o > d ? o : d; }
+    if (threadIdx.x == 0) out[2 * b + tree] = (uint32_t)d;
+}
+
 extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     if (!zk) return;
     ZKC_LOCK(zk->ctx);
     (void)hipSetDevice(zk->ctx->device);
     (void)hipStreamSynchronize(zk->ctx->stream);
     void* ptrs[] = {zk->d_perm, zk->d_rowlen, zk->d_jdptr, zk->d_col, zk->d_val, zk->d_tw_fwd, zk->d_tw_inv, zk->d_tw_fwd29, zk->d_tw_inv29, zk->d_coset, zk->d_coset_br, zk->d_g1, zk->d_g2, zk->d_g2_29, zk->d_flags,
-                    zk->d_tblDelta1, zk->d_tblAlpha1, zk->d_tblBeta1, zk->d_tblDelta2, zk->d_fb4, zk->d_fb4g2, zk->call[0].d_rs, zk->call[0].d_proofs, zk->call[1].d_rs, zk->call[1].d_proofs};
+                    zk->d_tblDelta1, zk->d_tblAlpha1, zk->d_tblBeta1, zk->d_tblDelta2, zk->d_fb4, zk->d_fb4g2, zk->d_depths, zk->call[0].d_rs, zk->call[0].d_proofs, zk->call[1].d_rs, zk->call[1].d_proofs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : zk->fold.vmaps) if (kv.second.d) (void)hipFree(kv.second.d);
     for (void* q : {(void*)zk->fold.d_foldA, (void*)zk->fold.d_foldB1, (void*)zk->fold.d_foldC, (void*)zk->fold.d_foldB2}) if (q) (void)hipFree(q);
     if (zk->h_flags) (void)hipHostFree(zk->h_flags);
-    for (auto& c : zk->call) { if (c.h_out) (void)hipHostFree(c.h_out); if (c.h_rs) (void)hipHostFree(c.h_rs); if (c.h_xyzz) (void)hipHostFree(c.h_xyzz); if (c.d_xyzz) (void)hipFree(c.d_xyzz); for (hipEvent_t e : c.ev_done) if (e) (void)hipEventDestroy(e); }
+    if (zk->h_depths) (void)hipHostFree(zk->h_depths);
+    for (auto& c : zk->call) { if (c.h_out) (void)hipHostFree(c.h_out); if (c.h_rs) (void)hipHostFree(c.h_rs); if (c.h_xyzz) (void)hipHostFree(c.h_xyzz); if (c.h_early) (void)hipHostFree(c.h_early); if (c.d_xyzz) (void)hipFree(c.d_xyzz); for (hipEvent_t e : c.ev_done) if (e) (void)hipEventDestroy(e); }
     if (zk->ev_start) (void)hipEventDestroy(zk->ev_start);
     for (hipEvent_t e : zk->ev_chunk) (void)hipEventDestroy(e);
     for (auto& L : zk->lane) {
@@ -480,6 +497,20 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
             ZKC_HIP_CHECK(ctx, hipMalloc((void**)&zk->d_flags, nflags * 4)); ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&zk->h_flags, nflags * 4)); zk->flags_cap = nflags;
         }
     }
+    // [r3] a call of one or two voters that brings its inputs: the depths its folding needs are read from the inputs now (zkc_input_depths, on a stream of its own, ~30 us),
+    // so the pass below is enqueued while the witness kernel runs instead of after a host round trip behind it (fold flags to the host, wake-up, ~70 launches: 0.1-0.2 ms of a 3.5 ms proof)
+    CS.early_n = 0;
+    if (d_inputs && can_fold && B <= 2 && B <= zk->max_inflight && zk->d_fb4) {        // one pass
+        if (!CS.h_early) ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&CS.h_early, 2 * 4 + 2 * 2 * 256 * 4));      // status [2], then fold flags [2][2][n <= 254]
+        if (!zk->d_depths) { ZKC_HIP_CHECK(ctx, hipMalloc((void**)&zk->d_depths, 4 * 4)); ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&zk->h_depths, 2 * 4 * 4)); }
+        uint32_t* hd = zk->h_depths + 4 * cs;
+        hipLaunchKernelGGL(zkc_input_depths, dim3(B, 2), dim3(64), 0, ctx->stream2, (const uint32_t*)d_inputs, L.nInputs, L.n, zk->d_depths);
+        ZKC_HIP_CHECK(ctx, hipGetLastError());
+        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(hd, zk->d_depths, 8 * (size_t)B, hipMemcpyDeviceToHost, ctx->stream2));
+        ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream2));
+        bool ok = true; for (int i = 0; i < 2 * B; i++) ok = ok && hd[i] < (uint32_t)L.n;          // a non-zero LAST sibling fails SMTLevIns: no early path for that call
+        if (ok) { CS.early_n = B; for (int i = 0; i < 2 * B; i++) CS.early_depth[i] = (uint8_t)hd[i]; }
+    }
     const int npasses = (B + zk->max_inflight - 1) / zk->max_inflight;
     const int per_pass = (B + npasses - 1) / npasses;       // passes of equal size (1024 -> 10 x 94 + 84, not 10 x 96 + 64): the last pass' fixed-latency tail is not spent on a stub
     while ((int)zk->ev_chunk.size() < npasses) { hipEvent_t e; ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); zk->ev_chunk.push_back(e); }
@@ -507,6 +538,10 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
             ZKC_HIP_CHECK(ctx, hipGetLastError());
             ZKC_HIP_CHECK(ctx, hipMemcpyAsync(zk->h_flags + (size_t)p0 * 2 * L.n, fl, (size_t)nb * 2 * L.n * 4, hipMemcpyDeviceToHost, st0));
         }
+        if (CS.early_n) {            // the early layout's evidence for finish, in this call's own pinned memory (the key's flag buffer belongs to whichever call began last)
+            ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.h_early, d_status, 4 * (size_t)B, hipMemcpyDeviceToHost, st0));
+            ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.h_early + 2, zk->d_flags + (size_t)p0 * 2 * L.n, (size_t)nb * 2 * L.n * 4, hipMemcpyDeviceToHost, st0));
+        }
         ZKC_HIP_CHECK(ctx, hipEventRecord(zk->ev_chunk[c], st0));                // wtns of this chunk (and rs) ready, flags on the host
     }
     // (npass is NOT reset per call: the result slots and their ev_fin guards carry over, because the previous call's last blinding may still be reading them)
@@ -519,7 +554,8 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         const int nb = std::min(per_pass, B - p0);
         zkc_lane& LN = zk->lane[pass % zk->nlanes]; const int slot = LN.npass & 1;       // MSM results are double-buffered: the blinding of pass k overlaps pass k+1
         tr[0] = now_ms();
-        ZKC_HIP_CHECK(ctx, hipEventSynchronize(zk->ev_chunk[pass]));              // host: this chunk's fold flags have arrived
+        const bool early = CS.early_n > 0;
+        if (!early) ZKC_HIP_CHECK(ctx, hipEventSynchronize(zk->ev_chunk[pass]));              // host: this chunk's fold flags have arrived
         tr[1] = now_ms();
         ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(LN.st, zk->ev_chunk[pass], 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(LN.st2, zk->ev_chunk[pass], 0));
         hipStream_t st = LN.st, st2 = LN.st2, fin = LN.fin;
@@ -527,7 +563,8 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         // constant folding is per proof: voter q keeps the census levels below its own leaf depth dcq[q] (sik: dsq[q]) in its MSMs; the levels
         // above are the template's and come back as a constant in the blinding kernel.  One foreign witness (n2bOld block differs) unfolds the pass.
         uint8_t dcq[MSM_MAX_JOBS / 4], dsq[MSM_MAX_JOBS / 4]; bool fold = can_fold;
-        for (int q = 0; q < nb && fold; q++) for (int t = 0; t < 2; t++) {
+        if (early) for (int q = 0; q < nb; q++) { dcq[q] = CS.early_depth[2 * q]; dsq[q] = CS.early_depth[2 * q + 1]; }
+        else for (int q = 0; q < nb && fold; q++) for (int t = 0; t < 2; t++) {
             const uint32_t* f = zk->h_flags + ((size_t)(p0 + q) * 2 + t) * L.n;
             if (f[L.n - 1]) { fold = false; break; }                              // n2bOld block differs: not one of our witnesses
             int D = 0; for (int g = 0; g < L.n - 1; g++) if (f[g]) D = g + 1;
@@ -656,6 +693,17 @@ int zkc::prove_batch_finish(zkc_zkey* zk, int cs, uint8_t* proofs, uint8_t* publ
     for (int l = 0; l < zk->nlanes && e == hipSuccess; l++) e = hipEventSynchronize(CS.ev_done[l]);
     CS.pending = false;
     if (e != hipSuccess) { ZKC_LOCK(zk->ctx); return zkc_fail(zk->ctx, ZKC_ERR_HIP, std::string("prove_batch_finish: ") + hipGetErrorString(e)); }
+    if (CS.early_n) {                // the pass was laid out from the inputs' depths before its witness existed: the fold check of the finished witness has to agree
+        const WitnessLayout L = WitnessLayout::make(zk->nLevels);
+        for (int q = 0; q < CS.early_n; q++) {
+            if ((int32_t)CS.h_early[q] != ZKC_W_OK) continue;                   // a rejected voter: its proof is discarded whatever it is
+            for (int t = 0; t < 2; t++) {
+                const uint32_t* f = CS.h_early + 2 + ((size_t)q * 2 + t) * L.n;
+                int D = 0; for (int g = 0; g < L.n - 1; g++) if (f[g]) D = g + 1;
+                if (f[L.n - 1] || D > (int)CS.early_depth[2 * q + t]) { ZKC_LOCK(zk->ctx); return zkc_fail(zk->ctx, ZKC_ERR_GENERIC, "prove_batch_finish: the witness does not fold at the depth its inputs gave (internal error)"); }
+            }
+        }
+    }
     memcpy(proofs, CS.h_out, 256ull * CS.B);
     // the proofs of a small pass (one or two proofs: a call of that size, or the stub at the end of a larger one) arrive as XYZZ and are divided here: three inversions,
     // microseconds on a core, ~0.2 ms at the end of the device's chain

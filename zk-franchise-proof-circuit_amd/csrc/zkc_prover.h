@@ -175,6 +175,7 @@ struct zkc_zkey {
     zkc_lane lane[2]; int nlanes = 2; bool serial_streams = false;          // serial_streams: the lanes borrow ctx->stream (ZKC_SERIAL_STREAMS, measurement only)
     uint32_t *d_flags = nullptr, *h_flags = nullptr; size_t flags_cap = 0;  // fold check: [B][2][n]
     zkc::G1Affine *d_tblDelta1 = nullptr, *d_tblAlpha1 = nullptr, *d_tblBeta1 = nullptr; zkc::G2Affine* d_tblDelta2 = nullptr;
+    uint32_t *d_depths = nullptr, *h_depths = nullptr;                     // zkc_input_depths: device [4], pinned [2 call slots][4]
     zkc::G1XYZZ* d_fb4 = nullptr; zkc::G2XYZZ* d_fb4g2 = nullptr; int fb4_bases = 0;   // 4-bit fixed-base tables of the small-pass blinding (FinalizeArgs::fb4)
     // per CALL state, two slots: a call is begin (everything enqueued, returns) + finish (wait, copy out), and the proving service lets the begin of the next
     // call run while the previous one drains (its witness kernels beside the other call's MSMs, its transforms beside the other's bucket reduction and blinding)
@@ -185,6 +186,7 @@ struct zkc_zkey {
         uint8_t *d_xyzz = nullptr, *h_xyzz = nullptr; std::vector<uint8_t> as_xyzz;     // [B][512]: a small pass (one or two proofs) hands its three points over as XYZZ; as_xyzz[q]: proof q is to be made affine by finish
         hipEvent_t ev_done[2] = {nullptr, nullptr};                         // per lane: recorded on its blinding stream behind the call's last copy
         int B = 0; bool pending = false;
+        int early_n = 0; uint8_t early_depth[4] = {0, 0, 0, 0}; uint32_t* h_early = nullptr;      // [r3] a call of <= 2 voters laid out from zkc_input_depths (prove_batch_begin): voters, (census, sik) depths; pinned: their status [2], then the fold flags of the finished witness [2][2][n]
     } call[2];
     int last_lane = -1;                                                     // lane of the latest pass that was enqueued (prove_tail_reached)
     hipEvent_t ev_start = nullptr; std::vector<hipEvent_t> ev_chunk;        // ev_chunk[p]: witness (if made here) and fold flags of pass p are ready
