@@ -579,6 +579,7 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     constexpr bool kG2 = sizeof(F) == sizeof(Fq2);
     static const bool bw_off = [] { const char* e = getenv("ZKC_G2_BUCKET_WAVE"); return e && atoi(e) == 0; }();
     const uint32_t bw_slices = (uint32_t)std::min<size_t>(32, w.max_segments / std::max<uint32_t>(nb, 1u));      // slices a heavy bucket may be cut into: nb x slices partial sums must fit
+    const uint32_t* const g2_table29 = (kG2 && jl.job[0].c == (uint32_t)MSM_C_G2_LONE) ? zk->d_g2_29_lone : zk->d_g2_29;       // a G2 pass is of one window size
     const bool bucket_wave = kG2 && !bw_off && nb <= 8192 && bw_slices >= 1;         // a small G2 pass: half a wave per bucket (zkc_msm_bucketwave_g2), no segment lists
     uint64_t alg_bytes = 0; uint32_t maxcount = 0;
     uint64_t streamed_bytes = 0;
@@ -621,12 +622,12 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
         if constexpr (kG2) {
           if (bucket_wave) {
             ZKC_HIP_CHECK(ctx, hipMemsetAsync(w.heavy + MSM_MAX_HEAVY, 0, 4, st));
-            hipLaunchKernelGGL(zkc_msm_bucketwave_g2, dim3((nb + 1) / 2, bw_slices), dim3(64), 0, st, zk->d_g2_29, (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.bcnt, w.segoff, w.segcnt, w.heavy,
+            hipLaunchKernelGGL(zkc_msm_bucketwave_g2, dim3((nb + 1) / 2, bw_slices), dim3(64), 0, st, g2_table29, (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.bcnt, w.segoff, w.segcnt, w.heavy,
                                w.heavy + MSM_MAX_HEAVY, reinterpret_cast<XYZZ<Fq2>*>(partial), nb, bw_slices);
           }
           else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate29_g2<1>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
-                               zk->d_g2_29, (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.bcnt, w.segoff, w.seg2bucket, w.perm, nb, reinterpret_cast<XYZZ<Fq2>*>(partial), (uint32_t)w.max_segments);
+                               g2_table29, (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.bcnt, w.segoff, w.seg2bucket, w.perm, nb, reinterpret_cast<XYZZ<Fq2>*>(partial), (uint32_t)w.max_segments);
         } else    // G1: same layout, field type with the inlined product.  160 VGPRs = 3 waves per SIMD; capped at 128 (4 waves) the accumulator spills and the kernel is 3.6x slower
             hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate29<2>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
                                reinterpret_cast<const Affine<Fq>*>(table), (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.bcnt, w.segoff, w.seg2bucket, w.perm, nb,
@@ -651,6 +652,7 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
                                (const MsmWindow*)w.d_windows, reinterpret_cast<XYZZ<Fq>*>(wres), (uint32_t)w.max_segments);
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_window");
         static_assert(msm_half(MSM_C_SMALL) / MSM_VW_MIN <= MSM_MAX_VW_PER_JOB, "G2 per-job sum: one lane per virtual window");
+        if (kG2 && jl.job[0].c == (uint32_t)MSM_C_G2_LONE && !zk->d_g2_29_lone) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: no 8-bit-window G2 table on this key");
         for (int j = 0; j < nj; j++) if ((1u << (jl.job[j].c - 1)) / jl.job[j].vw > (uint32_t)(kG2 ? MSM_MAX_VW_PER_JOB : MSM_MAX_VW_G1)) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: too many virtual windows in a job for the per-job sum");
         if constexpr (kG2)
             hipLaunchKernelGGL(zkc_msm_final29_g2, dim3(nj), dim3(MSM_MAX_VW_PER_JOB), 0, st, reinterpret_cast<const XYZZ<Fq2>*>(wres), (const MsmJobList*)w.d_jobs,

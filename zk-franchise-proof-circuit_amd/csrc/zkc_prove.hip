@@ -84,7 +84,7 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     ZKC_LOCK(zk->ctx);
     (void)hipSetDevice(zk->ctx->device);
     (void)hipStreamSynchronize(zk->ctx->stream);
-    void* ptrs[] = {zk->d_perm, zk->d_rowlen, zk->d_jdptr, zk->d_col, zk->d_val, zk->d_tw_fwd, zk->d_tw_inv, zk->d_tw_fwd29, zk->d_tw_inv29, zk->d_coset, zk->d_coset_br, zk->d_g1, zk->d_g2, zk->d_g2_29, zk->d_flags,
+    void* ptrs[] = {zk->d_perm, zk->d_rowlen, zk->d_jdptr, zk->d_col, zk->d_val, zk->d_tw_fwd, zk->d_tw_inv, zk->d_tw_fwd29, zk->d_tw_inv29, zk->d_coset, zk->d_coset_br, zk->d_g1, zk->d_g2, zk->d_g2_29, zk->d_g2_29_lone, zk->d_flags,
                     zk->d_tblDelta1, zk->d_tblAlpha1, zk->d_tblBeta1, zk->d_tblDelta2, zk->d_fb4, zk->d_fb4g2, zk->d_depths, zk->call[0].d_rs, zk->call[0].d_proofs, zk->call[1].d_rs, zk->call[1].d_proofs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : zk->fold.vmaps) if (kv.second.d) (void)hipFree(kv.second.d);
@@ -241,6 +241,22 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
         (rc = msm_precompute_g1(ctx, nc, zk->d_g1 + zk->offC, MSM_C_SMALL)) || (rc = msm_precompute_g1(ctx, n, zk->d_g1 + zk->offH, MSM_C_BIG)) ||
         (rc = msm_precompute_g2(ctx, nv, zk->d_g2, MSM_C_SMALL))) return bail(rc);
     if ((rc = dmalloc(ctx, &zk->d_g2_29, 60 * (size_t)NWS * nv)) || (rc = msm_g2_table29(ctx, zk->d_g2, zk->d_g2_29, (size_t)NWS * nv))) return bail(rc);
+    {   // [r3] the 8-bit-window G2 table of the lone-proof path (MSM_C_G2_LONE): shifted in a temporary affine table, kept in radix 2^29 only
+        const char* e_lone = getenv("ZKC_G2_LONE_TABLE");
+        if (!(e_lone && atoi(e_lone) == 0)) {
+            constexpr int NWL = msm_nw(MSM_C_G2_LONE);
+            G2Affine* tmp = nullptr;
+            if ((rc = dmalloc(ctx, &tmp, (size_t)NWL * nv))) return bail(rc);
+            hipError_t e2 = hipMemcpyAsync(tmp, zk->d_g2, 128ull * nv, hipMemcpyDeviceToDevice, ctx->stream);
+            if (e2 == hipSuccess) rc = msm_precompute_g2(ctx, nv, tmp, MSM_C_G2_LONE);
+            if (e2 == hipSuccess && !rc) rc = dmalloc(ctx, &zk->d_g2_29_lone, 60 * (size_t)NWL * nv);
+            if (e2 == hipSuccess && !rc) rc = msm_g2_table29(ctx, tmp, zk->d_g2_29_lone, (size_t)NWL * nv);
+            if (e2 == hipSuccess && !rc) e2 = hipStreamSynchronize(ctx->stream);
+            (void)hipFree(tmp);
+            if (rc) return bail(rc);
+            if (e2 != hipSuccess) return bail(zkc_fail(ctx, ZKC_ERR_HIP, std::string("lone-proof G2 table: ") + hipGetErrorString(e2)));
+        }
+    }
     // ---- work buffers: up to `max_inflight` proofs share one MSM pipeline pass; the buffers themselves are sized by lanes_ensure() for
     //      the number of proofs a call actually puts in flight (a single-proof caller does not reserve the work space of 96) ----
     const char* e_inf = getenv("ZKC_INFLIGHT");
@@ -580,17 +596,17 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         const bool mv_prefetch = mv_prefetch_env && zk->nlanes == 1;
         const bool mv_done = mv_prefetch && pass > 0;
         if (mv_done) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, LN.ev_mv, 0));
-        // a pass of a few proofs is a latency chain and its G2 side is the longer one: its kernels are enqueued FIRST (ahead of the dozen launches of buildABC and the
-        // transforms, ~5 us of host time each) and its accumulation does not wait for the transforms
-        const bool small = nb <= 4;
-        if (!small) {
-            if ((rc = h_evals_dev(zk, LN, w0, nb, !mv_done))) return rc;
-            ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_ntt, st));
-        }
+        // (tried for passes of a few proofs while their G2 side was the longer chain: G2 enqueued first and its accumulation not held for the transforms -- its 1024 fat waves
+        // then slowed buildABC and the first transform kernel threefold; with the 8-bit-window G2 table the G1 side is the longer one and goes first again)
+        if ((rc = h_evals_dev(zk, LN, w0, nb, !mv_done))) return rc;
+        ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_ntt, st));
         tr[2] = now_ms();
         static thread_local MsmJobList j1, j2;     // 6 KB each: kept off the stack frame of a C-ABI entry point
         const uint32_t vws = nb <= 4 ? 64u : 256u, vwb = nb <= 4 ? 256u : 1024u;          // few proofs in the pass: favour latency in the bucket reduction
-        j1.clear(vws, vwb); j2.clear(vws);
+        // the G2 section of one or two proofs takes the 8-bit-window table: 128 buckets per job, reduced by one wave (vw = 128), if the G2 work space holds 32 entries per scalar
+        size_t lone_entries = 0; for (int q = 0; q < nb; q++) lone_entries += (size_t)msm_nw(MSM_C_G2_LONE) * (fold ? vms[q].nB : nv);
+        const int c2 = (nb <= 2 && zk->d_g2_29_lone && lone_entries <= LN.w2.max_entries) ? MSM_C_G2_LONE : MSM_C_SMALL;
+        j1.clear(vws, vwb); j2.clear(c2 == MSM_C_G2_LONE ? 128u : vws);
         // job order of the G1 pass: the nb H jobs first (the 16-bit bucket sort wants the jobs with the larger bucket count in front), then
         // A, B1, C per proof.  zkc_finalize reads results[q] = H_q and results[nb + 3 q + {0, 1, 2}] = A_q, B1_q, C_q.
         for (int q = 0; q < nb; q++) j1.add(LN.d_p + 8 * (size_t)n * q, nullptr, n, zk->offH, n, 0, MSM_C_BIG);
@@ -610,14 +626,14 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
                 j1.add(w, vm.d + vm.offB, vm.nB, zk->offB1, nv, 0, MSM_C_SMALL);
                 j1.add(w, vm.d + vm.offC, vm.nC, zk->offC, nc, (int32_t)np + 1, MSM_C_SMALL);
                 if (tree) { j1.add(bs, vm.d + vm.offA, vm.nA, zk->offA, nv, 0, MSM_C_SMALL); j1.add(bs + 8ull * nv, vm.d + vm.offB, vm.nB, zk->offB1, nv, 0, MSM_C_SMALL); }
-                j2.add(w, vm.d + vm.offB, vm.nB, 0, nv, 0, MSM_C_SMALL);
+                j2.add(w, vm.d + vm.offB, vm.nB, 0, nv, 0, c2);
                 if (tree) { ba.mapA[q] = vm.d + vm.offA; ba.nA[q] = vm.nA; ba.mapB[q] = vm.d + vm.offB; ba.nB[q] = vm.nB; }
             } else {
                 j1.add(w, nullptr, nv, zk->offA, nv, 0, MSM_C_SMALL);
                 j1.add(w, nullptr, nv, zk->offB1, nv, 0, MSM_C_SMALL);
                 j1.add(w + 8ull * (np + 1), nullptr, nc, zk->offC, nc, 0, MSM_C_SMALL);
                 if (tree) { j1.add(bs, nullptr, nv, zk->offA, nv, 0, MSM_C_SMALL); j1.add(bs + 8ull * nv, nullptr, nv, zk->offB1, nv, 0, MSM_C_SMALL); }
-                j2.add(w, nullptr, nv, 0, nv, 0, MSM_C_SMALL);
+                j2.add(w, nullptr, nv, 0, nv, 0, c2);
                 if (tree) { ba.mapA[q] = ba.mapB[q] = nullptr; ba.nA[q] = ba.nB[q] = nv; }
             }
         }
@@ -638,13 +654,9 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         // runs beside the G1 bucketing and segment kernels, which wait on memory and LDS atomics, instead of beside the NTT, which is VALU-bound too
         static const bool g2_acc_with_sort = getenv("ZKC_G2_ACC_EARLY") == nullptr;
         if (g2_early) {
-            if ((rc = msm_pass_g2(zk, LN.w2, j2, slot, false, st2, g2_acc_with_sort && !small ? LN.ev_ntt : nullptr))) return rc;
+            if ((rc = msm_pass_g2(zk, LN.w2, j2, slot, false, st2, g2_acc_with_sort ? LN.ev_ntt : nullptr))) return rc;
             if (tree && (rc = finalize_tree_g2_launch(ctx, st2, fa, nb))) return rc;
             ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_msm2, st2));
-        }
-        if (small) {
-            if ((rc = h_evals_dev(zk, LN, w0, nb, !mv_done))) return rc;
-            ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_ntt, st));
         }
         tr[3] = now_ms();
         if ((rc = msm_pass_g1(zk, LN.w1, j1, slot, false, st, LN.ev_sorted, LN.ev_acc))) return rc;

@@ -10,6 +10,9 @@ namespace zkc {
 // C, B2 (8-11 k wires after constant folding): c = 12 -> 22 additions per scalar into 2048 buckets (same box: c = 14 -> 1798, 13 -> 1919,
 // 12 -> 1958, 11 -> ~1856 proofs/s; round 2, per-job bucketing: 12 -> 3030, 13 -> 2965).
 constexpr int MSM_C_BIG = 17, MSM_C_SMALL = 12;
+// [r3] the G2 section of a pass of one or two proofs: 8-bit windows -> 32 additions per scalar into 128 buckets.  A lone proof's B2 MSM is ~5 000 scalars and its latency is the
+// bucket REDUCTION (2048 buckets: ~30 of the ~55 G2 additions in a row); with 128 buckets one wave reduces the job.  Costs a second pre-shifted G2 table (0.6 GB at nLevels 160).
+constexpr int MSM_C_G2_LONE = 8;
 constexpr int msm_nw(int c) { return (254 + c) / c; }          // 17 -> 15 windows (255 bits), 12 -> 22 windows (264 bits)
 constexpr int msm_half(int c) { return 1 << (c - 1); }         // buckets per job
 // buckets per workgroup of the reduction ("virtual window"): 1024 for H (64 waves per job; 512: 1496, 1024: 1548, 2048: 1505 proofs/s),
@@ -166,6 +169,7 @@ struct zkc_zkey {
     // pre-shifted base tables, one allocation per group: G1 = [A | B1 | C | H], G2 = [B2]; T[w][i] = 2^(c*w) * P_i
     zkc::G1Affine* d_g1 = nullptr; zkc::G2Affine* d_g2 = nullptr;
     uint32_t* d_g2_29 = nullptr;                                            // the G2 table again in radix 2^29 (60 words per point: x, y, -y), read by the accumulation
+    uint32_t* d_g2_29_lone = nullptr;                                       // the same bases pre-shifted for MSM_C_G2_LONE (32 windows), radix 2^29 only; nullptr: not built (ZKC_G2_LONE_TABLE=0)
     uint32_t offA = 0, offB1 = 0, offC = 0, offH = 0;                       // table offsets inside d_g1 (points)
     // per-proof work buffers
     int max_inflight = 0;                                                   // proofs per pipeline pass (upper limit)
