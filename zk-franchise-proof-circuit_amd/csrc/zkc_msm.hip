@@ -188,7 +188,7 @@ zkc_msm_accumulate29_g2(const uint32_t* __restrict__ table29_all, const MsmJobLi
 // up to eight full ones in the window walk and a merge pass for the heavier buckets -- the longest link of a lone proof's G2 chain (0.9 of 1.7 ms).  Here 32 lanes stride over
 // the bucket's entries (three or four additions in a row for 100 entries) and a five-step butterfly sums them; 2048 buckets are 1024 waves, one per SIMD, one round.  No segment
 // lists.  A bucket of more than 128 entries (the wires that are 1: thousands of entries in digit 1 of the lowest window) is cut into up to `nslice` slices, a half-wave each
-// (grid.y), whose sums are the bucket's "segments": the merge kernel adds them when there are more than two.  What the window kernel reads: partial[b nslice + y], segoff[b] = b nslice,
+// (grid.y), whose sums are the bucket's "segments": the merge kernel adds them.  What the window kernel reads: partial[b nslice + y], segoff[b] = b nslice,
 // segcnt[b] = slices in use.  A full pass (192 k buckets) keeps the lane-per-segment kernel: there every lane has work for the whole walk.
 __global__ void __launch_bounds__(64)
 zkc_msm_bucketwave_g2(const uint32_t* __restrict__ table29_all, const MsmJobList* __restrict__ jlp, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ off,
@@ -200,7 +200,7 @@ zkc_msm_bucketwave_g2(const uint32_t* __restrict__ table29_all, const MsmJobList
     uint32_t m = (cnt + 127) / 128; if (m > nslice) m = nslice;               // slices in use
     if (b < nbuckets && y == 0 && lane == 0) {
         segoff[b] = b * nslice; segcnt[b] = m;
-        if (m > 2) { const uint32_t h = atomicAdd(heavy_count, 1u); if (h < (uint32_t)MSM_MAX_HEAVY) heavy[h] = b; }
+        if (m > 1) { const uint32_t h = atomicAdd(heavy_count, 1u); if (h < (uint32_t)MSM_MAX_HEAVY) heavy[h] = b; }
     }
     const uint32_t lo = y < m ? (uint32_t)(((uint64_t)cnt * y) / m) : 0u, hi = y < m ? (uint32_t)(((uint64_t)cnt * (y + 1)) / m) : 0u;
     Acc29G2 acc; f29g2_pt_set_inf(acc); bool inf = true;
