@@ -490,7 +490,7 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
     if (CS.cap < (size_t)B) {                                    // the slot is idle (finished), so its buffers are nobody's
         if (CS.d_rs) { ZKC_HIP_CHECK(ctx, hipFree(CS.d_rs)); ZKC_HIP_CHECK(ctx, hipFree(CS.d_proofs)); ZKC_HIP_CHECK(ctx, hipHostFree(CS.h_out)); ZKC_HIP_CHECK(ctx, hipHostFree(CS.h_rs)); ZKC_HIP_CHECK(ctx, hipFree(CS.d_xyzz)); ZKC_HIP_CHECK(ctx, hipHostFree(CS.h_xyzz));
                        CS.d_rs = CS.d_proofs = CS.h_out = CS.h_rs = CS.d_xyzz = CS.h_xyzz = nullptr; CS.cap = 0; }
-        const size_t want = std::max<size_t>((size_t)B, std::min<size_t>(2 * CS.cap, 4096));
+        const size_t want = std::max<size_t>((size_t)B, std::max<size_t>(256, std::min<size_t>(2 * CS.cap, 4096)));      // never less than 256 proofs (0.5 MB): a service whose batches grow from 1 to 60 does not come through this (device-synchronising) path six times
         ZKC_HIP_CHECK(ctx, hipMalloc((void**)&CS.d_rs, 64 * want)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&CS.d_proofs, 256 * want));
         ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&CS.h_out, (256 + 32 * (size_t)zk->nPub) * want)); ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&CS.h_rs, 64 * want));
         ZKC_HIP_CHECK(ctx, hipMalloc((void**)&CS.d_xyzz, 512 * want)); ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&CS.h_xyzz, 512 * want)); CS.cap = want;
