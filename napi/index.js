@@ -23,19 +23,30 @@ function le32(x) {
   return Buffer.from(v.toString(16).padStart(64, "0"), "hex").reverse();
 }
 function fromLe(b, off) { return BigInt("0x" + Buffer.from(b.subarray(off, off + 32)).reverse().toString("hex")); }
+// the 12-key input object -> (12 + 2 (nLevels + 1)) x 32 bytes, in place in one buffer.  Zero siblings (most of a padded list) are skipped: converting every "0" through BigInt
+// cost 0.2 ms per voter, a fifth of a 64-voter burst's wall time
 function flatten(input, nLevels) {
-  const parts = [];
+  const out = Buffer.alloc(32 * (12 + 2 * (nLevels + 1)));
+  let o = 0;
+  const put = (x) => {
+    if (x === "0" || x === 0 || x === 0n) { o += 32; return; }
+    let v = BigInt(x); if (v < 0n || v >= R) v = ((v % R) + R) % R;
+    const h = v.toString(16), b = Buffer.from(h.length & 1 ? "0" + h : h, "hex");
+    for (let i = 0, k = b.length - 1; k >= 0; i++, k--) out[o + i] = b[k];
+    o += 32;
+  };
   for (const k of INPUT_KEYS) {
     if (!(k in input)) throw new Error(`Error: Signal not found.\n(input ${k})`);
-    let v = input[k];
+    const v = input[k];
     if (k.endsWith("Siblings")) {
-      v = Array.from(v);
-      if (v.length > nLevels + 1) throw new Error(`Too many values for input signal ${k}`);
-      while (v.length < nLevels + 1) v.push("0");
-    }
-    for (const x of (Array.isArray(v) ? v : [v])) parts.push(le32(x));
+      const n = v.length;
+      if (n > nLevels + 1) throw new Error(`Too many values for input signal ${k}`);
+      for (let i = 0; i < n; i++) put(v[i]);
+      o += 32 * (nLevels + 1 - n);
+    } else if (Array.isArray(v)) for (const x of v) put(x);
+    else put(v);
   }
-  return Buffer.concat(parts);
+  return out;
 }
 // a path is read once per (path, size, mtime): snarkjs re-reads the 55 MB .zkey on every fullProve, which here would cost more than the proof
 const fileCache = new Map();
