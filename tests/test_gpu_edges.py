@@ -179,3 +179,35 @@ def test_small_pass_blinding_without_variable_base_products_matches_the_general_
         assert rc == 0 and pk.prove_batch_dev(d_w.data_ptr(), 1, bytes(64))[0] == op
     finally:
         pk_general.close(); pk_stub.close()
+
+
+def test_lone_calls_soak_against_the_oracle(env):
+    """Sixty inputs -> proof calls of one or two voters (the path that lays its pass out from the inputs' sibling depths while the witness kernel runs, blinds without variable-base
+    products, takes the 8-bit-window G2 table and lets the host divide): random depths 0..nLevels in both trees, random (r, s), every sixth voter rejected by the circuit (weight),
+    one call with a non-zero LAST sibling (no early layout for that call).  Every accepted voter's proof equals the CPU oracle's bytes; a rejected voter fails alone."""
+    zkc, ctx, pk, zk, vk, nl = env
+    import torch, numpy as np
+    from census_gen import random_voter
+    rng = random.Random(20261004)
+    nW, nIn = ctx.n_wires(nl), ctx.n_inputs(nl)
+    d_w = torch.empty(2 * nW * 32, dtype=torch.uint8, device='cuda'); d_st = torch.zeros(2, dtype=torch.int32, device='cuda')
+    k = 0
+    for call in range(60):
+        B = 1 + (call & 1)
+        voters = []
+        for _ in range(B):
+            v = random_voter(rng, ol.poseidon, nLevels=nl, depth_c=rng.randrange(0, nl + 1), depth_s=rng.randrange(0, nl + 1))
+            if k % 6 == 5: v = dict(v, voteWeight=str(int(v['availableWeight']) + 1))
+            if call == 31: v = dict(v, sikSiblings=list(v['sikSiblings'][:nl]) + ['9'])
+            voters.append(v); k += 1
+        flat = b''.join(zkc.flatten_inputs(v, nl) for v in voters)
+        rs = [(rng.randrange(ol.R), rng.randrange(ol.R)) for _ in range(B)]
+        d_in = torch.from_numpy(np.frombuffer(flat, dtype=np.uint8).copy()).cuda()
+        proofs, pubs = pk.fullprove_batch_dev(d_in.data_ptr(), B, d_w.data_ptr(), d_st.data_ptr(), b''.join(r.to_bytes(32, 'little') + s.to_bytes(32, 'little') for r, s in rs))
+        st = d_st.cpu().tolist()[:B]
+        for q, v in enumerate(voters):
+            rc, w = ol.witness(v, nl)
+            assert st[q] == rc, (call, q)
+            if rc == 0:
+                rc2, op, ou = ol.prove(zk, w, rs[q][0], rs[q][1])
+                assert rc2 == 0 and proofs[256 * q:256 * q + 256] == op and pubs[256 * q:256 * q + 256] == ou, (call, q)
