@@ -23,7 +23,7 @@ for k, v in acc.items():
     busy = v.get('SQ_ACTIVE_INST_VALU', 0.0) * 4 / 1024 / 1e6
     rows.append({'kernel': k, 'launches': len(launches[k]), 'valu_busy_Mcycles_per_simd': round(busy, 3), 'valu_instructions_G': round(v.get('SQ_INSTS_VALU', 0.0) / 1e9, 3),
                  'waves': int(v.get('SQ_WAVES', 0)), 'gui_active_Mcycles': round(v.get('GRBM_GUI_ACTIVE', 0.0) / 8 / 1e6, 3)})
-SETUP = ('zkc_msm_shift_bases', 'zkc_fold_mul', 'zkc_fold_gsum', 'zkc_g2_table29', 'zkc_tw29', 'zkc_bitrev_copy', 'zkc_poseidon_batch_kernel', 'zkc_witness_tmpl')
+SETUP = ('zkc_msm_shift_bases', 'zkc_fold_mul', 'zkc_fold_gsum', 'zkc_g2_table29', 'zkc_tw29', 'zkc_bitrev_copy', 'zkc_poseidon_batch_kernel', 'zkc_witness_tmpl', 'zkc_fb4_build')
 for r in rows:
     r['phase'] = 'key load / first use (once per key)' if r['kernel'].startswith(SETUP) else 'pass'
 tot = sum(r['valu_busy_Mcycles_per_simd'] for r in rows if r['phase'] == 'pass') or 1.0
