@@ -14,6 +14,7 @@
 #include <node_api.h>
 #include <dlfcn.h>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -266,6 +267,31 @@ napi_value StatusText(napi_env env, napi_callback_info info) {
     const std::string t = assert_text(nl, st);
     napi_value out; napi_create_string_utf8(env, t.c_str(), t.size(), &out); return out;
 }
+// decimals(buf: Buffer) -> string[]: every 32-byte little-endian word of buf as a decimal string (what snarkjs' proof.json / public.json hold).  In C++ because
+// BigInt("0x..").toString() costs Node 4 us per value -- 16 values per proof, on the main thread, after the GPU is done: a tenth of a 256-voter burst
+napi_value Decimals(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value a[1]; napi_get_cb_info(env, info, &argc, a, nullptr, nullptr);
+    void* p = nullptr; size_t n = 0; napi_get_buffer_info(env, a[0], &p, &n);
+    const size_t words = n / 32;
+    napi_value arr; napi_create_array_with_length(env, words, &arr);
+    for (size_t w = 0; w < words; w++) {
+        uint64_t v[4]; memcpy(v, (const uint8_t*)p + 32 * w, 32);
+        char digits[80]; int len = 0;
+        uint64_t chunk[5]; int nchunk = 0;                       // base 10^19 digits, least significant first
+        while (v[0] | v[1] | v[2] | v[3]) {
+            unsigned __int128 rem = 0;
+            for (int i = 3; i >= 0; i--) { const unsigned __int128 cur = (rem << 64) | v[i]; v[i] = (uint64_t)(cur / 10000000000000000000ull); rem = cur % 10000000000000000000ull; }
+            chunk[nchunk++] = (uint64_t)rem;
+        }
+        if (nchunk == 0) { digits[len++] = '0'; }
+        else {
+            len += snprintf(digits + len, sizeof digits - len, "%llu", (unsigned long long)chunk[nchunk - 1]);
+            for (int i = nchunk - 2; i >= 0; i--) len += snprintf(digits + len, sizeof digits - len, "%019llu", (unsigned long long)chunk[i]);
+        }
+        napi_value str; napi_create_string_utf8(env, digits, (size_t)len, &str); napi_set_element(env, arr, (uint32_t)w, str);
+    }
+    return arr;
+}
 // verifyJson(vkeyJson, publicJson, proofJson, libPath) -> boolean   (CPU pairing check, milliseconds)
 napi_value VerifyJson(napi_env env, napi_callback_info info) {
     size_t argc = 4; napi_value a[4]; napi_get_cb_info(env, info, &argc, a, nullptr, nullptr);
@@ -280,7 +306,7 @@ napi_value Init(napi_env env, napi_value exports) {
     napi_create_threadsafe_function(env, nullptr, nullptr, name, 0, 1, nullptr, nullptr, nullptr, settle_js, &g_tsfn);
     napi_unref_threadsafe_function(env, g_tsfn);
 #define EXPORT(name, fn) napi_create_function(env, name, NAPI_AUTO_LENGTH, fn, nullptr, &f); napi_set_named_property(env, exports, name, f);
-    EXPORT("fullProveRaw", FullProveRaw) EXPORT("fullProveBatchRaw", FullProveBatchRaw) EXPORT("proveRaw", ProveRaw) EXPORT("witnessRaw", WitnessRaw) EXPORT("circuitFromWasm", CircuitFromWasm) EXPORT("verifyJson", VerifyJson) EXPORT("statusText", StatusText)
+    EXPORT("fullProveRaw", FullProveRaw) EXPORT("fullProveBatchRaw", FullProveBatchRaw) EXPORT("proveRaw", ProveRaw) EXPORT("witnessRaw", WitnessRaw) EXPORT("circuitFromWasm", CircuitFromWasm) EXPORT("verifyJson", VerifyJson) EXPORT("statusText", StatusText) EXPORT("decimals", Decimals)
 #undef EXPORT
     return exports;
 }

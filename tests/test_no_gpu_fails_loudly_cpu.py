@@ -53,6 +53,16 @@ const inp = require("./tests/golden/ref/inputs_example.json");
   const bad = pub.slice(); bad[0] = String(BigInt(bad[0]) ^ 1n); out.tampered = await groth16.verify(vk, bad, proof);
   try { await groth16.fullProve(Object.assign({}, inp, { censusSiblings: inp.censusSiblings.slice(0, 11), sikSiblings: inp.sikSiblings.slice(0, 11) }), null, process.argv[1], null, { nLevels: 10 }); out.proved = true; }
   catch (e) { out.rejected = String(e); }
+  // the addon's 32-byte-word -> decimal-string conversion (what proof.json / public.json are made of) against BigInt, and ragged / numeric / bigint input values through flatten
+  const native = require("./napi/zkcensus.node"); let nbad = 0;
+  for (let it = 0; it < 500; it++) {
+    const b = crypto.randomBytes(64); if (it == 0) b.fill(0); if (it == 1) b.fill(255); if (it == 2) { b.fill(0); b[0] = 1; b[32] = 10; }
+    const d = native.decimals(b);
+    for (let k = 0; k < 2; k++) if (d[k] !== BigInt("0x" + Buffer.from(b.subarray(32 * k, 32 * k + 32)).reverse().toString("hex")).toString()) nbad++;
+  }
+  out.decimals_bad = nbad; out.decimals_empty = native.decimals(Buffer.alloc(0)).length;
+  const ragged = Object.assign({}, inp, { censusSiblings: inp.censusSiblings.filter((x, i) => i < 12).map((x, i) => i % 2 ? BigInt(x) : x), sikSiblings: inp.sikSiblings.slice(0, 12), voteWeight: Number(inp.voteWeight) });
+  out.ragged_equal = Buffer.compare(flatten(ragged, 160), flatten(Object.assign({}, inp, { censusSiblings: inp.censusSiblings.slice(0, 12).concat(Array(149).fill("0")), sikSiblings: inp.sikSiblings.slice(0, 12).concat(Array(149).fill("0")) }), 160)) === 0;
   console.log(JSON.stringify(out));
 })();
 '''
@@ -63,3 +73,4 @@ const inp = require("./tests/golden/ref/inputs_example.json");
     assert j['flat'] == hashlib.sha256(ol.flat_inputs(ol.load_json('ref/inputs_example.json'))).hexdigest()      # the JS and Python flatteners agree byte for byte
     assert j['verified'] is True and j['tampered'] is False                                                    # the reference's own proof triple, through the addon's host path
     assert 'proved' not in j and 'no GPU visible' in j['rejected']
+    assert j['decimals_bad'] == 0 and j['decimals_empty'] == 0 and j['ragged_equal'] is True
