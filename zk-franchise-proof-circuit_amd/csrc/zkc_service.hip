@@ -225,16 +225,16 @@ void process(zkc_service* s, zkc_service::Worker* w, std::vector<Req*>&& first) 
         else std::this_thread::sleep_for(std::chrono::microseconds(100));
     }
     // an idle device and a burst still arriving (Promise.all over a census: one request every ~25 us from one thread): beginning with the first handful would spend a
-    // latency-bound call on them while the rest queue up behind it.  While requests keep coming, keep taking them: stop after two polls of 30 us without a new one, at `cap`,
-    // or after 2 ms.  A lone request with nothing behind it does not wait at all.
+    // latency-bound call on them while the rest queue up behind it.  While requests keep coming, keep taking them: stop after three polls of 50 us without a new one, at `cap`,
+    // or after 3 ms.  A lone request with nothing behind it does not wait at all.
     {
         bool idle_dev; { std::lock_guard<std::mutex> fl(d->fl_mu); idle_dev = d->in_flight == 0; }
         const uint64_t t_l0 = now_us(); int quiet = 0; bool first = true;
-        while (idle_dev && b.reqs.size() < cap && quiet < 2 && now_us() - t_l0 < 2000) {
+        while (idle_dev && b.reqs.size() < cap && quiet < 3 && now_us() - t_l0 < 3000) {
             const size_t from = b.reqs.size();
             { std::lock_guard<std::mutex> g(s->mu); std::vector<Req*> more = grab(s, w, cap - from, &cls); for (Req* r : more) if (full || r->nW == nW) b.reqs.push_back(r); else finish(r, ZKC_ERR_INVALID_WITNESS_LENGTH, 0, "Invalid witness length"); }
             if (b.reqs.size() > from) { if (!stage(w, b, from, nIn, nW, err)) { (void)hipGetLastError(); return fail_all(s, b, ZKC_ERR_HIP, err); } quiet = 0; }
-            else { if (first && from == 1) break; std::this_thread::sleep_for(std::chrono::microseconds(30)); quiet++; }
+            else { if (first && from == 1) break; std::this_thread::sleep_for(std::chrono::microseconds(50)); quiet++; }
             first = false;
         }
     }
