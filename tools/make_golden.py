@@ -43,6 +43,12 @@ def main():
         ('d13_17', make_voter(rng, depth_c=13, depth_s=17, zero_frac=0.0)),
         ('zero_weight_vote', make_voter(rng, depth_c=5, depth_s=5, avail=77, vote=0)),
     ]
+    # [r3] a dozen more with the depths a real census has (2^10 .. 2^20 voters: leaves 10-20 levels down) and random weights, from their own generator so that the
+    # eighteen above keep their values
+    rng2 = random.Random(0x7A6B43454E535533)
+    for i in range(12):
+        avail = rng2.randrange(1, 1 << rng2.choice((8, 64, 200)))
+        voters.append(('census_%02d' % i, make_voter(rng2, depth_c=rng2.randrange(10, 21), depth_s=rng2.randrange(10, 21), zero_frac=rng2.choice((0.0, 0.1, 0.5)), avail=avail, vote=rng2.randrange(0, avail + 1))))
     base = voters[1][1]
 
     def mut(**kw):
