@@ -195,13 +195,16 @@ __device__ Fr poseidon_trace29(const Fr* in, unsigned cmask, const PoseidonTable
 // The three trace values of partial round r are parked in lane r and stored once, 57 lanes side by side, after the last partial round.
 // A partial round is about 1100 instructions instead of 1900 (S-box 650, one product 250, selects and 45 v_readlane), a full round 1450
 // instead of 4100.  Values are congruent to, not identical with, the single-lane routine's (separate reductions); the wires are canonical.
-// The empty asm pins every gathered limb in a VGPR and hides from the compiler that it is wave-uniform: left alone, hipcc moved the whole S-box of
-// the (uniform) word 0 to the SCALAR unit -- 81 limb products as s_mul_i32 / s_mul_hi_u32 / s_add_u32 / s_addc_u32 quadruples, 1850 scalar
-// instructions per partial round where the vector unit needs 650 (v_mad_u64_u32 multiplies and accumulates in one instruction).
+// PIN = true: an empty asm pins every gathered limb in a VGPR and hides from the compiler that it is wave-uniform.  Round 2 needed it: word 0 of the state was uniform
+// through its whole S-box and hipcc moved that S-box to the SCALAR unit -- 81 limb products as s_mul_i32 / s_mul_hi_u32 / s_add_u32 / s_addc_u32 quadruples, 1850 scalar
+// instructions per partial round where the vector unit needs 650.  [r3] With three products per round every product has a per-lane operand (lanes play different roles), nothing
+// of that size is uniform any more, and the gathered limbs may stay in SGPRs as operands: 54 v_mov and 37 s_nop less per partial round (949 -> 870 instructions), the carry of the
+// uniform word 0 on the scalar unit.  The ISA holds 11 s_mul in all; tools/single_proof_trace.py: witness chain 2.00 -> 1.90 ms.
+template <bool PIN = false>
 __device__ __forceinline__ W29 bcast29(const W29& v, int src) {
     W29 r;
 #pragma unroll
-    for (int k = 0; k < 9; k++) { uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)v.l[k], src); asm volatile("" : "+v"(x)); r.l[k] = x; }
+    for (int k = 0; k < 9; k++) { uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)v.l[k], src); if (PIN) asm volatile("" : "+v"(x)); r.l[k] = x; }
     return r;
 }
 __device__ __forceinline__ void emit29_any(const Emit& e, int wire, const W29& v) {
@@ -276,7 +279,7 @@ __device__ Fr poseidon_wave29(const Fr* in, unsigned cmask, const PoseidonTable&
         for (int j = 1; j < T; j++) if (lane == j) Xa = st[j];
         W29 A; f29_mul<FrParams>(A.l, Xa.l, Ya.l);
         W29 B; f29_sqr<FrParams>(B.l, A.l);
-        const W29 x4 = bcast29(B, 63);
+        const W29 x4 = bcast29<false>(B, 63);
         W29 H;
         { const int ki = lane == 0 ? 0 : (lane >= T && lane < CH0 ? lane - T + 1 : 0);
           const uint4* q = reinterpret_cast<const uint4*>(K29 + 12 * (size_t)(r * T + ki)); const uint4 a = q[0], b = q[1], d = q[2];
@@ -287,14 +290,14 @@ __device__ Fr poseidon_wave29(const Fr* in, unsigned cmask, const PoseidonTable&
             for (int k = 0; k < 9; k++) H.l[k] += st[i2].l[k];
         }
         W29 Pd; f29_mul_addhi<FrParams>(Pd.l, A.l, x4.l, H.l);
-        W29 n0 = bcast29(Pd, 0);
+        W29 n0 = bcast29<false>(Pd, 0);
 #pragma unroll
-        for (int j = 1; j < T; j++) { const W29 t = bcast29(A, j);
+        for (int j = 1; j < T; j++) { const W29 t = bcast29<false>(A, j);
 #pragma unroll
             for (int k = 0; k < 9; k++) n0.l[k] += t.l[k]; }
         f29_carry(n0.l);
 #pragma unroll
-        for (int i2 = 1; i2 < T; i2++) st[i2] = bcast29(Pd, T + i2 - 1);
+        for (int i2 = 1; i2 < T; i2++) st[i2] = bcast29<false>(Pd, T + i2 - 1);
         st[0] = n0;
         if (lane == CH0 + r) { E1 = A; E2 = x4; E3 = n0; }
     }
