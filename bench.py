@@ -174,7 +174,7 @@ def extra_legs(args, ctx, pk, zkey_bytes, vk, B, d_inputs, d_wtns, d_status, fla
     res['single_proof'] = {'ms_min': round(one[0], 3), 'ms_median': round(one[len(one) // 2], 3), 'bytes_equal_proof_of_the_timed_batch': bool(p1 == out['proofs'][:256] and u1 == out['pubs'][:len(u1)]),
                            'note': 'voter 0 of the timed batch alone, same (r, s): a pass of one proof takes the latency-shaped path (blinding without variable-base products, small virtual '
                                    'windows, half a wave per G2 bucket; DESIGN.md section 7) and gives the bytes the batch gave; 12 calls after 2 warm-ups.  The witness chain grows with the depth of the voter\'s leaf: this census puts it 13-14 levels down '
-                                   '(the reference\'s inputs_example.json, shallower, takes 3.3 ms: profiles/r03_single_proof_latency.json)'}
+                                   '(the reference\'s inputs_example.json, shallower, takes 3.2 ms: profiles/r03_single_proof_latency.json)'}
     # ---- folding: worst cases ----
     Bd = min(B, 188)
     deep = census.deep_voters(ctx, Bd, nl)
