@@ -565,7 +565,7 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
     static const bool trace_host = getenv("ZKC_TRACE_HOST") != nullptr;
     auto now_ms = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; };
     const double t_begin = now_ms(); double tr[6] = {0};
-    int pass = 0;
+    int pass = 0; bool done_on_st = false;
     for (int p0 = 0; p0 < B; p0 += per_pass, pass++) {
         const int nb = std::min(per_pass, B - p0);
         zkc_lane& LN = zk->lane[pass % zk->nlanes]; const int slot = LN.npass & 1;       // MSM results are double-buffered: the blinding of pass k overlaps pass k+1
@@ -679,19 +679,23 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
             ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_mv, fin));
         }
         // a7 on the second stream: overlaps the next pass
-        ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm, 0));
+        // a call that is one small pass: its blinding and its copy go on the G1 stream itself -- nothing follows that they could overlap with, and a hop to the blinding stream is
+        // ~25 us of a 3.2 ms proof
+        hipStream_t bl = (tree && npasses == 1) ? st : fin;
+        if (bl == fin) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm, 0));
         if (!tree) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm2, 0));      // a small pass' piB is written on the G2 stream: piA and piC need not wait for it ...
-        if ((rc = finalize_launch(ctx, fin, fa, nb))) return rc;
-        if (tree) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm2, 0));       // ... only the copy of the finished proof does
-        if (tree) { ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.h_xyzz + 512ull * p0, CS.d_xyzz + 512 * (size_t)p0, 512ull * nb, hipMemcpyDeviceToHost, fin)); for (int q = 0; q < nb; q++) CS.as_xyzz[p0 + q] = 1; }
+        if ((rc = finalize_launch(ctx, bl, fa, nb))) return rc;
+        if (tree) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(bl, LN.ev_msm2, 0));        // ... only the copy of the finished proof does
+        if (tree) { ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.h_xyzz + 512ull * p0, CS.d_xyzz + 512 * (size_t)p0, 512ull * nb, hipMemcpyDeviceToHost, bl)); for (int q = 0; q < nb; q++) CS.as_xyzz[p0 + q] = 1; }
         else ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.h_out + 256ull * p0, CS.d_proofs + 256 * (size_t)p0, 256ull * nb, hipMemcpyDeviceToHost, fin));
-        ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_fin[slot], fin));
+        ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_fin[slot], bl));
+        if (bl == st) done_on_st = true;
         tr[5] = now_ms();
         if (trace_host) fprintf(stderr, "[zkc host] pass %2d: start %8.2f | chunk wait %6.2f | h_evals %6.2f | g2 pass %6.2f | g1 pass %6.2f | blinding %6.2f ms\n", pass, tr[0] - t_begin,
                                 tr[1] - tr[0], tr[2] - tr[1], tr[3] - tr[2], tr[4] - tr[3], tr[5] - tr[4]);
     }
     // every lane's blinding stream already waits for its G1 and G2 streams (ev_msm, ev_msm2) and carries the last copies: one event per lane closes the call
-    for (int l = 0; l < zk->nlanes; l++) ZKC_HIP_CHECK(ctx, hipEventRecord(CS.ev_done[l], zk->lane[l].fin));
+    for (int l = 0; l < zk->nlanes; l++) ZKC_HIP_CHECK(ctx, hipEventRecord(CS.ev_done[l], (done_on_st && l == 0) ? zk->lane[l].st : zk->lane[l].fin));      // (a one-pass call runs on lane 0)
     CS.B = B; CS.pending = true;
     return ZKC_OK;
 }
