@@ -41,7 +41,8 @@ def setup_key(r1cs_path, seed):
     return open(z, 'rb').read(), json.load(open(v))
 
 
-SIZES = [(3, 6, 1), (5, 9, 2), (50, 64, 3), (300, 200, 0), (1000, 900, 5), (5000, 3000, 8)]
+SIZES = [(3, 6, 1), (5, 9, 2), (50, 64, 3), (300, 200, 0), (1000, 900, 5), (5000, 3000, 8), (12000, 9000, 2)]       # domains 8 .. 2^14
+GPU_SIZES = SIZES + [(28000, 20000, 1), (50000, 40000, 6)]                                                                  # .. 2^15, 2^16 (2^18 and up: tests/test_gpu_generic_large.py)
 
 
 @pytest.mark.parametrize('n_cons,n_wires,n_pub', SIZES)
@@ -57,7 +58,7 @@ def test_oracle_and_closed_form_on_random_circuits(tmp_path, n_cons, n_wires, n_
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('n_cons,n_wires,n_pub', SIZES)
+@pytest.mark.parametrize('n_cons,n_wires,n_pub', GPU_SIZES)
 def test_gpu_prover_on_random_circuits(tmp_path, n_cons, n_wires, n_pub):
     import torch  # noqa: F401
     import zkcensus_amd

@@ -290,29 +290,33 @@ __device__ __forceinline__ void ntt_nr_stages(uint32_t* tile, Slot slot, int b, 
     }
 }
 extern "C" __global__ void __launch_bounds__(256)
-zkc_ntt_nr_head(const Fr* src_all, Fr* dst_all, const uint32_t* __restrict__ tw29, int logn, int b) {      // src_all == dst_all: in place
-    // tile: mid = top b position bits (stride 2^(logn-b)), lo_t = NTT_TILE >> b neighbouring positions starting at lo0
+zkc_ntt_nr_head(const Fr* src_all, Fr* dst_all, const uint32_t* __restrict__ tw29, int logn, int q0, int b) {      // src_all == dst_all: in place
+    // NR stages q0 .. q0+b-1.  tile: mid = the b position bits below the top q0 (stride 2^sh, sh = logn-q0-b), lo_t = NTT_TILE >> b neighbouring positions starting
+    // at lo0; the top q0 bits (`prefix`) are fixed per block.  q0 = 0: the first kernel of a transform (stage 0 is twiddle-free, operands as large as 32 p).
+    // [r4] domains above 2^18 run two of these in a row (q0 = 0, then q0 = b of the first): the mid kernel always takes the last nine NR stages.
     const Fr* src = src_all + ((size_t)blockIdx.y << logn);
     Fr* dst = dst_all + ((size_t)blockIdx.y << logn);
     extern __shared__ uint32_t tile[];
-    const int mid_n = 1 << b, sh = logn - b, lo_t = NTT_TILE >> b, elems = mid_n * lo_t;
-    const int lo0 = blockIdx.x * lo_t;
+    const int mid_n = 1 << b, sh = logn - q0 - b, lo_t = NTT_TILE >> b, elems = mid_n * lo_t;
+    const int bpp = (1 << sh) / lo_t;                                    // blocks per prefix
+    const uint32_t prefix = blockIdx.x / bpp;
+    const size_t base = ((size_t)prefix << (logn - q0)) + (size_t)(blockIdx.x % bpp) * lo_t;
     for (int e = threadIdx.x; e < elems; e += blockDim.x) {
         const int mid = e / lo_t, l = e - mid * lo_t;
-        const Fr x = ld_fr(src + (((size_t)mid << sh) + lo0 + l));
+        const Fr x = ld_fr(src + (base + ((size_t)mid << sh) + l));
         uint32_t t[9]; f29_from_fp_shl5(t, x.v);
 #pragma unroll
         for (int k = 0; k < 9; k++) tile[9 * e + k] = t[k];
     }
     __syncthreads();
-    ntt_nr_stages<false>(tile, [lo_t](int mid, int l) { return mid * lo_t + l; }, b, lo_t, 0, 0u, 0, tw29, logn, true);
+    ntt_nr_stages<false>(tile, [lo_t](int mid, int l) { return mid * lo_t + l; }, b, lo_t, q0, prefix, 0, tw29, logn, q0 == 0);
     for (int e = threadIdx.x; e < elems; e += blockDim.x) {
         const int mid = e / lo_t, l = e - mid * lo_t;
         uint32_t r[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) r[k] = tile[9 * e + k];
         f29_reduce_small<FrParams>(r);
-        st_fr(dst + (((size_t)mid << sh) + lo0 + l), f29_to_fp<FrParams>(r));
+        st_fr(dst + (base + ((size_t)mid << sh) + l), f29_to_fp<FrParams>(r));
     }
 }
 // NR stages logn-9 .. logn-1 of the inverse, the scale, RN stages 1 .. 9 of the forward transform: NTT_TILE consecutive positions = two blocks of 512
@@ -383,14 +387,20 @@ int ntt_bitrev_table(zkc_ctx* ctx, const Fr* d_src, Fr** out, int logn) {
     ZKC_HIP_CHECK(ctx, hipGetLastError());
     return ZKC_OK;
 }
-// the prover's transform pair on `nvec` contiguous vectors: data <- NTT(scale x iNTT(data)), in place (tmp is not needed); logn >= 12
+// the prover's transform pair on `nvec` contiguous vectors: data <- NTT(scale x iNTT(data)), in place (tmp is not needed); 12 <= logn <= 27.
+// Up to 2^18: head (NR 0 .. logn-10) -> mid -> tail (RN 10 .. logn), three HBM round trips.  [r4] Above (BASELINE configs[4]: a 2^20 domain, the ceiling of the reference's
+// powers of tau, circuit/circuit-compiler.sh:57) the logn-9 head stages and the logn-9 tail stages no longer fit one tile of 1024 elements with whole cache lines per row,
+// so each side is two kernels: five round trips, still in place and still without a single permuted access (the stand-alone ntt_run needs six, two of them bit-reversed gathers).
 int ntt_pair_run(zkc_ctx* ctx, hipStream_t st, Fr* data, const uint32_t* tw_inv29, const uint32_t* tw_fwd29, const Fr* scale_br, int logn, int nvec) {
-    if (logn < 12 || logn > 18) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "ntt_pair_run: 12 <= logn <= 18");
+    if (logn < 12 || logn > 27) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "ntt_pair_run: 12 <= logn <= 27");
     const int bh = logn - 9;                                     // head: NR stages 0 .. logn-10, tail: RN stages 10 .. logn (bh stages each)
-    hipLaunchKernelGGL(zkc_ntt_nr_head, dim3((1 << logn) / NTT_TILE, nvec), dim3(256), (size_t)NTT_TILE * 36, st, (const Fr*)data, data, tw_inv29, logn, bh);
-    hipLaunchKernelGGL(zkc_ntt_mid, dim3((1 << logn) / NTT_TILE, nvec), dim3(256), (size_t)NTT_TILE * 36, st, data, tw_inv29, tw_fwd29, scale_br, logn);
-    const int lo_t = NTT_TILE >> bh;
-    hipLaunchKernelGGL(zkc_ntt_pass, dim3((1 << logn) / ((1 << bh) * lo_t), nvec), dim3(256), (size_t)NTT_TILE * 36, st, (const Fr*)data, data, tw_fwd29, (const Fr*)nullptr, logn, 9, bh, 0);
+    const int b1 = bh <= 9 ? bh : (bh + 1) / 2, b2 = bh - b1;    // one kernel each side up to 2^18, two above
+    const unsigned blocks = (1u << logn) / NTT_TILE;
+    hipLaunchKernelGGL(zkc_ntt_nr_head, dim3(blocks, nvec), dim3(256), (size_t)NTT_TILE * 36, st, (const Fr*)data, data, tw_inv29, logn, 0, b1);
+    if (b2) hipLaunchKernelGGL(zkc_ntt_nr_head, dim3(blocks, nvec), dim3(256), (size_t)NTT_TILE * 36, st, (const Fr*)data, data, tw_inv29, logn, b1, b2);
+    hipLaunchKernelGGL(zkc_ntt_mid, dim3(blocks, nvec), dim3(256), (size_t)NTT_TILE * 36, st, data, tw_inv29, tw_fwd29, scale_br, logn);
+    hipLaunchKernelGGL(zkc_ntt_pass, dim3(blocks, nvec), dim3(256), (size_t)NTT_TILE * 36, st, (const Fr*)data, data, tw_fwd29, (const Fr*)nullptr, logn, 9, b1, 0);
+    if (b2) hipLaunchKernelGGL(zkc_ntt_pass, dim3(blocks, nvec), dim3(256), (size_t)NTT_TILE * 36, st, (const Fr*)data, data, tw_fwd29, (const Fr*)nullptr, logn, 9 + b1, b2, 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return zkc_fail(ctx, ZKC_ERR_HIP, std::string("ntt_pair_run: ") + hipGetErrorString(e));
     return ZKC_OK;

@@ -116,9 +116,9 @@ static int lanes_ensure(zkc_zkey* zk, int inflight) {
     inflight = inflight <= 4 ? 4 : zk->max_inflight;
     inflight = std::min(inflight, zk->max_inflight);
     zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n, nv = zk->nVars; int rc;
-    constexpr int NWS = msm_nw(MSM_C_SMALL), NWB = msm_nw(MSM_C_BIG);
+    const int NWS = msm_nw(zk->c_sec), NWB = msm_nw(MSM_C_BIG);
     const size_t per_proof_entries = (size_t)NWS * 3 * nv + (size_t)NWB * n;
-    const size_t per_proof_buckets = 3 * (size_t)msm_half(MSM_C_SMALL) + msm_half(MSM_C_BIG);
+    const size_t per_proof_buckets = 3 * (size_t)msm_half(zk->c_sec) + msm_half(MSM_C_BIG);
     // the old work space goes first (a key at nLevels = 160 with 96 proofs in flight holds ~6 GB): from here until every allocation has succeeded the key
     // has NO work space, and says so (cur_inflight = 0), so a failure leaves a key that re-allocates on its next call instead of launching on freed buffers
     zk->cur_inflight = 0;
@@ -141,7 +141,7 @@ static int lanes_ensure(zkc_zkey* zk, int inflight) {
         if (!rc && hipMalloc(&L.d_fin, finalize_scratch_bytes(inflight)) != hipSuccess) rc = zkc_fail(ctx, ZKC_ERR_HIP, "lanes_ensure: hipMalloc failed (blinding scratch)");
         if (!rc) rc = dmalloc(ctx, &L.d_bs, 2 * 2 * 8 * (size_t)nv);
         if (!rc) rc = msm_work_alloc(ctx, L.w1, per_proof_entries * inflight, per_proof_buckets * inflight, 4 * inflight, false);
-        if (!rc) rc = msm_work_alloc(ctx, L.w2, (size_t)NWS * nv * inflight, (size_t)msm_half(MSM_C_SMALL) * inflight, inflight, true);
+        if (!rc) rc = msm_work_alloc(ctx, L.w2, (size_t)NWS * nv * inflight, (size_t)msm_half(zk->c_sec) * inflight, inflight, true);
         if (rc) { (void)hipGetLastError(); release(); return rc; }
     }
     zk->cur_inflight = inflight;
@@ -229,7 +229,10 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
     }
     // ---- bases: one G1 array [A | B1 | C | H] and one G2 array [B2]; window 0 = the zkey points as stored (affine,
     //      Montgomery), windows 1..19 pre-shifted on the device ----
-    constexpr int NWS = msm_nw(MSM_C_SMALL), NWB = msm_nw(MSM_C_BIG);
+    // [r4] window of the witness sections, per key: 12 bits (22 additions per scalar into 2048 buckets) suits the census circuit's 8-11 k wires per section after folding; a
+    // section of 2^16 wires and more (BASELINE configs[4]: a 2^20-constraint circuit) takes H's 17 bits -- 15 additions per scalar, and 65536 buckets are then cheap beside them
+    { const char* e_c = getenv("ZKC_C_SECTIONS"); zk->c_sec = e_c ? std::max(8, std::min(atoi(e_c), MSM_C_BIG)) : ((zk->nLevels < 0 && nv >= (1u << 16)) ? MSM_C_BIG : MSM_C_SMALL); }
+    const int NWS = msm_nw(zk->c_sec), NWB = msm_nw(MSM_C_BIG);
     zk->offA = 0; zk->offB1 = NWS * nv; zk->offC = 2 * NWS * nv; zk->offH = 2 * NWS * nv + NWS * nc;
     const size_t g1_points = (size_t)NWS * (2 * (size_t)nv + nc) + (size_t)NWB * n;
     if (g1_points >= (1ull << 31)) return bail(zkc_fail(ctx, ZKC_ERR_FORMAT, "zkey too large for 31-bit point indices"));
@@ -237,13 +240,13 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
     ZKC_UP(zk->d_g1 + zk->offA, sec[5], 64ull * nv); ZKC_UP(zk->d_g1 + zk->offB1, sec[6], 64ull * nv);
     ZKC_UP(zk->d_g1 + zk->offC, sec[8], 64ull * nc); ZKC_UP(zk->d_g1 + zk->offH, sec[9], 64ull * n);
     ZKC_UP(zk->d_g2, sec[7], 128ull * nv);
-    if ((rc = msm_precompute_g1(ctx, nv, zk->d_g1 + zk->offA, MSM_C_SMALL)) || (rc = msm_precompute_g1(ctx, nv, zk->d_g1 + zk->offB1, MSM_C_SMALL)) ||
-        (rc = msm_precompute_g1(ctx, nc, zk->d_g1 + zk->offC, MSM_C_SMALL)) || (rc = msm_precompute_g1(ctx, n, zk->d_g1 + zk->offH, MSM_C_BIG)) ||
-        (rc = msm_precompute_g2(ctx, nv, zk->d_g2, MSM_C_SMALL))) return bail(rc);
+    if ((rc = msm_precompute_g1(ctx, nv, zk->d_g1 + zk->offA, zk->c_sec)) || (rc = msm_precompute_g1(ctx, nv, zk->d_g1 + zk->offB1, zk->c_sec)) ||
+        (rc = msm_precompute_g1(ctx, nc, zk->d_g1 + zk->offC, zk->c_sec)) || (rc = msm_precompute_g1(ctx, n, zk->d_g1 + zk->offH, MSM_C_BIG)) ||
+        (rc = msm_precompute_g2(ctx, nv, zk->d_g2, zk->c_sec))) return bail(rc);
     if ((rc = dmalloc(ctx, &zk->d_g2_29, 60 * (size_t)NWS * nv)) || (rc = msm_g2_table29(ctx, zk->d_g2, zk->d_g2_29, (size_t)NWS * nv))) return bail(rc);
     {   // [r3] the 8-bit-window G2 table of the lone-proof path (MSM_C_G2_LONE): shifted in a temporary affine table, kept in radix 2^29 only
         const char* e_lone = getenv("ZKC_G2_LONE_TABLE");
-        if (!(e_lone && atoi(e_lone) == 0)) {
+        if (!(e_lone && atoi(e_lone) == 0) && (zk->nLevels >= 0 || nv < (1u << 16))) {      // (a key of 2^16 wires and more that is not the census circuit: 32 x 240 B per wire for a latency path its proofs are too large to notice)
             constexpr int NWL = msm_nw(MSM_C_G2_LONE);
             G2Affine* tmp = nullptr;
             if ((rc = dmalloc(ctx, &tmp, (size_t)NWL * nv))) return bail(rc);
@@ -260,7 +263,13 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
     // ---- work buffers: up to `max_inflight` proofs share one MSM pipeline pass; the buffers themselves are sized by lanes_ensure() for
     //      the number of proofs a call actually puts in flight (a single-proof caller does not reserve the work space of 96) ----
     const char* e_inf = getenv("ZKC_INFLIGHT");
-    zk->max_inflight = e_inf ? std::max(1, std::min(atoi(e_inf), MSM_MAX_JOBS / 4)) : 96;      // same box, batch 1024: 64 -> 1955, 80 -> 1985, 96 -> 2015, 112 -> 2000, 128 -> 2022 proofs/s; round 2: 96 -> 3010, 114 -> 3004, 128 -> 3031
+    zk->max_inflight = e_inf ? std::max(1, std::min(atoi(e_inf), MSM_MAX_JOBS / 4)) : 96;
+    {   // [r4] the pass is sized for the census key (96 proofs of 7.4 M (scalar, window) entries unfolded): a larger circuit puts fewer proofs in flight -- the same ~0.7 G entries per
+        // pass, which also keeps every entry index of a pass inside 32 bits (MsmJob::ent_off) -- 11 at a 2^20 domain, where ONE proof is 60 M additions and fills the chip
+        const size_t per_proof_entries = (size_t)NWS * 3 * nv + (size_t)NWB * n, census_pass = 96ull * (22ull * 3 * 82754 + 15ull * 131072);
+        const int fit = (int)std::max<size_t>(1, census_pass / std::max<size_t>(per_proof_entries, 1));
+        zk->max_inflight = std::min(zk->max_inflight, fit);
+    }      // same box, batch 1024: 64 -> 1955, 80 -> 1985, 96 -> 2015, 112 -> 2000, 128 -> 2022 proofs/s; round 2: 96 -> 3010, 114 -> 3004, 128 -> 3031
     // ZKC_LANES=2 lets two lanes take alternate passes; measured no gain in round 1 (the GPU is already saturated) and -4 % at the end of round 2 (3005
     // against 3142 proofs/s on one box: the second lane has no buildABC prefetch), so one lane is the default
     { const char* e_l = getenv("ZKC_LANES"); zk->nlanes = e_l ? std::max(1, std::min(atoi(e_l), 2)) : 1; }
@@ -423,7 +432,7 @@ static int h_evals_dev(zkc_zkey* zk, zkc_lane& L, const uint32_t* d_wtns0, int n
     zkc_prof_scope _pn(ctx, ZKC_PROF_NTT, (uint64_t)nb * (6ull * 2 * n * 32 + 4ull * n * 32), st);   // 6 transforms r+w, joinABC
     int rc;
     static const bool ntt_two_transforms = getenv("ZKC_NTT_SEPARATE") != nullptr;      // diagnostics: the round-1 path (two full transforms, four HBM round trips)
-    if (!ntt_two_transforms && zk->logn >= 12 && zk->logn <= 18) {
+    if (!ntt_two_transforms && zk->logn >= 12 && zk->logn <= 27) {
         if ((rc = ntt_pair_run(ctx, st, L.d_abc, zk->d_tw_inv29, zk->d_tw_fwd29, zk->d_coset_br, (int)zk->logn, 3 * nb))) return rc;
     } else {
         if ((rc = ntt_run(ctx, st, L.d_abc, L.d_t, zk->d_tw_inv29, zk->d_coset, (int)zk->logn, 3 * nb))) return rc;
@@ -462,7 +471,7 @@ extern "C" int zkc_msm_debug(zkc_zkey* zk, int which, const void* d_scalars, uin
     if (count != full) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_msm_debug: count must equal the section size");
     static thread_local MsmJobList jl; jl.clear();
     const uint32_t offs[5] = {zk->offA, zk->offB1, 0, zk->offC, zk->offH};
-    jl.add((const uint32_t*)d_scalars, nullptr, count, offs[which], full, 0, which == 4 ? MSM_C_BIG : MSM_C_SMALL);
+    jl.add((const uint32_t*)d_scalars, nullptr, count, offs[which], full, 0, which == 4 ? MSM_C_BIG : zk->c_sec);
     int rc = which == 2 ? msm_pass_g2(zk, L0.w2, jl, 0, true, L0.st) : msm_pass_g1(zk, L0.w1, jl, 0, true, L0.st); if (rc) return rc;
     ZKC_HIP_CHECK(ctx, hipStreamSynchronize(L0.st));
     if (which == 2) g2_to_std((uint8_t*)host_out, xyzz_to_affine(*(G2XYZZ*)L0.w2.h_results));
@@ -605,7 +614,7 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         const uint32_t vws = nb <= 4 ? 64u : 256u, vwb = nb <= 4 ? 256u : 1024u;          // few proofs in the pass: favour latency in the bucket reduction
         // the G2 section of one or two proofs takes the 8-bit-window table: 128 buckets per job, reduced by one wave (vw = 128), if the G2 work space holds 32 entries per scalar
         size_t lone_entries = 0; for (int q = 0; q < nb; q++) lone_entries += (size_t)msm_nw(MSM_C_G2_LONE) * (fold ? vms[q].nB : nv);
-        const int c2 = (nb <= 2 && zk->d_g2_29_lone && lone_entries <= LN.w2.max_entries) ? MSM_C_G2_LONE : MSM_C_SMALL;
+        const int c2 = (nb <= 2 && zk->d_g2_29_lone && lone_entries <= LN.w2.max_entries) ? MSM_C_G2_LONE : zk->c_sec;
         j1.clear(vws, vwb); j2.clear(c2 == MSM_C_G2_LONE ? 128u : vws);
         // job order of the G1 pass: the nb H jobs first (the 16-bit bucket sort wants the jobs with the larger bucket count in front), then
         // A, B1, C per proof.  zkc_finalize reads results[q] = H_q and results[nb + 3 q + {0, 1, 2}] = A_q, B1_q, C_q.
@@ -613,26 +622,27 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         // [r3] a pass of one or two proofs carries its blinding's two variable-base products as two more MSM jobs each -- sum (s w_i) A_i and sum (r w_i) B1_i over the
         // wires that stay in the proof's MSMs -- so that the blinding kernel is left with fixed-base products only (zkc_finalize.hip)
         // (the lanes' work space is sized for max(4, passes of this key) proofs of 3 + 1 jobs each: two proofs of 5 + 1 fit unless ZKC_INFLIGHT made the passes smaller than that)
-        size_t tree_entries = 0; for (int q = 0; q < nb; q++) tree_entries += (size_t)msm_nw(MSM_C_BIG) * n + (size_t)msm_nw(MSM_C_SMALL) * (fold ? 2 * (size_t)vms[q].nA + 2 * (size_t)vms[q].nB + vms[q].nC : 4 * (size_t)nv + nc);
-        const bool tree = zk->d_fb4 != nullptr && nb <= 2 && 6 * nb <= LN.w1.max_jobs && tree_entries <= LN.w1.max_entries && (size_t)nb * (5 * msm_half(MSM_C_SMALL) + msm_half(MSM_C_BIG)) <= LN.w1.max_buckets;
+        size_t tree_entries = 0; for (int q = 0; q < nb; q++) tree_entries += (size_t)msm_nw(MSM_C_BIG) * n + (size_t)msm_nw(zk->c_sec) * (fold ? 2 * (size_t)vms[q].nA + 2 * (size_t)vms[q].nB + vms[q].nC : 4 * (size_t)nv + nc);
+        const bool tree = zk->d_fb4 != nullptr && nb <= 2 && 6 * nb <= LN.w1.max_jobs && tree_entries <= LN.w1.max_entries && (size_t)nb * (5 * msm_half(zk->c_sec) + msm_half(MSM_C_BIG)) <= LN.w1.max_buckets;
         BlindArgs ba{}; ba.rs = CS.d_rs + 64 * (size_t)p0; ba.nv = nv;
+        const int cs = zk->c_sec;
         for (int q = 0; q < nb; q++) {
             const uint32_t* w = w0 + (size_t)q * nv * 8;
             uint32_t* bs = tree ? LN.d_bs + (size_t)q * 2 * nv * 8 : nullptr;
             if (tree) { ba.w[q] = w; ba.out[q] = bs; }
             if (fold) {
                 const zkc_zkey::Fold::VMap& vm = vms[q];
-                j1.add(w, vm.d + vm.offA, vm.nA, zk->offA, nv, 0, MSM_C_SMALL);
-                j1.add(w, vm.d + vm.offB, vm.nB, zk->offB1, nv, 0, MSM_C_SMALL);
-                j1.add(w, vm.d + vm.offC, vm.nC, zk->offC, nc, (int32_t)np + 1, MSM_C_SMALL);
-                if (tree) { j1.add(bs, vm.d + vm.offA, vm.nA, zk->offA, nv, 0, MSM_C_SMALL); j1.add(bs + 8ull * nv, vm.d + vm.offB, vm.nB, zk->offB1, nv, 0, MSM_C_SMALL); }
+                j1.add(w, vm.d + vm.offA, vm.nA, zk->offA, nv, 0, cs);
+                j1.add(w, vm.d + vm.offB, vm.nB, zk->offB1, nv, 0, cs);
+                j1.add(w, vm.d + vm.offC, vm.nC, zk->offC, nc, (int32_t)np + 1, cs);
+                if (tree) { j1.add(bs, vm.d + vm.offA, vm.nA, zk->offA, nv, 0, cs); j1.add(bs + 8ull * nv, vm.d + vm.offB, vm.nB, zk->offB1, nv, 0, cs); }
                 j2.add(w, vm.d + vm.offB, vm.nB, 0, nv, 0, c2);
                 if (tree) { ba.mapA[q] = vm.d + vm.offA; ba.nA[q] = vm.nA; ba.mapB[q] = vm.d + vm.offB; ba.nB[q] = vm.nB; }
             } else {
-                j1.add(w, nullptr, nv, zk->offA, nv, 0, MSM_C_SMALL);
-                j1.add(w, nullptr, nv, zk->offB1, nv, 0, MSM_C_SMALL);
-                j1.add(w + 8ull * (np + 1), nullptr, nc, zk->offC, nc, 0, MSM_C_SMALL);
-                if (tree) { j1.add(bs, nullptr, nv, zk->offA, nv, 0, MSM_C_SMALL); j1.add(bs + 8ull * nv, nullptr, nv, zk->offB1, nv, 0, MSM_C_SMALL); }
+                j1.add(w, nullptr, nv, zk->offA, nv, 0, cs);
+                j1.add(w, nullptr, nv, zk->offB1, nv, 0, cs);
+                j1.add(w + 8ull * (np + 1), nullptr, nc, zk->offC, nc, 0, cs);
+                if (tree) { j1.add(bs, nullptr, nv, zk->offA, nv, 0, cs); j1.add(bs + 8ull * nv, nullptr, nv, zk->offB1, nv, 0, cs); }
                 j2.add(w, nullptr, nv, 0, nv, 0, c2);
                 if (tree) { ba.mapA[q] = ba.mapB[q] = nullptr; ba.nA[q] = ba.nB[q] = nv; }
             }

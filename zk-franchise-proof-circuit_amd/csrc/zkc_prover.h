@@ -172,6 +172,7 @@ struct zkc_zkey {
     uint32_t* d_g2_29_lone = nullptr;                                       // the same bases pre-shifted for MSM_C_G2_LONE (32 windows), radix 2^29 only; nullptr: not built (ZKC_G2_LONE_TABLE=0)
     uint32_t offA = 0, offB1 = 0, offC = 0, offH = 0;                       // table offsets inside d_g1 (points)
     // per-proof work buffers
+    int c_sec = zkc::MSM_C_SMALL;                                                // [r4] window bits of the witness sections A, B1, C, B2 of THIS key (zkc_zkey_load: 12, or 17 for sections of 2^16 wires and more)
     int max_inflight = 0;                                                   // proofs per pipeline pass (upper limit)
     int cur_inflight = 0;                                                   // what the lanes' work space is currently sized for (lanes_ensure)
     uint8_t sha256[32] = {0};                                               // of the whole .zkey image (taken once, at load)
