@@ -149,7 +149,9 @@ int  zkc_pool_fullprove_batch(zkc_pool* pool, const void* inputs, int B, const u
  * whatever has accumulated in ONE pipeline pass sequence (zkc_fullprove_batch_dev / zkc_prove_batch_dev): a lone caller is served at once,
  * concurrent callers share passes (64 concurrent callers reach most of the batch rate instead of 64 x the single-proof latency).
  * Devices: hip_devices[n], or n = 0: $ZKC_DEVICE ("2", "0,1,2,3", "all"), unset = every visible device; a device is brought up (context, key
- * tables) only when the queue is long enough to pay for it, and loads its key before it takes requests.  Key identity: the service keeps its own copy of
+ * tables) only when the queue is long enough to pay for it, and loads its key before it takes requests.  A device keeps up to $ZKC_SERVICE_KEYS keys resident
+ * (default 4, ~2 GB of tables each at nLevels 160; least recently used out first): callers with different keys -- one per environment and depth,
+ * circuit/circuit-compiler.sh:15,82 -- share a GPU without reloads, each batch of one key.  Key identity: the service keeps its own copy of
  * every .zkey image it has seen (at most four); a request finds its image through zkc_zkey_fingerprint (a SAMPLED hash) and, the first time a given caller
  * buffer (pointer, length) shows up, through the SHA-256 of the whole image -- so the caller's .zkey buffer need only stay valid during the call itself.
  * The blocking calls return the voter's own result: ZKC_OK, ZKC_ERR_WITNESS (status = ZKC_W_*: that voter failed a circuit assert; other
@@ -174,7 +176,8 @@ int zkc_service_submit_prove(zkc_service* svc, const void* zkey, size_t zkey_len
  * wholesale (HIP / key errors), [7] requests waiting now */
 int zkc_service_stats(zkc_service* svc, uint64_t out[8]);
 /* where the workers' time went, microseconds summed over all batches: out[0] uploads before the GPU is free, [1] waiting for the GPU (the other worker's
- * batch), [2] key check / load + top-up upload, [3] the batch call itself, [4] handing results back; [5] proofs, [6] batches */
+ * batch), [2] key check / load + top-up upload, [3] the batch call itself, [4] handing results back; [5] proofs, [6] batches, [7] keys evicted (a device keeps
+ * $ZKC_SERVICE_KEYS keys resident, default 4, least recently used out first; the reference has one key per environment and depth, circuit/circuit-compiler.sh:15,82) */
 int zkc_service_timing(zkc_service* svc, uint64_t out[8]);
 
 /* ---- the rapidsnark entry point (go-rapidsnark prover.h `groth16_prover`, reached from prover.Prove at

@@ -1,5 +1,5 @@
 // The reference's ts_inputs/src/example.ts:358-362 call, against this package (needs an MI355X and a test zkey):
-//     node napi/example.js <zkey> [verification_key.json] [circuit.wasm | -] [voters.json]
+//     node napi/example.js <zkey> [verification_key.json] [circuit.wasm | -] [voters.json | -] [toy.zkey toy_vkey.json [nl10.zkey nl10_vkey.json nl10_voter.json]]
 // With a wasm path the circuit is selected by its sha256 exactly as a snarkjs caller names it; without one the native nLevels = 160
 // circuit is used.  Also drives the two-step path (wtns.calculate -> groth16.prove), four concurrent fullProve calls and, with a file of voters
 // (a JSON array of input objects), the reference's call shape under load: Promise.all over one fullProve PER VOTER, which the library's proving service
@@ -28,7 +28,7 @@ const inputs = require("../tests/golden/ref/inputs_example.json");
   for (const m of many) concurrentOk = concurrentOk && JSON.stringify(m.publicSignals) === JSON.stringify(publicSignals) && (!vk || await groth16.verify(vk, m.publicSignals, m.proof));
   // one fullProve per voter, all at once (what a ballot-box service does with example.ts:358): every proof verified, rate = voters / wall time
   let burst = null;
-  if (process.argv[5]) {
+  if (process.argv[5] && process.argv[5] !== "-") {
     const voters = JSON.parse(fs.readFileSync(process.argv[5]));
     const run = async (list) => { const t = process.hrtime.bigint(); const out = await Promise.all(list.map((v) => groth16.fullProve(v, wasm, zkey))); return [out, Number(process.hrtime.bigint() - t) / 1e6]; };
     const many4 = [].concat(voters, voters, voters, voters);
@@ -55,5 +55,33 @@ const inputs = require("../tests/golden/ref/inputs_example.json");
   try { await groth16.fullProve(Object.assign({}, inputs, { nullifier: "1" }), wasm, zkey); } catch (e) { badInputRejected = e.message === NULLIFIER_ASSERT; }
   let unknownWasmRejected = false;
   try { await groth16.fullProve(inputs, Buffer.from("not a circuit"), zkey); } catch (e) { unknownWasmRejected = /unknown circuit wasm/.test(String(e)); }
-  console.log(JSON.stringify({ ms, msWarm: Math.round(msWarm * 100) / 100, publicSignals, verified, twoStepEqual, concurrentOk, batchOk, badInputRejected, unknownWasmRejected, burst, wasm: wasm ? "by sha256" : "native nLevels=160" }));
+  // [r4] a circuit this build has NO native witness generator for: the caller's wasm is executed in Node (napi/wasm_witness.js), the proof is made on the GPU from that
+  // witness.  argv[6..7] = key and verification key of tests/golden/toy_passthrough.wasm's circuit (out <== a; assert(a != 0)); argv[8..10] = an nLevels-10 census key, its
+  // verification key and a voter for it: wasmFile null, no opts.nLevels -- the depth is read off the key.
+  let wasmFallback = null, depthFromKey = null;
+  if (process.argv[7]) {
+    const toyWasm = require("path").join(__dirname, "..", "tests", "golden", "toy_passthrough.wasm"), toyZkey = process.argv[6], toyVk = JSON.parse(fs.readFileSync(process.argv[7]));
+    const t = await groth16.fullProve({ a: "5", b: "7" }, toyWasm, toyZkey);
+    const proves = t.publicSignals.length === 1 && t.publicSignals[0] === "5" && await groth16.verify(toyVk, t.publicSignals, t.proof);
+    const m2 = { type: "mem" };
+    await wtns.calculate({ a: "5", b: "7" }, toyWasm, m2);
+    const p1 = await groth16.prove(toyZkey, m2, null, { r: 3n, s: 4n }), p2 = await groth16.fullProve({ a: "5", b: "7" }, toyWasm, toyZkey, null, { r: 3n, s: 4n });
+    const twoStep = JSON.stringify(p1) === JSON.stringify(p2);
+    let assertText = false;
+    try { await groth16.fullProve({ a: "0", b: "7" }, toyWasm, toyZkey); } catch (e) { assertText = e.message === "Assert Failed.\nError in template Toy_0 line: 7\n"; }
+    const many16 = await Promise.all([...Array(16).keys()].map((i) => groth16.fullProve({ a: String(i + 1), b: "9" }, toyWasm, toyZkey)));
+    let burstOk = true;
+    for (let i = 0; i < 16; i++) burstOk = burstOk && many16[i].publicSignals[0] === String(i + 1) && await groth16.verify(toyVk, many16[i].publicSignals, many16[i].proof);
+    const bt = await groth16.fullProveBatch([{ a: "5", b: "7" }, { a: "0", b: "1" }], toyWasm, toyZkey, { rs: [[3n, 4n], [1n, 2n]] });
+    const batchOkW = JSON.stringify(bt[0]) === JSON.stringify(p2) && bt[1] instanceof Error && /Assert Failed/.test(bt[1].message);
+    let noWasmRefused = false;
+    try { await groth16.fullProve({ a: "1", b: "2" }, null, toyZkey); } catch (e) { noWasmRefused = /not a ZkFranchiseProofCircuit key/.test(e.message); }
+    wasmFallback = { proves, twoStep, assertText, burstOk, batchOk: batchOkW, noWasmRefused };
+  }
+  if (process.argv[10]) {
+    const vk10 = JSON.parse(fs.readFileSync(process.argv[9])), v10 = JSON.parse(fs.readFileSync(process.argv[10]));
+    const d = await groth16.fullProve(v10, null, process.argv[8]);
+    depthFromKey = d.publicSignals[2] === String(v10.nullifier) && await groth16.verify(vk10, d.publicSignals, d.proof);
+  }
+  console.log(JSON.stringify({ wasmFallback, depthFromKey, ms, msWarm: Math.round(msWarm * 100) / 100, publicSignals, verified, twoStepEqual, concurrentOk, batchOk, badInputRejected, unknownWasmRejected, burst, wasm: wasm ? "by sha256" : "native nLevels=160" }));
 })().catch((e) => { console.error(String(e)); process.exit(1); });

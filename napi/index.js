@@ -3,9 +3,12 @@
 // plus groth16.prove(zkeyFile, wtnsFile), groth16.verify(vk, publicSignals, proof) and wtns.calculate(input, wasmFile, wtnsFile).
 // Host code stays JavaScript/TypeScript; the arithmetic runs in libzkcensus.so's HIP kernels.  CommonJS, Node >= 12.
 //
-// wasmFile names the circuit, as it does for snarkjs: its SHA-256 selects the native witness generator (80a73567...c139 = the reference's
-// dev/160 circuit.wasm, artifacts/zkCensus/dev/circuits-info.md:7).  A wasm this build has no native circuit for is rejected loudly --
-// nothing here executes wasm.  wasmFile null/undefined + opts.nLevels selects ZkFranchiseProofCircuit(nLevels) directly (test keys).
+// wasmFile names the circuit, as it does for snarkjs: its SHA-256 selects the native (HIP) witness generator (80a73567...c139 = the reference's
+// dev/160 circuit.wasm, artifacts/zkCensus/dev/circuits-info.md:7).  [r4] A wasm this build has no native circuit for is EXECUTED, as snarkjs would execute it
+// (wasm_witness.js: the caller's circom-2 witness calculator in Node's own WebAssembly; SURVEY.md 8b), and the proof is made on the GPU from the resulting witness
+// through groth16.prove's unfolded path -- any circom-2 circuit, any depth the reference's compiler script builds (circuit/circuit-compiler.sh:174-175).
+// opts.forceWasm takes that route for a known wasm too.  wasmFile null/undefined selects ZkFranchiseProofCircuit(n) natively: n = opts.nLevels, or read off the key's
+// header (wire count), or 160 where there is no key (wtns.calculate).
 "use strict";
 const fs = require("fs");
 const path = require("path");
@@ -61,16 +64,35 @@ function readArtifact(f) {
   if (f && f.type === "mem") return Buffer.from(f.data);
   return Buffer.from(f);
 }
-function circuitNLevels(wasmFile, opts) {
+const { WasmWitnessCalculator, wtnsImage } = require("./wasm_witness.js");
+const wasmCache = new Map();                                  // sha256 of a wasm this build executes -> its compiled calculator (at most four)
+// which witness generator a call takes: {nLevels, calc}.  calc === null: the native HIP generator of ZkFranchiseProofCircuit(nLevels); else the caller's wasm, executed here
+async function circuitOf(wasmFile, zkeyFile, opts) {
   const want = opts && opts.nLevels;
-  if (wasmFile === null || wasmFile === undefined) return want || 160;
-  const c = native.circuitFromWasm(readArtifact(wasmFile), LIB);
-  if (c.nLevels < 0) {
-    throw new Error(`unknown circuit wasm (sha256 ${c.sha256}): this build has a native witness generator for the zkCensus circuit only ` +
-      "(dev/160 circuit.wasm, sha256 80a73567...c139) and does not execute wasm");
+  if (wasmFile === null || wasmFile === undefined) {
+    if (want) return { nLevels: want, calc: null };
+    if (zkeyFile === null || zkeyFile === undefined) return { nLevels: 160, calc: null };
+    const k = native.zkeyInfo(readArtifact(zkeyFile), LIB);
+    if (k.nLevels < 0) {
+      throw new Error(`no wasmFile given and the key (${k.nVars} wires, ${k.nPublic} public signals) is not a ZkFranchiseProofCircuit key: ` +
+        "pass the circuit's witness-calculator wasm, or compute the witness elsewhere and call groth16.prove(zkeyFile, wtnsFile)");
+    }
+    return { nLevels: k.nLevels, calc: null };
   }
-  if (want && want !== c.nLevels) throw new Error(`wasm file is the nLevels=${c.nLevels} circuit but nLevels=${want} was requested`);
-  return c.nLevels;
+  const code = readArtifact(wasmFile);
+  const c = native.circuitFromWasm(code, LIB);
+  if (c.nLevels >= 0 && !(opts && opts.forceWasm)) {
+    if (want && want !== c.nLevels) throw new Error(`wasm file is the nLevels=${c.nLevels} circuit but nLevels=${want} was requested`);
+    return { nLevels: c.nLevels, calc: null };
+  }
+  let calc = wasmCache.get(c.sha256);
+  if (!calc) {
+    try { calc = await WasmWitnessCalculator.compile(code); await calc.instantiate(); }
+    catch (e) { throw new Error(`unknown circuit wasm (sha256 ${c.sha256}) and it cannot be executed as a circom 2 witness calculator: ${e.message}`); }
+    if (wasmCache.size >= 4) wasmCache.delete(wasmCache.keys().next().value);
+    wasmCache.set(c.sha256, calc);
+  }
+  return { nLevels: c.nLevels, calc };
 }
 function toJson(out) {
   const d = native.decimals(out.proof);                       // 8 x 32-byte words -> decimal strings (C++: Node's BigInt -> decimal was 4 us a value)
@@ -83,8 +105,8 @@ const blind = (opts, k) => (opts && opts[k] !== undefined ? le32(opts[k]) : null
 const wtns = {
   // snarkjs wtns.calculate(input, wasmFile, wtnsFileName): writes the .wtns file (or fills {type: "mem"}.data); also returns the image
   async calculate(input, wasmFile, wtnsFile, opts) {
-    const nLevels = circuitNLevels(wasmFile, opts);
-    const image = await native.witnessRaw(flatten(input, nLevels), nLevels, LIB);
+    const c = await circuitOf(wasmFile, null, opts);
+    const image = c.calc ? wtnsImage(await c.calc.calculate(input), c.calc.prime) : await native.witnessRaw(flatten(input, c.nLevels), c.nLevels, LIB);
     if (typeof wtnsFile === "string") fs.writeFileSync(wtnsFile, image);
     else if (wtnsFile && wtnsFile.type === "mem") wtnsFile.data = new Uint8Array(image);
     return image;
@@ -92,14 +114,24 @@ const wtns = {
 };
 const groth16 = {
   async fullProve(input, wasmFile, zkeyFile, logger, opts) {
-    const nLevels = circuitNLevels(wasmFile, opts);
-    return toJson(await native.fullProveRaw(flatten(input, nLevels), nLevels, readArtifact(zkeyFile), blind(opts, "r"), blind(opts, "s"), LIB));
+    const c = await circuitOf(wasmFile, zkeyFile, opts);
+    if (c.calc) return toJson(await native.proveRaw(readArtifact(zkeyFile), wtnsImage(await c.calc.calculate(input), c.calc.prime), blind(opts, "r"), blind(opts, "s"), LIB));
+    return toJson(await native.fullProveRaw(flatten(input, c.nLevels), c.nLevels, readArtifact(zkeyFile), blind(opts, "r"), blind(opts, "s"), LIB));
   },
   // Not in snarkjs: a census worth of voters in one call, split over opts.devices (default [0]) -- one context, resident key and host thread per GPU
   // (zkc_pool_* in include/zkcensus.h).  Resolves to one entry per voter, in order: {proof, publicSignals}, or an Error for a voter whose inputs fail
   // a circuit assert (the others are unaffected).  opts.rs: [[r, s], ...] per voter for reproducible bytes.
   async fullProveBatch(inputs, wasmFile, zkeyFile, opts) {
-    const nLevels = circuitNLevels(wasmFile, opts);
+    const c = await circuitOf(wasmFile, zkeyFile, opts);
+    if (c.calc) {                 // a circuit without a native witness generator: witnesses one by one in Node, proofs coalesced by the library's proving service
+      return Promise.all(inputs.map(async (x, i) => {
+        try {
+          const o = opts && opts.rs ? { r: opts.rs[i][0], s: opts.rs[i][1] } : null;
+          return toJson(await native.proveRaw(readArtifact(zkeyFile), wtnsImage(await c.calc.calculate(x), c.calc.prime), blind(o, "r"), blind(o, "s"), LIB));
+        } catch (e) { return e instanceof Error ? e : new Error(String(e)); }
+      }));
+    }
+    const nLevels = c.nLevels;
     const devs = Buffer.alloc(4 * ((opts && opts.devices) || [0]).length);
     ((opts && opts.devices) || [0]).forEach((d, i) => devs.writeInt32LE(d, 4 * i));
     const rs = opts && opts.rs ? Buffer.concat(opts.rs.map(([r, s]) => Buffer.concat([le32(r), le32(s)]))) : null;

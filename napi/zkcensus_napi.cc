@@ -258,6 +258,22 @@ napi_value CircuitFromWasm(napi_env env, napi_callback_info info) {
     napi_set_named_property(env, obj, "nLevels", v); napi_set_named_property(env, obj, "sha256", s);
     return obj;
 }
+// zkeyInfo(zkey: Buffer, libPath) -> {nVars, nPublic, domainSize, nLevels}: from the file header alone (host only); nLevels = the depth n for which the key has the shape of
+// ZkFranchiseProofCircuit(n) (8 public signals, zkc_circuit_n_wires(n) wires), -1 for any other circuit
+napi_value ZkeyInfo(napi_env env, napi_callback_info info) {
+    size_t argc = 2; napi_value a[2]; napi_get_cb_info(env, info, &argc, a, nullptr, nullptr);
+    std::lock_guard<std::mutex> guard(g_mu);
+    if (!load_api(str_arg(env, a[1]))) { napi_throw_error(env, nullptr, g.err.c_str()); return nullptr; }
+    void* p; size_t n; napi_get_buffer_info(env, a[0], &p, &n);
+    uint32_t nv = 0, np = 0, dom = 0;
+    if (g.header_info(p, n, &nv, &np, &dom)) { napi_throw_error(env, nullptr, "not a Groth16 .zkey file"); return nullptr; }
+    int nl = -1;
+    if (np == 8) for (int k = 3; k <= 253; k++) if ((uint32_t)g.n_wires(k) == nv) { nl = k; break; }
+    napi_value obj, v; napi_create_object(env, &obj);
+    napi_create_uint32(env, nv, &v); napi_set_named_property(env, obj, "nVars", v); napi_create_uint32(env, np, &v); napi_set_named_property(env, obj, "nPublic", v);
+    napi_create_uint32(env, dom, &v); napi_set_named_property(env, obj, "domainSize", v); napi_create_int32(env, nl, &v); napi_set_named_property(env, obj, "nLevels", v);
+    return obj;
+}
 // statusText(nLevels, status, libPath) -> string: the Error.message of the reference for a per-voter witness status (fullProveBatch builds its Error objects from it)
 napi_value StatusText(napi_env env, napi_callback_info info) {
     size_t argc = 3; napi_value a[3]; napi_get_cb_info(env, info, &argc, a, nullptr, nullptr);
@@ -306,7 +322,7 @@ napi_value Init(napi_env env, napi_value exports) {
     napi_create_threadsafe_function(env, nullptr, nullptr, name, 0, 1, nullptr, nullptr, nullptr, settle_js, &g_tsfn);
     napi_unref_threadsafe_function(env, g_tsfn);
 #define EXPORT(name, fn) napi_create_function(env, name, NAPI_AUTO_LENGTH, fn, nullptr, &f); napi_set_named_property(env, exports, name, f);
-    EXPORT("fullProveRaw", FullProveRaw) EXPORT("fullProveBatchRaw", FullProveBatchRaw) EXPORT("proveRaw", ProveRaw) EXPORT("witnessRaw", WitnessRaw) EXPORT("circuitFromWasm", CircuitFromWasm) EXPORT("verifyJson", VerifyJson) EXPORT("statusText", StatusText) EXPORT("decimals", Decimals)
+    EXPORT("fullProveRaw", FullProveRaw) EXPORT("fullProveBatchRaw", FullProveBatchRaw) EXPORT("proveRaw", ProveRaw) EXPORT("witnessRaw", WitnessRaw) EXPORT("circuitFromWasm", CircuitFromWasm) EXPORT("verifyJson", VerifyJson) EXPORT("statusText", StatusText) EXPORT("zkeyInfo", ZkeyInfo) EXPORT("decimals", Decimals)
 #undef EXPORT
     return exports;
 }

@@ -242,7 +242,7 @@ class ProvingService:
     def timing(self):
         out = (ctypes.c_uint64 * 8)()
         self._lib.zkc_service_timing(self._h, out)
-        return dict(zip(('us_upload', 'us_wait_gpu', 'us_key', 'us_prove', 'us_finish', 'proofs', 'batches'), [int(x) for x in out]))
+        return dict(zip(('us_upload', 'us_wait_gpu', 'us_key', 'us_prove', 'us_finish', 'proofs', 'batches', 'key_evictions'), [int(x) for x in out]))
 
     def close(self):
         if getattr(self, '_h', None) and self._own:

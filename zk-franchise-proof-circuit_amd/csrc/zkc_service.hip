@@ -10,6 +10,9 @@
 // or, unset, every visible device -- but a device is only brought up (context + 1 GB of key tables, 0.6 s) when the queue is long enough to pay for
 // it, so a sequential caller stays on the first one; and a device that is brought up loads its key from the service's OWN copy of the image BEFORE it takes
 // any request, so nobody waits behind a key load that a warm device could have served meanwhile.
+// [r4] A device keeps SEVERAL keys resident (least recently used out first, $ZKC_SERVICE_KEYS of them, default 4: the reference has a key per environment and per depth,
+// circuit/circuit-compiler.sh:15,82, and 288 GB hold dozens): requests for different keys alternate on one GPU without a reload, each batch still of one key.  A key is freed
+// only by a worker that holds the device's GPU lock, after it has left the routing table and its last call in flight has finished.
 // Key identity: the service keeps a copy of every .zkey image it has seen (at most four), found per call through the sampled fingerprint and confirmed, the
 // first time a given caller buffer (pointer, length) shows up, by the SHA-256 of the whole image: two images that differ only in unsampled bytes are two keys.
 // Host code over the public batch entry points; launches no kernel of its own.
@@ -58,13 +61,19 @@ struct HipBuf {     // grow-only buffer on the calling thread's current device (
 }  // namespace
 
 struct zkc_service {
+    struct KeySlot { std::shared_ptr<KeyImage> img; zkc_zkey* key = nullptr; int in_flight = 0; uint64_t last_use = 0; };      // in_flight: split calls begun on this key and not finished yet
     struct Dev {
-        int device = 0; std::mutex gpu_mu;              // held while a worker owns the GPU pipeline of this device (key switch + batch call)
-        zkc_ctx* ctx = nullptr; zkc_zkey* key = nullptr;
-        // under zkc_service::mu: the image whose key is resident (set after a successful load) and the one a worker of this device is loading right now
-        std::shared_ptr<KeyImage> resident, loading;
+        int device = 0; std::mutex gpu_mu;              // held while a worker owns the GPU pipeline of this device (key load / eviction + the begin half of a batch call)
+        zkc_ctx* ctx = nullptr;
+        // under zkc_service::mu -- the routing table: the images whose keys are resident here (entered after a successful load, removed BEFORE the key is freed) and the one a
+        // worker of this device is loading right now
+        std::vector<std::shared_ptr<KeyImage>> resident; std::shared_ptr<KeyImage> loading;
+        bool has(const KeyImage* img) const { for (auto& r : resident) if (r.get() == img) return true; return false; }
         uint64_t batches = 0, proofs = 0;
-        std::mutex fl_mu; std::condition_variable fl_cv; int in_flight = 0;      // split calls begun on this device's key and not finished yet (a key switch waits for zero)
+        // under fl_mu -- the keys themselves.  The vector changes only under gpu_mu AND fl_mu; a slot is erased (and its key freed) only when its in_flight is zero, and
+        // in_flight rises only under gpu_mu: whoever reads a slot's key under fl_mu with in_flight > 0, or under gpu_mu, reads a live key.
+        std::mutex fl_mu; std::condition_variable fl_cv; std::vector<KeySlot> keys; uint64_t use_clock = 0;
+        int calls_in_flight() const { int n = 0; for (auto& k : keys) n += k.in_flight; return n; }
     };
     struct Worker {
         Dev* dev = nullptr; int index = 0; std::thread th; std::condition_variable cv; bool wake = false, idle = false;
@@ -75,8 +84,8 @@ struct zkc_service {
     std::mutex mu; std::deque<Req*> q; bool stop = false;
     std::mutex img_mu; std::vector<std::shared_ptr<KeyImage>> images; uint64_t img_clock = 0;      // key images by (fingerprint, SHA-256); at most four kept
     std::vector<std::unique_ptr<Dev>> devs; std::vector<std::unique_ptr<Worker>> workers;
-    int max_batch = 256, spill = 32;
-    uint64_t n_requests = 0, n_batches = 0, largest_batch = 0, key_loads = 0, n_failed = 0;
+    int max_batch = 256, spill = 32, keys_per_dev = 4;
+    uint64_t n_requests = 0, n_batches = 0, largest_batch = 0, key_loads = 0, key_evictions = 0, n_failed = 0;
     uint64_t us_stage = 0, us_gpu_wait = 0, us_key = 0, us_prove = 0, us_finish = 0, n_proved = 0;      // where the workers' time went (microseconds, summed over batches)
 };
 static thread_local std::string g_service_err;
@@ -85,9 +94,9 @@ namespace {
 void finish(Req* r, int rc, int32_t status, const std::string& err) { r->done(r->user, rc, status, err.c_str()); delete r; }
 
 // ---- dispatch (all under svc->mu) ----
-bool any_dev_has(zkc_service* s, const KeyImage* img) { for (auto& d : s->devs) if (d->resident.get() == img || d->loading.get() == img) return true; return false; }
+bool any_dev_has(zkc_service* s, const KeyImage* img) { for (auto& d : s->devs) if (d->has(img) || d->loading.get() == img) return true; return false; }
 // the requests worker w takes now, up to `cap` of one class in arrival order:
-//   its device holds a key            -> the class of the first queued request for that key;
+//   its device holds keys             -> the class of the first queued request for any of them (arrival order: two resident keys take turns);
 //   else, no device holds or is loading the head's key (the very first request, or a new key)
 //                                     -> the head's class: this worker will load the key with those requests in hand (somebody has to);
 //   else                              -> nothing: other devices serve that key (if the queue grows past `spill`, dispatch brings this device up FIRST, without requests)
@@ -96,7 +105,7 @@ std::vector<Req*> grab(zkc_service* s, zkc_service::Worker* w, size_t cap, const
     if (s->q.empty() || cap == 0) return out;
     zkc_service::Dev* d = w->dev;
     const Req* cls = like;
-    if (!cls && d->resident && !d->loading) for (Req* r : s->q) if (r->img.get() == d->resident.get()) { cls = r; break; }
+    if (!cls && !d->resident.empty() && !d->loading) for (Req* r : s->q) if (d->has(r->img.get())) { cls = r; break; }
     if (!cls && !d->loading && !any_dev_has(s, s->q.front()->img.get())) { cls = s->q.front(); d->loading = cls->img; }
     if (!cls) return out;
     const Req key = *cls;
@@ -109,17 +118,17 @@ void dispatch(zkc_service* s) {
     if (s->q.empty()) return;
     const Req* head = s->q.front();
     zkc_service::Worker* pick = nullptr;
-    for (auto& w : s->workers) if (w->idle && !w->wake && !w->dev->loading && w->dev->resident.get() == head->img.get()) { pick = w.get(); break; }
+    for (auto& w : s->workers) if (w->idle && !w->wake && !w->dev->loading && w->dev->has(head->img.get())) { pick = w.get(); break; }
     if (!pick && !any_dev_has(s, head->img.get())) {
-        for (auto& w : s->workers) if (w->idle && !w->wake && !w->dev->resident && !w->dev->loading) { pick = w.get(); break; }      // a cold device first
-        if (!pick) for (auto& w : s->workers) if (w->idle && !w->wake && !w->dev->loading) { pick = w.get(); break; }
+        // the device with the fewest resident keys first (a cold one, then one with room, then one that has to evict)
+        for (auto& w : s->workers) if (w->idle && !w->wake && !w->dev->loading && (!pick || w->dev->resident.size() < pick->dev->resident.size())) pick = w.get();
     }
     if (!pick && s->q.size() >= (size_t)s->spill) {
         for (auto& w : s->workers)
-            if (w->idle && !w->wake && !w->dev->loading && w->dev->resident.get() != head->img.get()) {
-                bool sibling_busy = false;                                  // a device whose other worker is in a call keeps its key: do not pull it out from under it
+            if (w->idle && !w->wake && !w->dev->loading && !w->dev->has(head->img.get())) {
+                bool sibling_busy = false;                                  // a FULL device whose other worker is in a call keeps its keys: do not pull one out from under it
                 for (auto& o : s->workers) if (o.get() != w.get() && o->dev == w->dev && !o->idle) sibling_busy = true;
-                if (sibling_busy) continue;
+                if (sibling_busy && (int)w->dev->resident.size() >= s->keys_per_dev) continue;
                 pick = w.get(); pick->warm = head->img; pick->dev->loading = head->img; break;
             }
     }
@@ -152,20 +161,40 @@ void fail_all(zkc_service* s, Batch& b, int rc, const std::string& err) {
     for (Req* r : b.reqs) finish(r, rc, 0, err);
     b.reqs.clear();
 }
-// makes `img` the resident key of device d.  Caller holds d->gpu_mu.  Waits for the device's calls in flight before it frees the key they read.
-int ensure_key(zkc_service* s, zkc_service::Dev* d, const std::shared_ptr<KeyImage>& img, std::string& why) {
-    int rc = ZKC_OK;
+// makes `img` a resident key of device d and returns it in *out.  Caller holds d->gpu_mu.  A full device gives up its least recently used key: the key leaves the routing
+// table first (no new batch is formed for it), then its calls in flight are waited for, then it is freed.
+int ensure_key(zkc_service* s, zkc_service::Dev* d, const std::shared_ptr<KeyImage>& img, zkc_zkey** out, std::string& why) {
+    int rc = ZKC_OK; *out = nullptr;
     if (!d->ctx && (rc = zkc_ctx_create(d->device, &d->ctx))) { d->ctx = nullptr; why = std::string("device ") + std::to_string(d->device) + ": " + zkc_last_error(nullptr); }
-    bool have = false;
-    { std::lock_guard<std::mutex> g(s->mu); have = d->key && d->resident.get() == img.get(); }
-    if (!rc && !have) {
-        { std::unique_lock<std::mutex> fl(d->fl_mu); d->fl_cv.wait(fl, [&] { return d->in_flight == 0; }); }      // the other worker's call still reads the old key
-        { std::lock_guard<std::mutex> g(s->mu); d->resident.reset(); }
-        if (d->key) { zkc_zkey_free(d->key); d->key = nullptr; }
-        rc = zkc_zkey_load(d->ctx, img->bytes.data(), img->bytes.size(), &d->key);
-        if (rc) { d->key = nullptr; why = zkc_last_error(d->ctx); }
+    if (!rc) {
+        std::lock_guard<std::mutex> fl(d->fl_mu);
+        for (auto& k : d->keys) if (k.img.get() == img.get()) { k.last_use = ++d->use_clock; *out = k.key; }
+    }
+    if (!rc && !*out) {
+        for (;;) {                                                             // make room
+            std::shared_ptr<KeyImage> victim;
+            {
+                std::lock_guard<std::mutex> fl(d->fl_mu);
+                if ((int)d->keys.size() < s->keys_per_dev) break;
+                size_t v = 0; for (size_t i = 1; i < d->keys.size(); i++) if (d->keys[i].last_use < d->keys[v].last_use) v = i;
+                victim = d->keys[v].img;
+            }
+            { std::lock_guard<std::mutex> g(s->mu); for (size_t i = 0; i < d->resident.size(); i++) if (d->resident[i].get() == victim.get()) { d->resident.erase(d->resident.begin() + (long)i); break; } }
+            zkc_zkey* dead = nullptr;
+            {
+                std::unique_lock<std::mutex> fl(d->fl_mu);
+                auto slot = [&]() -> zkc_service::KeySlot* { for (auto& k : d->keys) if (k.img.get() == victim.get()) return &k; return nullptr; };
+                d->fl_cv.wait(fl, [&] { zkc_service::KeySlot* k = slot(); return !k || k->in_flight == 0; });      // the other worker's call still reads that key
+                for (size_t i = 0; i < d->keys.size(); i++) if (d->keys[i].img.get() == victim.get()) { dead = d->keys[i].key; d->keys.erase(d->keys.begin() + (long)i); break; }
+            }
+            if (dead) { zkc_zkey_free(dead); std::lock_guard<std::mutex> g(s->mu); s->key_evictions++; }
+        }
+        zkc_zkey* key = nullptr;
+        rc = zkc_zkey_load(d->ctx, img->bytes.data(), img->bytes.size(), &key);
+        if (rc) { key = nullptr; why = zkc_last_error(d->ctx); }
+        if (!rc) { std::lock_guard<std::mutex> fl(d->fl_mu); zkc_service::KeySlot k; k.img = img; k.key = key; k.last_use = ++d->use_clock; d->keys.push_back(k); }
         std::lock_guard<std::mutex> g(s->mu); s->key_loads++;
-        if (!rc) d->resident = img;
+        if (!rc) { d->resident.push_back(img); *out = key; }
     }
     { std::lock_guard<std::mutex> g(s->mu); if (d->loading.get() == img.get()) d->loading.reset(); }
     return rc;
@@ -210,11 +239,13 @@ void process(zkc_service* s, zkc_service::Worker* w, std::vector<Req*>&& first) 
     uint64_t t_b = now_us(), t_c = 0, t_d = 0, t_e = 0;
     // while the other worker's call is in its body (accumulations still running) there is nothing to gain from beginning: this call's kernels would only queue
     // behind it.  Keep collecting requests instead and begin when that call reaches its tail (bucket reduction, blinding, copies: 4-5 ms of latency chains that
-    // this call's witness kernels and transforms run beside).  The key cannot change meanwhile: a switch waits for in_flight == 0.
+    // this call's witness kernels and transforms run beside).  [r4] The calls in flight may be on any of the device's keys; each key is asked UNDER fl_mu while its
+    // in_flight is positive -- an eviction waits, under the same mutex, for that count to reach zero before it frees the key, so the query never sees a freed key
+    // (round 3 read d->key after dropping the lock: a use-after-free window when the other worker switched keys in between).
     for (;;) {
-        bool other = false;
-        { std::lock_guard<std::mutex> fl(d->fl_mu); other = d->in_flight > 0; }
-        if (!other || zkc::prove_tail_reached(d->key)) break;
+        bool body = false;
+        { std::lock_guard<std::mutex> fl(d->fl_mu); for (auto& k : d->keys) if (k.in_flight > 0 && !zkc::prove_tail_reached(k.key)) body = true; }
+        if (!body) break;
         const size_t from = b.reqs.size();
         if (from < cap) {
             std::lock_guard<std::mutex> g(s->mu);
@@ -228,7 +259,7 @@ void process(zkc_service* s, zkc_service::Worker* w, std::vector<Req*>&& first) 
     // latency-bound call on them while the rest queue up behind it.  While requests keep coming, keep taking them: stop after three polls of 50 us without a new one, at `cap`,
     // or after 3 ms.  A lone request with nothing behind it does not wait at all.
     {
-        bool idle_dev; { std::lock_guard<std::mutex> fl(d->fl_mu); idle_dev = d->in_flight == 0; }
+        bool idle_dev; { std::lock_guard<std::mutex> fl(d->fl_mu); idle_dev = d->calls_in_flight() == 0; }
         const uint64_t t_l0 = now_us(); int quiet = 0; bool first = true;
         while (idle_dev && b.reqs.size() < cap && quiet < 3 && now_us() - t_l0 < 3000) {
             const size_t from = b.reqs.size();
@@ -247,24 +278,24 @@ void process(zkc_service* s, zkc_service::Worker* w, std::vector<Req*>&& first) 
         if (!stage(w, b, from, nIn, nW, err)) { (void)hipGetLastError(); return fail_all(s, b, ZKC_ERR_HIP, err); }
         const int B = (int)b.reqs.size();
         // resident key: the service's own image object is the identity (fingerprint + full SHA-256 were settled when the request was accepted)
-        { std::string why; if ((rc = ensure_key(s, d, cls.img, why))) return fail_all(s, b, rc, why); }
-        if (full && d->key->nLevels != cls.nLevels) return fail_all(s, b, ZKC_ERR_BAD_ARG, "the key is not a ZkFranchiseProofCircuit(" + std::to_string(cls.nLevels) + ") key");
+        { std::string why; if ((rc = ensure_key(s, d, cls.img, &zk, why))) return fail_all(s, b, rc, why); }
+        if (full && zk->nLevels != cls.nLevels) return fail_all(s, b, ZKC_ERR_BAD_ARG, "the key is not a ZkFranchiseProofCircuit(" + std::to_string(cls.nLevels) + ") key");
         b.rs.resize((size_t)B * 64);
         for (int i = 0; i < B; i++) memcpy(b.rs.data() + 64 * (size_t)i, b.reqs[i]->rs, 64);
         t_d = now_us();
         // the call in two halves: begin enqueues every pass and returns (its witness kernels run beside the other worker's MSMs); the GPU lock is given up
         // before finish waits, so that the other worker's next begin overlaps this call's bucket reduction, blinding and copies
-        zk = d->key; slot = w->index & 1;
+        slot = w->index & 1;
         rc = zkc::prove_batch_begin(zk, slot, w->d_wtns.p, (uint32_t)nW, B, b.rs.data(), true, full ? w->d_in.p : nullptr, full ? (int32_t*)w->d_status.p : nullptr);
         if (rc) return fail_all(s, b, rc, zkc_last_error(d->ctx));
-        { std::lock_guard<std::mutex> fl(d->fl_mu); d->in_flight++; }
+        { std::lock_guard<std::mutex> fl(d->fl_mu); for (auto& k : d->keys) if (k.key == zk) k.in_flight++; }      // still under gpu_mu: the slot is there
     }
     {
         const int B = (int)b.reqs.size();
         rc = zkc::prove_batch_finish(zk, slot, (uint8_t*)w->h_proofs.p, (uint8_t*)w->h_pubs.p);
         if (!rc && full && (hipMemcpyAsync(w->h_status.p, w->d_status.p, (size_t)B * 4, hipMemcpyDeviceToHost, w->st) != hipSuccess || hipStreamSynchronize(w->st) != hipSuccess)) { (void)hipGetLastError(); rc = ZKC_ERR_HIP; }
         const std::string why = rc ? (rc == ZKC_ERR_HIP ? std::string("HIP failure while the batch finished: ") : std::string()) + zkc_last_error(d->ctx) : std::string();
-        { std::lock_guard<std::mutex> fl(d->fl_mu); d->in_flight--; } d->fl_cv.notify_all();
+        { std::lock_guard<std::mutex> fl(d->fl_mu); for (auto& k : d->keys) if (k.key == zk) k.in_flight--; } d->fl_cv.notify_all();
         if (rc) return fail_all(s, b, rc, why);
     }
     const size_t B = b.reqs.size();
@@ -290,7 +321,7 @@ void worker_main(zkc_service* s, zkc_service::Worker* w) {
         if (!s->stop && w->warm) {                           // bring this device up for that key first; the queue is being served by the devices that have it
             std::shared_ptr<KeyImage> img = std::move(w->warm); w->warm.reset();
             lk.unlock();
-            if (hipSetDevice(w->dev->device) == hipSuccess) { std::lock_guard<std::mutex> gpu(w->dev->gpu_mu); std::string why; (void)ensure_key(s, w->dev, img, why); }
+            if (hipSetDevice(w->dev->device) == hipSuccess) { std::lock_guard<std::mutex> gpu(w->dev->gpu_mu); std::string why; zkc_zkey* k = nullptr; (void)ensure_key(s, w->dev, img, &k, why); }
             else { (void)hipGetLastError(); std::lock_guard<std::mutex> g(s->mu); if (w->dev->loading.get() == img.get()) w->dev->loading.reset(); }
             lk.lock();
             continue;
@@ -324,6 +355,7 @@ extern "C" int zkc_service_create(const int* hip_devices, int n, zkc_service** o
     zkc_service* s = new zkc_service();
     if (const char* e = getenv("ZKC_SERVICE_MAX_BATCH")) s->max_batch = std::max(1, std::min(atoi(e), 4096));
     if (const char* e = getenv("ZKC_SERVICE_SPILL")) s->spill = std::max(1, atoi(e));
+    if (const char* e = getenv("ZKC_SERVICE_KEYS")) s->keys_per_dev = std::max(1, std::min(atoi(e), 64));
     for (int dv : devs) { s->devs.emplace_back(new zkc_service::Dev()); s->devs.back()->device = dv; }
     int idx = 0;
     for (auto& d : s->devs) for (int k = 0; k < 2; k++) { s->workers.emplace_back(new zkc_service::Worker()); s->workers.back()->dev = d.get(); s->workers.back()->index = idx++; }
@@ -336,7 +368,7 @@ extern "C" void zkc_service_destroy(zkc_service* s) {
     for (auto& w : s->workers) if (w->th.joinable()) w->th.join();
     for (Req* r : s->q) finish(r, ZKC_ERR_GENERIC, 0, "the proving service was shut down");
     s->q.clear();
-    for (auto& d : s->devs) { (void)hipSetDevice(d->device); if (d->key) zkc_zkey_free(d->key); if (d->ctx) zkc_ctx_destroy(d->ctx); }
+    for (auto& d : s->devs) { (void)hipSetDevice(d->device); for (auto& k : d->keys) if (k.key) zkc_zkey_free(k.key); if (d->ctx) zkc_ctx_destroy(d->ctx); }
     delete s;
 }
 extern "C" zkc_service* zkc_service_default(void) {
@@ -430,7 +462,7 @@ extern "C" int zkc_service_prove(zkc_service* s, const void* zkey, size_t zkey_l
 extern "C" int zkc_service_timing(zkc_service* s, uint64_t out[8]) {
     if (!s || !out) return ZKC_ERR_BAD_ARG;
     std::lock_guard<std::mutex> g(s->mu);
-    out[0] = s->us_stage; out[1] = s->us_gpu_wait; out[2] = s->us_key; out[3] = s->us_prove; out[4] = s->us_finish; out[5] = s->n_proved; out[6] = s->n_batches; out[7] = 0;
+    out[0] = s->us_stage; out[1] = s->us_gpu_wait; out[2] = s->us_key; out[3] = s->us_prove; out[4] = s->us_finish; out[5] = s->n_proved; out[6] = s->n_batches; out[7] = s->key_evictions;
     return ZKC_OK;
 }
 extern "C" int zkc_service_stats(zkc_service* s, uint64_t out[8]) {
