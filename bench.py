@@ -110,25 +110,55 @@ def dry_run(args, rank, world):
     if world > 1:
         dist.init_process_group('gloo')
     B = min(args.batch, 64); total = B * world
+    if os.environ.get('ZKC_BENCH_TEST_UNEVEN') == '1':                   # test hook: a census that does not divide by the ranks (the last ranks prove one voter less)
+        total -= world // 2 + 1
     lo, hi = parallel.shard_range(rank, world, total)
+    # the census hand-out of the real run: rank 0 holds every voter's input block, one broadcast, each rank keeps its slice
+    blk = 64
+    allin = torch.tensor([(v * 13 + k) % 251 for v in range(total) for k in range(blk)], dtype=torch.uint8) if rank == 0 else torch.empty(total * blk, dtype=torch.uint8)
+    if world > 1:
+        dist.broadcast(allin, src=0)
+    census_ok = allin[lo * blk:hi * blk].tolist() == [(v * 13 + k) % 251 for v in range(lo, hi) for k in range(blk)]
     fab = lambda v, m: bytes((v * 7 + k * m) % 251 for k in range(256))
     rec = parallel.pack_records(b''.join(fab(v, 1) for v in range(lo, hi)), b''.join(fab(v, 3) for v in range(lo, hi)), [0] * (hi - lo))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         allrec = parallel.gather_records(rec, world, dist, total) if world > 1 else rec
     tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    each = [tmax.clone()]
     if world > 1:
+        each = [torch.empty_like(tmax) for _ in range(world)]
+        dist.all_gather(each, tmax.clone())
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    ok = allrec.shape[0] == total and all(bytes(allrec[v, :256].tolist()) == fab(v, 1) for v in range(total)) and bool((allrec[lo:hi] == rec).all())
+    ok = census_ok and allrec.shape[0] == total and all(bytes(allrec[v, :256].tolist()) == fab(v, 1) for v in range(total)) and bool((allrec[lo:hi] == rec).all())
     okt = torch.tensor([1 if ok else 0])
     if world > 1:
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
     if rank == 0:
         print(json.dumps({'metric': 'DRY RUN (CPU, gloo, fabricated records) -- not a measurement', 'value': None, 'unit': 'proofs/s', 'n_gpus': world,
-                          'steps': args.steps, 'warmup': args.warmup, 'dry_run': True, 'valid': False, 'gathered_records_equal_per_rank_records': bool(okt.item())}))
+                          'steps': args.steps, 'warmup': args.warmup, 'dry_run': True, 'valid': False, 'gathered_records_equal_per_rank_records': bool(okt.item()),
+                          'voters': total, 'ms_per_step_per_rank': [round(float(t.item()) / max(1, args.steps) * 1e3, 3) for t in each]}))
     if world > 1:
         dist.destroy_process_group()
     return 0 if okt.item() else 1
+
+
+def cores_received(ol, nthreads, seconds=0.4):
+    """the cores' worth of CPU time this container actually gets when it asks for `nthreads`: the C oracle's own NTT (2^13 points, a few ms per call, ctypes releases the GIL)
+    on that many threads, process CPU seconds over wall seconds.  About nthreads on an unconstrained host, the CPU-time quota on a constrained one.  (cpu_baseline leg only.)"""
+    import threading
+    lib = ol.lib(); stop = time.perf_counter() + seconds
+
+    def spin():
+        d = (ctypes.c_uint64 * (4 << 13))()
+        while time.perf_counter() < stop:
+            lib.zko_ntt(d, 13, 0)
+    th = [threading.Thread(target=spin) for _ in range(nthreads)]
+    t0 = os.times(); w0 = time.perf_counter()
+    for t in th: t.start()
+    for t in th: t.join()
+    t1 = os.times(); wall = time.perf_counter() - w0
+    return ((t1.user - t0.user) + (t1.system - t0.system)) / wall
 
 
 def read_prof(ctx):
@@ -294,9 +324,26 @@ def main():
     # the census is the 8 192-voter one of configs 3/4 whatever N is (leaf depth 13-17 decides how much of a witness folds away);
     # rank r proves voters [r B, (r+1) B)
     lo, hi = parallel.shard_range(rank, world, B * world)
-    voters = census.synthetic_census(ctx, max(8192, B * world), args.nlevels)[lo:hi]
-    flat = b''.join(zkcensus_amd.flatten_inputs(v, args.nlevels) for v in voters)
-    d_inputs = torch.from_numpy(np.frombuffer(flat, dtype=np.uint8).copy()).cuda(dev)
+    # [r4] the census is built ONCE, by rank 0 (GPU Poseidon, ~10 s for 8 192 voters, most of it Python), and every rank is handed its block of input records over the
+    # process group (one broadcast of total x 334 x 32 bytes: 87 MB for 8 192 voters) -- not eight identical builds beside each other.  ZKC_BENCH_CENSUS_PER_RANK=1: the old form.
+    nIn = ctx.n_inputs(args.nlevels)
+    if world == 1 or os.environ.get('ZKC_BENCH_CENSUS_PER_RANK') == '1':
+        voters = census.synthetic_census(ctx, max(8192, B * world), args.nlevels)[lo:hi]
+        flat = b''.join(zkcensus_amd.flatten_inputs(v, args.nlevels) for v in voters)
+        d_inputs = torch.from_numpy(np.frombuffer(flat, dtype=np.uint8).copy()).cuda(dev)
+    else:
+        voters = None
+        if rank == 0:
+            every = census.synthetic_census(ctx, max(8192, B * world), args.nlevels)[:B * world]
+            allflat = torch.from_numpy(np.frombuffer(b''.join(zkcensus_amd.flatten_inputs(v, args.nlevels) for v in every), dtype=np.uint8).copy())
+            voters = every[lo:hi]
+        else:
+            allflat = torch.empty(B * world * nIn * 32, dtype=torch.uint8)
+        d_all = allflat if share else allflat.cuda(dev)
+        dist.broadcast(d_all, src=0)
+        d_inputs = d_all[lo * nIn * 32:hi * nIn * 32].clone().cuda(dev)
+        flat = bytes(d_inputs.cpu().numpy().tobytes())
+        del d_all, allflat
     nW = ctx.n_wires(args.nlevels)
     # two sets of witness / status buffers: a step is begun (everything enqueued: zkc_batch_begin) before the previous one is finished (zkc_batch_finish), so that
     # the tail of step k -- bucket reduction and blinding of its last pass, copies -- runs beside the head of step k + 1 (its first witness kernels and transforms):
@@ -360,6 +407,12 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elif world > 1:
         t = tmax.cpu(); dist.all_reduce(t, op=dist.ReduceOp.MAX); tmax = t
+    per_rank_ms = [round(dt / args.steps * 1e3, 3)]
+    if world > 1:                                         # every rank's own step time beside the maximum: a straggler is visible in the line
+        mine = torch.tensor([dt], dtype=torch.float64) if share else torch.tensor([dt], dtype=torch.float64, device='cuda')
+        each = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(each, mine)
+        per_rank_ms = [round(float(t.item()) / args.steps * 1e3, 3) for t in each]
     dt = float(tmax.item())
     assert all(int(t.abs().sum().item()) == 0 for t in d_status_s), 'a synthetic voter failed a circuit assert'
 
@@ -437,8 +490,13 @@ def main():
         # CPU baseline = the oracle's witness + Groth16 prove, one proof per host thread (ctypes releases the GIL), on voters of the timed batch
         # with the (r, s) the GPU used for them: each oracle proof doubles as a byte-for-byte parity check of a proof that was timed.
         from concurrent.futures import ThreadPoolExecutor
+        # [r4] "all host cores" = the cores' worth of CPU TIME this container receives, which on the GPU boxes is far below the 256 cores the affinity mask shows: a CPU-time
+        # quota (tools/cpu_baseline_scaling.py, profiles/r04_cpu_baseline_scaling.json: 64 threads receive the same ~16-32 cores' worth as 32, proofs/s flat, every proof slower).
+        # cores_received() measures it in 0.4 s (the oracle's NTT on one thread per schedulable core: CPU seconds / wall); the leg runs on that many threads.
         avail = len(os.sched_getaffinity(0))
-        cores = max(1, min(avail, int(os.environ.get('ZKC_CPU_BASELINE_THREADS', '32'))))            # the oracle stops scaling past ~16-32 threads on the GPU boxes (64 threads: 1.98 proofs/s, 16: 2.2); cores_available is printed beside it
+        quota = cores_received(ol, avail)
+        want = os.environ.get('ZKC_CPU_BASELINE_THREADS')
+        cores = max(1, min(avail, int(want))) if want else max(1, min(avail, int(quota + 0.5)))
         wt = d_wtns.view(B, nW * 32)
         order = sample + [i for i in range(B) if i not in set(sample)]
         ol.lib()
@@ -460,7 +518,7 @@ def main():
             assert bytes(wt[i].cpu().numpy().tobytes()) == w, 'GPU witness of voter %d differs from the CPU oracle' % i
             assert out['proofs'][256 * i:256 * i + 256] == p and out['pubs'][256 * i:256 * i + 256] == pub, 'GPU proof of voter %d differs from the CPU oracle' % i
         verified['oracle_prover_bytes_equal'] = len(done); verified['oracle_prover_indices'] = [i for i, *_ in done]
-        cpu = {'value': round(len(done) / cdt, 4), 'unit': 'proofs/s', 'cores': cores, 'cores_available': avail, 'cores_on_host': os.cpu_count(), 'kind': 'port',
+        cpu = {'value': round(len(done) / cdt, 4), 'unit': 'proofs/s', 'cores': cores, 'cores_available': avail, 'cores_on_host': os.cpu_count(), 'cores_received_when_all_are_asked_for': round(quota, 1), 'kind': 'port',
                'sample': '%d full proofs (witness + Groth16 prove) of voters of the timed batch, %d at a time on %d threads, %.1f s; '
                          'the build\'s own C oracle, not snarkjs/rapidsnark (neither can run here)' % (len(done), cores, cores, cdt)}
 
@@ -471,7 +529,7 @@ def main():
         total = args.steps * B * world
         line = {
             'metric': 'zkCensus proofs/sec (nLevels=%d)' % args.nlevels, 'value': round(total / dt, 3), 'unit': 'proofs/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'ms_per_step_per_rank': per_rank_ms,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u256 (8 x u32 Montgomery, BN254 Fr/Fq)',
             'data': 'synthetic',
             'config': {'workload': 'zkCensus nLevels=%d, batch of %d voter proofs per GPU per step (BASELINE configs[2]/[3] shape), '

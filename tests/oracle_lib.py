@@ -174,6 +174,19 @@ def h_evals(zkey, wtns):
     return P.raw
 
 
+def pmap(fn, items, workers=None):
+    """fn over items on host threads (every oracle entry point is a ctypes call that releases the GIL): the GPU suite's oracle legs are tens to hundreds of CPU proofs and ran
+    one after the other until round 4 -- most of the suite's wall time.  Order of results = order of items."""
+    from concurrent.futures import ThreadPoolExecutor
+    items = list(items)
+    if not items:
+        return []
+    workers = workers or max(1, min(16, len(os.sched_getaffinity(0)), len(items)))
+    lib()
+    with ThreadPoolExecutor(workers) as ex:
+        return list(ex.map(fn, items))
+
+
 def golden(name):
     return os.path.join(ROOT, 'tests', 'golden', name)
 

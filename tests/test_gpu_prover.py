@@ -210,13 +210,15 @@ def test_max_levels_nl253_config5(env):
     voters = [random_voter(rng, ol.poseidon, nLevels=nl, depth_c=7, depth_s=5), random_voter(rng, ol.poseidon, nLevels=nl, depth_c=nl, depth_s=nl)]
     ws, st = ctx.witness(voters, nLevels=nl)
     assert st == [0, 0]
-    for v, w in zip(voters, ws):
-        rc, ow = ol.witness(v, nLevels=nl)
-        assert rc == 0 and w == ow
-        p, pub = pk.prove(w, 111, 222)
-        rc, op, opub = ol.prove(zk, w, 111, 222)
-        assert rc == 0 and p == op and pub == opub
-        assert ol.verify(vk, pub, p)
+    gpu = [pk.prove(w, 111, 222) for w in ws]
+
+    def check(k):
+        rc, ow = ol.witness(voters[k], nLevels=nl)
+        assert rc == 0 and ws[k] == ow
+        rc, op, opub = ol.prove(zk, ws[k], 111, 222)
+        assert rc == 0 and gpu[k] == (op, opub)
+        assert ol.verify(vk, gpu[k][1], gpu[k][0])
+    ol.pmap(check, range(2))
 
 
 def test_fullprove_batch_equals_witness_then_prove(env):
@@ -308,13 +310,16 @@ def test_fullprove_batch_nl160_three_passes_config3(env):
     for i in (0, 66, 67, 95, 96, 133, 134, B - 1):
         assert ol.verify(vk, pubs[256 * i:256 * i + 256], proofs[256 * i:256 * i + 256]), i
     wt = d_w.view(B, nW * 32)
-    for i in (67, B - 1):
-        w = wt[i].cpu().numpy().tobytes()
+    dev_w = {i: wt[i].cpu().numpy().tobytes() for i in (67, B - 1)}
+
+    def check(i):
+        w = dev_w[i]
         rc, ow = ol.witness(voters[i], nLevels=nl)
         assert rc == 0 and ow == w
         r_i = int.from_bytes(rs[64 * i:64 * i + 32], 'little'); s_i = int.from_bytes(rs[64 * i + 32:64 * i + 64], 'little')
         rc, op, opub = ol.prove(zk, w, r_i, s_i)
         assert rc == 0 and op == proofs[256 * i:256 * i + 256] and opub == pubs[256 * i:256 * i + 256], i
+    ol.pmap(check, (67, B - 1))
     # a tampered proof in the middle of the batch is caught by the batch verifier
     bad = bytearray(proofs); bad[256 * 100 + 5] ^= 1
     assert not groth16.verify_batch(ctx, vk, pubs, bytes(bad))
