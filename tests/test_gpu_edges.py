@@ -134,6 +134,17 @@ def test_split_batch_calls_overlap_and_match_the_synchronous_call(env):
     assert got == sync
     with pytest.raises(zkc.ZkcError):
         pk.batch_finish(0, 5)                                           # nothing in flight on slot 0 any more
+    # [r4] a call of several proofs with a call of ONE proof begun right behind it, forty times: the lone call blinds on the G1 stream, the larger one on the blinding stream,
+    # and both use the lane's one blinding scratch -- the lone call has to wait for the other's blinding (round 3 did not: a wrong proof once in a few hundred service batches)
+    B9, _, rs9, d_in9, d_w9, d_st9 = batches[1]
+    d_w1 = torch.empty(nW * 32, dtype=torch.uint8, device='cuda'); d_st1 = torch.zeros(1, dtype=torch.int32, device='cuda')
+    lone_sync = pk.fullprove_batch_dev(d_in9.data_ptr(), 1, d_w1.data_ptr(), d_st1.data_ptr(), rs9[:64])
+    assert lone_sync[0] == sync[1][0][:256]
+    for k in range(40):
+        pk.batch_begin(k & 1, d_in9.data_ptr(), B9, d_w9.data_ptr(), d_st9.data_ptr(), rs9)
+        pk.batch_begin(1 - (k & 1), d_in9.data_ptr(), 1, d_w1.data_ptr(), d_st1.data_ptr(), rs9[:64])
+        assert pk.batch_finish(k & 1, B9) == sync[1], k
+        assert pk.batch_finish(1 - (k & 1), 1) == lone_sync, k
     # witnesses given (d_inputs = NULL): the groth16.prove shape through the same two halves
     B, voters, rs, d_in, d_w, d_st = batches[1]
     pk.batch_begin(0, None, B, d_w.data_ptr(), None, rs)

@@ -229,7 +229,10 @@ def test_queue_spills_over_further_device_entries(monkeypatch):
     def check(i):
         rc, w = ol.witness(voters[i], nl)
         rc2, op, ou = ol.prove(zk, w, int.from_bytes(rs[i][:32], 'little'), int.from_bytes(rs[i][32:], 'little'))
-        assert rc == 0 and rc2 == 0 and out[i] == (op, ou, 0)
+        if not (rc == 0 and rc2 == 0 and out[i] == (op, ou, 0)):
+            whose = [j for j in range(len(voters)) if out[j][0] == out[i][0]]
+            raise AssertionError('caller %d: rc %d/%d, status %r, public signals %s, proof %s; verifier on what it got: %r; callers holding these bytes: %r' % (
+                i, rc, rc2, out[i][2], 'equal' if out[i][1] == ou else 'DIFFER', 'equal' if out[i][0] == op else 'DIFFERS', ol.verify(vk, out[i][1], out[i][0]), whose))
     ol.pmap(check, range(0, len(voters), 13))
     # an image that differs from the resident one ONLY in bytes the sampled fingerprint does not look at is another key: it must not be served the resident one
     import struct

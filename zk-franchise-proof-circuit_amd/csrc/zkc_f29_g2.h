@@ -60,6 +60,9 @@ ZKC_HD void f29g2_sqr(F2x29& r, const F2x29& a) {
     const uint32_t z[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     f29g2_sqr_addhi(r, a, z, z);
 }
+ZKC_HD void f29g2_neg_hi(F2x29& h, const F2x29& v, const L9& D) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) { h.c0[k] = D.l[k] - v.c0[k]; h.c1[k] = D.l[k] - v.c1[k]; } }
 ZKC_HD bool f29g2_is_zero(const F2x29& a) { return f29_is_zero_mod_p<FqParams>(a.c0) && f29_is_zero_mod_p<FqParams>(a.c1); }
 
 // acc += (x2, y2); x2, y2 tame and below 1.2 p.  Returns false and leaves acc alone when the x coordinates agree.
@@ -98,6 +101,39 @@ ZKC_HD bool f29g2_madd(Acc29G2& acc, const F2x29& x2, const F2x29& y2, bool& sam
     return true;
 }
 
+// [r4] the same addition with its ten products in an order that keeps few values alive, and scheduling fences between them so that the compiler does not interleave
+// independent products (which is what holds ~330 registers in f29g2_madd: more instruction-level parallelism than ONE wave per SIMD can use, no room for a second wave).
+// Alive at the widest point (PPP = P PP): Y, ZZ, ZZZ, R, Q, P, PP, the product's 18 column sums and one negated operand: about 190 registers.  Same operations, same magnitudes.
+__device__ __forceinline__ bool f29g2_madd_lean(Acc29G2& acc, const F2x29& x2, const F2x29& y2, bool& same_y) {
+#define ZKC_FENCE() __builtin_amdgcn_sched_barrier(0)
+    F2x29 Pn, Rn, h;
+    f29g2_neg_hi(h, acc.X, Dom29G2::D24);
+    f29g2_mul_addhi(Pn, x2, acc.ZZ, h.c0, h.c1); ZKC_FENCE();
+    f29g2_neg_hi(h, acc.Y, Dom29G2::D24);
+    f29g2_mul_addhi(Rn, y2, acc.ZZZ, h.c0, h.c1); ZKC_FENCE();
+    if (f29g2_is_zero(Pn)) { same_y = f29g2_is_zero(Rn); return false; }
+    F2x29 PP, PPP, Q, W, V;
+    f29g2_sqr(PP, Pn); ZKC_FENCE();
+    f29g2_mul(Q, acc.X, PP); ZKC_FENCE();                       // the old X dies here
+    f29g2_mul(acc.ZZ, acc.ZZ, PP); ZKC_FENCE();
+    f29g2_mul(PPP, Pn, PP); ZKC_FENCE();                        // P and PP die here
+    f29g2_mul(acc.ZZZ, acc.ZZZ, PPP); ZKC_FENCE();
+    f29g2_mul(V, acc.Y, PPP); ZKC_FENCE();                      // the old Y dies here
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        h.c0[k] = Dom29G2::D24x3.l[k] - PPP.c0[k] - 2 * Q.c0[k];
+        h.c1[k] = Dom29G2::D24x3.l[k] - PPP.c1[k] - 2 * Q.c1[k];
+    }
+    f29g2_sqr_addhi(acc.X, Rn, h.c0, h.c1);
+    f29_reduce_small<FqParams>(acc.X.c0); f29_reduce_small<FqParams>(acc.X.c1); ZKC_FENCE();
+    f29_sub(W.c0, Q.c0, acc.X.c0, Dom29G2::D24); f29_carry(W.c0); f29_sub(W.c1, Q.c1, acc.X.c1, Dom29G2::D24); f29_carry(W.c1);
+    f29g2_neg_hi(h, V, Dom29G2::D24);
+    f29g2_mul_addhi(acc.Y, Rn, W, h.c0, h.c1);
+    f29_reduce_small<FqParams>(acc.Y.c0); f29_reduce_small<FqParams>(acc.Y.c1); ZKC_FENCE();
+#undef ZKC_FENCE
+    return true;
+}
+
 // ---- bucket reduction in G2: points with all coordinates carried and below 10 p per component ("tame": what the operations below return;
 // a canonical 8 x u32 point enters by slicing 32 x value and one f29_reduce_small per component).  Infinity is ZZ with all limbs zero.
 // Product outputs are below (A + 22.2) B / 169 + 1 [+ addend] for operands below A p, B p, so with tame inputs:
@@ -120,9 +156,6 @@ ZKC_HD void f29g2_enter(F2x29& r, const Fq2& a) {
 ZKC_HD Acc29G2 f29g2_pt_from_xyzz(const XYZZ<Fq2>& p) { Acc29G2 a; f29g2_enter(a.X, p.X); f29g2_enter(a.Y, p.Y); f29g2_enter(a.ZZ, p.ZZ); f29g2_enter(a.ZZZ, p.ZZZ); return a; }
 ZKC_HD Fq2 f29g2_leave(const F2x29& a) { return {f29_to_fp<FqParams>(a.c0), f29_to_fp<FqParams>(a.c1)}; }
 ZKC_HD XYZZ<Fq2> f29g2_pt_to_xyzz(const Acc29G2& a) { return {f29g2_leave(a.X), f29g2_leave(a.Y), f29g2_leave(a.ZZ), f29g2_leave(a.ZZZ)}; }
-ZKC_HD void f29g2_neg_hi(F2x29& h, const F2x29& v, const L9& D) {
-#pragma unroll
-    for (int k = 0; k < 9; k++) { h.c0[k] = D.l[k] - v.c0[k]; h.c1[k] = D.l[k] - v.c1[k]; } }
 ZKC_HD void f29g2_reduce(F2x29& a) { f29_reduce_small<FqParams>(a.c0); f29_reduce_small<FqParams>(a.c1); }
 
 ZKC_HD void f29g2_pt_dbl(Acc29G2& r, const Acc29G2& a) {          // a finite

@@ -184,6 +184,79 @@ zkc_msm_accumulate29_g2(const uint32_t* __restrict__ table29_all, const MsmJobLi
     partial[s] = out;
 }
 
+// ---- [r4] K5, G2, with the NEXT entry's table row fetched by the LDS-DMA path (global_load_lds_dwordx4: memory -> LDS without passing through VGPRs).
+// The kernel above keeps the next entry's two 80-byte chunks in 40 registers for the whole of the current addition (367 VGPRs: one wave per SIMD, VALU-busy 0.70 -- the
+// one heavy kernel of a pass with idle issue slots).  Here the prefetch lives in LDS (160 bytes per lane, laid out [piece][lane]: lane i of a wave writes
+// M0 base + 16 i), the lane copies it into registers only when the addition starts, and the register budget is capped for two waves per SIMD.  One wave per workgroup:
+// nothing is shared, no barrier.
+constexpr int G2DMA_T = 64;
+template <int MINW>
+__global__ void __launch_bounds__(G2DMA_T, MINW)
+zkc_msm_accumulate29_g2_dma(const uint32_t* __restrict__ table29_all, const MsmJobList* __restrict__ jlp, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ off,
+                            const uint32_t* __restrict__ bcnt, const uint32_t* __restrict__ segoff, const uint32_t* __restrict__ seg2bucket, const uint32_t* __restrict__ perm, uint32_t nbuckets,
+                            XYZZ<Fq2>* __restrict__ partial, uint32_t max_segments) {
+    __shared__ uint4 stage[10][G2DMA_T];
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x;
+    uint32_t nseg = segoff[nbuckets]; if (nseg > max_segments) nseg = max_segments;
+    if (gid >= nseg) return;
+    const uint32_t s = perm[gid];
+    const uint32_t b = seg2bucket[s];
+    uint32_t lo, hi; msm_seg_range(bcnt[b], segoff[b + 1] - segoff[b], s - segoff[b], lo, hi);
+    const uint32_t start = off[b] + lo, end = off[b] + hi;
+    uint32_t bd, bj; jlp->decode(b, bd, bj);
+    const uint32_t* __restrict__ table29 = table29_all + (size_t)jlp->job[bj].tbl_off * G2T29_WORDS;
+    constexpr uint32_t rowmask = 0x7fffffffu;
+    typedef const __attribute__((address_space(1))) void* gptr; typedef __attribute__((address_space(3))) void* lptr;
+    auto fetch = [&](uint32_t v) {
+        const uint32_t* px = table29 + (size_t)(v & rowmask) * G2T29_WORDS;
+        const uint32_t* py = px + ((v >> 31) ? 40 : 20);
+#pragma unroll
+        for (int k = 0; k < 5; k++) __builtin_amdgcn_global_load_lds((gptr)(px + 4 * k), (lptr)&stage[k][0], 16, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 5; k++) __builtin_amdgcn_global_load_lds((gptr)(py + 4 * k), (lptr)&stage[5 + k][0], 16, 0, 0);
+    };
+    Acc29G2 acc; bool inf = true;
+    uint32_t v = vals[start];
+    fetch(v);
+    for (uint32_t j = start; j < end; j++) {
+        const uint32_t vn = (j + 1 < end) ? vals[j + 1] : v;
+        F2x29 x2, y2; uint32_t isinf;
+        {
+            uint32_t w[40];
+#pragma unroll
+            for (int k = 0; k < 10; k++) { const uint4 q = stage[k][lane]; w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w; }
+#pragma unroll
+            for (int k = 0; k < 9; k++) { x2.c0[k] = w[k]; x2.c1[k] = w[9 + k]; y2.c0[k] = w[20 + k]; y2.c1[k] = w[29 + k]; }
+            isinf = w[18];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the row is in registers before its LDS slot is handed to the next fetch
+        if (j + 1 < end) fetch(vn);                                    // in flight during this addition
+        if (!isinf) {
+            bool same_y = false;
+            if (inf) {
+                acc.X = x2; acc.Y = y2;
+#pragma unroll
+                for (int k = 0; k < 9; k++) { acc.ZZ.c0[k] = acc.ZZZ.c0[k] = F29K<FqParams>::one.l[k]; acc.ZZ.c1[k] = acc.ZZZ.c1[k] = 0; }
+                inf = false;
+            } else if (!f29g2_madd_lean(acc, x2, y2, same_y)) {
+                if (same_y) {                                               // the bucket holds this very point: double it (rare; generic code)
+                    Affine<Fq2> a; a.x = {f29_to_fp<FqParams>(x2.c0), f29_to_fp<FqParams>(x2.c1)}; a.y = {f29_to_fp<FqParams>(y2.c0), f29_to_fp<FqParams>(y2.c1)};
+                    const XYZZ<Fq2> d = xyzz_dbl_affine(a);
+                    f29_enter_fq(acc.X.c0, d.X.c0.v); f29_enter_fq(acc.X.c1, d.X.c1.v); f29_enter_fq(acc.Y.c0, d.Y.c0.v); f29_enter_fq(acc.Y.c1, d.Y.c1.v);
+                    f29_enter_fq(acc.ZZ.c0, d.ZZ.c0.v); f29_enter_fq(acc.ZZ.c1, d.ZZ.c1.v); f29_enter_fq(acc.ZZZ.c0, d.ZZZ.c0.v); f29_enter_fq(acc.ZZZ.c1, d.ZZZ.c1.v);
+                } else inf = true;                                          // P + (-P)
+            }
+        }
+        v = vn;
+    }
+    XYZZ<Fq2> out = XYZZ<Fq2>::inf();
+    if (!inf) {
+        out.X = {f29_to_fp<FqParams>(acc.X.c0), f29_to_fp<FqParams>(acc.X.c1)}; out.Y = {f29_to_fp<FqParams>(acc.Y.c0), f29_to_fp<FqParams>(acc.Y.c1)};
+        out.ZZ = {f29_to_fp<FqParams>(acc.ZZ.c0), f29_to_fp<FqParams>(acc.ZZ.c1)}; out.ZZZ = {f29_to_fp<FqParams>(acc.ZZZ.c0), f29_to_fp<FqParams>(acc.ZZZ.c1)};
+    }
+    partial[s] = out;
+}
+
 // ---- [r3] K5 for a SMALL G2 pass (one to four proofs): half a WAVE per bucket.  With a lane per segment of 16 entries a bucket of ~100 entries is 16 mixed additions in a row,
 // up to eight full ones in the window walk and a merge pass for the heavier buckets -- the longest link of a lone proof's G2 chain (0.9 of 1.7 ms).  Here 32 lanes stride over
 // the bucket's entries (three or four additions in a row for 100 entries) and a five-step butterfly sums them; 2048 buckets are 1024 waves, one per SIMD, one round.  No segment
@@ -625,9 +698,18 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
             hipLaunchKernelGGL(zkc_msm_bucketwave_g2, dim3((nb + 1) / 2, bw_slices), dim3(64), 0, st, g2_table29, (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.bcnt, w.segoff, w.segcnt, w.heavy,
                                w.heavy + MSM_MAX_HEAVY, reinterpret_cast<XYZZ<Fq2>*>(partial), nb, bw_slices);
           }
-          else
+          else {
+            static const int g2_form = [] { const char* e = getenv("ZKC_G2_ACC"); return e ? atoi(e) : 0; }();      // 0: registers hold the next row (one wave per SIMD); 1 / 2: LDS-DMA prefetch at one / two waves per SIMD
+            if (g2_form == 2)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate29_g2_dma<2>), dim3((unsigned)((seg_bound + G2DMA_T - 1) / G2DMA_T)), dim3(G2DMA_T), 0, st,
+                                   g2_table29, (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.bcnt, w.segoff, w.seg2bucket, w.perm, nb, reinterpret_cast<XYZZ<Fq2>*>(partial), (uint32_t)w.max_segments);
+            else if (g2_form == 1)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate29_g2_dma<1>), dim3((unsigned)((seg_bound + G2DMA_T - 1) / G2DMA_T)), dim3(G2DMA_T), 0, st,
+                                   g2_table29, (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.bcnt, w.segoff, w.seg2bucket, w.perm, nb, reinterpret_cast<XYZZ<Fq2>*>(partial), (uint32_t)w.max_segments);
+            else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate29_g2<1>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
                                g2_table29, (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.bcnt, w.segoff, w.seg2bucket, w.perm, nb, reinterpret_cast<XYZZ<Fq2>*>(partial), (uint32_t)w.max_segments);
+          }
         } else    // G1: same layout, field type with the inlined product.  160 VGPRs = 3 waves per SIMD; capped at 128 (4 waves) the accumulator spills and the kernel is 3.6x slower
             hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate29<2>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
                                reinterpret_cast<const Affine<Fq>*>(table), (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.bcnt, w.segoff, w.seg2bucket, w.perm, nb,

@@ -693,6 +693,11 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         // ~25 us of a 3.2 ms proof
         hipStream_t bl = (tree && npasses == 1) ? st : fin;
         if (bl == fin) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm, 0));
+        // [r4] ... but the blinding scratch (LN.d_fin) is the lane's, and the pass before this one -- the last pass of the PREVIOUS call, begun on the other call slot -- blinds on
+        // `fin`: without this wait its lane-per-product kernels and this call's tree kernels could write the scratch at the same time (a wrong proof for one of the two callers,
+        // seen once in tests/test_gpu_service.py::test_queue_spills_over_further_device_entries under a load of mixed batch sizes).  That pass' blinding is long over when
+        // this call's MSMs are through, so the wait costs nothing.
+        else if (LN.npass >= 2) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, LN.ev_fin[slot ^ 1], 0));
         if (!tree) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm2, 0));      // a small pass' piB is written on the G2 stream: piA and piC need not wait for it ...
         if ((rc = finalize_launch(ctx, bl, fa, nb))) return rc;
         if (tree) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(bl, LN.ev_msm2, 0));        // ... only the copy of the finished proof does
