@@ -495,6 +495,12 @@ def main():
         # cores_received() measures it in 0.4 s (the oracle's NTT on one thread per schedulable core: CPU seconds / wall); the leg runs on that many threads.
         avail = len(os.sched_getaffinity(0))
         quota = cores_received(ol, avail)
+        try:                                                      # where the container shows its cgroup-v2 CPU quota (the GPU boxes: "1600000 100000" = 16 cores), that is the number
+            q_us, per_us = open('/sys/fs/cgroup/cpu.max').read().split()
+            if q_us != 'max':
+                quota = min(quota, int(q_us) / int(per_us))
+        except (OSError, ValueError):
+            pass
         want = os.environ.get('ZKC_CPU_BASELINE_THREADS')
         cores = max(1, min(avail, int(want))) if want else max(1, min(avail, int(quota + 0.5)))
         wt = d_wtns.view(B, nW * 32)

@@ -413,6 +413,27 @@ static int fold_vmap(zkc_zkey* zk, int Dc, int Ds, zkc_zkey::Fold::VMap* out) {
     return ZKC_OK;
 }
 
+// [r4] the same three lists with NOTHING folded: every wire whose base is not the point at infinity.  A third of the census circuit's wires have a zero B polynomial (27 263 of
+// 82 754: B1 and B2 bases at infinity) and real R1CS are like that in general; an unfolded pass (a foreign circuit, a foreign witness, ZKC_NO_FOLD) used to carry them through
+// digit extraction, bucketing and the gathers only to skip them inside the accumulation, where a skipped entry still costs its wave an addition's time.  out->d == nullptr:
+// the key has no such wires, the pass indexes the sections directly.
+static int nofold_vmap(zkc_zkey* zk, zkc_zkey::Fold::VMap* out) {
+    auto it = zk->fold.vmaps.find({-1, -1});
+    if (it != zk->fold.vmaps.end()) { *out = it->second; return ZKC_OK; }
+    zkc_ctx* ctx = zk->ctx; const uint32_t nv = zk->nVars, np = zk->nPub;
+    std::vector<uint32_t> v; zkc_zkey::Fold::VMap m;
+    m.offA = 0; for (uint32_t w = 0; w < nv; w++) if (!zk->fold.infA[w]) v.push_back(w); m.nA = (uint32_t)v.size();
+    m.offB = (uint32_t)v.size(); for (uint32_t w = 0; w < nv; w++) if (!zk->fold.infB[w]) v.push_back(w); m.nB = (uint32_t)v.size() - m.offB;
+    m.offC = (uint32_t)v.size(); for (uint32_t w = np + 1; w < nv; w++) if (!zk->fold.infC[w]) v.push_back(w); m.nC = (uint32_t)v.size() - m.offC;
+    if ((size_t)m.nA + m.nB + m.nC + (size_t)nv / 50 < 3 * (size_t)nv - np - 1) {          // worth an indirection only when at least ~2 % of a section's entries drop out
+        ZKC_HIP_CHECK(ctx, hipMalloc((void**)&m.d, v.size() * 4 + 4));
+        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(m.d, v.data(), v.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    zk->fold.vmaps[{-1, -1}] = m; *out = m;
+    return ZKC_OK;
+}
+
 // stages a2..a4 for `nb` proofs: leaves (A'B' - C') on the odd coset in d_p[q] (standard form), q < nb
 // buildABC (a2) for `nb` proofs on stream `mv`: A_w, B_w by the jagged-diagonal mat-vec, C_w = A_w o B_w
 static int h_matvec_dev(zkc_zkey* zk, zkc_lane& L, const uint32_t* d_wtns0, int nb, hipStream_t mv) {
@@ -597,6 +618,12 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         }
         static thread_local zkc_zkey::Fold::VMap vms[MSM_MAX_JOBS / 4];
         if (fold) for (int q = 0; q < nb; q++) if ((rc = fold_vmap(zk, dcq[q], dsq[q], &vms[q]))) return rc;
+        static const bool nofold_lists = [] { const char* e = getenv("ZKC_NOFOLD_LISTS"); return !(e && atoi(e) == 0); }();
+        if (!fold && nofold_lists) {                        // an unfolded pass still leaves out the wires whose bases are at infinity (one list set per key)
+            zkc_zkey::Fold::VMap nf; if ((rc = nofold_vmap(zk, &nf))) return rc;
+            for (int q = 0; q < nb; q++) vms[q] = nf;
+        }
+        const bool listed = fold || (nofold_lists && vms[0].d != nullptr);                      // the pass' jobs run over wire lists (vms) instead of whole sections
         if (LN.npass >= 2) { ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, LN.ev_fin[slot], 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st2, LN.ev_fin[slot], 0)); }   // slot still read by the blinding two passes back?
         LN.npass++;
         // [r2] buildABC is gather-bound and needs only the witness: the one of pass p+1 is issued on the blinding stream as soon as the accumulation
@@ -613,7 +640,7 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         static thread_local MsmJobList j1, j2;     // 6 KB each: kept off the stack frame of a C-ABI entry point
         const uint32_t vws = nb <= 4 ? 64u : 256u, vwb = nb <= 4 ? 256u : 1024u;          // few proofs in the pass: favour latency in the bucket reduction
         // the G2 section of one or two proofs takes the 8-bit-window table: 128 buckets per job, reduced by one wave (vw = 128), if the G2 work space holds 32 entries per scalar
-        size_t lone_entries = 0; for (int q = 0; q < nb; q++) lone_entries += (size_t)msm_nw(MSM_C_G2_LONE) * (fold ? vms[q].nB : nv);
+        size_t lone_entries = 0; for (int q = 0; q < nb; q++) lone_entries += (size_t)msm_nw(MSM_C_G2_LONE) * (listed ? vms[q].nB : nv);
         const int c2 = (nb <= 2 && zk->d_g2_29_lone && lone_entries <= LN.w2.max_entries) ? MSM_C_G2_LONE : zk->c_sec;
         j1.clear(vws, vwb); j2.clear(c2 == MSM_C_G2_LONE ? 128u : vws);
         // job order of the G1 pass: the nb H jobs first (the 16-bit bucket sort wants the jobs with the larger bucket count in front), then
@@ -622,7 +649,7 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         // [r3] a pass of one or two proofs carries its blinding's two variable-base products as two more MSM jobs each -- sum (s w_i) A_i and sum (r w_i) B1_i over the
         // wires that stay in the proof's MSMs -- so that the blinding kernel is left with fixed-base products only (zkc_finalize.hip)
         // (the lanes' work space is sized for max(4, passes of this key) proofs of 3 + 1 jobs each: two proofs of 5 + 1 fit unless ZKC_INFLIGHT made the passes smaller than that)
-        size_t tree_entries = 0; for (int q = 0; q < nb; q++) tree_entries += (size_t)msm_nw(MSM_C_BIG) * n + (size_t)msm_nw(zk->c_sec) * (fold ? 2 * (size_t)vms[q].nA + 2 * (size_t)vms[q].nB + vms[q].nC : 4 * (size_t)nv + nc);
+        size_t tree_entries = 0; for (int q = 0; q < nb; q++) tree_entries += (size_t)msm_nw(MSM_C_BIG) * n + (size_t)msm_nw(zk->c_sec) * (listed ? 2 * (size_t)vms[q].nA + 2 * (size_t)vms[q].nB + vms[q].nC : 4 * (size_t)nv + nc);
         const bool tree = zk->d_fb4 != nullptr && nb <= 2 && 6 * nb <= LN.w1.max_jobs && tree_entries <= LN.w1.max_entries && (size_t)nb * (5 * msm_half(zk->c_sec) + msm_half(MSM_C_BIG)) <= LN.w1.max_buckets;
         BlindArgs ba{}; ba.rs = CS.d_rs + 64 * (size_t)p0; ba.nv = nv;
         const int cs = zk->c_sec;
@@ -630,7 +657,7 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
             const uint32_t* w = w0 + (size_t)q * nv * 8;
             uint32_t* bs = tree ? LN.d_bs + (size_t)q * 2 * nv * 8 : nullptr;
             if (tree) { ba.w[q] = w; ba.out[q] = bs; }
-            if (fold) {
+            if (listed) {
                 const zkc_zkey::Fold::VMap& vm = vms[q];
                 j1.add(w, vm.d + vm.offA, vm.nA, zk->offA, nv, 0, cs);
                 j1.add(w, vm.d + vm.offB, vm.nB, zk->offB1, nv, 0, cs);
