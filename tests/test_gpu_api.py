@@ -29,6 +29,14 @@ def test_snarkjs_surface_and_rapidsnark_entry():
     assert out2['proof'] != out['proof'] and groth16.verify(vk, out2['publicSignals'], out2['proof'])
     a = groth16.fullProve(ex, None, zkey_path, rs=(5, 7)); b = groth16.fullProve(ex, None, zkey_path, rs=(5, 7))
     assert a == b
+    # [r4] wasm None and no nLevels: the depth is read off the key (a voter of an nLevels-10 census through an nLevels-10 key, no option needed); a key that is no census key says so
+    import random, sys, os
+    sys.path.insert(0, os.path.join(ol.ROOT, 'tools'))
+    from census_gen import random_voter
+    _, z10, v10 = setup.ensure_test_artifacts(10)
+    assert groth16.key_nlevels(z10) == 10 and groth16.key_nlevels(zkey_path) == 160
+    o10 = groth16.fullProve(random_voter(random.Random(3), ol.poseidon, nLevels=10, depth_c=4, depth_s=6), None, z10)
+    assert groth16.verify(json.load(open(v10)), o10['publicSignals'], o10['proof'])
     # a failing circuit assert surfaces like snarkjs' "Assert Failed"
     bad = dict(ex); bad['voteWeight'] = str(int(ex['availableWeight']) + 1)
     with pytest.raises(RuntimeError) as e:

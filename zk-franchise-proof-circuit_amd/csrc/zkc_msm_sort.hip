@@ -133,7 +133,11 @@ zkc_msm_split(const MsmJobList* __restrict__ jlp, const uint16_t* __restrict__ t
 }
 // one workgroup per level-1 bin: its entries (contiguous in `vals`) go to `vals2` grouped by bucket; off / bcnt for the bin's 2^lbits buckets.
 // A bin of up to 8192 entries (every bin of an H job: 7.7 k) is held in registers, 32 loads in flight per lane, and read once; larger bins
-// (repeated witness values) take two passes over global memory in chunks of 2048.
+// (repeated witness values; every bin of a job of 2^19 scalars and more) are counted first and then staged through LDS in chunks of 4096.
+// CHUNKED = false: the kernel of rounds 2-3 (52 VGPRs: two of its waves fit beside a wave of the G2 accumulation, which it is scheduled beside in a census pass; bins above 8192
+// entries -- a few, from repeated witness values -- take the slow two-pass path).  CHUNKED = true: bins above 8192 entries are the rule (jobs of 2^19 scalars and more) and go
+// through LDS in chunks (108 VGPRs).  msm_bucket_entries picks by the expected bin size of the pass' largest job.
+template <bool CHUNKED>
 __global__ void __launch_bounds__(256)
 zkc_msm_bucket(const MsmJobList* __restrict__ jlp, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ bin_start, const uint32_t* __restrict__ vals,
                uint32_t* __restrict__ vals2, uint32_t* __restrict__ off, uint32_t* __restrict__ bcnt) {
@@ -183,7 +187,7 @@ zkc_msm_bucket(const MsmJobList* __restrict__ jlp, const uint32_t* __restrict__ 
         }
         // scattered 4-byte stores into a 31 KB window left the L2 as partial lines (2.4 ms per pass); from LDS the bin goes out coalesced
         for (uint32_t i = threadIdx.x; i < n; i += 256) vals2[start + i] = stage[i];
-    } else {
+    } else if constexpr (!CHUNKED) {
         for (uint32_t i0 = 0; i0 < n; i0 += 256 * SMALL) {
             uint32_t v[SMALL];
 #pragma unroll
@@ -193,6 +197,42 @@ zkc_msm_bucket(const MsmJobList* __restrict__ jlp, const uint32_t* __restrict__ 
                 if (i0 + k * 256 + threadIdx.x < n) { const uint32_t p = atomicAdd(&pos[(v[k] >> lowshift) & lowmask], 1u); vals2[start + p] = (v[k] & 0x80000000u) | (v[k] & rowmask); }
                 __syncthreads();
             }
+        }
+    } else {
+        // [r4] a bin of more than 8192 entries (repeated witness values; every bin of a job of 2^19 scalars and more: 30 k entries at 2^20) goes through the same LDS staging in
+        // CHUNKS of 4096: a chunk is ranked by bucket inside LDS and leaves as one contiguous run per bucket (~32 entries = 128 B each at 128 buckets per bin) behind that bucket's
+        // running position, instead of one scattered 4-byte store per entry (which left the L2 as partial lines: 3.7 ms per launch at a 2^20 domain, the largest bucketing
+        // kernel there).  Order inside a bucket: chunk, then 256-entry group -- the (tile, window) order of the bin, as before.  pos[] = running position of every bucket.
+        uint32_t* ccnt = cnt;                              // per-chunk bucket counts (the bin-wide counts have been consumed: off / bcnt are written)
+        __shared__ uint32_t cbase[256];                    // exclusive scan of ccnt: where a bucket's run starts inside the staged chunk
+        __shared__ uint32_t cpos[256];
+        constexpr int CH = BIG / 2;                        // 4096 entries per chunk: the staged words take half of stage[], their bucket numbers (a byte each) sit in the other half -- no more LDS than the register path (occupancy)
+        uint8_t* sbkt = reinterpret_cast<uint8_t*>(stage + 256 * CH);
+        for (uint32_t c0 = 0; c0 < n; c0 += 256u * CH) {
+            const uint32_t m = n - c0 < 256u * CH ? n - c0 : 256u * CH;
+            ccnt[threadIdx.x] = 0; __syncthreads();
+#pragma unroll
+            for (int k = 0; k < CH; k++) { const uint32_t i = k * 256 + threadIdx.x; e[k] = i < m ? vals[start + c0 + i] : 0u; }
+#pragma unroll
+            for (int k = 0; k < CH; k++) if ((uint32_t)k * 256 + threadIdx.x < m) atomicAdd(&ccnt[(e[k] >> lowshift) & lowmask], 1u);
+            __syncthreads();
+            const uint32_t cm = ccnt[threadIdx.x];
+            cpos[threadIdx.x] = cm; __syncthreads();
+            for (int o = 1; o < 256; o <<= 1) { uint32_t a2 = (int)threadIdx.x >= o ? cpos[threadIdx.x - o] : 0; __syncthreads(); cpos[threadIdx.x] += a2; __syncthreads(); }
+            const uint32_t cex = cpos[threadIdx.x] - cm;
+            __syncthreads();
+            cbase[threadIdx.x] = cex; cpos[threadIdx.x] = cex; __syncthreads();
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                if ((uint32_t)k * 256 < m) {                 // uniform
+                    if ((uint32_t)k * 256 + threadIdx.x < m) { const uint32_t bk = (e[k] >> lowshift) & lowmask, q = atomicAdd(&cpos[bk], 1u); stage[q] = (e[k] & 0x80000000u) | (e[k] & rowmask); sbkt[q] = (uint8_t)bk; }
+                    __syncthreads();
+                }
+            }
+            for (uint32_t i = threadIdx.x; i < m; i += 256) { const uint32_t bk = sbkt[i]; vals2[start + pos[bk] + (i - cbase[bk])] = stage[i]; }
+            __syncthreads();
+            pos[threadIdx.x] += cm;                          // (buckets >= nb2 have cm = 0)
+            __syncthreads();
         }
     }
 }
@@ -320,7 +360,10 @@ int msm_bucket_entries(zkc_ctx* ctx, MsmWork& w, const MsmJobList& jl, hipStream
     ZKC_SORT_LAUNCH_CHECK("zkc_msm_binscan");
     hipLaunchKernelGGL(zkc_msm_split, dim3(jl.total_tiles), dim3(MSM_TILE), 0, st, dj, (const uint16_t*)w.d_tilejob, w.tilecnt, w.vals);
     ZKC_SORT_LAUNCH_CHECK("zkc_msm_split");
-    hipLaunchKernelGGL(zkc_msm_bucket, dim3(jl.total_bins), dim3(256), 0, st, dj, w.hist, w.bin_start, w.vals, w.vals2, w.off, w.bcnt);
+    uint64_t biggest_bin = 0;                               // expected entries per level-1 bin of the pass' largest job (uniform digits)
+    for (int j = 0; j < jl.njobs; j++) biggest_bin = std::max<uint64_t>(biggest_bin, ((uint64_t)jl.job[j].count * jl.job[j].nw) >> jl.job[j].hbits);
+    if (biggest_bin > 8192) hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_bucket<true>), dim3(jl.total_bins), dim3(256), 0, st, dj, w.hist, w.bin_start, w.vals, w.vals2, w.off, w.bcnt);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_bucket<false>), dim3(jl.total_bins), dim3(256), 0, st, dj, w.hist, w.bin_start, w.vals, w.vals2, w.off, w.bcnt);
     ZKC_SORT_LAUNCH_CHECK("zkc_msm_bucket");
     return ZKC_OK;
 }

@@ -137,7 +137,24 @@ def prove(zkey_file, wtns_file, rs=None):
     return {'proof': pj, 'publicSignals': sj}
 
 
+def key_nlevels(zkey_file):
+    """The depth n for which the key has the shape of ZkFranchiseProofCircuit(n) -- 8 public signals, zkc_circuit_n_wires(n) wires -- read off the file header alone
+    (zkc_zkey_header_info, host only); None for any other circuit."""
+    lib = _native.load()
+    raw = _read(zkey_file)
+    nv, npub, dom = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+    if lib.zkc_zkey_header_info(raw, len(raw), ctypes.byref(nv), ctypes.byref(npub), ctypes.byref(dom)) != 0:
+        raise ValueError('not a Groth16 .zkey file')
+    if npub.value != 8:
+        return None
+    return next((n for n in range(3, 254) if lib.zkc_circuit_n_wires(n) == nv.value), None)
+
+
 def fullProve(inputs, wasm_file, zkey_file, rs=None, nLevels=None):
+    if wasm_file is None and nLevels is None:           # [r4] no wasm names the circuit: the depth is the key's (a caller with a key of another depth needs no option)
+        nLevels = key_nlevels(zkey_file)
+        if nLevels is None:
+            raise ValueError('no wasm_file given and the key is not a ZkFranchiseProofCircuit key: compute the witness elsewhere and call groth16.prove(zkey_file, wtns_file)')
     return prove(zkey_file, wtns.calculate(inputs, wasm_file, nLevels), rs)
 
 
