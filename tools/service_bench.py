@@ -100,6 +100,46 @@ def main():
                 'worker_ms': {k: round((tm1[k] - tm0[k]) / 1e3, 1) for k in ('us_upload', 'us_wait_gpu', 'us_key', 'us_prove', 'us_finish')}}
     out['groth16_prover_threads'] = run('groth16_prover')
     out['service_fullprove_threads'] = run('fullprove')
+    # [r4] two keys of the same circuit (two ceremonies: the reference keeps a key per environment, circuit/circuit-compiler.sh:15,82) hammered at once, half of the threads each:
+    # with both resident (ZKC_SERVICE_KEYS >= 2, default 4) against one slot per device (every change of key frees 2 GB of tables and reloads for 0.6 s)
+    def two_keys(slots):
+        import tempfile
+        os.environ['ZKC_SERVICE_KEYS'] = str(slots)
+        try:
+            svc2 = zkcensus_amd.ProvingService([0])
+        finally:
+            del os.environ['ZKC_SERVICE_KEYS']
+        with tempfile.TemporaryDirectory() as d:
+            _, z2, v2 = setup.ensure_test_artifacts(NL, seed=77, directory=d)
+            zkB = open(z2, 'rb').read(); vkB = vk_bytes(json.load(open(v2)))
+        keys = [(zk, vk), (zkB, vkB)]
+        for k in keys:
+            svc2.fullprove(k[0], flats[0], nLevels=NL)                   # both loaded once before the clock starts
+        res = [[] for _ in range(T)]
+
+        def caller(t):
+            for _ in range(PER):
+                p, u, s_ = svc2.fullprove(keys[t & 1][0], flats[t], nLevels=NL); assert s_ == 0
+                res[t].append((p, u))
+        if slots > 1:                                                    # an untimed round first: both keys' work space grows to a full pass (0.5 s each, once per key)
+            th = [threading.Thread(target=caller, args=(t,)) for t in range(T)]
+            for x in th: x.start()
+            for x in th: x.join()
+            for r_ in res: r_.clear()
+        s0 = svc2.stats(); e0 = svc2.timing()['key_evictions']; th = [threading.Thread(target=caller, args=(t,)) for t in range(T)]
+        t0 = time.time()
+        for x in th: x.start()
+        for x in th: x.join()
+        dt = time.time() - t0; s1 = svc2.stats(); e1 = svc2.timing()['key_evictions']
+        ok = True
+        for par in (0, 1):
+            pr = b''.join(p for t in range(par, T, 2) for p, _ in res[t]); pu = b''.join(u for t in range(par, T, 2) for _, u in res[t])
+            ok = ok and lib.zkc_verify_batch(ctx._h, keys[par][1], 8, pu, pr, len(pr) // 256, None) == 1
+        svc2.close()
+        n = T * PER
+        return {'resident_key_slots': slots, 'proofs': n, 'seconds': round(dt, 3), 'proofs_per_s': round(n / dt, 1), 'batches': s1['batches'] - s0['batches'],
+                'key_loads_during_the_run': s1['key_loads'] - s0['key_loads'], 'evictions_during_the_run': e1 - e0, 'all_verified_under_their_own_key': bool(ok)}
+    out['two_keys_half_the_threads_each'] = [two_keys(4), two_keys(1)]
     # one caller, one call at a time: the latency a lone sequential caller sees through the same entry points
     t0 = time.time(); [svc.fullprove(zk, flats[0], nLevels=NL) for _ in range(20)]; out['sequential_fullprove_ms'] = round((time.time() - t0) / 20 * 1e3, 2)
     print(json.dumps(out))
