@@ -37,7 +37,7 @@ def single_context(zkcensus_amd, torch, ctx, pk, voters, rs, nl=10):
     return p, pub, d_st.cpu().tolist()
 
 
-@pytest.mark.parametrize('devices,B', [([0], 5), ([0, 0], 5), ([0, 0], 1), ([0, 0, 0], 200)])
+@pytest.mark.parametrize('devices,B', [([0], 5), ([0, 0], 5), ([0, 0], 1), ([0, 0, 0], 200), ([0] * 8, 61)])      # [r4] eight entries: the node of BASELINE configs[3] in one host process (eight contexts, keys and host threads; blocks of 8 and 7 voters)
 def test_pool_equals_single_context(env, devices, B):
     zkcensus_amd, torch, zk, vk, ctx, pk = env
     nl = 10

@@ -34,16 +34,34 @@ __device__ __forceinline__ void st_fr(Fr* p, const Fr& r) {
 // [r2] tried and not kept: accumulating a row in the 64-bit column sums of the radix-2^29 product with one reduction per four terms.  It costs
 // 218 instructions per term + 323 for the way back to a canonical element, against ~450 per term here; the zkCensus rows hold 1.77 coefficients on
 // average (most hold one), so nothing is gained: 1.877 M VALU-busy cycles per pass either way (rocprofv3 SQ counters).
+// [r4] Coefficients that are +1 or -1 (276 k of the census circuit's 463 k; 84 % of its non-empty rows hold nothing else) are marked in the two top bits of `col` at key load
+// and cost an addition of the wire's MONTGOMERY form, which zkc_wtns_mont makes once per wire (82 754 products per proof) -- the product by the stored val R^2 was doing
+// nothing for them but that conversion, once per TERM.  wm == nullptr: no such buffer (more wires than 3 n), every term is a product as before.
+constexpr uint32_t MV_UNIT = 0x80000000u, MV_NEG = 0x40000000u, MV_COL = 0x3fffffffu;
+extern "C" __global__ void __launch_bounds__(256)
+zkc_wtns_mont(const Fr* __restrict__ wtns_std, size_t wtns_stride, Fr* __restrict__ wm, size_t wm_stride, uint32_t nv) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    Fr r2;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r2.v[k] = FrParams::r2[k];
+    st_fr(wm + (size_t)blockIdx.y * wm_stride + i, ld_fr(wtns_std + (size_t)blockIdx.y * wtns_stride + i) * r2);
+}
+__device__ __forceinline__ Fr mv_term(const Fr* __restrict__ val, const Fr* __restrict__ w, const Fr* __restrict__ wm, uint32_t idx, uint32_t c) {
+    if (wm && (c & MV_UNIT)) { const Fr x = ld_fr(wm + (c & MV_COL)); return (c & MV_NEG) ? fp_neg(x) : x; }
+    return ld_fr(val + idx) * ld_fr(w + (c & MV_COL));
+}
 extern "C" __global__ void __launch_bounds__(256)
 zkc_matvec_jds(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ rowlen, const uint32_t* __restrict__ jdptr,
                const uint32_t* __restrict__ col, const Fr* __restrict__ val, const Fr* __restrict__ wtns_std, size_t wtns_stride,
-               Fr* __restrict__ abc, int n, uint32_t nlong) {
+               Fr* __restrict__ abc, int n, uint32_t nlong, const Fr* __restrict__ wm_all, size_t wm_stride) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;      // rows [0,n) = A, [n,2n) = B ; abc layout [proof][3][n]
     const Fr* __restrict__ w = wtns_std + (size_t)blockIdx.y * wtns_stride;
+    const Fr* __restrict__ wm = wm_all ? wm_all + (size_t)blockIdx.y * wm_stride : nullptr;
     Fr acc = Fr::zero();
     if ((t >> 6) < nlong) {                         // wave-uniform
         const uint32_t r = t >> 6, len = rowlen[r];
-        for (uint32_t k = lane; k < len; k += 64) { const uint32_t idx = jdptr[k] + r; acc = acc + ld_fr(val + idx) * ld_fr(w + col[idx]); }
+        for (uint32_t k = lane; k < len; k += 64) { const uint32_t idx = jdptr[k] + r; acc = acc + mv_term(val, w, wm, idx, col[idx]); }
         for (int d = 32; d > 0; d >>= 1) {
             Fr o;
 #pragma unroll
@@ -56,7 +74,7 @@ zkc_matvec_jds(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ r
     const uint32_t r = t - nlong * 63u;             // = nlong + (t - 64 nlong)
     if (r >= 2u * (uint32_t)n) return;
     const uint32_t len = rowlen[r];
-    for (uint32_t k = 0; k < len; k++) { const uint32_t idx = jdptr[k] + r; acc = acc + ld_fr(val + idx) * ld_fr(w + col[idx]); }
+    for (uint32_t k = 0; k < len; k++) { const uint32_t idx = jdptr[k] + r; acc = acc + mv_term(val, w, wm, idx, col[idx]); }
     st_fr(abc + (size_t)blockIdx.y * 3 * n + perm[r], acc);
 }
 // c = a * b

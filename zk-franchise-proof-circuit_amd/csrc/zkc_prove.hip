@@ -16,10 +16,22 @@
 
 using namespace zkc;
 
-extern "C" __global__ void zkc_matvec_jds(const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, const Fr*, const Fr*, size_t, Fr*, int, uint32_t);
-static constexpr uint32_t MATVEC_LONG = 16;      // rows with more coefficients are summed by a whole wave
+extern "C" __global__ void zkc_matvec_jds(const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, const Fr*, const Fr*, size_t, Fr*, int, uint32_t, const Fr*, size_t);
+extern "C" __global__ void zkc_wtns_mont(const Fr*, size_t, Fr*, size_t, uint32_t);
 extern "C" __global__ void zkc_pointwise_mul(Fr*, int);
 extern "C" __global__ void zkc_join_abc(const Fr*, uint32_t*, int);
+// buildABC for `nb` proofs on stream `mv` (zkc_ntt.hip): unit coefficients add the wire's Montgomery form, made once per wire in the lane's transform scratch (d_t is idle here:
+// the pair runs in place, the two-transform form writes it afterwards) when it is large enough for nVars elements per proof
+static void matvec_launch(zkc_zkey* zk, zkc_lane& L, const uint32_t* d_wtns0, int nb, hipStream_t mv) {
+    const uint32_t n = zk->n, nv = zk->nVars;
+    static const bool unit_off = [] { const char* e = getenv("ZKC_MATVEC_UNITS"); return e && atoi(e) == 0; }();
+    const bool units = zk->n_unit_coeffs > 0 && nv <= 3 * (size_t)n && !unit_off;
+    if (units) hipLaunchKernelGGL(zkc_wtns_mont, dim3((nv + 255) / 256, nb), dim3(256), 0, mv, (const Fr*)d_wtns0, (size_t)nv, L.d_t, 3 * (size_t)n, nv);
+    hipLaunchKernelGGL(zkc_matvec_jds, dim3((2 * n + 63 * zk->nlong + 255) / 256, nb), dim3(256), 0, mv, zk->d_perm, zk->d_rowlen, zk->d_jdptr, zk->d_col, zk->d_val,
+                       (const Fr*)d_wtns0, (size_t)nv, L.d_abc, (int)n, zk->nlong, units ? (const Fr*)L.d_t : (const Fr*)nullptr, 3 * (size_t)n);
+    hipLaunchKernelGGL(zkc_pointwise_mul, dim3((n + 255) / 256, nb), dim3(256), 0, mv, L.d_abc, (int)n);
+}
+static constexpr uint32_t MATVEC_LONG = 16;      // rows with more coefficients are summed by a whole wave
 
 namespace {
 uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
@@ -203,9 +215,17 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
         std::vector<uint32_t> jdptr(maxlen + 1, 0);
         { size_t live = nrows; for (uint32_t k = 0; k < maxlen; k++) { while (live > 0 && rowlen[live - 1] <= k) live--; jdptr[k + 1] = jdptr[k] + (uint32_t)live; } }
         std::vector<uint32_t> jcol(zk->nCoeffs); std::vector<Fr> jval(zk->nCoeffs);
+        // [r4] +1 and -1 (stored, like every coefficient, times R^2) are marked in the top bits of the column word: zkc_matvec_jds adds or subtracts the wire's Montgomery form
+        // for them instead of multiplying (276 k of the census circuit's 463 k coefficients)
+        if (nv >= (1u << 30)) return bail(zkc_fail(ctx, ZKC_ERR_FORMAT, "zkey too large for 30-bit wire indices"));
+        Fr one_r2, neg_r2; for (int i = 0; i < 8; i++) one_r2.v[i] = FrParams::r2[i];
+        neg_r2 = Fr::zero() - one_r2;
+        zk->n_unit_coeffs = 0;
         for (size_t r = 0; r < nrows; r++) for (uint32_t k = 0; k < rowlen[r]; k++) {
             const size_t dst = (size_t)jdptr[k] + r, src = (size_t)rowptr[perm[r]] + k;
-            jcol[dst] = col[src]; jval[dst] = val[src];
+            uint32_t c = col[src];
+            if (val[src] == one_r2) { c |= 0x80000000u; zk->n_unit_coeffs++; } else if (val[src] == neg_r2) { c |= 0xc0000000u; zk->n_unit_coeffs++; }
+            jcol[dst] = c; jval[dst] = val[src];
         }
         if ((rc = dmalloc(ctx, &zk->d_perm, nrows)) || (rc = dmalloc(ctx, &zk->d_rowlen, nrows)) || (rc = dmalloc(ctx, &zk->d_jdptr, jdptr.size())) ||
             (rc = dmalloc(ctx, &zk->d_col, jcol.size() + 1)) || (rc = dmalloc(ctx, &zk->d_val, jval.size() + 1))) return bail(rc);
@@ -439,9 +459,7 @@ static int nofold_vmap(zkc_zkey* zk, zkc_zkey::Fold::VMap* out) {
 static int h_matvec_dev(zkc_zkey* zk, zkc_lane& L, const uint32_t* d_wtns0, int nb, hipStream_t mv) {
     zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n, nv = zk->nVars;
     zkc_prof_scope _ps(ctx, ZKC_PROF_MATVEC, (uint64_t)nb * ((uint64_t)zk->nCoeffs * 68 + 3ull * n * 32), mv);
-    hipLaunchKernelGGL(zkc_matvec_jds, dim3((2 * n + 63 * zk->nlong + 255) / 256, nb), dim3(256), 0, mv, zk->d_perm, zk->d_rowlen, zk->d_jdptr, zk->d_col, zk->d_val,
-                       (const Fr*)d_wtns0, (size_t)nv, L.d_abc, (int)n, zk->nlong);
-    hipLaunchKernelGGL(zkc_pointwise_mul, dim3((n + 255) / 256, nb), dim3(256), 0, mv, L.d_abc, (int)n);
+    matvec_launch(zk, L, d_wtns0, nb, mv);
     ZKC_HIP_CHECK(ctx, hipGetLastError());
     return ZKC_OK;
 }
@@ -470,9 +488,7 @@ extern "C" int zkc_debug_stage(zkc_zkey* zk, const void* d_wtns, int stage, void
     ZKC_LOCK(ctx);
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device)); ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (stage == 0) {
-        hipLaunchKernelGGL(zkc_matvec_jds, dim3((2 * n + 63 * zk->nlong + 255) / 256, 1), dim3(256), 0, L0.st, zk->d_perm, zk->d_rowlen, zk->d_jdptr, zk->d_col, zk->d_val,
-                           (const Fr*)d_wtns, (size_t)zk->nVars, L0.d_abc, (int)n, zk->nlong);
-        hipLaunchKernelGGL(zkc_pointwise_mul, dim3((n + 255) / 256, 1), dim3(256), 0, L0.st, L0.d_abc, (int)n);
+        matvec_launch(zk, L0, (const uint32_t*)d_wtns, 1, L0.st);
         ZKC_HIP_CHECK(ctx, hipGetLastError());
         ZKC_HIP_CHECK(ctx, hipMemcpyAsync(host_out, L0.d_abc, 96ull * n, hipMemcpyDeviceToHost, L0.st));
     } else {

@@ -163,6 +163,7 @@ struct zkc_zkey {
     std::vector<zkc::G1Affine> ic;
     // device: section 4 in jagged-diagonal order (rows [0,n) = A, [n,2n) = B, sorted by length), values as stored (val * R^2)
     uint32_t *d_perm = nullptr, *d_rowlen = nullptr, *d_jdptr = nullptr, *d_col = nullptr; zkc::Fr* d_val = nullptr; uint32_t nlong = 0;
+    uint32_t n_unit_coeffs = 0;                    // [r4] coefficients that are +1 / -1: marked in the two top bits of d_col (bit 31 unit, bit 30 negative)
     zkc::Fr *d_tw_fwd = nullptr, *d_tw_inv = nullptr, *d_coset = nullptr;   // w^j, w^-j (j < n/2), g^i / n
     zkc::Fr *d_coset_br = nullptr;                                          // g^i / n at bit-reversed positions (ntt_pair_run)
     uint32_t *d_tw_fwd29 = nullptr, *d_tw_inv29 = nullptr;                  // the twiddles in radix 2^29 (what the NTT passes read)
