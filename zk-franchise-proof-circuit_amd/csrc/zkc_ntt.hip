@@ -137,10 +137,6 @@ __device__ __forceinline__ void ntt_ld_w(uint32_t w[9], const uint32_t* __restri
     const uint4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
     w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w; w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w; w[8] = w2.x;
 }
-#ifndef ZKC_NTT_LAZY_CARRY
-#define ZKC_NTT_LAZY_CARRY 1
-#endif
-__device__ __forceinline__ constexpr bool ntt_lazy_carry() { return ZKC_NTT_LAZY_CARRY != 0; }
 // one multiply-then-add butterfly on two LDS slots; `plain`: twiddle is 1 and v may be as large as 32 p (freshly loaded)
 __device__ __forceinline__ void ntt_bfly(uint32_t* pu, uint32_t* pv, const uint32_t w[9], bool plain, bool carry) {
     uint32_t u[9], v[9], tt[9];
@@ -161,10 +157,7 @@ __device__ __forceinline__ void ntt_bfly(uint32_t* pu, uint32_t* pv, const uint3
 // two stages at once on four LDS slots (one LDS round trip, one carry pass for two stages): x1 = v1 wa, x3 = v3 wa, then (p0 +- x1), (p2 +- x3),
 // then the second stage pairs (0, 2) with wb and (1, 3) with wc.  Which slots are 0..3 differs between the RN and NR orders; the arithmetic is the
 // same.  Limbs: a carried value plus a dominator minus a product is below 2^30.6, and 2^30.6 x 2^29 still fits the column sums of the next product.
-// [r4] `carry` = false leaves the four outputs uncarried (limbs below 2^30.7 for carried inputs): the NEXT double stage may then not skip its carry -- its first products take
-// operands below 2^31.6 (twiddle limbs are below 2^29: column sums stay under 2^64), its second-stage operands reach 2^31.1, its outputs 2^31.4 < 2^32 -- so every other
-// double stage of a kernel skips the 64 instructions of its four carry passes (the last one of a kernel always carries: what follows expects carried limbs).
-__device__ __forceinline__ void ntt_r4(uint32_t* p0, uint32_t* p1, uint32_t* p2, uint32_t* p3, const uint32_t wa[9], const uint32_t wb[9], const uint32_t wc[9], bool carry) {
+__device__ __forceinline__ void ntt_r4(uint32_t* p0, uint32_t* p1, uint32_t* p2, uint32_t* p3, const uint32_t wa[9], const uint32_t wb[9], const uint32_t wc[9], bool swap_mid) {
     uint32_t a[9], b[9], c[9], d[9], t[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) { a[i] = p0[i]; b[i] = p1[i]; c[i] = p2[i]; d[i] = p3[i]; }
@@ -182,7 +175,8 @@ __device__ __forceinline__ void ntt_r4(uint32_t* p0, uint32_t* p1, uint32_t* p2,
     f29_mul<FrParams>(t, d, wc);
 #pragma unroll
     for (int i = 0; i < 9; i++) { d[i] = b[i] + NttDom::D24.l[i] - t[i]; b[i] += t[i]; }
-    if (carry) { f29_carry(a); f29_carry(b); f29_carry(c); f29_carry(d); }
+    f29_carry(a); f29_carry(b); f29_carry(c); f29_carry(d);
+    (void)swap_mid;
 #pragma unroll
     for (int i = 0; i < 9; i++) { p0[i] = a[i]; p1[i] = b[i]; p2[i] = c[i]; p3[i] = d[i]; }
 }
@@ -229,7 +223,6 @@ zkc_ntt_pass(const Fr* src_all, Fr* dst_all, const uint32_t* __restrict__ tw29, 
     if (s0 == 0) { single(1, true); t = 2; }
     for (; t + 1 <= b; t += 2) {
         const int half = 1 << (t - 1), s = s0 + t;
-        const bool carry = !ntt_lazy_carry() || ((b - 1 - t) / 2) % 2 == 0;          // double stages left after this one: even -> carry (the last one always does)
         for (int q = threadIdx.x; q < elems / 4; q += blockDim.x) {
             const int l = q % lo_t, u = q / lo_t;
             const int j = u & (half - 1), blk = u >> (t - 1);
@@ -238,7 +231,7 @@ zkc_ntt_pass(const Fr* src_all, Fr* dst_all, const uint32_t* __restrict__ tw29, 
             uint32_t wa[9], wb[9], wc[9];
             ntt_ld_w(wa, tw29, (size_t)k << (logn - s)); ntt_ld_w(wb, tw29, (size_t)k << (logn - s - 1)); ntt_ld_w(wc, tw29, (size_t)kh << (logn - s - 1));
             uint32_t* p = tile + 9 * (m * lo_t + l);
-            ntt_r4(p, p + 9 * half * lo_t, p + 9 * 2 * half * lo_t, p + 9 * 3 * half * lo_t, wa, wb, wc, carry);
+            ntt_r4(p, p + 9 * half * lo_t, p + 9 * 2 * half * lo_t, p + 9 * 3 * half * lo_t, wa, wb, wc, false);
         }
         __syncthreads();
     }
@@ -288,7 +281,6 @@ __device__ __forceinline__ void ntt_nr_stages(uint32_t* tile, Slot slot, int b, 
     }
     for (; R4 && r + 1 < b; r += 2) {               // stages q, q + 1 together: slots m, m + span/2, m + span, m + 3 span/2
         const int q = q0 + r, span = mid_n >> (r + 1), hspan = span >> 1, units = (mid_n >> 2) * lo_t;
-        const bool carry = !ntt_lazy_carry() || ((b - 2 - r) / 2) % 2 == 0;          // double stages left after this one: even -> carry
         for (int x = threadIdx.x; x < units; x += blockDim.x) {
             const int l = x % lo_t, u = x / lo_t;
             const int blk = u / hspan, j = u - blk * hspan;
@@ -298,7 +290,7 @@ __device__ __forceinline__ void ntt_nr_stages(uint32_t* tile, Slot slot, int b, 
             ntt_ld_w(wa, tw29, tw_of(q, i)); ntt_ld_w(wb, tw29, tw_of(q + 1, 2 * i)); ntt_ld_w(wc, tw29, tw_of(q + 1, 2 * i + 1));
             // stage q pairs (m, m + span) and (m + hspan, m + span + hspan); stage q + 1 pairs (m, m + hspan) in block 2i and (m + span, m + span + hspan) in block 2i + 1
             // ntt_r4 takes (a, b), (c, d) as first-stage pairs and (a, c), (b, d) as second-stage pairs: a = m, b = m + span, c = m + hspan, d = m + span + hspan
-            ntt_r4(tile + 9 * slot(m, l), tile + 9 * slot(m + span, l), tile + 9 * slot(m + hspan, l), tile + 9 * slot(m + span + hspan, l), wa, wb, wc, carry);
+            ntt_r4(tile + 9 * slot(m, l), tile + 9 * slot(m + span, l), tile + 9 * slot(m + hspan, l), tile + 9 * slot(m + span + hspan, l), wa, wb, wc, false);
         }
         __syncthreads();
     }
@@ -381,7 +373,6 @@ zkc_ntt_mid(Fr* __restrict__ data_all, const uint32_t* __restrict__ tw_inv29, co
     }
     __syncthreads();
     for (int t = 2; t + 1 <= B; t += 2) {
-        const bool carry = !ntt_lazy_carry() || ((B - 1 - t) / 2) % 2 == 0;
         const int half = 1 << (t - 1);              // stage t: pairs (m, m + half), j < half; stage t + 1: pairs (m, m + 2 half) with j and (m + half, m + 3 half) with j + half
         for (int x = threadIdx.x; x < NTT_TILE / 4; x += blockDim.x) {
             const int l = x / (MID / 4), u = x - l * (MID / 4);
@@ -390,7 +381,7 @@ zkc_ntt_mid(Fr* __restrict__ data_all, const uint32_t* __restrict__ tw_inv29, co
             uint32_t wa[9], wb[9], wc[9];
             ntt_ld_w(wa, tw_fwd29, (size_t)j << (logn - t)); ntt_ld_w(wb, tw_fwd29, (size_t)j << (logn - t - 1)); ntt_ld_w(wc, tw_fwd29, (size_t)(j + half) << (logn - t - 1));
             uint32_t* p = tile + 9 * (l * MID + m);
-            ntt_r4(p, p + 9 * half, p + 9 * 2 * half, p + 9 * 3 * half, wa, wb, wc, carry);
+            ntt_r4(p, p + 9 * half, p + 9 * 2 * half, p + 9 * 3 * half, wa, wb, wc, false);
         }
         __syncthreads();
     }
