@@ -325,6 +325,14 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
 #undef ZKC_HIP_BAIL
 }
 
+// the work space of a full pass now, instead of at the first call that brings more than four proofs (the proving service: a key that serves concurrent callers will see
+// such a call, and growing then stalls the device for the free + re-allocation of ~6 GB in the middle of the first burst)
+int zkc::prove_reserve(zkc_zkey* zk, int inflight) {
+    if (!zk) return ZKC_ERR_BAD_ARG;
+    ZKC_LOCK(zk->ctx);
+    ZKC_HIP_CHECK(zk->ctx, hipSetDevice(zk->ctx->device));
+    return lanes_ensure(zk, inflight);
+}
 extern "C" int zkc_zkey_info(const zkc_zkey* zk, uint32_t* nVars, uint32_t* nPublic, uint32_t* domainSize) {
     if (!zk) return ZKC_ERR_BAD_ARG;
     if (nVars) *nVars = zk->nVars; if (nPublic) *nPublic = zk->nPub; if (domainSize) *domainSize = zk->n;

@@ -237,6 +237,7 @@ int prove_batch_finish(zkc_zkey* zk, int cs, uint8_t* proofs, uint8_t* publics);
 // has the call begun last on this key reached its tail (the last pass' G1 accumulation is through; bucket reduction, blinding and copies remain)?  The proving
 // service begins the next call then: its witness kernels and transforms run beside that tail, and until then it keeps collecting requests.
 bool prove_tail_reached(zkc_zkey* zk);
+int prove_reserve(zkc_zkey* zk, int inflight);              // grow the key's work space to `inflight` proofs per pass now (clamped to the key's own limit)
 size_t finalize_scratch_bytes(int nproofs);
 int msm_precompute_g1(zkc_ctx* ctx, uint32_t count, G1Affine* d_table, int c);   // d_table[0..count) = base on entry
 int msm_precompute_g2(zkc_ctx* ctx, uint32_t count, G2Affine* d_table, int c);

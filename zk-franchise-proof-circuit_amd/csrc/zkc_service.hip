@@ -192,6 +192,10 @@ int ensure_key(zkc_service* s, zkc_service::Dev* d, const std::shared_ptr<KeyIma
         zkc_zkey* key = nullptr;
         rc = zkc_zkey_load(d->ctx, img->bytes.data(), img->bytes.size(), &key);
         if (rc) { key = nullptr; why = zkc_last_error(d->ctx); }
+        // [r4] the work space of a full pass at once: a key behind the service is there for concurrent callers, and growing from four proofs to a pass in the middle of the
+        // first burst stalled the device for ~0.5 s (free + re-allocation of ~6 GB at nLevels 160).  ZKC_SERVICE_RESERVE=0: grow on demand as the direct entry points do.
+        static const bool reserve = [] { const char* e = getenv("ZKC_SERVICE_RESERVE"); return !(e && atoi(e) == 0); }();
+        if (!rc && reserve && zkc::prove_reserve(key, 1 << 20) != ZKC_OK) (void)zkc_last_error(d->ctx);      // not fatal: the first large call will try again and report
         if (!rc) { std::lock_guard<std::mutex> fl(d->fl_mu); zkc_service::KeySlot k; k.img = img; k.key = key; k.last_use = ++d->use_clock; d->keys.push_back(k); }
         std::lock_guard<std::mutex> g(s->mu); s->key_loads++;
         if (!rc) { d->resident.push_back(img); *out = key; }
