@@ -4,8 +4,8 @@
 Same argument meaning and result shapes as snarkjs 0.7.0: proof = {pi_a, pi_b, pi_c, protocol, curve} of decimal strings,
 publicSignals = list of decimal strings.  The `wasm_file` argument names the circuit the way it does for snarkjs: its SHA-256 selects
 the native witness generator (80a73567...c139 = the reference's dev/160 circuit.wasm, artifacts/zkCensus/dev/circuits-info.md:7); a
-wasm this build has no native circuit for is refused loudly -- nothing here executes wasm.  `wasm_file=None` with an explicit
-`nLevels` selects the native ZkFranchiseProofCircuit(nLevels) directly (the build's own test keys have no wasm).  An optional
+wasm this build has no native circuit for is refused loudly here -- Python has no wasm runtime; the Node surface (napi/) executes such a wasm the way snarkjs does and
+proves from its witness on the GPU.  `wasm_file=None` selects the native ZkFranchiseProofCircuit(nLevels) directly: the explicit `nLevels`, or the depth read off the key.  An optional
 `rs=(r, s)` makes the proof deterministic for parity tests (snarkjs draws them at random)."""
 import collections
 import ctypes
