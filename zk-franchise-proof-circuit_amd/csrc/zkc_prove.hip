@@ -662,7 +662,13 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_ntt, st));
         tr[2] = now_ms();
         static thread_local MsmJobList j1, j2;     // 6 KB each: kept off the stack frame of a C-ABI entry point
-        const uint32_t vws = nb <= 4 ? 64u : 256u, vwb = nb <= 4 ? 256u : 1024u;          // few proofs in the pass: favour latency in the bucket reduction
+        // buckets per wave of the bucket reduction ("virtual window"): a lane walks vw / 64 buckets with two full additions each, then the 64 lanes pay ~17 more for the scan and
+        // the tree -- fixed cost per wave, so a full pass wants large windows (fewer additions in all), a small one small windows (fewer in a row).  [r4] re-measured on the
+        // round-4 pipeline, one box, (H, sections): (1024, 256) 3195 / 3205 / 3212 / 3214 proofs/s -- round 1's optimum, the default until now -- (2048, 512) 3235 / 3238,
+        // (4096, 1024) 3229, (4096, 2048) 3248 / 3261 / 3264 / 3268 (+1.8 %), (8192, 1024) 3100.  Passes of fewer than 32 proofs keep the smaller windows (latency).
+        static const uint32_t vwb_env = [] { const char* e = getenv("ZKC_VW_BIG"); return e ? (uint32_t)atoi(e) : 0u; }();
+        static const uint32_t vws_env = [] { const char* e = getenv("ZKC_VW_SMALL"); return e ? (uint32_t)atoi(e) : 0u; }();
+        const uint32_t vws = nb <= 4 ? 64u : vws_env ? vws_env : nb < 32 ? 256u : 2048u, vwb = nb <= 4 ? 256u : vwb_env ? vwb_env : nb < 32 ? 1024u : 4096u;
         // the G2 section of one or two proofs takes the 8-bit-window table: 128 buckets per job, reduced by one wave (vw = 128), if the G2 work space holds 32 entries per scalar
         size_t lone_entries = 0; for (int q = 0; q < nb; q++) lone_entries += (size_t)msm_nw(MSM_C_G2_LONE) * (listed ? vms[q].nB : nv);
         const int c2 = (nb <= 2 && zk->d_g2_29_lone && lone_entries <= LN.w2.max_entries) ? MSM_C_G2_LONE : zk->c_sec;
