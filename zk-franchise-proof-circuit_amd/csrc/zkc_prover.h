@@ -74,7 +74,8 @@ struct MsmJobList {
     uint32_t vw_small = 256;                            // virtual window of the c < 16 jobs: 256 for throughput, 64 for the latency of a small pass (same box: 256 -> 2431 proofs/s, 4.9 ms ; 128 -> 2375, 4.0 ms ; 64 -> 2304, 3.9 ms single prove)
     void add(const uint32_t* scalars, const uint32_t* vmap, uint32_t count, uint32_t tbl_off, uint32_t tbl_count, int32_t pt_shift, int c) {
         MsmJob& j = job[njobs++];
-        const uint32_t vw = c >= 16 ? vw_big : vw_small;
+        uint32_t vw = c >= 16 ? vw_big : vw_small;
+        if (vw > (uint32_t)msm_half(c)) vw = (uint32_t)msm_half(c);          // a job never has less than one virtual window (ZKC_C_SECTIONS below 12 with the 2048-bucket windows of a full pass)
         j = MsmJob{scalars, vmap, count, tbl_off, tbl_count, pt_shift, (uint32_t)c, (uint32_t)msm_nw(c), vw, total_entries, total_windows, 0, 0, 0, 0, 0, 0};
         total_entries += count * (uint32_t)msm_nw(c); total_windows += (uint32_t)msm_half(c) / vw;
     }
