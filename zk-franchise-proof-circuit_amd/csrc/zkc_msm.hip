@@ -632,7 +632,8 @@ static const bool g_debug_sync = getenv("ZKC_DEBUG_SYNC") != nullptr;   // seria
                     hipGetErrorString(_e)); fflush(stderr); } } while (0)
 
 template <class F>
-static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJobList& jl_in, int slot, bool to_host, hipStream_t st, hipEvent_t ev_sorted, hipEvent_t wait_before_acc = nullptr, hipEvent_t ev_acc = nullptr) {
+static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJobList& jl_in, int slot, bool to_host, hipStream_t st, hipEvent_t ev_sorted, hipEvent_t wait_before_acc = nullptr, hipEvent_t ev_acc = nullptr,
+                    hipStream_t st_red = nullptr, hipEvent_t ev_red = nullptr) {
     zkc_ctx* ctx = zk->ctx;
     const int nj = jl_in.njobs;
     if (nj <= 0 || nj > w.max_jobs) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: job count");
@@ -717,6 +718,13 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_accumulate");
         if (ev_acc) ZKC_HIP_CHECK(ctx, hipEventRecord(ev_acc, st));                 // the long kernel of the pass is through: what follows (bucket reduction, blinding) is the latency-bound tail
     }
+    // [r4] the bucket reduction of a full G1 pass on a stream of its own (st_red): a few thousand latency-shaped waves that leave most of the chip's issue slots idle -- the G1 stream
+    // goes on to the next pass' buildABC / transforms meanwhile, and takes this pass' work space back only when ev_red says so (the caller waits for it before its next msm_pass)
+    if (st_red && st_red != st) {
+        if (!ev_acc) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: a reduction stream needs ev_acc");
+        ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st_red, ev_acc, 0));
+        st = st_red;
+    }
     {
         zkc_prof_scope _pr(ctx, ZKC_PROF_MSM_REDUCE, 0, st);
         if constexpr (kG2) {
@@ -744,9 +752,12 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_final");
     }
     if (to_host) ZKC_HIP_CHECK(ctx, hipMemcpyAsync(w.h_results, results, (size_t)nj * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+    if (ev_red) ZKC_HIP_CHECK(ctx, hipEventRecord(ev_red, st));
     return ZKC_OK;
 }
-int msm_pass_g1(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st, hipEvent_t ev_sorted, hipEvent_t ev_acc) { return msm_pass<Fq>(zk, w, zk->d_g1, jl, slot, to_host, st, ev_sorted, nullptr, ev_acc); }
+int msm_pass_g1(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st, hipEvent_t ev_sorted, hipEvent_t ev_acc, hipStream_t st_red, hipEvent_t ev_red) {
+    return msm_pass<Fq>(zk, w, zk->d_g1, jl, slot, to_host, st, ev_sorted, nullptr, ev_acc, st_red, ev_red);
+}
 int msm_pass_g2(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st, hipEvent_t wait_before_acc) { return msm_pass<Fq2>(zk, w, zk->d_g2, jl, slot, to_host, st, nullptr, wait_before_acc); }
 
 }  // namespace zkc

@@ -107,7 +107,8 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     if (zk->ev_start) (void)hipEventDestroy(zk->ev_start);
     for (hipEvent_t e : zk->ev_chunk) (void)hipEventDestroy(e);
     for (auto& L : zk->lane) {
-        for (hipStream_t q : {L.st, L.st2, L.fin}) if (q) { (void)hipStreamSynchronize(q); if (!zk->serial_streams) (void)hipStreamDestroy(q); }
+        for (hipStream_t q : {L.st, L.st2, L.fin, L.red}) if (q) { (void)hipStreamSynchronize(q); if (!zk->serial_streams) (void)hipStreamDestroy(q); }
+        if (L.ev_red) (void)hipEventDestroy(L.ev_red);
         for (void* q : {(void*)L.d_abc, (void*)L.d_t, (void*)L.d_p, L.d_fin, (void*)L.d_bs}) if (q) (void)hipFree(q);
         for (hipEvent_t e : {L.ev_msm, L.ev_msm2, L.ev_sorted, L.ev_ntt, L.ev_mv, L.ev_acc, L.ev_fin[0], L.ev_fin[1]}) if (e) (void)hipEventDestroy(e);
         msm_work_free(L.w1); msm_work_free(L.w2);
@@ -141,7 +142,7 @@ static int lanes_ensure(zkc_zkey* zk, int inflight) {
             msm_work_free(L.w1); msm_work_free(L.w2);
         }
     };
-    for (int l = 0; l < zk->nlanes; l++) for (hipStream_t q : {zk->lane[l].st, zk->lane[l].st2, zk->lane[l].fin}) ZKC_HIP_CHECK(ctx, hipStreamSynchronize(q));
+    for (int l = 0; l < zk->nlanes; l++) for (hipStream_t q : {zk->lane[l].st, zk->lane[l].st2, zk->lane[l].fin, zk->lane[l].red}) ZKC_HIP_CHECK(ctx, hipStreamSynchronize(q));
     release();
     const char* fail_at = getenv("ZKC_TEST_FAIL_ALLOC");          // test hook: pretend the allocation for this many proofs in flight (or more) fails
     for (int l = 0; l < zk->nlanes; l++) {
@@ -298,13 +299,15 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
         // ZKC_SERIAL_STREAMS=1 (measurement only): every stage of a pass on the context's one stream, so that the per-category HIP-event brackets of
         // zkc_profile_* are ISOLATED kernel times (bench.py's per-stage roofline); the pipeline's overlap is gone, the proofs are the same bytes
         zk->serial_streams = getenv("ZKC_SERIAL_STREAMS") != nullptr;
-        if (zk->serial_streams) L.st = L.st2 = L.fin = ctx->stream;
+        if (zk->serial_streams) L.st = L.st2 = L.fin = L.red = ctx->stream;
         else {
+            ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.red, hipStreamNonBlocking));
             ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking)); ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.st2, hipStreamNonBlocking));
             ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.fin, hipStreamNonBlocking));
         }
         ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_msm, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_msm2, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_sorted, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_ntt, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_mv, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_acc, hipEventDisableTiming));
         ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_fin[0], hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_fin[1], hipEventDisableTiming));
+        ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_red, hipEventDisableTiming));
     }
     if ((rc = lanes_ensure(zk, 1))) return bail(rc);
     {   // fixed-base tables for the blinding step (delta1, alpha1, beta1 in G1; delta2 in G2)
@@ -726,7 +729,14 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
             ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_msm2, st2));
         }
         tr[3] = now_ms();
-        if ((rc = msm_pass_g1(zk, LN.w1, j1, slot, false, st, LN.ev_sorted, LN.ev_acc))) return rc;
+        // [r4] the work space of the G1 pass (segment lists, partial sums, job and window lists) is the previous pass' until its bucket reduction is through -- which, for a
+        // full pass, runs on the lane's reduction stream beside THIS pass' buildABC and transforms (a no-op wait when the reduction ran on this stream)
+        ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, LN.ev_red, 0));
+        // (measured, alternating on one box: 3102 / 3089 / 3083 proofs/s with the reduction on its own stream, 3074 / 3087 / 3097 without -- nothing: the pass is bound by the
+        // sum of its kernels' VALU work, and where the reduction's waves run does not change that sum.  Off unless ZKC_REDUCE_STREAM=1.)
+        static const bool red_on = [] { const char* e = getenv("ZKC_REDUCE_STREAM"); return e && atoi(e) == 1; }();
+        const bool red_split = red_on && !zk->serial_streams && nb >= 32;
+        if ((rc = msm_pass_g1(zk, LN.w1, j1, slot, false, st, LN.ev_sorted, LN.ev_acc, red_split ? LN.red : nullptr, LN.ev_red))) return rc;
         zk->last_lane = pass % zk->nlanes;
         tr[4] = now_ms();
         if (!g2_early) {
@@ -749,7 +759,7 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         // a call that is one small pass: its blinding and its copy go on the G1 stream itself -- nothing follows that they could overlap with, and a hop to the blinding stream is
         // ~25 us of a 3.2 ms proof
         hipStream_t bl = (tree && npasses == 1) ? st : fin;
-        if (bl == fin) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm, 0));
+        if (bl == fin) { ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm, 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_red, 0)); }      // ev_msm: the G1 stream up to the copy of the public signals; ev_red: the G1 results
         // [r4] ... but the blinding scratch (LN.d_fin) is the lane's, and the pass before this one -- the last pass of the PREVIOUS call, begun on the other call slot -- blinds on
         // `fin`: without this wait its lane-per-product kernels and this call's tree kernels could write the scratch at the same time (a wrong proof for one of the two callers,
         // seen once in tests/test_gpu_service.py::test_queue_spills_over_further_device_entries under a load of mixed batch sizes).  That pass' blinding is long over when

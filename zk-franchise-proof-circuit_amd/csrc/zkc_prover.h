@@ -148,6 +148,7 @@ struct MsmWork {
 // latency-bound tail of a pass (window reduce, final sums, blinding) overlaps the throughput-bound head of the next one.
 struct zkc_lane {
     hipStream_t st = nullptr, st2 = nullptr, fin = nullptr;               // buildABC/NTT/G1 MSM ; G2 MSM ; blinding + D2H
+    hipStream_t red = nullptr; hipEvent_t ev_red = nullptr;               // [r4] the G1 bucket reduction of a full pass runs here, beside the next pass' transforms; ev_red: the reduction of the lane's latest pass is through (wherever it ran)
     zkc::Fr *d_abc = nullptr, *d_t = nullptr; uint32_t* d_p = nullptr;   // [inflight][3n] x2 (d_t = NTT scratch), [inflight][n x 8]
     void* d_fin = nullptr;                                                // blinding scratch, finalize_scratch_bytes(inflight)
     uint32_t* d_bs = nullptr;                                             // [2 proofs][2 sections][nVars x 8]: the blinded scalars of a small pass (zkc_blind_scalars)
@@ -220,7 +221,9 @@ void msm_work_free(MsmWork& w);
 // runs all jobs of `jl` through one pipeline pass; results (XYZZ per job) go to device slot `slot` (0/1) of w.results and, when
 // to_host is set, to w.h_results (valid after the caller syncs the stream)
 // ev_sorted (optional): recorded on st once the digit/sort/segment kernels are through, i.e. right before the long accumulation kernel
-int msm_pass_g1(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st, hipEvent_t ev_sorted = nullptr, hipEvent_t ev_acc = nullptr);
+// st_red (optional, needs ev_acc): the bucket reduction (merge, windows, per-job sums) runs on that stream behind ev_acc instead of on st; ev_red (optional) is recorded behind it
+int msm_pass_g1(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st, hipEvent_t ev_sorted = nullptr, hipEvent_t ev_acc = nullptr,
+                hipStream_t st_red = nullptr, hipEvent_t ev_red = nullptr);
 int msm_pass_g2(zkc_zkey* zk, MsmWork& w, const MsmJobList& jl, int slot, bool to_host, hipStream_t st, hipEvent_t wait_before_acc = nullptr);
 // zkc_msm_sort.hip -- K4: scalars -> signed digits -> entries bucketed per job (vals2, off, bcnt), then the segment lists of the accumulation
 // (segcnt, segoff, seg2bucket, seglen, perm, heavy).  `jl` is the finished host copy of what w.d_jobs already holds on the device.
