@@ -330,3 +330,18 @@ def test_two_keys_hammered_concurrently(monkeypatch, keys_per_device):
         assert ol.verify(keys[160][1], out[160][i][1], out[160][i][0])
     fut160.result(); bg.shutdown()
     pk.close(); ctx.close()
+
+
+def test_soak_of_mixed_batch_sizes_on_two_keys(capsys):
+    """[r4] tools/service_soak.py for four seconds at nLevels 10: 32 callers with random think times on two keys, inputs and witness calls mixed, so that batches of one, two, a
+    few and dozens of proofs follow each other on both call slots -- the load under which round 3's shared-scratch race produced a wrong proof.  Every proof is verified under the
+    key it was asked for and carries the public signals of the voter it was asked for (25 s at nLevels 160: profiles/r04_service_soak.json, 41 638 proofs in 3 679 batches)."""
+    import service_soak
+    old = sys.argv
+    service_soak.SECONDS, service_soak.T, service_soak.NL = 4.0, 32, 10
+    try:
+        rc = service_soak.main()
+    finally:
+        sys.argv = old
+    out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert rc == 0 and out['all_valid'] and out['proofs'] > 500 and out['batches'] > 50 and out['key_loads'] == 2, out
