@@ -20,7 +20,7 @@ from .inputs import R_MOD
 _ctx = None
 _keys = collections.OrderedDict()      # sha256 of the .zkey image -> ProvingKey; at most MAX_RESIDENT_KEYS stay in HBM
 _path_digest = {}                       # (path, mtime_ns, size) -> sha256, so that an unchanged file is not re-read per proof
-MAX_RESIDENT_KEYS = 2
+MAX_RESIDENT_KEYS = int(os.environ.get("ZKC_SERVICE_KEYS", "4"))      # [r4] as many as the proving service keeps per device
 
 
 def _context(device=None):
