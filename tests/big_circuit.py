@@ -60,3 +60,52 @@ def big_instance(path, n_cons, n_wires, n_pub, seed, bool_frac=0.1):
         for sid, data in ((1, hdr), (2, body), (3, w2l)):
             f.write(pk('<IQ', sid, len(data))); f.write(data)
     return b''.join(le)
+
+
+# ---- a circuit-shaped instance: every constraint DEFINES a wire, so any assignment of the inputs has a witness ----
+def _chain_rows(n_cons, n_in, seed):
+    """row k: (A terms, B terms) over wires that exist before wire n_in + 1 + k; the row's C side is that new wire.  Structure only -- no witness values enter, so the
+    writer and the witness generator below draw the same rows from the same seed."""
+    rng = random.Random(seed); gb = rng.getrandbits
+    for k in range(n_cons):
+        hi = n_in + 1 + k                            # wires [0, hi) exist
+        if k % 7 == 0:
+            a = [(0, 1 + gb(5))]
+        else:
+            a = [(i, gb(253) or 1) for i in sorted({gb(30) % hi for _ in range(1 + gb(2) % 3)})]
+        # half of the operands are recent wires (a chain: the witness cannot be computed out of order), half are anywhere
+        b = [(i, gb(253) or 1) for i in sorted({(hi - 1 - gb(30) % min(hi, 64)) if gb(1) else gb(30) % hi for _ in range(1 + gb(1))})]
+        yield a, b
+
+
+def chain_instance(path, n_cons, n_in, n_pub, seed):
+    """writes `path` (.r1cs): wires [1 | n_in inputs, the first n_pub of them public | one wire per constraint], constraint k: <A_k, w> . <B_k, w> = w[n_in + 1 + k]"""
+    pk = struct.pack
+    out = []
+    for k, (a, b) in enumerate(_chain_rows(n_cons, n_in, seed)):
+        out.append(pk('<I', len(a)) + b''.join(pk('<I', i) + c.to_bytes(32, 'little') for i, c in a))
+        out.append(pk('<I', len(b)) + b''.join(pk('<I', i) + c.to_bytes(32, 'little') for i, c in b))
+        out.append(pk('<II', 1, n_in + 1 + k) + (1).to_bytes(32, 'little'))
+    n_wires = 1 + n_in + n_cons
+    hdr = pk('<I', 32) + R.to_bytes(32, 'little') + pk('<IIIIQI', n_wires, 0, n_pub, n_wires - 1 - n_pub, n_wires, n_cons)
+    w2l = b''.join(pk('<Q', i) for i in range(n_wires))
+    with open(path, 'wb') as f:
+        f.write(b'r1cs' + pk('<II', 1, 3))
+        for sid, data in ((1, hdr), (2, b''.join(out)), (3, w2l)):
+            f.write(pk('<IQ', sid, len(data))); f.write(data)
+    return n_wires
+
+
+def chain_witness(n_cons, n_in, seed, inputs):
+    """the witness of chain_instance(.., seed) for the given n_in input values: forward evaluation, one product per constraint"""
+    assert len(inputs) == n_in
+    w = [1] + [x % R for x in inputs] + [0] * n_cons
+    for k, (a, b) in enumerate(_chain_rows(n_cons, n_in, seed)):
+        av = 0
+        for i, c in a:
+            av += c * w[i]
+        bv = 0
+        for i, c in b:
+            bv += c * w[i]
+        w[n_in + 1 + k] = (av % R) * (bv % R) % R
+    return b''.join(x.to_bytes(32, 'little') for x in w)

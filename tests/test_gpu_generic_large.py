@@ -5,6 +5,8 @@ rapidsnark's groth16_prover, zk_census_test.go:89) -- beyond the 2^17 domain of 
 What these sizes exercise that the census key never does: the five-kernel transform pair (domains above 2^18), 17-bit windows for witness sections of 2^16 wires and more,
 level-1 bins that no longer fit the register path of the bucketing, the pass size cut down by the key's entry count (zkc_zkey_load), 10^5 .. 10^6-row jagged-diagonal matrices.
 
+Two kinds of instance (tests/big_circuit.py): a random R1CS with a tenth of boolean wires (rows solved for a coefficient: one witness), and a circuit-shaped one whose every
+constraint defines a wire, which has a witness for any inputs -- the batch tests prove DIFFERENT witnesses side by side.
 Checked against the toxic-waste closed form (tests/closed_form.py: no NTT, no MSM, no .zkey), the pinned verifier, and -- stage by stage -- the C oracle's h evaluations.
 ZKC_TEST_FULL=1 adds the 2^20 cases (minutes of host-side key generation); tools/generic_bench.py measures them (profiles/r04_generic_2p20.json)."""
 import os
@@ -46,14 +48,20 @@ def test_transform_pair_above_2p18_matches_oracle(tmp_path, logn):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('n_cons,n_wires,n_pub', [(200000, 150000, 4)] + ([(1000000, 1000000, 8)] if FULL else []))
-def test_generic_prover_large_domain(tmp_path, n_cons, n_wires, n_pub):
-    """a full Groth16 proof at a domain of 2^18 (2^20 with ZKC_TEST_FULL=1): sections of >= 2^16 wires take the 17-bit window, the pass holds fewer proofs"""
+@pytest.mark.parametrize('n_cons,n_in,n_pub', [(200000, 64, 4)] + ([(1000000, 64, 8)] if FULL else []))
+def test_generic_prover_large_domain(tmp_path, n_cons, n_in, n_pub):
+    """Full Groth16 proofs at a domain of 2^18 (2^20 with ZKC_TEST_FULL=1) for a circuit-shaped instance -- every constraint defines a wire, so any inputs have a witness -- and
+    THREE DIFFERENT witnesses of it: sections of >= 2^16 wires take the 17-bit window, the pass holds fewer proofs.  Each proof alone, then the three in one batch, then the
+    batch in passes of two; two of them against the closed form, all three through the pinned verifier."""
     import torch
     import zkcensus_amd
+    import random
     t0 = time.time()
-    r1 = str(tmp_path / 'big.r1cs')
-    w = bc.big_instance(r1, n_cons, n_wires, n_pub, seed=n_cons)
+    r1 = str(tmp_path / 'chain.r1cs')
+    n_wires = bc.chain_instance(r1, n_cons, n_in, n_pub, seed=n_cons)
+    rng = random.Random(n_cons + 1)
+    ws = [bc.chain_witness(n_cons, n_in, n_cons, [rng.getrandbits(253) if k else rng.getrandbits(1) for k in range(n_in)]) for _ in range(3)]
+    assert len({w[-32:] for w in ws}) == 3                                   # different inputs, different last wires
     t1 = time.time()
     zk, vk = setup_key(r1, 777 + n_cons)
     t2 = time.time()
@@ -61,22 +69,21 @@ def test_generic_prover_large_domain(tmp_path, n_cons, n_wires, n_pub):
     t3 = time.time()
     logn = (n_cons + n_pub).bit_length()
     assert pk.n_vars == n_wires and pk.n_public == n_pub and pk.domain_size == 1 << logn
-    r, s = ol.R - 5, 98765432109876543210
-    proof, pub = pk.prove(w, r, s)
+    rs_int = [(ol.R - 5, 98765432109876543210), (8, 10), (3, ol.R - 1)]
+    singles = [pk.prove(w, r, s) for w, (r, s) in zip(ws, rs_int)]
     t4 = time.time()
-    assert pub == w[32:32 * (1 + n_pub)]
-    a, b, c = cf.proof_scalars(r1, 777 + n_cons, w, r, s)
-    assert proof == cf.proof_from_scalars(ol, a, b, c), 'GPU proof differs from the closed form at domain 2^%d' % logn
-    assert ol.verify(vk, pub, proof)
+    for k, (w, (proof, pub)) in enumerate(zip(ws, singles)):
+        assert pub == w[32:32 * (1 + n_pub)]
+        if k < 2:
+            a, b, c = cf.proof_scalars(r1, 777 + n_cons, w, *rs_int[k])
+            assert proof == cf.proof_from_scalars(ol, a, b, c), 'GPU proof differs from the closed form at domain 2^%d (witness %d)' % (logn, k)
+        assert ol.verify(vk, pub, proof)
     t5 = time.time()
-    # a batch of three (one pass) and the same witness twice in it: bytes per proof equal the single calls
     B = 3
-    d_w = _dev(torch, w * B)
-    rs = b''.join(int(x).to_bytes(32, 'little') for k in range(B) for x in ((r, s) if k == 0 else (7 + k, 9 + k)))
+    d_w = _dev(torch, b''.join(ws))
+    rs = b''.join(int(x).to_bytes(32, 'little') for r_s in rs_int for x in r_s)
     proofs, pubs = pk.prove_batch_dev(d_w.data_ptr(), B, rs)
-    assert proofs[:256] == proof
-    p1, _ = pk.prove(w, 8, 10)
-    assert proofs[256:512] == p1
+    assert [proofs[256 * k:256 * k + 256] for k in range(B)] == [p for p, _ in singles] and pubs == b''.join(u for _, u in singles)
     # the same batch in passes of two proofs (ZKC_INFLIGHT is read at key load): the pass loop, result-slot alternation and the buildABC prefetch at this size
     os.environ['ZKC_INFLIGHT'] = '2'
     try:
@@ -86,5 +93,5 @@ def test_generic_prover_large_domain(tmp_path, n_cons, n_wires, n_pub):
     proofs2, pubs2 = pk2.prove_batch_dev(d_w.data_ptr(), B, rs)
     assert proofs2 == proofs and pubs2 == pubs
     pk2.close()
-    print('\n[generic 2^%d] instance %.1f s, setup %.1f s, key load %.1f s, first proof %.2f s, closed form + verifier %.1f s' % (logn, t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4))
+    print('\n[generic 2^%d] instance + 3 witnesses %.1f s, setup %.1f s, key load %.1f s, three proofs %.2f s, closed form x 2 + verifier %.1f s' % (logn, t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4))
     pk.close(); ctx.close()

@@ -1,8 +1,8 @@
 """Measures the GENERIC prover -- groth16.prove(zkey, wtns) for a circuit that is not the census circuit -- at domains 2^14 .. 2^20 (BASELINE configs[4]: "~2^20-constraint
-R1CS"; the ceiling of the reference's powers of tau, circuit/circuit-compiler.sh:57).  Per size: a random satisfiable R1CS (tests/big_circuit.py), the test-only setup, key load,
+R1CS"; the ceiling of the reference's powers of tau, circuit/circuit-compiler.sh:57).  Per size: a circuit-shaped random R1CS (tests/big_circuit.py chain_instance: every constraint defines a wire), the test-only setup, key load,
 one proof checked against the toxic-waste closed form and the pinned verifier (the checkers: tests/closed_form.py, the C oracle's verifier), then
 
-  proofs/s        B proofs of the same witness with different (r, s) through prove_batch_dev (device-resident witnesses), pipelined on three streams
+  proofs/s        B proofs over four different witnesses with different (r, s) through prove_batch_dev (device-resident witnesses), pipelined on three streams
   stages          one call of the same B with every kernel on ONE stream (ZKC_SERIAL_STREAMS=1): isolated per-stage ms, algorithmic bytes and GB/s against 8 TB/s,
                   and for the G1 accumulation the mixed additions per second against the VALU capacity of profiles/r03_valu_model.json
 
@@ -43,11 +43,17 @@ def main():
     results = []
     for logn in [int(x) for x in args.logn.split(',')]:
         n = 1 << logn
-        n_cons = n - n // 16; n_wires = n_cons - n // 32; n_pub = 8
+        n_cons = n - n // 16; n_in = 64; n_pub = 8; n_wires = 1 + n_in + n_cons
         B = {20: 24, 19: 48, 18: 64}.get(logn, 96)              # at least two passes at every size (zkc_zkey_load sizes a pass by the key's entry count: 12 proofs at 2^20)
         tmp = tempfile.mkdtemp(prefix='zkc_generic_')
         r1 = os.path.join(tmp, 'c.r1cs')
-        t0 = time.time(); w = bc.big_instance(r1, n_cons, n_wires, n_pub, seed=logn); t_inst = time.time() - t0
+        # a circuit-shaped instance (every constraint defines a wire: any inputs have a witness) and NW different witnesses of it, tiled over the batch
+        NW = 4
+        t0 = time.time(); assert bc.chain_instance(r1, n_cons, n_in, n_pub, seed=logn) == n_wires
+        import random
+        rng = random.Random(logn)
+        wits = [bc.chain_witness(n_cons, n_in, logn, [rng.getrandbits(253) for _ in range(n_in)]) for _ in range(NW)]
+        w = wits[0]; t_inst = time.time() - t0
         t0 = time.time(); zk, vk = setup_key(r1, 2024 + logn); t_setup = time.time() - t0
         t0 = time.time(); pk = zkcensus_amd.ProvingKey(ctx, zk); torch.cuda.synchronize(); t_load = time.time() - t0
         assert pk.domain_size == n and pk.n_vars == n_wires
@@ -59,7 +65,7 @@ def main():
             a, b, c = cf.proof_scalars(r1, 2024 + logn, w, r, s)
             checked = {'equals_closed_form': proof == cf.proof_from_scalars(ol, a, b, c), 'verifier_accepts': bool(ol.verify(vk, pub, proof)), 'seconds': round(time.time() - t0, 1)}
             assert checked['equals_closed_form'] and checked['verifier_accepts'], checked
-        d_w = torch.from_numpy(np.frombuffer(w, dtype=np.uint8).copy()).cuda().repeat(B)
+        d_w = torch.from_numpy(np.frombuffer(b''.join(wits), dtype=np.uint8).copy()).cuda().repeat((B + NW - 1) // NW)[:B * len(w)].contiguous()
         rs = b''.join(int(x).to_bytes(32, 'little') for k in range(B) for x in ((r, s) if k == 0 else (3 + 2 * k, 5 + 3 * k)))
         lat = []
         for _ in range(3):
@@ -107,7 +113,7 @@ def main():
             os.remove(os.path.join(tmp, f))
         os.rmdir(tmp)
     out = {'what': 'generic Groth16 prover (groth16.prove(zkey, wtns), no constant folding, no witness generation) on random satisfiable R1CS instances; one MI355X; witnesses device-resident; '
-                   'B proofs of one witness with distinct (r, s) per call', 'sizes': results}
+                   'B proofs per call over four different witnesses of the instance, distinct (r, s)', 'sizes': results}
     if args.out:
         json.dump(out, open(args.out, 'w'), indent=1)
     ctx.close()
