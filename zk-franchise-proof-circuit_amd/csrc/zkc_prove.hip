@@ -675,7 +675,8 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         // the G2 section of one or two proofs takes the 8-bit-window table: 128 buckets per job, reduced by one wave (vw = 128), if the G2 work space holds 32 entries per scalar
         size_t lone_entries = 0; for (int q = 0; q < nb; q++) lone_entries += (size_t)msm_nw(MSM_C_G2_LONE) * (listed ? vms[q].nB : nv);
         const int c2 = (nb <= 2 && zk->d_g2_29_lone && lone_entries <= LN.w2.max_entries) ? MSM_C_G2_LONE : zk->c_sec;
-        j1.clear(vws, vwb); j2.clear(c2 == MSM_C_G2_LONE ? 128u : vws);
+        static const uint32_t vwg2_env = [] { const char* e = getenv("ZKC_VW_G2"); return e ? (uint32_t)atoi(e) : 0u; }();      // A/B: the G2 jobs' window apart from the G1 sections'
+        j1.clear(vws, vwb); j2.clear(c2 == MSM_C_G2_LONE ? 128u : (vwg2_env && nb >= 32) ? vwg2_env : vws);
         // job order of the G1 pass: the nb H jobs first (the 16-bit bucket sort wants the jobs with the larger bucket count in front), then
         // A, B1, C per proof.  zkc_finalize reads results[q] = H_q and results[nb + 3 q + {0, 1, 2}] = A_q, B1_q, C_q.
         for (int q = 0; q < nb; q++) j1.add(LN.d_p + 8 * (size_t)n * q, nullptr, n, zk->offH, n, 0, MSM_C_BIG);
@@ -722,7 +723,11 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         static const bool g2_early = getenv("ZKC_G2_LATE") == nullptr;
         // [r2] its bucketing starts with the pass, but its accumulation (VALU-bound, 3.3 ms alone) is held until the G1 stream leaves the NTT: it then
         // runs beside the G1 bucketing and segment kernels, which wait on memory and LDS atomics, instead of beside the NTT, which is VALU-bound too
-        static const bool g2_acc_with_sort = getenv("ZKC_G2_ACC_EARLY") == nullptr;
+        // [r4] ... which was right for round 2's pipeline and is not for this one: with the larger reduction windows the G2 side's tail is longer (one wave walks a job's 2048
+        // buckets: ~64 G2 additions in a row), and holding its accumulation back makes the blinding -- and with it the result slot the pass after next needs -- wait for it.
+        // Alternating on one box: 3160 / 3143 / 3160 / 3150 / 3151 proofs/s held back, 3205 / 3198 / 3206 / 3169 / 3206 started with the pass: +1.4 %.  ZKC_G2_ACC_HOLD=1: the old order.
+        // (Two pipeline lanes, -4 % in round 2, are +1.4 % now too -- 3202 / 3206 / 3197 / 3202 / 3201 -- but not on top of this (3107 / 3115 with both) and for twice the work space.)
+        static const bool g2_acc_with_sort = getenv("ZKC_G2_ACC_HOLD") != nullptr && getenv("ZKC_G2_ACC_EARLY") == nullptr;
         if (g2_early) {
             if ((rc = msm_pass_g2(zk, LN.w2, j2, slot, false, st2, g2_acc_with_sort ? LN.ev_ntt : nullptr))) return rc;
             if (tree && (rc = finalize_tree_g2_launch(ctx, st2, fa, nb))) return rc;
