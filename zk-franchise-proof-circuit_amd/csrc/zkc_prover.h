@@ -21,7 +21,10 @@ constexpr int msm_half(int c) { return 1 << (c - 1); }         // buckets per jo
 constexpr int MSM_VW_MIN = 64, MSM_MAX_VW_PER_JOB = 64;
 constexpr int MSM_MAX_VW_G1 = 256;                 // virtual windows per G1 job the per-job sum takes (zkc_msm_final29): H with windows of 256 buckets in a small pass
 constexpr int MSM_SEG_MIN = 16;                    // ... down to this for small passes (latency of a single proof)
-constexpr int MSM_SEG = 128;                       // sorted entries per accumulation lane; with length-sorted waves (same box): 32 -> 2200, 40 -> 2222, 64 -> 2270, 128 -> 2297, 256 -> 2274, 512 -> 2220 proofs/s
+#ifndef ZKC_MSM_SEG
+#define ZKC_MSM_SEG 128
+#endif
+constexpr int MSM_SEG = ZKC_MSM_SEG;               // [r4] re-measured on the round-4 pipeline (variant builds, alternating on one box): 64 -> 3181 / 3181, 128 -> 3215 / 3212, 256 -> 3217 / 3191 proofs/s                       // sorted entries per accumulation lane; with length-sorted waves (same box): 32 -> 2200, 40 -> 2222, 64 -> 2270, 128 -> 2297, 256 -> 2274, 512 -> 2220 proofs/s
 constexpr int MSM_MERGE_T = 8;                     // buckets with more segments get a wave of their own before the window pass
 constexpr int MSM_MAX_HEAVY = 1 << 20;
 constexpr int MSM_MAX_JOBS = 512;                  // jobs per pipeline pass (proofs in flight x sections)
