@@ -755,7 +755,8 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_msm, st));
         if (mv_prefetch && p0 + per_pass < B) {                                   // buildABC of the next pass, beside this pass' accumulation
             const int p1 = p0 + per_pass, nb1 = std::min(per_pass, B - p1);
-            ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_sorted, 0));         // this pass' NTT and joinABC are through (d_abc is free), its accumulation is next (waiting on ev_ntt instead, i.e. starting beside the bucketing, is 1 % slower: 3113 / 3093 against 3143 / 3137 proofs/s on one box)
+            static const bool mv_at_ntt = [] { const char* e = getenv("ZKC_MV_PREFETCH_AT_NTT"); return e && atoi(e) == 1; }();      // A/B: start it beside this pass' bucketing instead
+            ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, mv_at_ntt ? LN.ev_ntt : LN.ev_sorted, 0));         // this pass' NTT and joinABC are through (d_abc is free), its accumulation is next (waiting on ev_ntt instead, i.e. starting beside the bucketing, is 1 % slower: 3113 / 3093 against 3143 / 3137 proofs/s on one box)
             ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, zk->ev_chunk[pass + 1], 0));
             if ((rc = h_matvec_dev(zk, LN, (const uint32_t*)d_wtns + (size_t)p1 * nv * 8, nb1, fin))) return rc;
             ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_mv, fin));
