@@ -727,7 +727,10 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         // buckets: ~64 G2 additions in a row), and holding its accumulation back makes the blinding -- and with it the result slot the pass after next needs -- wait for it.
         // Alternating on one box: 3160 / 3143 / 3160 / 3150 / 3151 proofs/s held back, 3205 / 3198 / 3206 / 3169 / 3206 started with the pass: +1.4 %.  ZKC_G2_ACC_HOLD=1: the old order.
         // (Two pipeline lanes, -4 % in round 2, are +1.4 % now too -- 3202 / 3206 / 3197 / 3202 / 3201 -- but not on top of this (3107 / 3115 with both) and for twice the work space.)
-        static const bool g2_acc_with_sort = getenv("ZKC_G2_ACC_HOLD") != nullptr && getenv("ZKC_G2_ACC_EARLY") == nullptr;
+        // Passes of fewer than 32 proofs keep the hold: a lone proof's G2 kernels (1024 waves of 400 registers) slowed buildABC and the first transform kernel threefold when they were
+        // not held (round 3), and the twelve-proof passes of a 2^20-domain key run 140 proofs/s held against 136 early (their bucketing phase is 9 ms long: room for the G2 accumulation).
+        static const bool g2_hold_env = getenv("ZKC_G2_ACC_HOLD") != nullptr, g2_early_env = getenv("ZKC_G2_ACC_EARLY") != nullptr;
+        const bool g2_acc_with_sort = g2_hold_env || (nb < 32 && !g2_early_env);
         if (g2_early) {
             if ((rc = msm_pass_g2(zk, LN.w2, j2, slot, false, st2, g2_acc_with_sort ? LN.ev_ntt : nullptr))) return rc;
             if (tree && (rc = finalize_tree_g2_launch(ctx, st2, fa, nb))) return rc;
