@@ -41,7 +41,7 @@ def setup_key(r1cs_path, seed):
     return open(z, 'rb').read(), json.load(open(v))
 
 
-SIZES = [(3, 6, 1), (5, 9, 2), (50, 64, 3), (300, 200, 0), (1000, 900, 5), (5000, 3000, 8), (12000, 9000, 2)]       # domains 8 .. 2^14
+SIZES = [(3, 6, 1), (5, 9, 2), (50, 64, 3), (40, 1500, 2), (300, 200, 0), (1000, 900, 5), (5000, 3000, 8), (12000, 9000, 2)]       # domains 8 .. 2^14; (40, 1500, 2): far more wires than 3 x the domain (most of them in no constraint: bases at infinity)
 GPU_SIZES = SIZES + [(28000, 20000, 1), (50000, 40000, 6)]                                                                  # .. 2^15, 2^16 (2^18 and up: tests/test_gpu_generic_large.py)
 
 
