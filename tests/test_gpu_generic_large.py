@@ -95,3 +95,24 @@ def test_generic_prover_large_domain(tmp_path, n_cons, n_in, n_pub):
     pk2.close()
     print('\n[generic 2^%d] instance + 3 witnesses %.1f s, setup %.1f s, key load %.1f s, three proofs %.2f s, closed form x 2 + verifier %.1f s' % (logn, t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4))
     pk.close(); ctx.close()
+
+
+@pytest.mark.gpu
+def test_generic_prover_half_of_the_wires_boolean(tmp_path):
+    """Real witnesses are full of bits: half of the 150 000 wires here are 0 or 1, so digit 1 of the lowest window collects ~37 000 entries per section in ONE bucket (hundreds of
+    segments: the heavy-bucket merge at a size the census key never reaches) while the zero wires drop out of every window.  One proof against the closed form, one batch."""
+    import torch
+    import zkcensus_amd
+    n_cons, n_wires, n_pub = 200000, 150000, 4
+    r1 = str(tmp_path / 'bits.r1cs')
+    w = bc.big_instance(r1, n_cons, n_wires, n_pub, seed=4242, bool_frac=0.5)
+    zk, vk = setup_key(r1, 909)
+    ctx = zkcensus_amd.Context(0); pk = zkcensus_amd.ProvingKey(ctx, zk)
+    proof, pub = pk.prove(w, 21, 34)
+    a, b, c = cf.proof_scalars(r1, 909, w, 21, 34)
+    assert proof == cf.proof_from_scalars(ol, a, b, c) and ol.verify(vk, pub, proof)
+    d_w = _dev(torch, w * 5)
+    rs = b''.join(int(x).to_bytes(32, 'little') for k in range(5) for x in ((21, 34) if k == 0 else (k, k + 1)))
+    proofs, _ = pk.prove_batch_dev(d_w.data_ptr(), 5, rs)
+    assert proofs[:256] == proof and len({proofs[256 * k:256 * k + 256] for k in range(5)}) == 5
+    pk.close(); ctx.close()
