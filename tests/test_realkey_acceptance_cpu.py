@@ -32,6 +32,7 @@ def test_parser_half_accepts_a_key_with_its_own_verification_key(tmp_path, capsy
     rc, out = _run([z160, '--parse-only'], capsys)
     assert rc == 1 and 'NOT ACCEPTED' in out
     assert 'FAIL step 1' in out and 'FAIL step 2  section 2 alpha1' in out and 'FAIL step 2  section 3' in out and 'PASS step 3  shape' in out, out
+    assert 'FAIL step 2  e(alpha1, beta2) of the key file == vk_alphabeta_12' in out
     # what the points are compared with is the oracle's independent reading of the same file (tests only): both readers agree on the test key
     k = ra.parse_key(open(z160, 'rb').read())
     vko = ol.zkey_vk(open(z160, 'rb').read())
@@ -60,6 +61,7 @@ def test_parser_half_notices_disagreements(tmp_path, capsys):
     p = tmp_path / 'gd.zkey'; p.write_bytes(bad)
     rc, out = _run([str(p), '--vkey', v10, '--sha256', 'none', '--parse-only', '--any-shape'], capsys)
     assert rc == 1 and 'FAIL step 2  section 2 gamma2' in out and 'FAIL step 2  section 2 delta2' in out and 'PASS step 2  section 2 alpha1' in out
+    assert 'PASS step 2  e(alpha1, beta2) of the key file == vk_alphabeta_12' in out             # alpha and beta are untouched in that file
     # a truncated file and a file that is not a key
     p = tmp_path / 'short.zkey'; p.write_bytes(raw[:len(raw) // 2])
     rc, out = _run([str(p), '--vkey', v10, '--sha256', 'none', '--parse-only', '--any-shape'], capsys)

@@ -8,7 +8,7 @@ misreading of the snarkjs .zkey layout by setup, loader and oracle parser would 
 and gets a PASS / FAIL line per step:
 
   1  sha256 of the file            == the published one (artifacts/zkCensus/dev/circuits-info.md:5, committed copy tests/golden/ref/circuits-info.md)
-  2  section 2 / section 3         alpha1, beta2, gamma2, delta2 and the nPublic + 1 IC points, read with THIS build's reading of the format (Montgomery, little endian, G2 as
+  2  section 2 / section 3         alpha1, beta2, gamma2, delta2, the pairing e(alpha1, beta2) against vk_alphabeta_12, and the nPublic + 1 IC points, read with THIS build's reading of the format (Montgomery, little endian, G2 as
                                    x.c0 x.c1 y.c0 y.c1), == the committed verification_key.json (verification_key.json:1-128) -- the first place a misreading would show
   3  shapes                        nVars 82754, nPublic 8, domain 2^17 (ZkFranchiseProofCircuit(160)); section sizes consistent with them; beta1 / delta1 on the curve
   4  groth16.fullProve             of the reference's own inputs_example.json through the key, on the GPU (native witness generator + HIP prover)
@@ -124,6 +124,19 @@ def check_file(buf, vk, want_sha, shape, rep):
     v = vk_points(vk)
     for name in ('alpha1', 'beta2', 'gamma2', 'delta2'):
         rep.add(2, k[name] == v[name], 'section 2 %s == verification key' % name, '' if k[name] == v[name] else 'key file %s..., verification key %s...' % (str(k[name])[:40], str(v[name])[:40]))
+    if 'vk_alphabeta_12' in vk:         # e(alpha1, beta2) of the KEY FILE's points through the product's host pairing (no GPU) == the member snarkjs wrote into the verification key
+        try:
+            import ctypes
+            sys.path.insert(0, ROOT)
+            from zkcensus_amd import _native
+            le = lambda x: int(x).to_bytes(32, 'little')
+            out = ctypes.create_string_buffer(384)
+            rc = _native.load().zkc_pairing_bin(le(k['alpha1'][0]) + le(k['alpha1'][1]), b''.join(le(c) for pair in k['beta2'] for c in pair), out)
+            got = [str(int.from_bytes(out.raw[32 * i:32 * i + 32], 'little')) for i in range(12)]
+            want12 = [str(x) for h in vk['vk_alphabeta_12'] for c in h for x in c]
+            rep.add(2, rc == 0 and got == want12, 'e(alpha1, beta2) of the key file == vk_alphabeta_12 of the verification key')
+        except OSError as e:
+            rep.add(2, False, 'e(alpha1, beta2) of the key file == vk_alphabeta_12', 'libzkcensus.so not loadable: %s' % e)
     rep.add(2, k['nPublic'] == v['nPublic'] and k['IC'] == v['IC'], 'section 3: the %d IC points == verification key' % (k['nPublic'] + 1),
             '' if k['IC'] == v['IC'] else 'first mismatch at IC[%d]' % next((i for i, (a, b) in enumerate(zip(k['IC'], v['IC'])) if a != b), min(len(k['IC']), len(v['IC']))))
     nV, nP, dom = k['nVars'], k['nPublic'], k['domainSize']
