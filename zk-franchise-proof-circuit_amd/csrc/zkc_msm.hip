@@ -14,7 +14,7 @@
 //       in radix-2^29 coordinates (zkc_f29*.h) with 64-byte gathers from T.  Cutting buckets into segments keeps lanes
 //       balanced when many scalars repeat (witness bits; the circuit has only ~4.5k distinct values among 82k wires).
 //   K6  zkc_msm_merge       buckets of more than 8 segments: a wave each, shuffle tree
-//       zkc_msm_window[29]  one wave per virtual window (1024 or 256 consecutive buckets of a job): per-lane running
+//       zkc_msm_window[29]  one wave per virtual window (4096 / 2048 consecutive buckets of a job in a full pass, 1024 / 256 or 256 / 64 in smaller ones): per-lane running
 //       sums, a suffix scan across the 64 lanes in LDS, x per, tree sum  ->  W = sum_j j B_j and S = sum_j B_j
 //       zkc_msm_final       one workgroup per job: sum_k W_k + vw sum_k k S_k over its virtual windows.
 #include <cstdio>
