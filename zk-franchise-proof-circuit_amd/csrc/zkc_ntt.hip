@@ -264,7 +264,7 @@ zkc_ntt_pass(const Fr* src_all, Fr* dst_all, const uint32_t* __restrict__ tw29, 
 // Element format between kernels stays 8 x u32 Montgomery (R = 2^256); inside a tile nine 29-bit limbs (R' = 2^261) as in zkc_ntt_pass.
 // NR stages q0 .. q0+b-1 over a tile whose `mid` index (b bits) is the position bits those stages pair up; slot(mid, l) gives the LDS slot.
 // prefix = the position bits above mid (q0 of them): block index of stage q0 + r is (prefix << r) | (mid >> (b - r)).
-template <bool R4, class Slot>
+template <int RADIX, class Slot>
 __device__ __forceinline__ void ntt_nr_stages(uint32_t* tile, Slot slot, int b, int lo_t, int q0, uint32_t prefix_of_l0, int prefix_per_l, const uint32_t* __restrict__ tw29, int logn, bool fresh) {
     const int mid_n = 1 << b;
     auto tw_of = [&](int q, uint32_t i) -> size_t { return q ? (size_t)((__brev(i) >> (32 - q)) << (logn - q - 1)) : (size_t)0; };      // block i of the stage with 2^q blocks
@@ -279,7 +279,7 @@ __device__ __forceinline__ void ntt_nr_stages(uint32_t* tile, Slot slot, int b, 
         __syncthreads();
         r = 1;
     }
-    for (; R4 && r + 1 < b; r += 2) {               // stages q, q + 1 together: slots m, m + span/2, m + span, m + 3 span/2
+    for (; RADIX >= 4 && r + 1 < b; r += 2) {               // stages q, q + 1 together: slots m, m + span/2, m + span, m + 3 span/2
         const int q = q0 + r, span = mid_n >> (r + 1), hspan = span >> 1, units = (mid_n >> 2) * lo_t;
         for (int x = threadIdx.x; x < units; x += blockDim.x) {
             const int l = x % lo_t, u = x / lo_t;
@@ -302,13 +302,13 @@ __device__ __forceinline__ void ntt_nr_stages(uint32_t* tile, Slot slot, int b, 
             const int m0 = blk * 2 * span + j;
             const uint32_t i = ((prefix_of_l0 + (uint32_t)(prefix_per_l * l)) << r) | (uint32_t)blk;
             uint32_t w[9]; ntt_ld_w(w, tw29, tw_of(q, i));
-            ntt_bfly(tile + 9 * slot(m0, l), tile + 9 * slot(m0 + span, l), w, false, R4 || (r & 1) == 1 || r == b - 1);
+            ntt_bfly(tile + 9 * slot(m0, l), tile + 9 * slot(m0 + span, l), w, false, RADIX >= 4 || (r & 1) == 1 || r == b - 1);
         }
         __syncthreads();
     }
 }
-extern "C" __global__ void __launch_bounds__(256)
-zkc_ntt_nr_head(const Fr* src_all, Fr* dst_all, const uint32_t* __restrict__ tw29, int logn, int q0, int b) {      // src_all == dst_all: in place
+template <int RADIX>
+__device__ __forceinline__ void ntt_nr_head_body(const Fr* src_all, Fr* dst_all, const uint32_t* __restrict__ tw29, int logn, int q0, int b) {      // src_all == dst_all: in place
     // NR stages q0 .. q0+b-1.  tile: mid = the b position bits below the top q0 (stride 2^sh, sh = logn-q0-b), lo_t = NTT_TILE >> b neighbouring positions starting
     // at lo0; the top q0 bits (`prefix`) are fixed per block.  q0 = 0: the first kernel of a transform (stage 0 is twiddle-free, operands as large as 32 p).
     // [r4] domains above 2^18 run two of these in a row (q0 = 0, then q0 = b of the first): the mid kernel always takes the last nine NR stages.
@@ -327,7 +327,7 @@ zkc_ntt_nr_head(const Fr* src_all, Fr* dst_all, const uint32_t* __restrict__ tw2
         for (int k = 0; k < 9; k++) tile[9 * e + k] = t[k];
     }
     __syncthreads();
-    ntt_nr_stages<false>(tile, [lo_t](int mid, int l) { return mid * lo_t + l; }, b, lo_t, q0, prefix, 0, tw29, logn, q0 == 0);
+    ntt_nr_stages<RADIX>(tile, [lo_t](int mid, int l) { return mid * lo_t + l; }, b, lo_t, q0, prefix, 0, tw29, logn, q0 == 0);
     for (int e = threadIdx.x; e < elems; e += blockDim.x) {
         const int mid = e / lo_t, l = e - mid * lo_t;
         uint32_t r[9];
@@ -337,6 +337,10 @@ zkc_ntt_nr_head(const Fr* src_all, Fr* dst_all, const uint32_t* __restrict__ tw2
         st_fr(dst + (base + ((size_t)mid << sh) + l), f29_to_fp<FrParams>(r));
     }
 }
+extern "C" __global__ void __launch_bounds__(256)
+zkc_ntt_nr_head(const Fr* src_all, Fr* dst_all, const uint32_t* __restrict__ tw29, int logn, int q0, int b) { ntt_nr_head_body<1>(src_all, dst_all, tw29, logn, q0, b); }
+extern "C" __global__ void __launch_bounds__(256)
+zkc_ntt_nr_head_r4(const Fr* src_all, Fr* dst_all, const uint32_t* __restrict__ tw29, int logn, int q0, int b) { ntt_nr_head_body<4>(src_all, dst_all, tw29, logn, q0, b); }
 // NR stages logn-9 .. logn-1 of the inverse, the scale, RN stages 1 .. 9 of the forward transform: NTT_TILE consecutive positions = two blocks of 512
 extern "C" __global__ void __launch_bounds__(256)
 zkc_ntt_mid(Fr* __restrict__ data_all, const uint32_t* __restrict__ tw_inv29, const uint32_t* __restrict__ tw_fwd29, const Fr* __restrict__ scale_br, int logn) {
@@ -352,7 +356,7 @@ zkc_ntt_mid(Fr* __restrict__ data_all, const uint32_t* __restrict__ tw_inv29, co
     }
     __syncthreads();
     // slot(mid, l) = l * 512 + mid : sub-block l of the tile, position mid inside it; its prefix = the logn-9 position bits above = blockIdx.x * NSUB + l
-    ntt_nr_stages<true>(tile, [](int mid, int l) { return l * MID + mid; }, B, NSUB, logn - B, (uint32_t)blockIdx.x * NSUB, 1, tw_inv29, logn, false);
+    ntt_nr_stages<4>(tile, [](int mid, int l) { return l * MID + mid; }, B, NSUB, logn - B, (uint32_t)blockIdx.x * NSUB, 1, tw_inv29, logn, false);
     // x g^k / n at bit-reversed positions (scale_br[p] = scale[brev(p)]): a product, so the value is back below 2 p
     for (int e = threadIdx.x; e < NTT_TILE; e += blockDim.x) {
         uint32_t r[9], s29[9], o[9];
@@ -414,8 +418,14 @@ int ntt_pair_run(zkc_ctx* ctx, hipStream_t st, Fr* data, const uint32_t* tw_inv2
     const int bh = logn - 9;                                     // head: NR stages 0 .. logn-10, tail: RN stages 10 .. logn (bh stages each)
     const int b1 = bh <= 9 ? bh : (bh + 1) / 2, b2 = bh - b1;    // one kernel each side up to 2^18, two above
     const unsigned blocks = (1u << logn) / NTT_TILE;
-    hipLaunchKernelGGL(zkc_ntt_nr_head, dim3(blocks, nvec), dim3(256), (size_t)NTT_TILE * 36, st, (const Fr*)data, data, tw_inv29, logn, 0, b1);
-    if (b2) hipLaunchKernelGGL(zkc_ntt_nr_head, dim3(blocks, nvec), dim3(256), (size_t)NTT_TILE * 36, st, (const Fr*)data, data, tw_inv29, logn, b1, b2);
+    // [r4] the head kernel runs its stages two at a time like the other two (one LDS round trip, three twiddles and one carry pass per two stages: 290 instead of ~365
+    // instructions per butterfly; alternating on one box 3196 / 3166 against 3175 / 3146 proofs/s, +0.65 %, equal on a second box).  ZKC_NTT_RADIX=1: one stage at a time, the
+    // round-2 form ("measured slower two at a time" was true of the round-2 pipeline, whose transforms ran alone).  Three stages at a time on eight slots was built and measured
+    // too: 137 instead of 145 instructions per element and stage, but 162-168 VGPRs (three waves per SIMD instead of four) -- 2856 / 2845 against 2997 / 2990 proofs/s, -5 %; removed.
+    static const int radix = [] { const char* e = getenv("ZKC_NTT_RADIX"); return e ? atoi(e) : 4; }();
+    auto head = radix >= 4 ? zkc_ntt_nr_head_r4 : zkc_ntt_nr_head;
+    hipLaunchKernelGGL(head, dim3(blocks, nvec), dim3(256), (size_t)NTT_TILE * 36, st, (const Fr*)data, data, tw_inv29, logn, 0, b1);
+    if (b2) hipLaunchKernelGGL(head, dim3(blocks, nvec), dim3(256), (size_t)NTT_TILE * 36, st, (const Fr*)data, data, tw_inv29, logn, b1, b2);
     hipLaunchKernelGGL(zkc_ntt_mid, dim3(blocks, nvec), dim3(256), (size_t)NTT_TILE * 36, st, data, tw_inv29, tw_fwd29, scale_br, logn);
     hipLaunchKernelGGL(zkc_ntt_pass, dim3(blocks, nvec), dim3(256), (size_t)NTT_TILE * 36, st, (const Fr*)data, data, tw_fwd29, (const Fr*)nullptr, logn, 9, b1, 0);
     if (b2) hipLaunchKernelGGL(zkc_ntt_pass, dim3(blocks, nvec), dim3(256), (size_t)NTT_TILE * 36, st, (const Fr*)data, data, tw_fwd29, (const Fr*)nullptr, logn, 9 + b1, b2, 0);
