@@ -45,3 +45,37 @@ def test_poseidon_batch_and_census():
     rc, wo = ol.witness(deep[1]); assert rc == 0 and wo == ws[1]
     assert all(v['censusSiblings'][159] != '0' and v['censusSiblings'][160] == '0' for v in deep)
     ctx.close()
+
+
+def test_deep_pass_takes_the_17_bit_section_tables():
+    """[r4] A pass whose voters keep more than 30 000 wires per section (leaves at the bottom of both trees: nothing folds) runs its sections over the key's second,
+    17-bit-window tables: 15 instead of 22 additions per scalar.  Four voters 160 levels down and one 9 levels down in one call: proof bytes equal the oracle's, the
+    verifier accepts, and the device's count of G1 additions says which tables the pass took (H: 15 per scalar either way)."""
+    import ctypes, json, random
+    import zkcensus_amd
+    from zkcensus_amd import census, setup
+    nl = 160
+    _, zp, vp = setup.ensure_test_artifacts(nl)
+    zk = open(zp, 'rb').read(); vk = json.load(open(vp))
+    ctx = zkcensus_amd.Context(0); pk = zkcensus_amd.ProvingKey(ctx, zk)
+    voters = census.deep_voters(ctx, 4, nl) + census.synthetic_census(ctx, 600)[:1]
+    ws, st = ctx.witness(voters)
+    assert st == [0] * 5
+    import numpy as np, torch
+    rng = random.Random(17)
+    rs = [(rng.randrange(ol.R), rng.randrange(ol.R)) for _ in voters]
+    rsb = b''.join(r.to_bytes(32, 'little') + s_.to_bytes(32, 'little') for r, s_ in rs)
+    d_w = torch.from_numpy(np.frombuffer(b''.join(ws), dtype=np.uint8).copy()).cuda()
+    lib = ctx._lib
+    lib.zkc_profile_enable(ctx._h, 0x10)
+    p_all, u_all = pk.prove_batch_dev(d_w.data_ptr(), 5, rsb)
+    ms, n, by = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
+    lib.zkc_profile_read(ctx._h, 7, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(by))      # ZKC_PROF_MSM_G1_STREAMED: launches = mixed additions counted on the device
+    lib.zkc_profile_enable(ctx._h, 0)
+    want = ol.pmap(lambda a: ol.prove(zk, a[0], a[1][0], a[1][1]), list(zip(ws, rs)))
+    for q, (rc, op, ou) in enumerate(want):
+        assert rc == 0 and (p_all[256 * q:256 * q + 256], u_all[256 * q:256 * q + 256]) == (op, ou), q
+        assert ol.verify(vk, ou, op)
+    # 22 additions per section scalar: 6.55 M per deep proof; 15: about 5.1 M (H: 15 per scalar either way, 1.97 M)
+    assert n.value < 5 * 5.3e6, n.value
+    pk.close(); ctx.close()

@@ -653,7 +653,7 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     constexpr bool kG2 = sizeof(F) == sizeof(Fq2);
     static const bool bw_off = [] { const char* e = getenv("ZKC_G2_BUCKET_WAVE"); return e && atoi(e) == 0; }();
     const uint32_t bw_slices = (uint32_t)std::min<size_t>(32, w.max_segments / std::max<uint32_t>(nb, 1u));      // slices a heavy bucket may be cut into: nb x slices partial sums must fit
-    const uint32_t* const g2_table29 = (kG2 && jl.job[0].c == (uint32_t)MSM_C_G2_LONE) ? zk->d_g2_29_lone : zk->d_g2_29;       // a G2 pass is of one window size
+    const uint32_t* const g2_table29 = (kG2 && jl.job[0].c == (uint32_t)MSM_C_G2_LONE) ? zk->d_g2_29_lone : (kG2 && zk->c_deep && jl.job[0].c == (uint32_t)zk->c_deep) ? zk->d_g2_29_deep : zk->d_g2_29;       // a G2 pass is of one window size
     const bool bucket_wave = kG2 && !bw_off && nb <= 8192 && bw_slices >= 1;         // a small G2 pass: half a wave per bucket (zkc_msm_bucketwave_g2), no segment lists
     uint64_t alg_bytes = 0; uint32_t maxcount = 0;
     uint64_t streamed_bytes = 0;

@@ -96,7 +96,7 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     ZKC_LOCK(zk->ctx);
     (void)hipSetDevice(zk->ctx->device);
     (void)hipStreamSynchronize(zk->ctx->stream);
-    void* ptrs[] = {zk->d_perm, zk->d_rowlen, zk->d_jdptr, zk->d_col, zk->d_val, zk->d_tw_fwd, zk->d_tw_inv, zk->d_tw_fwd29, zk->d_tw_inv29, zk->d_coset, zk->d_coset_br, zk->d_g1, zk->d_g2, zk->d_g2_29, zk->d_g2_29_lone, zk->d_flags,
+    void* ptrs[] = {zk->d_perm, zk->d_rowlen, zk->d_jdptr, zk->d_col, zk->d_val, zk->d_tw_fwd, zk->d_tw_inv, zk->d_tw_fwd29, zk->d_tw_inv29, zk->d_coset, zk->d_coset_br, zk->d_g1, zk->d_g2, zk->d_g2_29, zk->d_g2_29_lone, zk->d_g2_29_deep, zk->d_flags,
                     zk->d_tblDelta1, zk->d_tblAlpha1, zk->d_tblBeta1, zk->d_tblDelta2, zk->d_fb4, zk->d_fb4g2, zk->d_depths, zk->call[0].d_rs, zk->call[0].d_proofs, zk->call[1].d_rs, zk->call[1].d_proofs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : zk->fold.vmaps) if (kv.second.d) (void)hipFree(kv.second.d);
@@ -131,7 +131,7 @@ static int lanes_ensure(zkc_zkey* zk, int inflight) {
     zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n, nv = zk->nVars; int rc;
     const int NWS = msm_nw(zk->c_sec), NWB = msm_nw(MSM_C_BIG);
     const size_t per_proof_entries = (size_t)NWS * 3 * nv + (size_t)NWB * n;
-    const size_t per_proof_buckets = 3 * (size_t)msm_half(zk->c_sec) + msm_half(MSM_C_BIG);
+    const size_t per_proof_buckets = 3 * (size_t)msm_half(std::max(zk->c_sec, zk->c_deep)) + msm_half(MSM_C_BIG);      // (a deep pass has fewer entries and more buckets)
     // the old work space goes first (a key at nLevels = 160 with 96 proofs in flight holds ~6 GB): from here until every allocation has succeeded the key
     // has NO work space, and says so (cur_inflight = 0), so a failure leaves a key that re-allocates on its next call instead of launching on freed buffers
     zk->cur_inflight = 0;
@@ -154,7 +154,7 @@ static int lanes_ensure(zkc_zkey* zk, int inflight) {
         if (!rc && hipMalloc(&L.d_fin, finalize_scratch_bytes(inflight)) != hipSuccess) rc = zkc_fail(ctx, ZKC_ERR_HIP, "lanes_ensure: hipMalloc failed (blinding scratch)");
         if (!rc) rc = dmalloc(ctx, &L.d_bs, 2 * 2 * 8 * (size_t)nv);
         if (!rc) rc = msm_work_alloc(ctx, L.w1, per_proof_entries * inflight, per_proof_buckets * inflight, 4 * inflight, false);
-        if (!rc) rc = msm_work_alloc(ctx, L.w2, (size_t)NWS * nv * inflight, (size_t)msm_half(zk->c_sec) * inflight, inflight, true);
+        if (!rc) rc = msm_work_alloc(ctx, L.w2, (size_t)NWS * nv * inflight, (size_t)msm_half(std::max(zk->c_sec, zk->c_deep)) * inflight, inflight, true);
         if (rc) { (void)hipGetLastError(); release(); return rc; }
     }
     zk->cur_inflight = inflight;
@@ -255,7 +255,11 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
     { const char* e_c = getenv("ZKC_C_SECTIONS"); zk->c_sec = e_c ? std::max(8, std::min(atoi(e_c), MSM_C_BIG)) : ((zk->nLevels < 0 && nv >= (1u << 16)) ? MSM_C_BIG : MSM_C_SMALL); }
     const int NWS = msm_nw(zk->c_sec), NWB = msm_nw(MSM_C_BIG);
     zk->offA = 0; zk->offB1 = NWS * nv; zk->offC = 2 * NWS * nv; zk->offH = 2 * NWS * nv + NWS * nc;
-    const size_t g1_points = (size_t)NWS * (2 * (size_t)nv + nc) + (size_t)NWB * n;
+    // (ZKC_DEEP_TABLES=0: not built; =2: built for a census key of any size -- with ZKC_DEEP_WIRES=1 the switch test drives the deep path at nLevels = 10)
+    { const char* e_d = getenv("ZKC_DEEP_TABLES"); const int dt = e_d ? atoi(e_d) : 1; zk->c_deep = (zk->nLevels >= 0 && (nv >= (1u << 16) || dt == 2) && zk->c_sec < MSM_C_BIG && dt != 0) ? MSM_C_BIG : 0; }
+    const int NWD = zk->c_deep ? msm_nw(zk->c_deep) : 0;
+    zk->offA_deep = zk->offH + NWB * n; zk->offB1_deep = zk->offA_deep + NWD * nv; zk->offC_deep = zk->offB1_deep + NWD * nv;
+    const size_t g1_points = (size_t)NWS * (2 * (size_t)nv + nc) + (size_t)NWB * n + (size_t)NWD * (2 * (size_t)nv + nc);
     if (g1_points >= (1ull << 31)) return bail(zkc_fail(ctx, ZKC_ERR_FORMAT, "zkey too large for 31-bit point indices"));
     if ((rc = dmalloc(ctx, &zk->d_g1, g1_points)) || (rc = dmalloc(ctx, &zk->d_g2, (size_t)NWS * nv))) return bail(rc);
     ZKC_UP(zk->d_g1 + zk->offA, sec[5], 64ull * nv); ZKC_UP(zk->d_g1 + zk->offB1, sec[6], 64ull * nv);
@@ -265,6 +269,21 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
         (rc = msm_precompute_g1(ctx, nc, zk->d_g1 + zk->offC, zk->c_sec)) || (rc = msm_precompute_g1(ctx, n, zk->d_g1 + zk->offH, MSM_C_BIG)) ||
         (rc = msm_precompute_g2(ctx, nv, zk->d_g2, zk->c_sec))) return bail(rc);
     if ((rc = dmalloc(ctx, &zk->d_g2_29, 60 * (size_t)NWS * nv)) || (rc = msm_g2_table29(ctx, zk->d_g2, zk->d_g2_29, (size_t)NWS * nv))) return bail(rc);
+    if (zk->c_deep) {   // the sections again for 17-bit windows (15 x 64 B per wire and G1 section, 15 x 240 B for G2: 0.54 GB at nLevels = 160 beside the 0.8 GB of the 12-bit tables)
+        ZKC_UP(zk->d_g1 + zk->offA_deep, sec[5], 64ull * nv); ZKC_UP(zk->d_g1 + zk->offB1_deep, sec[6], 64ull * nv); ZKC_UP(zk->d_g1 + zk->offC_deep, sec[8], 64ull * nc);
+        if ((rc = msm_precompute_g1(ctx, nv, zk->d_g1 + zk->offA_deep, zk->c_deep)) || (rc = msm_precompute_g1(ctx, nv, zk->d_g1 + zk->offB1_deep, zk->c_deep)) ||
+            (rc = msm_precompute_g1(ctx, nc, zk->d_g1 + zk->offC_deep, zk->c_deep))) return bail(rc);
+        G2Affine* tmp = nullptr;
+        if ((rc = dmalloc(ctx, &tmp, (size_t)NWD * nv))) return bail(rc);
+        hipError_t e2 = hipMemcpyAsync(tmp, zk->d_g2, 128ull * nv, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e2 == hipSuccess) rc = msm_precompute_g2(ctx, nv, tmp, zk->c_deep);
+        if (e2 == hipSuccess && !rc) rc = dmalloc(ctx, &zk->d_g2_29_deep, 60 * (size_t)NWD * nv);
+        if (e2 == hipSuccess && !rc) rc = msm_g2_table29(ctx, tmp, zk->d_g2_29_deep, (size_t)NWD * nv);
+        if (e2 == hipSuccess && !rc) e2 = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(tmp);
+        if (rc) return bail(rc);
+        if (e2 != hipSuccess) return bail(zkc_fail(ctx, ZKC_ERR_HIP, std::string("17-bit section tables: ") + hipGetErrorString(e2)));
+    }
     {   // [r3] the 8-bit-window G2 table of the lone-proof path (MSM_C_G2_LONE): shifted in a temporary affine table, kept in radix 2^29 only
         const char* e_lone = getenv("ZKC_G2_LONE_TABLE");
         if (!(e_lone && atoi(e_lone) == 0) && (zk->nLevels >= 0 || nv < (1u << 16))) {      // (a key of 2^16 wires and more that is not the census circuit: 32 x 240 B per wire for a latency path its proofs are too large to notice)
@@ -674,7 +693,15 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         const uint32_t vws = nb <= 4 ? 64u : vws_env ? vws_env : nb < 32 ? 256u : 2048u, vwb = nb <= 4 ? 256u : vwb_env ? vwb_env : nb < 32 ? 1024u : 4096u;
         // the G2 section of one or two proofs takes the 8-bit-window table: 128 buckets per job, reduced by one wave (vw = 128), if the G2 work space holds 32 entries per scalar
         size_t lone_entries = 0; for (int q = 0; q < nb; q++) lone_entries += (size_t)msm_nw(MSM_C_G2_LONE) * (listed ? vms[q].nB : nv);
-        const int c2 = (nb <= 2 && zk->d_g2_29_lone && lone_entries <= LN.w2.max_entries) ? MSM_C_G2_LONE : zk->c_sec;
+        // [r4] deep pass: the voters of this pass keep, on average, more than ZKC_DEEP_WIRES (30 000) wires per section in their MSMs (leaves far down the trees, or witnesses that
+        // do not fold): the sections take the key's 17-bit tables.  Per section of W full-width scalars: 22 W + 2048 x 2.8 additions at 12 bits, 15 W + 65536 x 2.8 at 17 --
+        // even at W = 26 k; a census of 2^13 .. 2^20 voters keeps 8-11 k and stays at 12.
+        static const size_t deep_wires = [] { const char* e = getenv("ZKC_DEEP_WIRES"); return e ? (size_t)atol(e) : (size_t)30000; }();
+        size_t live_wires = 0; for (int q = 0; q < nb; q++) live_wires += listed ? (size_t)vms[q].nA + vms[q].nB + vms[q].nC : 2 * (size_t)nv + nc;
+        const bool deep = zk->c_deep != 0 && nb > 2 && live_wires >= 3 * deep_wires * (size_t)nb;
+        const int cs = deep ? zk->c_deep : zk->c_sec;
+        const uint32_t oA = deep ? zk->offA_deep : zk->offA, oB1 = deep ? zk->offB1_deep : zk->offB1, oC = deep ? zk->offC_deep : zk->offC;
+        const int c2 = (nb <= 2 && zk->d_g2_29_lone && lone_entries <= LN.w2.max_entries) ? MSM_C_G2_LONE : cs;
         static const uint32_t vwg2_env = [] { const char* e = getenv("ZKC_VW_G2"); return e ? (uint32_t)atoi(e) : 0u; }();      // A/B: the G2 jobs' window apart from the G1 sections'
         j1.clear(vws, vwb); j2.clear(c2 == MSM_C_G2_LONE ? 128u : (vwg2_env && nb >= 32) ? vwg2_env : vws);
         // job order of the G1 pass: the nb H jobs first (the 16-bit bucket sort wants the jobs with the larger bucket count in front), then
@@ -686,24 +713,23 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         size_t tree_entries = 0; for (int q = 0; q < nb; q++) tree_entries += (size_t)msm_nw(MSM_C_BIG) * n + (size_t)msm_nw(zk->c_sec) * (listed ? 2 * (size_t)vms[q].nA + 2 * (size_t)vms[q].nB + vms[q].nC : 4 * (size_t)nv + nc);
         const bool tree = zk->d_fb4 != nullptr && nb <= 2 && 6 * nb <= LN.w1.max_jobs && tree_entries <= LN.w1.max_entries && (size_t)nb * (5 * msm_half(zk->c_sec) + msm_half(MSM_C_BIG)) <= LN.w1.max_buckets;
         BlindArgs ba{}; ba.rs = CS.d_rs + 64 * (size_t)p0; ba.nv = nv;
-        const int cs = zk->c_sec;
         for (int q = 0; q < nb; q++) {
             const uint32_t* w = w0 + (size_t)q * nv * 8;
             uint32_t* bs = tree ? LN.d_bs + (size_t)q * 2 * nv * 8 : nullptr;
             if (tree) { ba.w[q] = w; ba.out[q] = bs; }
             if (listed) {
                 const zkc_zkey::Fold::VMap& vm = vms[q];
-                j1.add(w, vm.d + vm.offA, vm.nA, zk->offA, nv, 0, cs);
-                j1.add(w, vm.d + vm.offB, vm.nB, zk->offB1, nv, 0, cs);
-                j1.add(w, vm.d + vm.offC, vm.nC, zk->offC, nc, (int32_t)np + 1, cs);
-                if (tree) { j1.add(bs, vm.d + vm.offA, vm.nA, zk->offA, nv, 0, cs); j1.add(bs + 8ull * nv, vm.d + vm.offB, vm.nB, zk->offB1, nv, 0, cs); }
+                j1.add(w, vm.d + vm.offA, vm.nA, oA, nv, 0, cs);
+                j1.add(w, vm.d + vm.offB, vm.nB, oB1, nv, 0, cs);
+                j1.add(w, vm.d + vm.offC, vm.nC, oC, nc, (int32_t)np + 1, cs);
+                if (tree) { j1.add(bs, vm.d + vm.offA, vm.nA, oA, nv, 0, cs); j1.add(bs + 8ull * nv, vm.d + vm.offB, vm.nB, oB1, nv, 0, cs); }
                 j2.add(w, vm.d + vm.offB, vm.nB, 0, nv, 0, c2);
                 if (tree) { ba.mapA[q] = vm.d + vm.offA; ba.nA[q] = vm.nA; ba.mapB[q] = vm.d + vm.offB; ba.nB[q] = vm.nB; }
             } else {
-                j1.add(w, nullptr, nv, zk->offA, nv, 0, cs);
-                j1.add(w, nullptr, nv, zk->offB1, nv, 0, cs);
-                j1.add(w + 8ull * (np + 1), nullptr, nc, zk->offC, nc, 0, cs);
-                if (tree) { j1.add(bs, nullptr, nv, zk->offA, nv, 0, cs); j1.add(bs + 8ull * nv, nullptr, nv, zk->offB1, nv, 0, cs); }
+                j1.add(w, nullptr, nv, oA, nv, 0, cs);
+                j1.add(w, nullptr, nv, oB1, nv, 0, cs);
+                j1.add(w + 8ull * (np + 1), nullptr, nc, oC, nc, 0, cs);
+                if (tree) { j1.add(bs, nullptr, nv, oA, nv, 0, cs); j1.add(bs + 8ull * nv, nullptr, nv, oB1, nv, 0, cs); }
                 j2.add(w, nullptr, nv, 0, nv, 0, c2);
                 if (tree) { ba.mapA[q] = ba.mapB[q] = nullptr; ba.nA[q] = ba.nB[q] = nv; }
             }

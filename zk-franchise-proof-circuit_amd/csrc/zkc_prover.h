@@ -177,6 +177,9 @@ struct zkc_zkey {
     uint32_t* d_g2_29 = nullptr;                                            // the G2 table again in radix 2^29 (60 words per point: x, y, -y), read by the accumulation
     uint32_t* d_g2_29_lone = nullptr;                                       // the same bases pre-shifted for MSM_C_G2_LONE (32 windows), radix 2^29 only; nullptr: not built (ZKC_G2_LONE_TABLE=0)
     uint32_t offA = 0, offB1 = 0, offC = 0, offH = 0;                       // table offsets inside d_g1 (points)
+    // [r4] a census key of 2^16 wires and more keeps its witness sections a second time, pre-shifted for c_deep = 17-bit windows: a pass whose voters sit deep in the trees (or
+    // whose witnesses do not fold at all) has 50-80 k wires per section instead of 8-11 k, and 15 additions per scalar into 65536 buckets then beat 22 into 2048.  0: not built
+    int c_deep = 0; uint32_t offA_deep = 0, offB1_deep = 0, offC_deep = 0; uint32_t* d_g2_29_deep = nullptr;
     // per-proof work buffers
     int c_sec = zkc::MSM_C_SMALL;                                                // [r4] window bits of the witness sections A, B1, C, B2 of THIS key (zkc_zkey_load: 12, or 17 for sections of 2^16 wires and more)
     int max_inflight = 0;                                                   // proofs per pipeline pass (upper limit)
