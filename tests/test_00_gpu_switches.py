@@ -10,10 +10,10 @@ import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
 CONFIGS = [
-    {}, {'ZKC_G2_ACC': '1'}, {'ZKC_G2_ACC': '2'}, {'ZKC_G2_ACC_HOLD': '1'}, {'ZKC_REDUCE_STREAM': '1', 'ZKC_INFLIGHT': '40'}, {'ZKC_LANES': '2', 'ZKC_INFLIGHT': '40'},
+    {}, {'ZKC_G2_ACC': '1', 'ZKC_C_SECTIONS': '13'}, {'ZKC_G2_ACC': '2'}, {'ZKC_G2_ACC_HOLD': '1'}, {'ZKC_REDUCE_STREAM': '1', 'ZKC_INFLIGHT': '40'}, {'ZKC_LANES': '2', 'ZKC_INFLIGHT': '40'},
     {'ZKC_VW_BIG': '1024', 'ZKC_VW_SMALL': '256', 'ZKC_INFLIGHT': '40'}, {'ZKC_VW_BIG': '8192', 'ZKC_VW_SMALL': '512', 'ZKC_VW_G2': '256', 'ZKC_INFLIGHT': '40'},
-    {'ZKC_MATVEC_UNITS': '0'}, {'ZKC_NOFOLD_LISTS': '0', 'ZKC_NO_FOLD': '1'}, {'ZKC_NO_FOLD': '1'}, {'ZKC_MV_PREFETCH_AT_NTT': '1', 'ZKC_INFLIGHT': '8'}, {'ZKC_MATVEC_INLINE': '1', 'ZKC_INFLIGHT': '8'},
-    {'ZKC_NTT_SEPARATE': '1'}, {'ZKC_NTT_RADIX': '1'}, {'ZKC_C_SECTIONS': '13'}, {'ZKC_INFLIGHT': '40'}, {'ZKC_DEEP_TABLES': '2', 'ZKC_DEEP_WIRES': '1', 'ZKC_INFLIGHT': '40'},
+    {'ZKC_MATVEC_UNITS': '0', 'ZKC_NTT_RADIX': '1'}, {'ZKC_NOFOLD_LISTS': '0', 'ZKC_NO_FOLD': '1'}, {'ZKC_NO_FOLD': '1'}, {'ZKC_MV_PREFETCH_AT_NTT': '1', 'ZKC_INFLIGHT': '8'}, {'ZKC_MATVEC_INLINE': '1', 'ZKC_INFLIGHT': '8'},
+    {'ZKC_NTT_SEPARATE': '1'}, {'ZKC_INFLIGHT': '40'}, {'ZKC_DEEP_TABLES': '2', 'ZKC_DEEP_WIRES': '1', 'ZKC_INFLIGHT': '40'},
 ]
 
 
