@@ -78,4 +78,18 @@ def test_deep_pass_takes_the_17_bit_section_tables():
         assert ol.verify(vk, ou, op)
     # 22 additions per section scalar: 6.55 M per deep proof; 15: about 5.1 M (H: 15 per scalar either way, 1.97 M)
     assert n.value < 5 * 5.3e6, n.value
+    # a deep pass and a shallow one (12-bit tables, 2048 buckets per section) in flight together on the key's two call slots, sixteen times: the two layouts of the lanes' work
+    # space follow each other pass by pass, and every call gives the bytes it gives alone
+    shallow = census.synthetic_census(ctx, 600)[1:7]
+    ws2, st2 = ctx.witness(shallow); assert st2 == [0] * 6
+    rsb2 = b''.join(rng.randrange(ol.R).to_bytes(32, 'little') for _ in range(12))
+    d_w2 = torch.from_numpy(np.frombuffer(b''.join(ws2), dtype=np.uint8).copy()).cuda()
+    alone = pk.prove_batch_dev(d_w2.data_ptr(), 6, rsb2)
+    from zkcensus_amd import groth16
+    assert groth16.verify_batch(ctx, vk, alone[1], alone[0])
+    for k in range(16):
+        pk.batch_begin(k & 1, None, 5, d_w.data_ptr(), None, rsb)
+        pk.batch_begin(1 - (k & 1), None, 6, d_w2.data_ptr(), None, rsb2)
+        assert pk.batch_finish(k & 1, 5) == (p_all, u_all), k
+        assert pk.batch_finish(1 - (k & 1), 6) == alone, k
     pk.close(); ctx.close()
