@@ -108,7 +108,7 @@ extern "C" int zkc_msm_g1_load_dev(zkc_ctx* ctx, const void* d_bases_std, uint32
     if (!ctx || !d_bases_std || !out || n == 0 || n > (1u << 21)) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_msm_g1_load_dev: bad argument (1 <= n <= 2^21)");
     ZKC_LOCK(ctx);
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    zkc_msm* m = new zkc_msm(); m->zk.ctx = ctx; m->n = n; m->c = n >= (1u << 15) ? MSM_C_BIG : MSM_C_SMALL;
+    zkc_msm* m = new zkc_msm(); m->zk.ctx = ctx; m->n = n; m->c = msm_c_for(n);
     const int nw = msm_nw(m->c);
     uint32_t* d_bad = nullptr; uint32_t bad = 0; int rc = ZKC_OK;
     auto bail = [&](int code) { if (d_bad) (void)hipFree(d_bad); if (m->zk.d_g1) (void)hipFree(m->zk.d_g1); m->zk.d_g1 = nullptr; msm_work_free(m->w); delete m; return code; };

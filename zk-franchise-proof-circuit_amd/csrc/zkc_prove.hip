@@ -129,9 +129,9 @@ static int lanes_ensure(zkc_zkey* zk, int inflight) {
     inflight = inflight <= 4 ? 4 : zk->max_inflight;
     inflight = std::min(inflight, zk->max_inflight);
     zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n, nv = zk->nVars; int rc;
-    const int NWS = msm_nw(zk->c_sec), NWB = msm_nw(MSM_C_BIG);
+    const int NWS = msm_nw(zk->c_sec), NWB = msm_nw(zk->c_h);
     const size_t per_proof_entries = (size_t)NWS * 3 * nv + (size_t)NWB * n;
-    const size_t per_proof_buckets = 3 * (size_t)msm_half(std::max(zk->c_sec, zk->c_deep)) + msm_half(MSM_C_BIG);      // (a deep pass has fewer entries and more buckets)
+    const size_t per_proof_buckets = 3 * (size_t)msm_half(std::max(zk->c_sec, zk->c_deep)) + msm_half(zk->c_h);      // (a deep pass has fewer entries and more buckets)
     // the old work space goes first (a key at nLevels = 160 with 96 proofs in flight holds ~6 GB): from here until every allocation has succeeded the key
     // has NO work space, and says so (cur_inflight = 0), so a failure leaves a key that re-allocates on its next call instead of launching on freed buffers
     zk->cur_inflight = 0;
@@ -250,13 +250,21 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
     }
     // ---- bases: one G1 array [A | B1 | C | H] and one G2 array [B2]; window 0 = the zkey points as stored (affine,
     //      Montgomery), windows 1..19 pre-shifted on the device ----
-    // [r4] window of the witness sections, per key: 12 bits (22 additions per scalar into 2048 buckets) suits the census circuit's 8-11 k wires per section after folding; a
-    // section of 2^16 wires and more (BASELINE configs[4]: a 2^20-constraint circuit) takes H's 17 bits -- 15 additions per scalar, and 65536 buckets are then cheap beside them
-    { const char* e_c = getenv("ZKC_C_SECTIONS"); zk->c_sec = e_c ? std::max(8, std::min(atoi(e_c), MSM_C_BIG)) : ((zk->nLevels < 0 && nv >= (1u << 16)) ? MSM_C_BIG : MSM_C_SMALL); }
-    const int NWS = msm_nw(zk->c_sec), NWB = msm_nw(MSM_C_BIG);
-    zk->offA = 0; zk->offB1 = NWS * nv; zk->offC = 2 * NWS * nv; zk->offH = 2 * NWS * nv + NWS * nc;
+    // [r4] windows per key (msm_c_for, zkc_prover.h: the best window grows with the number of scalars):
+    auto c_for = [](size_t W) { return msm_c_for(W); };
+    //   sections of a census key : 12 -- what folding leaves in a voter's MSMs is 8-11 k wires per section (13 measured equal) -- plus the deep tables below
+    //   sections of any other key: by its wire count;   H: 17 for a census key (2^17 scalars: 16 and 17 tie), else by the domain size, never below the sections'
+    //   (msm_pass wants the jobs with the larger window first, and the H jobs are first)
+    { const char* e_c = getenv("ZKC_C_SECTIONS"); zk->c_sec = e_c ? std::max(8, std::min(atoi(e_c), MSM_C_BIG)) : zk->nLevels >= 0 ? MSM_C_SMALL : c_for(nv); }
+    { const char* e_h = getenv("ZKC_C_H"); zk->c_h = e_h ? std::max(8, std::min(atoi(e_h), MSM_C_BIG)) : zk->nLevels >= 0 ? MSM_C_BIG : std::max(c_for(n), n >= 12000 ? 15 : 12); }      // (H's scalars are all full width: at 2^14 points 15 bits measured 3 % ahead of 13, 17 5 % behind)
+    const int NWS = msm_nw(zk->c_sec);
     // (ZKC_DEEP_TABLES=0: not built; =2: built for a census key of any size -- with ZKC_DEEP_WIRES=1 the switch test drives the deep path at nLevels = 10)
-    { const char* e_d = getenv("ZKC_DEEP_TABLES"); const int dt = e_d ? atoi(e_d) : 1; zk->c_deep = (zk->nLevels >= 0 && (nv >= (1u << 16) || dt == 2) && zk->c_sec < MSM_C_BIG && dt != 0) ? MSM_C_BIG : 0; }
+    { const char* e_d = getenv("ZKC_DEEP_TABLES"); const int dt = e_d ? atoi(e_d) : 1; const char* e_c = getenv("ZKC_C_DEEP");
+      const int cd = e_c ? std::max(13, std::min(atoi(e_c), MSM_C_BIG)) : c_for(dt == 2 ? (size_t)40000 : (size_t)nv * 4 / 5);        // a deep voter keeps most of the key's wires
+      zk->c_deep = (zk->nLevels >= 0 && (nv >= (1u << 16) || dt == 2) && zk->c_sec < cd && dt != 0) ? cd : 0; }
+    zk->c_h = std::max(zk->c_h, std::max(zk->c_sec, zk->c_deep));
+    const int NWB = msm_nw(zk->c_h);
+    zk->offA = 0; zk->offB1 = NWS * nv; zk->offC = 2 * NWS * nv; zk->offH = 2 * NWS * nv + NWS * nc;
     const int NWD = zk->c_deep ? msm_nw(zk->c_deep) : 0;
     zk->offA_deep = zk->offH + NWB * n; zk->offB1_deep = zk->offA_deep + NWD * nv; zk->offC_deep = zk->offB1_deep + NWD * nv;
     const size_t g1_points = (size_t)NWS * (2 * (size_t)nv + nc) + (size_t)NWB * n + (size_t)NWD * (2 * (size_t)nv + nc);
@@ -266,7 +274,7 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
     ZKC_UP(zk->d_g1 + zk->offC, sec[8], 64ull * nc); ZKC_UP(zk->d_g1 + zk->offH, sec[9], 64ull * n);
     ZKC_UP(zk->d_g2, sec[7], 128ull * nv);
     if ((rc = msm_precompute_g1(ctx, nv, zk->d_g1 + zk->offA, zk->c_sec)) || (rc = msm_precompute_g1(ctx, nv, zk->d_g1 + zk->offB1, zk->c_sec)) ||
-        (rc = msm_precompute_g1(ctx, nc, zk->d_g1 + zk->offC, zk->c_sec)) || (rc = msm_precompute_g1(ctx, n, zk->d_g1 + zk->offH, MSM_C_BIG)) ||
+        (rc = msm_precompute_g1(ctx, nc, zk->d_g1 + zk->offC, zk->c_sec)) || (rc = msm_precompute_g1(ctx, n, zk->d_g1 + zk->offH, zk->c_h)) ||
         (rc = msm_precompute_g2(ctx, nv, zk->d_g2, zk->c_sec))) return bail(rc);
     if ((rc = dmalloc(ctx, &zk->d_g2_29, 60 * (size_t)NWS * nv)) || (rc = msm_g2_table29(ctx, zk->d_g2, zk->d_g2_29, (size_t)NWS * nv))) return bail(rc);
     if (zk->c_deep) {   // the sections again for 17-bit windows (15 x 64 B per wire and G1 section, 15 x 240 B for G2: 0.54 GB at nLevels = 160 beside the 0.8 GB of the 12-bit tables)
@@ -536,9 +544,9 @@ extern "C" int zkc_msm_debug(zkc_zkey* zk, int which, const void* d_scalars, uin
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device)); ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t full = which == 3 ? zk->nVars - zk->nPub - 1 : which == 4 ? zk->n : zk->nVars;
     if (count != full) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_msm_debug: count must equal the section size");
-    static thread_local MsmJobList jl; jl.clear();
+    static thread_local MsmJobList jl; jl.clear(256, 1024, which == 2 ? (uint32_t)MSM_MAX_VW_PER_JOB : (uint32_t)MSM_MAX_VW_G1);
     const uint32_t offs[5] = {zk->offA, zk->offB1, 0, zk->offC, zk->offH};
-    jl.add((const uint32_t*)d_scalars, nullptr, count, offs[which], full, 0, which == 4 ? MSM_C_BIG : zk->c_sec);
+    jl.add((const uint32_t*)d_scalars, nullptr, count, offs[which], full, 0, which == 4 ? zk->c_h : zk->c_sec);
     int rc = which == 2 ? msm_pass_g2(zk, L0.w2, jl, 0, true, L0.st) : msm_pass_g1(zk, L0.w1, jl, 0, true, L0.st); if (rc) return rc;
     ZKC_HIP_CHECK(ctx, hipStreamSynchronize(L0.st));
     if (which == 2) g2_to_std((uint8_t*)host_out, xyzz_to_affine(*(G2XYZZ*)L0.w2.h_results));
@@ -703,15 +711,15 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         const uint32_t oA = deep ? zk->offA_deep : zk->offA, oB1 = deep ? zk->offB1_deep : zk->offB1, oC = deep ? zk->offC_deep : zk->offC;
         const int c2 = (nb <= 2 && zk->d_g2_29_lone && lone_entries <= LN.w2.max_entries) ? MSM_C_G2_LONE : cs;
         static const uint32_t vwg2_env = [] { const char* e = getenv("ZKC_VW_G2"); return e ? (uint32_t)atoi(e) : 0u; }();      // A/B: the G2 jobs' window apart from the G1 sections'
-        j1.clear(vws, vwb); j2.clear(c2 == MSM_C_G2_LONE ? 128u : (vwg2_env && nb >= 32) ? vwg2_env : vws);
+        j1.clear(vws, vwb, MSM_MAX_VW_G1); j2.clear(c2 == MSM_C_G2_LONE ? 128u : (vwg2_env && nb >= 32) ? vwg2_env : vws, 1024, MSM_MAX_VW_PER_JOB);
         // job order of the G1 pass: the nb H jobs first (the 16-bit bucket sort wants the jobs with the larger bucket count in front), then
         // A, B1, C per proof.  zkc_finalize reads results[q] = H_q and results[nb + 3 q + {0, 1, 2}] = A_q, B1_q, C_q.
-        for (int q = 0; q < nb; q++) j1.add(LN.d_p + 8 * (size_t)n * q, nullptr, n, zk->offH, n, 0, MSM_C_BIG);
+        for (int q = 0; q < nb; q++) j1.add(LN.d_p + 8 * (size_t)n * q, nullptr, n, zk->offH, n, 0, zk->c_h);
         // [r3] a pass of one or two proofs carries its blinding's two variable-base products as two more MSM jobs each -- sum (s w_i) A_i and sum (r w_i) B1_i over the
         // wires that stay in the proof's MSMs -- so that the blinding kernel is left with fixed-base products only (zkc_finalize.hip)
         // (the lanes' work space is sized for max(4, passes of this key) proofs of 3 + 1 jobs each: two proofs of 5 + 1 fit unless ZKC_INFLIGHT made the passes smaller than that)
-        size_t tree_entries = 0; for (int q = 0; q < nb; q++) tree_entries += (size_t)msm_nw(MSM_C_BIG) * n + (size_t)msm_nw(zk->c_sec) * (listed ? 2 * (size_t)vms[q].nA + 2 * (size_t)vms[q].nB + vms[q].nC : 4 * (size_t)nv + nc);
-        const bool tree = zk->d_fb4 != nullptr && nb <= 2 && 6 * nb <= LN.w1.max_jobs && tree_entries <= LN.w1.max_entries && (size_t)nb * (5 * msm_half(zk->c_sec) + msm_half(MSM_C_BIG)) <= LN.w1.max_buckets;
+        size_t tree_entries = 0; for (int q = 0; q < nb; q++) tree_entries += (size_t)msm_nw(zk->c_h) * n + (size_t)msm_nw(zk->c_sec) * (listed ? 2 * (size_t)vms[q].nA + 2 * (size_t)vms[q].nB + vms[q].nC : 4 * (size_t)nv + nc);
+        const bool tree = zk->d_fb4 != nullptr && nb <= 2 && 6 * nb <= LN.w1.max_jobs && tree_entries <= LN.w1.max_entries && (size_t)nb * (5 * msm_half(zk->c_sec) + msm_half(zk->c_h)) <= LN.w1.max_buckets;
         BlindArgs ba{}; ba.rs = CS.d_rs + 64 * (size_t)p0; ba.nv = nv;
         for (int q = 0; q < nb; q++) {
             const uint32_t* w = w0 + (size_t)q * nv * 8;

@@ -13,6 +13,10 @@ constexpr int MSM_C_BIG = 17, MSM_C_SMALL = 12;
 // [r3] the G2 section of a pass of one or two proofs: 8-bit windows -> 32 additions per scalar into 128 buckets.  A lone proof's B2 MSM is ~5 000 scalars and its latency is the
 // bucket REDUCTION (2048 buckets: ~30 of the ~55 G2 additions in a row); with 128 buckets one wave reduces the job.  Costs a second pre-shifted G2 table (0.6 GB at nLevels 160).
 constexpr int MSM_C_G2_LONE = 8;
+// [r4] the window for an MSM of W full-width scalars: W x ceil(254 / c) mixed additions plus ~4 per bucket for the reduction (2^(c-1) buckets, two full additions each,
+// latency-shaped), so the best c grows with W.  Measured on circuit-shaped random R1CS (tools/gpu/csec_sweep.sh: proofs/s for c = 12 .. 17 at 15 k / 31 k / 62 k / 123 k / 246 k
+// wires per section): best 13 / 15 / 15 / 16 / 17; the 12 of rounds 1-3 is 15 % behind at 62 k wires, 17 is 3 % behind at 123 k.
+inline int msm_c_for(size_t W) { return W < 12000 ? 12 : W < 22000 ? 13 : W < 90000 ? 15 : W < 180000 ? 16 : 17; }
 constexpr int msm_nw(int c) { return (254 + c) / c; }          // 17 -> 15 windows (255 bits), 12 -> 22 windows (264 bits)
 constexpr int msm_half(int c) { return 1 << (c - 1); }         // buckets per job
 // buckets per workgroup of the reduction ("virtual window"): 1024 for H (64 waves per job; 512: 1496, 1024: 1548, 2048: 1505 proofs/s),
@@ -79,10 +83,12 @@ struct MsmJobList {
         MsmJob& j = job[njobs++];
         uint32_t vw = c >= 16 ? vw_big : vw_small;
         if (vw > (uint32_t)msm_half(c)) vw = (uint32_t)msm_half(c);          // a job never has less than one virtual window (ZKC_C_SECTIONS below 12 with the 2048-bucket windows of a full pass)
+        while ((uint32_t)msm_half(c) / vw > max_vw_per_job) vw <<= 1;        // ... and never more than the per-job sum takes (a lone G2 job of a 14- or 15-bit key without the 8-bit table)
         j = MsmJob{scalars, vmap, count, tbl_off, tbl_count, pt_shift, (uint32_t)c, (uint32_t)msm_nw(c), vw, total_entries, total_windows, 0, 0, 0, 0, 0, 0};
         total_entries += count * (uint32_t)msm_nw(c); total_windows += (uint32_t)msm_half(c) / vw;
     }
-    void clear(uint32_t vw_small_jobs = 256, uint32_t vw_big_jobs = 1024) { vw_small = vw_small_jobs; vw_big = vw_big_jobs; njobs = 0; total_buckets = total_entries = total_windows = total_bins = total_tiles = total_tilecnt = 0; hs = hb = nbig = 0; }
+    uint32_t max_vw_per_job = 256;                      // MSM_MAX_VW_G1 for a G1 list, MSM_MAX_VW_PER_JOB for a G2 list (clear)
+    void clear(uint32_t vw_small_jobs = 256, uint32_t vw_big_jobs = 1024, uint32_t max_per_job = 256) { vw_small = vw_small_jobs; vw_big = vw_big_jobs; max_vw_per_job = max_per_job; njobs = 0; total_buckets = total_entries = total_windows = total_bins = total_tiles = total_tilecnt = 0; hs = hb = nbig = 0; }
     // false: more than two distinct window sizes, big jobs not in front, or a table too large for the row field of the level-1 entry word
     bool finish() {
         hs = 0xffffffffu; hb = 0;
@@ -181,6 +187,7 @@ struct zkc_zkey {
     // whose witnesses do not fold at all) has 50-80 k wires per section instead of 8-11 k, and 15 additions per scalar into 65536 buckets then beat 22 into 2048.  0: not built
     int c_deep = 0; uint32_t offA_deep = 0, offB1_deep = 0, offC_deep = 0; uint32_t* d_g2_29_deep = nullptr;
     // per-proof work buffers
+    int c_h = zkc::MSM_C_BIG;                                                    // [r4] window bits of the H section of THIS key (17 for a census key, else by the domain size)
     int c_sec = zkc::MSM_C_SMALL;                                                // [r4] window bits of the witness sections A, B1, C, B2 of THIS key (zkc_zkey_load: 12, or 17 for sections of 2^16 wires and more)
     int max_inflight = 0;                                                   // proofs per pipeline pass (upper limit)
     int cur_inflight = 0;                                                   // what the lanes' work space is currently sized for (lanes_ensure)
