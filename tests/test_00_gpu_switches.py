@@ -2,7 +2,7 @@
 (`static const ... = getenv(...)`), so each configuration runs tests/host/prove_digest.py as a child process (started before this process needs the GPU for anything else) and the
 digests are compared.  What is covered: the two LDS-DMA forms of the G2 accumulation, the G2 accumulation held behind the transforms (round 2-3's order), the bucket reduction
 on its own stream, two pipeline lanes, round 1's reduction windows and odd ones, buildABC with products for the unit coefficients, unfolded passes with their infinity bases left
-in, the buildABC prefetch placements, the two-transform NTT, the one-stage head kernel, the 17-bit section tables of a deep pass, folding off.  This file sorts first on purpose (like the Node test): the children are started BEFORE this pytest
+in, the buildABC prefetch placements, the two-transform NTT, the one-stage head kernel, the second section tables of a deep pass, folding off.  This file sorts first on purpose (like the Node test): the children are started BEFORE this pytest
 process has initialised the GPU -- the GPU boxes refuse to start a program from a process that has."""
 import json, os, subprocess, sys
 import pytest

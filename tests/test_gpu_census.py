@@ -47,9 +47,9 @@ def test_poseidon_batch_and_census():
     ctx.close()
 
 
-def test_deep_pass_takes_the_17_bit_section_tables():
+def test_deep_pass_takes_the_second_section_tables():
     """[r4] A pass whose voters keep more than 30 000 wires per section (leaves at the bottom of both trees: nothing folds) runs its sections over the key's second,
-    17-bit-window tables: 15 instead of 22 additions per scalar.  Four voters 160 levels down and one 9 levels down in one call: proof bytes equal the oracle's, the
+    15-bit-window tables: 17 instead of 22 additions per scalar.  Four voters 160 levels down and one 9 levels down in one call: proof bytes equal the oracle's, the
     verifier accepts, and the device's count of G1 additions says which tables the pass took (H: 15 per scalar either way)."""
     import ctypes, json, random
     import zkcensus_amd
@@ -76,7 +76,7 @@ def test_deep_pass_takes_the_17_bit_section_tables():
     for q, (rc, op, ou) in enumerate(want):
         assert rc == 0 and (p_all[256 * q:256 * q + 256], u_all[256 * q:256 * q + 256]) == (op, ou), q
         assert ol.verify(vk, ou, op)
-    # 22 additions per section scalar: 6.55 M per deep proof; 15: about 5.1 M (H: 15 per scalar either way, 1.97 M)
+    # 22 additions per section scalar: 6.55 M per deep proof; 17: about 5.5 M (H: 15 per scalar either way, 1.97 M)
     assert n.value < 5 * 5.3e6, n.value
     # a deep pass and a shallow one (12-bit tables, 2048 buckets per section) in flight together on the key's two call slots, sixteen times: the two layouts of the lanes' work
     # space follow each other pass by pass, and every call gives the bytes it gives alone
