@@ -277,7 +277,7 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
         (rc = msm_precompute_g1(ctx, nc, zk->d_g1 + zk->offC, zk->c_sec)) || (rc = msm_precompute_g1(ctx, n, zk->d_g1 + zk->offH, zk->c_h)) ||
         (rc = msm_precompute_g2(ctx, nv, zk->d_g2, zk->c_sec))) return bail(rc);
     if ((rc = dmalloc(ctx, &zk->d_g2_29, 60 * (size_t)NWS * nv)) || (rc = msm_g2_table29(ctx, zk->d_g2, zk->d_g2_29, (size_t)NWS * nv))) return bail(rc);
-    if (zk->c_deep) {   // the sections again for 17-bit windows (15 x 64 B per wire and G1 section, 15 x 240 B for G2: 0.54 GB at nLevels = 160 beside the 0.8 GB of the 12-bit tables)
+    if (zk->c_deep) {   // the sections again for c_deep-bit windows (at nLevels = 160: 15 bits, 17 x 64 B per wire and G1 section, 17 x 240 B for G2: 0.6 GB beside the 0.8 GB of the 12-bit tables)
         ZKC_UP(zk->d_g1 + zk->offA_deep, sec[5], 64ull * nv); ZKC_UP(zk->d_g1 + zk->offB1_deep, sec[6], 64ull * nv); ZKC_UP(zk->d_g1 + zk->offC_deep, sec[8], 64ull * nc);
         if ((rc = msm_precompute_g1(ctx, nv, zk->d_g1 + zk->offA_deep, zk->c_deep)) || (rc = msm_precompute_g1(ctx, nv, zk->d_g1 + zk->offB1_deep, zk->c_deep)) ||
             (rc = msm_precompute_g1(ctx, nc, zk->d_g1 + zk->offC_deep, zk->c_deep))) return bail(rc);
@@ -290,7 +290,7 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
         if (e2 == hipSuccess && !rc) e2 = hipStreamSynchronize(ctx->stream);
         (void)hipFree(tmp);
         if (rc) return bail(rc);
-        if (e2 != hipSuccess) return bail(zkc_fail(ctx, ZKC_ERR_HIP, std::string("17-bit section tables: ") + hipGetErrorString(e2)));
+        if (e2 != hipSuccess) return bail(zkc_fail(ctx, ZKC_ERR_HIP, std::string("second section tables: ") + hipGetErrorString(e2)));
     }
     {   // [r3] the 8-bit-window G2 table of the lone-proof path (MSM_C_G2_LONE): shifted in a temporary affine table, kept in radix 2^29 only
         const char* e_lone = getenv("ZKC_G2_LONE_TABLE");
@@ -702,8 +702,8 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         // the G2 section of one or two proofs takes the 8-bit-window table: 128 buckets per job, reduced by one wave (vw = 128), if the G2 work space holds 32 entries per scalar
         size_t lone_entries = 0; for (int q = 0; q < nb; q++) lone_entries += (size_t)msm_nw(MSM_C_G2_LONE) * (listed ? vms[q].nB : nv);
         // [r4] deep pass: the voters of this pass keep, on average, more than ZKC_DEEP_WIRES (30 000) wires per section in their MSMs (leaves far down the trees, or witnesses that
-        // do not fold): the sections take the key's 17-bit tables.  Per section of W full-width scalars: 22 W + 2048 x 2.8 additions at 12 bits, 15 W + 65536 x 2.8 at 17 --
-        // even at W = 26 k; a census of 2^13 .. 2^20 voters keeps 8-11 k and stays at 12.
+        // do not fold): the sections take the key's second tables (c_deep bits: msm_c_for).  Per section of W full-width scalars: 22 W + 2048 x 4.2 additions at 12 bits,
+        // 17 W + 16384 x 4.2 at 15 -- even at W = 12 k; a census of 2^13 .. 2^20 voters keeps 8-11 k, and 30 000 leaves room for scalars that are not full width.
         static const size_t deep_wires = [] { const char* e = getenv("ZKC_DEEP_WIRES"); return e ? (size_t)atol(e) : (size_t)30000; }();
         size_t live_wires = 0; for (int q = 0; q < nb; q++) live_wires += listed ? (size_t)vms[q].nA + vms[q].nB + vms[q].nC : 2 * (size_t)nv + nc;
         const bool deep = zk->c_deep != 0 && nb > 2 && live_wires >= 3 * deep_wires * (size_t)nb;
