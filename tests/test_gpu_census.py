@@ -48,7 +48,7 @@ def test_poseidon_batch_and_census():
 
 
 def test_deep_pass_takes_the_second_section_tables():
-    """[r4] A pass whose voters keep more than 30 000 wires per section (leaves at the bottom of both trees: nothing folds) runs its sections over the key's second,
+    """[r4] A pass whose voters keep more than 16 000 wires per section (leaves at the bottom of both trees: nothing folds) runs its sections over the key's second,
     15-bit-window tables: 17 instead of 22 additions per scalar.  Four voters 160 levels down and one 9 levels down in one call: proof bytes equal the oracle's, the
     verifier accepts, and the device's count of G1 additions says which tables the pass took (H: 15 per scalar either way)."""
     import ctypes, json, random

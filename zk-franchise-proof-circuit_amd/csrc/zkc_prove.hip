@@ -701,10 +701,11 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         const uint32_t vws = nb <= 4 ? 64u : vws_env ? vws_env : nb < 32 ? 256u : 2048u, vwb = nb <= 4 ? 256u : vwb_env ? vwb_env : nb < 32 ? 1024u : 4096u;
         // the G2 section of one or two proofs takes the 8-bit-window table: 128 buckets per job, reduced by one wave (vw = 128), if the G2 work space holds 32 entries per scalar
         size_t lone_entries = 0; for (int q = 0; q < nb; q++) lone_entries += (size_t)msm_nw(MSM_C_G2_LONE) * (listed ? vms[q].nB : nv);
-        // [r4] deep pass: the voters of this pass keep, on average, more than ZKC_DEEP_WIRES (30 000) wires per section in their MSMs (leaves far down the trees, or witnesses that
+        // [r4] deep pass: the voters of this pass keep, on average, more than ZKC_DEEP_WIRES (16 000) wires per section in their MSMs (leaves far down the trees, or witnesses that
         // do not fold): the sections take the key's second tables (c_deep bits: msm_c_for).  Per section of W full-width scalars: 22 W + 2048 x 4.2 additions at 12 bits,
-        // 17 W + 16384 x 4.2 at 15 -- even at W = 12 k; a census of 2^13 .. 2^20 voters keeps 8-11 k, and 30 000 leaves room for scalars that are not full width.
-        static const size_t deep_wires = [] { const char* e = getenv("ZKC_DEEP_WIRES"); return e ? (size_t)atol(e) : (size_t)30000; }();
+        // 17 W + 16384 x 4.2 at 15: break-even at W = 12 k by that count, at 14 k measured (profiles/r04_deep_pass_threshold.json: voters 30 levels down; +1.4 % at 40 levels,
+        // +16 % at 160); a census of 2^13 .. 2^20 voters keeps 6-9 k and stays at 12 bits (-3 % if forced over the second tables).
+        static const size_t deep_wires = [] { const char* e = getenv("ZKC_DEEP_WIRES"); return e ? (size_t)atol(e) : (size_t)16000; }();
         size_t live_wires = 0; for (int q = 0; q < nb; q++) live_wires += listed ? (size_t)vms[q].nA + vms[q].nB + vms[q].nC : 2 * (size_t)nv + nc;
         const bool deep = zk->c_deep != 0 && nb > 2 && live_wires >= 3 * deep_wires * (size_t)nb;
         const int cs = deep ? zk->c_deep : zk->c_sec;
