@@ -242,7 +242,7 @@ def extra_legs(args, ctx, pk, zkey_bytes, vk, B, d_inputs, d_wtns, d_status, fla
                                        'same (r, s): proofs byte-identical to the folded ones of the timed step' % Bu,
                       'depth160_proofs_per_s': round(2 * Bd / dt_deep, 1), 'depth160_madds_per_proof': round(madds_deep), 'depth160_all_valid': bool(ok_deep),
                       'depth160_note': '%d voters whose leaves sit %d levels down both trees (every sibling non-zero), inputs -> witness -> proof through the SAME key as the headline: folding '
-                                       'stays enabled and removes only the old-key block' % (Bd, nl)}
+                                       'stays enabled and removes only the old-key block; such passes run their sections over the key\'s second (15-bit) tables (DESIGN.md section 3)' % (Bd, nl)}
     del dd_in, dd_w, dd_st
     # ---- isolated stage times: one pass, one stream ----
     Bs = min(B, int(os.environ.get('ZKC_INFLIGHT', '96')) - 2)
