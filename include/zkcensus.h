@@ -78,6 +78,14 @@ void zkc_sha256(const void* data, size_t len, uint8_t out[32]);
  * wtns   : B x n_wires x 32 B in the reference circuit.wasm's wire order (what .wtns section 2 holds)
  * status : B x int32 (ZKC_W_*).  Returns ZKC_ERR_WITNESS if any voter failed; the others are still valid. */
 int zkc_witness(zkc_ctx* ctx, int nLevels, const void* inputs, int B, void* wtns, int32_t* status);
+/* The inputs as the reference hands them over -- the TEXT of inputs_example.json (zk_census_test.go:85-89: prover.Prove's third argument is that file image;
+ * internal/inputs.go:14-31 is its schema; ts_inputs/src/example.ts:358 passes the same object to groth16.fullProve) -> the flat block above.  Reads the object the way
+ * circom_runtime 0.1.22's witness calculator does: the 12 names in any order, values as decimal strings, "0x" hex strings or integer literals of any length (with a sign),
+ * nested arrays flattened, everything reduced mod r.  Host only.  Returns ZKC_OK; ZKC_ERR_FORMAT: not a JSON object (err = where); ZKC_ERR_GENERIC with circom_runtime's
+ * message in err: "Signal <name> not found\n", "Too many values for input signal <name>\n", "Not enough values for input signal <name>\n", "Not all inputs have been set.
+ * Only <k> out of <n>", "Cannot convert <text> to a BigInt".  One extension: sibling lists shorter than nLevels + 1 are padded with zeros (the generators pad,
+ * internal/inputs.go:90-97; a caller that holds an arbo proof need not).  out: zkc_circuit_n_inputs(nLevels) x 32 B. */
+int zkc_inputs_from_json(const char* json, size_t len, int nLevels, void* out, char* err, size_t errlen);
 /* same with device-resident buffers (hipMalloc'ed or torch tensors), asynchronous on zkc_ctx_stream */
 int zkc_witness_dev(zkc_ctx* ctx, int nLevels, const void* d_inputs, int B, void* d_wtns, int32_t* d_status /* B */);
 
@@ -168,6 +176,11 @@ int zkc_service_fullprove(zkc_service* svc, const void* zkey, size_t zkey_len, i
                           uint8_t proof[256], uint8_t* publics /* nPublic x 32 B or NULL */, int32_t* status, char* err, size_t errlen);
 int zkc_service_prove(zkc_service* svc, const void* zkey, size_t zkey_len, const void* wtns /* nWitness x 32 B, host */, uint32_t nWitness, const uint8_t* rs,
                       uint8_t proof[256], uint8_t* publics, char* err, size_t errlen);
+/* prover.Prove(zkey, wasm, inputs) with the reference's three byte slices (zk_census_test.go:81-89): the circuit is named by the witness-calculator image as the reference's
+ * callers name it (its SHA-256 selects the native generator, zkc_circuit_nlevels_from_wasm; remembered per buffer, so the 3 MB hash is not taken per call) -- wasm NULL: by the
+ * key's own shape -- and the inputs are the JSON text (zkc_inputs_from_json).  Otherwise zkc_service_fullprove. */
+int zkc_service_fullprove_json(zkc_service* svc, const void* zkey, size_t zkey_len, const void* wasm, size_t wasm_len, const char* inputs_json, size_t inputs_len,
+                               const uint8_t* rs, uint8_t proof[256], uint8_t* publics, int32_t* status, char* err, size_t errlen);
 int zkc_service_submit_fullprove(zkc_service* svc, const void* zkey, size_t zkey_len, int nLevels, const void* inputs, const uint8_t* rs,
                                  uint8_t proof[256], uint8_t* publics, zkc_done_fn done, void* user);
 int zkc_service_submit_prove(zkc_service* svc, const void* zkey, size_t zkey_len, const void* wtns, uint32_t nWitness, const uint8_t* rs,
@@ -179,6 +192,10 @@ int zkc_service_stats(zkc_service* svc, uint64_t out[8]);
  * batch), [2] key check / load + top-up upload, [3] the batch call itself, [4] handing results back; [5] proofs, [6] batches, [7] keys evicted (a device keeps
  * $ZKC_SERVICE_KEYS keys resident, default 4, least recently used out first; the reference has one key per environment and depth, circuit/circuit-compiler.sh:15,82) */
 int zkc_service_timing(zkc_service* svc, uint64_t out[8]);
+/* what the service holds in memory NOW (bytes): out[0] resident keys over all devices, [1] their constant tables (pre-shifted bases, matrices, twiddles, folding tables),
+ * [2] their lanes' per-pass work space, [3] / [4] the same two for the largest key, [5] the workers' device staging (inputs, witnesses), [6] pinned host memory (staging +
+ * witness slots), [7] work-space reservations that failed so far (such a key grows on demand instead).  INTEGRATION.md section 5 has the figures per key at nLevels 160. */
+int zkc_service_memory(zkc_service* svc, uint64_t out[8]);
 
 /* ---- the rapidsnark entry point (go-rapidsnark prover.h `groth16_prover`, reached from prover.Prove at
  * zk_census_test.go:89): whole .zkey and .wtns file images in, NUL-terminated proof / public-signal JSON out.
@@ -189,8 +206,19 @@ int groth16_prover(const void* zkey_buffer, unsigned long zkey_size, const void*
                    char* proof_buffer, unsigned long* proof_size, char* public_buffer, unsigned long* public_size,
                    char* error_msg, unsigned long error_msg_maxsize);
 
+/* The same from the circuit INPUTS: what a cgo prover.Prove(zkey, wasm, inputs) calls in place of wasmer's witness calculator followed by groth16_prover
+ * (zk_census_test.go:89).  Three file images in -- .zkey, circuit.wasm (names the circuit; may be NULL: by the key's shape), inputs JSON --
+ * proof / public-signal JSON out, rapidsnark's return codes and buffer protocol.  A voter whose inputs fail a circuit assert: 1 with the wasm's own message
+ * ("Assert Failed.\nError in template ...") in error_msg; a malformed inputs object: 1 with circom_runtime's message. */
+int groth16_fullprove(const void* zkey_buffer, unsigned long zkey_size, const void* wasm_buffer, unsigned long wasm_size, const char* inputs_json, unsigned long inputs_size,
+                      char* proof_buffer, unsigned long* proof_size, char* public_buffer, unsigned long* public_size,
+                      char* error_msg, unsigned long error_msg_maxsize);
+
 /* ---- a9: verification on the CPU (replaces proof.Verify(vkey) zk_census_test.go:122 / snarkjs groth16.verify).
  * zkc_verify takes the texts of verification_key.json, signals.json and proof.json: 1 valid, 0 invalid, <0 = -ZKC_ERR_*.
+ * [r5] The three texts are parsed as JSON and must have the reference's shapes (objects / arrays of decimal strings, pi_a 3, pi_b 3 x 2, IC nPublic + 1; protocol
+ * "groth16" and curve "bn128" where present): anything Go's json.Unmarshal (prover.ParseProof, zk_census_test.go:118) or JSON.parse refuses is -ZKC_ERR_FORMAT, never 1.
+ * zkc_verify_last_error() is the text of the calling thread's LAST verify call (empty after a plain 0 or 1).
  * Never a positive value other than 1.  Proof points must be on their curves and B in the order-r subgroup of the twist (both
  * entry points, single and batch, apply the same membership checks); JSON points must have z = 1 (or 0 = infinity).
  * zkc_verify_bin takes vk = alpha1(64) beta2(128) gamma2(128) delta2(128) IC[nPublic+1](64 each), standard form. */

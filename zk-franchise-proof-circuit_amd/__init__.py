@@ -244,6 +244,12 @@ class ProvingService:
         self._lib.zkc_service_timing(self._h, out)
         return dict(zip(('us_upload', 'us_wait_gpu', 'us_key', 'us_prove', 'us_finish', 'proofs', 'batches', 'key_evictions'), [int(x) for x in out]))
 
+    def memory(self):
+        out = (ctypes.c_uint64 * 8)()
+        self._lib.zkc_service_memory(self._h, out)
+        return dict(zip(('resident_keys', 'table_bytes', 'work_bytes', 'largest_key_table_bytes', 'largest_key_work_bytes', 'staging_device_bytes', 'pinned_host_bytes', 'reserve_failures'),
+                        [int(x) for x in out]))
+
     def close(self):
         if getattr(self, '_h', None) and self._own:
             self._lib.zkc_service_destroy(self._h)

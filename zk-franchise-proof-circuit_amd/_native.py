@@ -89,6 +89,10 @@ def load():
     L.zkc_service_prove.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
     L.zkc_service_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.zkc_service_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    L.zkc_inputs_from_json.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+    L.zkc_service_fullprove_json.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, i32p, ctypes.c_char_p, ctypes.c_size_t]
+    L.groth16_fullprove.argtypes = [ctypes.c_char_p, ctypes.c_ulong, ctypes.c_char_p, ctypes.c_ulong, ctypes.c_char_p, ctypes.c_ulong, ctypes.c_char_p, ulp, ctypes.c_char_p, ulp, ctypes.c_char_p, ctypes.c_ulong]
+    L.zkc_service_memory.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.zkc_service_submit_fullprove.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, vp, vp]
     _lib = L
     return L

@@ -114,6 +114,13 @@ static void conv_consts(std::vector<Fr>& out, const unsigned long long (&src)[N]
     }
 }
 
+// [r5] Hardware queues.  ROCm maps a process' HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and a queue executes in order: a stream whose queue also
+// carries another stream's pending barrier packet (a hipStreamWaitEvent that has not fired) runs behind it.  This pipeline keeps seven to sixteen streams busy with cross-
+// stream waits; on four queues the batch path lost 5 % (3104 -> 3267 proofs/s with 8, same box) and the proving service's lanes ran one after another instead of side by
+// side (profiles/r05_service_hw_queues.txt).  The variable is read when the HIP runtime initialises, so it is set here, at library load, unless the host has set it; a host
+// that initialises HIP before loading this library (or wants another value) sets GPU_MAX_HW_QUEUES itself -- bench.py and the N-API addon do.
+__attribute__((constructor)) static void zkc_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 extern "C" int zkc_ctx_create(int device, zkc_ctx** out) {
     if (!out) return zkc_fail(nullptr, ZKC_ERR_BAD_ARG, "out == NULL");
     int ndev = 0;
@@ -125,6 +132,10 @@ extern "C" int zkc_ctx_create(int device, zkc_ctx** out) {
     auto fail = [&](hipError_t e, const char* what) { g_create_err = std::string(what) + ": " + hipGetErrorString(e); delete ctx; return (int)ZKC_ERR_HIP; };
     hipError_t e;
     if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
+    // [r5] host threads that wait for this device SLEEP (hipStreamSynchronize and friends yield to the driver's interrupt instead of spinning on a flag): a rank of an
+    // 8-GPU run has two cores' worth of CPU time on these boxes (cpu.max = 16 cores for the container, profiles/r04_cpu_baseline_scaling.json).  Best effort -- a host that
+    // has already initialised the device with other flags (torch) keeps them; the events this library waits on carry hipEventBlockingSync themselves.  ZKC_SPIN_WAIT=1: leave the default.
+    { const char* eb = getenv("ZKC_DEVICE_BLOCKING_SYNC"); if (eb && atoi(eb) == 1 && hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError(); }
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
     if ((e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate(2)");
     if ((e = hipStreamCreateWithFlags(&ctx->fin_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate(fin)");
@@ -184,10 +195,19 @@ extern "C" void zkc_ctx_destroy(zkc_ctx* ctx) {
     if (ctx->d_status3) (void)hipFree(ctx->d_status3);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_prof_entries) (void)hipFree(ctx->d_prof_entries);
+    for (auto& ls : ctx->lane_streams) for (hipStream_t q : {ls.st, ls.st2, ls.fin, ls.red}) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->fin_stream) (void)hipStreamDestroy(ctx->fin_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+// the three streams of lane l of this context (buildABC / NTT / G1 MSM ; G2 MSM ; blinding + D2H), created on first use; with_red: the optional bucket-reduction stream too
+int zkc_lane_streams(zkc_ctx* ctx, int l, bool with_red, zkc_ctx::LaneStreams* out) {
+    if (!ctx || l < 0 || l >= 4 || !out) return ZKC_ERR_BAD_ARG;
+    zkc_ctx::LaneStreams& ls = ctx->lane_streams[l];
+    for (hipStream_t* q : {&ls.st, &ls.st2, &ls.fin}) if (!*q) ZKC_HIP_CHECK(ctx, hipStreamCreateWithFlags(q, hipStreamNonBlocking));
+    if (with_red && !ls.red) ZKC_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ls.red, hipStreamNonBlocking));
+    *out = ls; return ZKC_OK;
 }
 extern "C" const char* zkc_last_error(const zkc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 extern "C" void* zkc_ctx_stream(zkc_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
@@ -219,30 +239,32 @@ uint32_t* zkc_get_template(zkc_ctx* ctx, int nLevels) {
     return get_template(ctx, L, &t) == ZKC_OK ? t : nullptr;
 }
 
-static int witness_dev3(zkc_ctx* ctx, const WitnessLayout& L, const void* d_inputs, int B, void* d_wtns, int32_t* d_status3, bool alone) {
+static int witness_dev3(zkc_ctx* ctx, const WitnessLayout& L, const void* d_inputs, int B, void* d_wtns, int32_t* d_status3, bool alone, hipStream_t st = nullptr) {
+    if (!st) st = ctx->stream;
     uint32_t* tmpl; int rc = get_template(ctx, L, &tmpl); if (rc) return rc;
     const size_t total = (size_t)L.nWires * 2 * (size_t)B;
     int fill_blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 16);
-    zkc_prof_scope _ps(ctx, ZKC_PROF_WITNESS, (uint64_t)B * ((uint64_t)L.nWires + L.nInputs) * 32);
-    hipLaunchKernelGGL(zkc_witness_fill, dim3(fill_blocks), dim3(256), 0, ctx->stream, (const uint4*)tmpl, (uint4*)d_wtns, L.nWires, B);
+    zkc_prof_scope _ps(ctx, ZKC_PROF_WITNESS, (uint64_t)B * ((uint64_t)L.nWires + L.nInputs) * 32, st);
+    hipLaunchKernelGGL(zkc_witness_fill, dim3(fill_blocks), dim3(256), 0, st, (const uint4*)tmpl, (uint4*)d_wtns, L.nWires, B);
     ZKC_HIP_CHECK(ctx, hipGetLastError());
     if (B <= (alone ? ZKC_WITNESS_WAVE_MAX_B_ALONE : ZKC_WITNESS_WAVE_MAX_B))             // one wave per (voter, chain): latency form
-        hipLaunchKernelGGL(zkc_witness_chains_wave, dim3(3 * B), dim3(64), 0, ctx->stream, L, ctx->ptab, (const uint32_t*)d_inputs, (uint32_t*)d_wtns, d_status3, B, 0);
+        hipLaunchKernelGGL(zkc_witness_chains_wave, dim3(3 * B), dim3(64), 0, st, L, ctx->ptab, (const uint32_t*)d_inputs, (uint32_t*)d_wtns, d_status3, B, 0);
     else                                         // one lane per (voter, chain), lanes of a wave share the chain kind when B % 64 == 0 (harmless otherwise): throughput form
-        hipLaunchKernelGGL(zkc_witness_chains, dim3((3 * B + 63) / 64), dim3(64), 0, ctx->stream, L, ctx->ptab, (const uint32_t*)d_inputs, (uint32_t*)d_wtns, d_status3, B, 0);
+        hipLaunchKernelGGL(zkc_witness_chains, dim3((3 * B + 63) / 64), dim3(64), 0, st, L, ctx->ptab, (const uint32_t*)d_inputs, (uint32_t*)d_wtns, d_status3, B, 0);
     {   // the chains leave their wires in Montgomery form, marked: convert them (every lane busy, unlike the chains)
         const size_t nw = (size_t)L.nWires * (size_t)B;
-        hipLaunchKernelGGL(zkc_witness_tostd, dim3((unsigned)std::min<size_t>((nw + 255) / 256, 256 * 64)), dim3(256), 0, ctx->stream, (uint32_t*)d_wtns, nw);
+        hipLaunchKernelGGL(zkc_witness_tostd, dim3((unsigned)std::min<size_t>((nw + 255) / 256, 256 * 64)), dim3(256), 0, st, (uint32_t*)d_wtns, nw);
     }
     ZKC_HIP_CHECK(ctx, hipGetLastError());
     return ZKC_OK;
 }
 
 // one chunk of voters, enqueued on ctx->stream without any synchronisation (the full-prove pipeline of zkc_prove.hip issues a chunk per pass)
-int zkc_witness_chunk_async(zkc_ctx* ctx, int nLevels, const void* d_inputs, int B, void* d_wtns, int32_t* d_status3, int32_t* d_status) {
+int zkc_witness_chunk_async(zkc_ctx* ctx, int nLevels, const void* d_inputs, int B, void* d_wtns, int32_t* d_status3, int32_t* d_status, hipStream_t st) {
+    if (!st) st = ctx->stream;
     WitnessLayout L = WitnessLayout::make(nLevels);
-    int rc = witness_dev3(ctx, L, d_inputs, B, d_wtns, d_status3, false); if (rc) return rc;
-    hipLaunchKernelGGL(zkc_status_combine, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, d_status3, d_status, B);
+    int rc = witness_dev3(ctx, L, d_inputs, B, d_wtns, d_status3, false, st); if (rc) return rc;
+    hipLaunchKernelGGL(zkc_status_combine, dim3((B + 255) / 256), dim3(256), 0, st, d_status3, d_status, B);
     ZKC_HIP_CHECK(ctx, hipGetLastError());
     return ZKC_OK;
 }

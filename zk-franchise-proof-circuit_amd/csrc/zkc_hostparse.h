@@ -11,6 +11,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include "zkc_json.h"
 
 namespace zkc { namespace parse {
 
@@ -96,62 +97,168 @@ inline std::string dec_of(const uint8_t* p) {
     while (nz) { uint64_t rem = 0; nz = false; for (int i = 7; i >= 0; i--) { uint64_t cur = (rem << 32) | s[i]; s[i] = (uint32_t)(cur / 10); rem = cur % 10; if (s[i]) nz = true; } out.push_back((char)('0' + rem)); }
     return std::string(out.rbegin(), out.rend());
 }
-// collects every string found under key `key` (nullptr: the document itself), flattened in document order
-inline bool json_strings_under(const std::string& js, const char* key, std::vector<std::string>& out) {
-    size_t k = key ? js.find(std::string("\"") + key + "\"") : 0;
-    if (k == std::string::npos) return false;
-    size_t p = key ? js.find(':', k) : 0; if (p == std::string::npos) return false;
-    if (key) p++;
-    while (p < js.size() && (js[p] == ' ' || js[p] == '\n' || js[p] == '\t' || js[p] == '\r')) p++;
-    if (p >= js.size()) return false;
-    if (js[p] == '"') { size_t e = js.find('"', p + 1); if (e == std::string::npos) return false; out.push_back(js.substr(p + 1, e - p - 1)); return true; }
-    if (js[p] != '[') return false;
-    int depth = 0;
-    for (; p < js.size(); p++) {
-        if (js[p] == '[') depth++;
-        else if (js[p] == ']') { if (--depth == 0) return true; }
-        else if (js[p] == '"') { size_t e = js.find('"', p + 1); if (e == std::string::npos) return false; out.push_back(js.substr(p + 1, e - p - 1)); p = e; }
-    }
-    return false;
-}
-// JSON projective points as snarkjs writes them: G1 [x, y, z], G2 [[x0,x1],[y0,y1],[z0,z1]] with z = 1 (affine) or 0 (infinity).
+// JSON projective points as snarkjs writes them: G1 [x, y, z], G2 [[x0,x1],[y0,y1],[z0,z1]] with z = 1 (affine) or 0 (infinity), every coordinate a decimal STRING.
 // Any other z is rejected: the artifacts never carry one, and silently treating it as affine would accept a different point.
-inline bool put_g1_json(const std::vector<std::string>& v, size_t at, uint8_t* out) {
-    uint32_t z[8]; if (at + 3 > v.size() || !dec_to_std(v[at + 2], z)) return false;
-    uint32_t hi = 0; for (int i = 1; i < 8; i++) hi |= z[i];
-    if (hi || z[0] > 1) return false;
-    if (z[0] == 0) { memset(out, 0, 64); return true; }
-    uint32_t s[8]; if (!dec_to_std(v[at], s)) return false; memcpy(out, s, 32);
-    if (!dec_to_std(v[at + 1], s)) return false; memcpy(out + 32, s, 32); return true;
+// Each returns 1 = read, 0 = the right shape with a value that is no point encoding (not decimal, >= 2^256, another z): an invalid proof; -1 = the wrong SHAPE (not an
+// array of the right length of strings): a malformed document, which encoding/json would refuse to unmarshal (zk_census_test.go:118)
+inline int strs_of(const json::Value& v, size_t n, const std::string** out) {
+    if (v.type != json::Value::Array || v.a.size() != n) return -1;
+    for (size_t i = 0; i < n; i++) { if (v.a[i].type != json::Value::String) return -1; out[i] = &v.a[i].s; }
+    return 1;
 }
-inline bool put_g2_json(const std::vector<std::string>& v, size_t at, uint8_t* out) {
-    uint32_t z0[8], z1[8]; if (at + 6 > v.size() || !dec_to_std(v[at + 4], z0) || !dec_to_std(v[at + 5], z1)) return false;
+inline int put_g1_json(const json::Value& v, uint8_t* out) {
+    const std::string* c[3]; if (strs_of(v, 3, c) < 0) return -1;
+    uint32_t z[8]; if (!dec_to_std(*c[2], z)) return 0;
+    uint32_t hi = 0; for (int i = 1; i < 8; i++) hi |= z[i];
+    if (hi || z[0] > 1) return 0;
+    if (z[0] == 0) { memset(out, 0, 64); return 1; }
+    uint32_t s[8]; if (!dec_to_std(*c[0], s)) return 0; memcpy(out, s, 32);
+    if (!dec_to_std(*c[1], s)) return 0; memcpy(out + 32, s, 32); return 1;
+}
+inline int put_g2_json(const json::Value& v, uint8_t* out) {
+    if (v.type != json::Value::Array || v.a.size() != 3) return -1;
+    const std::string* c[6];
+    for (int k = 0; k < 3; k++) if (strs_of(v.a[k], 2, c + 2 * k) < 0) return -1;
+    uint32_t z0[8], z1[8]; if (!dec_to_std(*c[4], z0) || !dec_to_std(*c[5], z1)) return 0;
     uint32_t hi = 0; for (int i = 1; i < 8; i++) hi |= z0[i]; for (int i = 0; i < 8; i++) hi |= z1[i];
-    if (hi || z0[0] > 1) return false;
-    if (z0[0] == 0) { memset(out, 0, 128); return true; }
-    for (int k = 0; k < 4; k++) { uint32_t s[8]; if (!dec_to_std(v[at + k], s)) return false; memcpy(out + 32 * k, s, 32); }
+    if (hi || z0[0] > 1) return 0;
+    if (z0[0] == 0) { memset(out, 0, 128); return 1; }
+    for (int k = 0; k < 4; k++) { uint32_t s[8]; if (!dec_to_std(*c[k], s)) return 0; memcpy(out + 32 * k, s, 32); }
+    return 1;
+}
+// "protocol" / "curve" as snarkjs writes them into verification_key.json and proof.json: where present they must say groth16 / bn128 (go-rapidsnark's types carry
+// both; a key or proof of another scheme or curve is not something this verifier can speak to)
+inline bool scheme_ok(const json::Value& doc, const char* what, std::string& err) {
+    const json::Value* p = doc.find("protocol"); const json::Value* c = doc.find("curve");
+    if (p && (p->type != json::Value::String || p->s != "groth16")) { err = std::string(what) + ": protocol is not \"groth16\""; return false; }
+    if (c && (c->type != json::Value::String || (c->s != "bn128" && c->s != "bn254" && c->s != "BN128" && c->s != "BN254" && c->s != "altbn128"))) { err = std::string(what) + ": curve is not \"bn128\""; return false; }
     return true;
 }
-// verification_key.json + signals.json + proof.json texts -> the binary layouts of zkc_verify_bin.
-// returns 1 ok, 0 = proof / signals malformed (an invalid proof), -1 = verification key malformed (err set)
+// verification_key.json + signals.json + proof.json texts -> the binary layouts of zkc_verify_bin.  [r5] The three are PARSED as JSON (zkc_json.h) and must have the
+// reference's shapes exactly: round 4 collected quoted strings and ignored everything between them, so a document with stray tokens, a damaged member name or a missing
+// comma still verified where prover.ParseProof's json.Unmarshal (zk_census_test.go:118) and snarkjs's JSON.parse refuse it.
+// returns 1 ok, 0 = well-formed documents whose VALUES are no valid encoding (an invalid proof), -1 = a malformed document (err set)
 inline int verify_inputs_from_json(const std::string& vk, const std::string& pj, const std::string& pr, std::vector<uint8_t>& vkb, std::vector<uint8_t>& pubb,
                                    std::vector<uint8_t>& prb, int& nPublic, std::string& err) {
-    std::vector<std::string> a1, b2, g2, d2, ic, pub, pa, pb, pc;
-    if (!json_strings_under(vk, "vk_alpha_1", a1) || !json_strings_under(vk, "vk_beta_2", b2) || !json_strings_under(vk, "vk_gamma_2", g2) ||
-        !json_strings_under(vk, "vk_delta_2", d2) || !json_strings_under(vk, "IC", ic)) { err = "verification key JSON: missing member"; return -1; }
-    if (!json_strings_under(pj, nullptr, pub)) { err = "public signals JSON: expected an array of decimal strings"; return -1; }
-    if (!json_strings_under(pr, "pi_a", pa) || !json_strings_under(pr, "pi_b", pb) || !json_strings_under(pr, "pi_c", pc)) { err = "proof JSON: missing member"; return -1; }
-    const size_t np = pub.size();
-    if (np > 4096 || ic.size() != 3 * (np + 1)) { err = "verification key: IC length does not match the public signals"; return -1; }
+    json::Value jv, jp, jr; std::string perr;
+    if (!json::parse(vk.data(), vk.size(), jv, perr)) { err = "verification key: " + perr; return -1; }
+    if (!json::parse(pj.data(), pj.size(), jp, perr)) { err = "public signals: " + perr; return -1; }
+    if (!json::parse(pr.data(), pr.size(), jr, perr)) { err = "proof: " + perr; return -1; }
+    if (jv.type != json::Value::Object) { err = "verification key JSON: expected an object"; return -1; }
+    if (jr.type != json::Value::Object) { err = "proof JSON: expected an object"; return -1; }
+    if (jp.type != json::Value::Array) { err = "public signals JSON: expected an array of decimal strings"; return -1; }
+    for (auto& x : jp.a) if (x.type != json::Value::String) { err = "public signals JSON: expected an array of decimal strings"; return -1; }
+    if (!scheme_ok(jv, "verification key JSON", err) || !scheme_ok(jr, "proof JSON", err)) return -1;
+    const json::Value *a1 = jv.find("vk_alpha_1"), *b2 = jv.find("vk_beta_2"), *g2 = jv.find("vk_gamma_2"), *d2 = jv.find("vk_delta_2"), *ic = jv.find("IC"), *npub = jv.find("nPublic");
+    const json::Value *pa = jr.find("pi_a"), *pb = jr.find("pi_b"), *pc = jr.find("pi_c");
+    if (!a1 || !b2 || !g2 || !d2 || !ic) { err = "verification key JSON: missing member"; return -1; }
+    if (!pa || !pb || !pc) { err = "proof JSON: missing member"; return -1; }
+    const size_t np = jp.a.size();
+    if (ic->type != json::Value::Array || np > 4096 || ic->a.size() != np + 1) { err = "verification key: IC length does not match the public signals"; return -1; }
+    if (npub && (npub->type != json::Value::Number || npub->s != std::to_string(np))) { err = "verification key: nPublic does not match the public signals"; return -1; }
     vkb.assign(448 + 64 * (np + 1), 0); pubb.assign(32 * np + 1, 0); prb.assign(256, 0);
-    if (!put_g1_json(a1, 0, vkb.data()) || !put_g2_json(b2, 0, vkb.data() + 64) || !put_g2_json(g2, 0, vkb.data() + 192) || !put_g2_json(d2, 0, vkb.data() + 320)) {
+    if (put_g1_json(*a1, vkb.data()) != 1 || put_g2_json(*b2, vkb.data() + 64) != 1 || put_g2_json(*g2, vkb.data() + 192) != 1 || put_g2_json(*d2, vkb.data() + 320) != 1) {
         err = "verification key JSON: bad point"; return -1;
     }
-    for (size_t i = 0; i <= np; i++) if (!put_g1_json(ic, 3 * i, vkb.data() + 448 + 64 * i)) { err = "verification key JSON: bad IC point"; return -1; }
+    for (size_t i = 0; i <= np; i++) if (put_g1_json(ic->a[i], vkb.data() + 448 + 64 * i) != 1) { err = "verification key JSON: bad IC point"; return -1; }
     nPublic = (int)np;
-    for (size_t i = 0; i < np; i++) { uint32_t s[8]; if (!dec_to_std(pub[i], s)) return 0; memcpy(pubb.data() + 32 * i, s, 32); }
-    if (!put_g1_json(pa, 0, prb.data()) || !put_g2_json(pb, 0, prb.data() + 64) || !put_g1_json(pc, 0, prb.data() + 192)) return 0;
+    const int ra = put_g1_json(*pa, prb.data()), rb = put_g2_json(*pb, prb.data() + 64), rc = put_g1_json(*pc, prb.data() + 192);
+    if (ra < 0 || rb < 0 || rc < 0) { err = "proof JSON: pi_a / pi_c must be three decimal strings, pi_b three pairs"; return -1; }
+    for (size_t i = 0; i < np; i++) { uint32_t s[8]; if (!dec_to_std(jp.a[i].s, s)) return 0; memcpy(pubb.data() + 32 * i, s, 32); }
+    if (ra == 0 || rb == 0 || rc == 0) return 0;
     return 1;
+}
+
+// ---- circuit inputs as the reference hands them over: the text of inputs_example.json (zk_census_test.go:85-89, prover.Prove's third argument; internal/inputs.go:14-31
+// is its schema) -> the flat block of the C ABI, census.circom:51-67 declaration order, 32-byte little-endian values reduced mod r.  What circom_runtime 0.1.22's
+// witness calculator does with the parsed object (witness_calculator.js _doCalculateWitness: flatArray, normalize = BigInt(v) mod r), with its messages:
+//   a name that is no input signal of the circuit      "Signal <name> not found\n"
+//   more values than the signal has                    "Too many values for input signal <name>\n"
+//   fewer (other than a sibling list, see below)       "Not enough values for input signal <name>\n"
+//   signals left unset at the end                      "Not all inputs have been set. Only <k> out of <n>"
+//   a value BigInt() would not take                    "Cannot convert <text> to a BigInt"
+// Values: decimal strings (what the reference's generators write, internal/inputs.go:82-97), "0x" hex strings and integer literals of any length (not rounded through a
+// double), with a sign; nested arrays are flattened.  One deliberate extension, kept from rounds 1-4's hosts: censusSiblings / sikSiblings shorter than nLevels + 1 are
+// padded with zeros (an arbo proof has as many siblings as the leaf is deep; the generators pad, inputs.go:90-97, callers need not).
+inline const char* const* circuit_input_names() {
+    static const char* const k[12] = {"electionId", "nullifier", "availableWeight", "voteHash", "sikRoot", "censusRoot", "address", "password", "signature", "voteWeight", "censusSiblings", "sikSiblings"};
+    return k;
+}
+inline void fr_addmod(uint64_t a[4], const uint64_t b[4]) {                      // a = a + b mod r, a, b < r
+    static const uint64_t R[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+    unsigned __int128 c = 0; uint64_t t[4];
+    for (int i = 0; i < 4; i++) { c += (unsigned __int128)a[i] + b[i]; t[i] = (uint64_t)c; c >>= 64; }
+    uint64_t d[4]; unsigned __int128 br = 0;
+    for (int i = 0; i < 4; i++) { const unsigned __int128 x = (unsigned __int128)t[i] - R[i] - (uint64_t)br; d[i] = (uint64_t)x; br = (x >> 64) & 1; }
+    const bool ge = c != 0 || br == 0;
+    for (int i = 0; i < 4; i++) a[i] = ge ? d[i] : t[i];
+}
+// text of an integer (decimal, or 0x / 0X hex; optional sign) -> its residue mod r as 32 little-endian bytes; false: BigInt() would throw
+inline bool integer_mod_r(const std::string& txt, uint8_t out[32]) {
+    size_t i = 0; bool neg = false;
+    while (i < txt.size() && (txt[i] == ' ' || txt[i] == '\t' || txt[i] == '\n' || txt[i] == '\r')) i++;      // BigInt("  12 ") = 12n
+    size_t e = txt.size(); while (e > i && (txt[e - 1] == ' ' || txt[e - 1] == '\t' || txt[e - 1] == '\n' || txt[e - 1] == '\r')) e--;
+    if (i == e) { memset(out, 0, 32); return true; }                             // BigInt("") = 0n
+    bool sign = false;
+    if (txt[i] == '-' || txt[i] == '+') { sign = true; neg = txt[i] == '-'; i++; }
+    const bool hex = e - i > 2 && txt[i] == '0' && (txt[i + 1] == 'x' || txt[i + 1] == 'X');
+    if (hex) { if (sign) return false; i += 2; }                                   // BigInt("-0x1") throws
+    if (i == e) return false;
+    uint64_t acc[4] = {0, 0, 0, 0};
+    for (; i < e; i++) {
+        const char ch = txt[i]; int dgt;
+        if (ch >= '0' && ch <= '9') dgt = ch - '0';
+        else if (hex && ch >= 'a' && ch <= 'f') dgt = ch - 'a' + 10;
+        else if (hex && ch >= 'A' && ch <= 'F') dgt = ch - 'A' + 10;
+        else return false;
+        uint64_t x2[4], x8[4]; memcpy(x2, acc, 32); fr_addmod(x2, acc);          // 2 acc
+        memcpy(x8, x2, 32); fr_addmod(x8, x2); fr_addmod(x8, x8);               // 8 acc
+        if (hex) { fr_addmod(x8, x8); memcpy(acc, x8, 32); }                     // 16 acc
+        else { fr_addmod(x8, x2); memcpy(acc, x8, 32); }                         // 10 acc
+        const uint64_t dd[4] = {(uint64_t)dgt, 0, 0, 0}; fr_addmod(acc, dd);
+    }
+    if (neg && (acc[0] | acc[1] | acc[2] | acc[3])) {
+        static const uint64_t R[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+        unsigned __int128 br = 0;
+        for (int k = 0; k < 4; k++) { const unsigned __int128 x = (unsigned __int128)R[k] - acc[k] - (uint64_t)br; acc[k] = (uint64_t)x; br = (x >> 64) & 1; }
+    }
+    memcpy(out, acc, 32); return true;
+}
+// a JSON number token that is an integer (no fraction, no exponent other than one that leaves an integer: kept simple -- digits only) -> true
+inline bool flatten_input_value(const json::Value& v, std::vector<const json::Value*>& out, int depth = 0) {
+    if (v.type == json::Value::Array) { if (depth > 8) return false; for (auto& x : v.a) if (!flatten_input_value(x, out, depth + 1)) return false; return true; }
+    out.push_back(&v); return true;
+}
+// returns ZKC_OK-style 0 on success; 1 = malformed JSON / not an object, 2 = a circuit-input error (err = circom_runtime's message)
+inline int circuit_inputs_from_json(const char* text, size_t len, int nLevels, uint8_t* out, std::string& err) {
+    json::Value doc; std::string perr;
+    if (!json::parse(text, len, doc, perr)) { err = perr; return 1; }
+    if (doc.type != json::Value::Object) { err = "JSON: the circuit inputs must be an object"; return 1; }
+    const char* const* names = circuit_input_names();
+    const size_t nsib = (size_t)nLevels + 1, total = 12 + 2 * nsib;
+    size_t size_of[12], off_of[12]; { size_t o = 0; for (int k = 0; k < 12; k++) { size_of[k] = (k == 0 || k == 3) ? 2 : k >= 10 ? nsib : 1; off_of[k] = o; o += size_of[k]; } }
+    bool seen[12] = {false}; size_t set = 0;
+    memset(out, 0, 32 * total);
+    for (auto& kv : doc.o) {
+        int k = -1; for (int i = 0; i < 12; i++) if (kv.first == names[i]) k = i;
+        if (k < 0) { err = "Signal " + kv.first + " not found\n"; return 2; }
+        std::vector<const json::Value*> vals;
+        if (!flatten_input_value(kv.second, vals)) { err = "Too many values for input signal " + kv.first + "\n"; return 2; }
+        if (vals.size() > size_of[k]) { err = "Too many values for input signal " + kv.first + "\n"; return 2; }
+        if (vals.size() < size_of[k] && k < 10) { err = "Not enough values for input signal " + kv.first + "\n"; return 2; }
+        if (seen[k]) memset(out + 32 * off_of[k], 0, 32 * size_of[k]);         // a repeated name: the last one stands (JSON.parse)
+        for (size_t i = 0; i < vals.size(); i++) {
+            const json::Value& x = *vals[i]; bool ok;
+            if (x.type == json::Value::String) ok = integer_mod_r(x.s, out + 32 * (off_of[k] + i));
+            else if (x.type == json::Value::Number) { ok = x.s.find_first_of(".eE") == std::string::npos && integer_mod_r(x.s, out + 32 * (off_of[k] + i)); }
+            else if (x.type == json::Value::Bool) { memset(out + 32 * (off_of[k] + i), 0, 32); out[32 * (off_of[k] + i)] = x.b ? 1 : 0; ok = true; }      // BigInt(true) = 1n
+            else ok = false;
+            if (!ok) { err = "Cannot convert " + (x.type == json::Value::Null ? std::string("null") : x.type == json::Value::Object ? std::string("[object Object]") : x.s) + " to a BigInt"; return 2; }
+        }
+        if (!seen[k]) { seen[k] = true; set += size_of[k]; }
+    }
+    if (set < total) { err = "Not all inputs have been set. Only " + std::to_string(set) + " out of " + std::to_string(total); return 2; }
+    return 0;
 }
 
 // ---- SHA-256 (FIPS 180-4) ----

@@ -30,6 +30,10 @@ struct zkc_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;        // G2 MSM pipeline (independent of buildABC/NTT): overlaps the G1 pipeline
     hipStream_t fin_stream = nullptr;     // blinding kernel + proof D2H, overlapping the next pipeline pass
+    // [r5] the stream sets of the pipeline lanes belong to the CONTEXT, not to a key: every key of the context runs its lane l on the same three streams.  Streams are a
+    // device resource -- each takes a hardware queue (or a share of one: GPU_MAX_HW_QUEUES), and a stream that shares its queue with another stream's barrier packet waits
+    // behind it -- so four resident keys must not mean four times the streams.  Created on first use (zkc_lane_streams), destroyed with the context.
+    struct LaneStreams { hipStream_t st = nullptr, st2 = nullptr, fin = nullptr, red = nullptr; } lane_streams[4];
     std::string err;
     zkc::PoseidonTable ptab{};            // device pointers
     void* d_ptab_mem = nullptr;

@@ -55,6 +55,7 @@ void g2_to_std(uint8_t* out, const G2Affine& a) {
 }  // namespace
 
 uint32_t* zkc_get_template(zkc_ctx* ctx, int nLevels);     // zkc_api.hip: device template witness (nullptr on error)
+int zkc_lane_streams(zkc_ctx* ctx, int l, bool with_red, zkc_ctx::LaneStreams* out);      // zkc_api.hip
 
 // ---- fold check: for every proof and every foldable group, does the witness equal the template there? ----
 // group g of a tree block = level g's non-control wires (g < n-1) ; group n-1 = the n2bOld block
@@ -96,18 +97,16 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     ZKC_LOCK(zk->ctx);
     (void)hipSetDevice(zk->ctx->device);
     (void)hipStreamSynchronize(zk->ctx->stream);
-    void* ptrs[] = {zk->d_perm, zk->d_rowlen, zk->d_jdptr, zk->d_col, zk->d_val, zk->d_tw_fwd, zk->d_tw_inv, zk->d_tw_fwd29, zk->d_tw_inv29, zk->d_coset, zk->d_coset_br, zk->d_g1, zk->d_g2, zk->d_g2_29, zk->d_g2_29_lone, zk->d_g2_29_deep, zk->d_flags,
-                    zk->d_tblDelta1, zk->d_tblAlpha1, zk->d_tblBeta1, zk->d_tblDelta2, zk->d_fb4, zk->d_fb4g2, zk->d_depths, zk->call[0].d_rs, zk->call[0].d_proofs, zk->call[1].d_rs, zk->call[1].d_proofs};
+    void* ptrs[] = {zk->d_perm, zk->d_rowlen, zk->d_jdptr, zk->d_col, zk->d_val, zk->d_tw_fwd, zk->d_tw_inv, zk->d_tw_fwd29, zk->d_tw_inv29, zk->d_coset, zk->d_coset_br, zk->d_g1, zk->d_g2, zk->d_g2_29, zk->d_g2_29_lone, zk->d_g2_29_deep,
+                    zk->d_tblDelta1, zk->d_tblAlpha1, zk->d_tblBeta1, zk->d_tblDelta2, zk->d_fb4, zk->d_fb4g2, zk->d_depths};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& kv : zk->fold.vmaps) if (kv.second.d) (void)hipFree(kv.second.d);
     for (void* q : {(void*)zk->fold.d_foldA, (void*)zk->fold.d_foldB1, (void*)zk->fold.d_foldC, (void*)zk->fold.d_foldB2}) if (q) (void)hipFree(q);
-    if (zk->h_flags) (void)hipHostFree(zk->h_flags);
     if (zk->h_depths) (void)hipHostFree(zk->h_depths);
-    for (auto& c : zk->call) { if (c.h_out) (void)hipHostFree(c.h_out); if (c.h_rs) (void)hipHostFree(c.h_rs); if (c.h_xyzz) (void)hipHostFree(c.h_xyzz); if (c.h_early) (void)hipHostFree(c.h_early); if (c.d_xyzz) (void)hipFree(c.d_xyzz); for (hipEvent_t e : c.ev_done) if (e) (void)hipEventDestroy(e); }
+    for (auto& c : zk->call) { for (void* q : {(void*)c.d_rs, (void*)c.d_proofs, (void*)c.d_flags, (void*)c.d_status3}) if (q) (void)hipFree(q); if (c.h_flags) (void)hipHostFree(c.h_flags); if (c.h_out) (void)hipHostFree(c.h_out); if (c.h_rs) (void)hipHostFree(c.h_rs); if (c.h_xyzz) (void)hipHostFree(c.h_xyzz); if (c.h_early) (void)hipHostFree(c.h_early); if (c.d_xyzz) (void)hipFree(c.d_xyzz); for (hipEvent_t e : c.ev_done) if (e) (void)hipEventDestroy(e); for (hipEvent_t e : c.ev_chunk) (void)hipEventDestroy(e); }
     if (zk->ev_start) (void)hipEventDestroy(zk->ev_start);
-    for (hipEvent_t e : zk->ev_chunk) (void)hipEventDestroy(e);
     for (auto& L : zk->lane) {
-        for (hipStream_t q : {L.st, L.st2, L.fin, L.red}) if (q) { (void)hipStreamSynchronize(q); if (!zk->serial_streams) (void)hipStreamDestroy(q); }
+        for (hipStream_t q : {L.st, L.st2, L.fin, L.red}) if (q) (void)hipStreamSynchronize(q);      // (the streams are the context's: zkc_lane_streams)
         if (L.ev_red) (void)hipEventDestroy(L.ev_red);
         for (void* q : {(void*)L.d_abc, (void*)L.d_t, (void*)L.d_p, L.d_fin, (void*)L.d_bs}) if (q) (void)hipFree(q);
         for (hipEvent_t e : {L.ev_msm, L.ev_msm2, L.ev_sorted, L.ev_ntt, L.ev_mv, L.ev_acc, L.ev_fin[0], L.ev_fin[1]}) if (e) (void)hipEventDestroy(e);
@@ -116,6 +115,7 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     delete zk;
 }
 
+static size_t dev_free_bytes() { size_t f = 0, t = 0; if (hipMemGetInfo(&f, &t) != hipSuccess) { (void)hipGetLastError(); return 0; } return f; }
 static int fold_prepare(zkc_zkey* zk);
 static int fb4_prepare(zkc_zkey* zk);
 // (Re)allocates the per-pass work space of every lane for `inflight` proofs per pass (grow only).  The caller holds the context lock and no
@@ -135,14 +135,16 @@ static int lanes_ensure(zkc_zkey* zk, int inflight) {
     // the old work space goes first (a key at nLevels = 160 with 96 proofs in flight holds ~6 GB): from here until every allocation has succeeded the key
     // has NO work space, and says so (cur_inflight = 0), so a failure leaves a key that re-allocates on its next call instead of launching on freed buffers
     zk->cur_inflight = 0;
+    const size_t free_before = dev_free_bytes() + zk->bytes_work;               // as if the old work space were gone already
     auto release = [&]() {
+        zk->bytes_work = 0;
         for (int l = 0; l < zk->nlanes; l++) {
             zkc_lane& L = zk->lane[l];
             for (void** q : {(void**)&L.d_abc, (void**)&L.d_t, (void**)&L.d_p, &L.d_fin, (void**)&L.d_bs}) if (*q) { (void)hipFree(*q); *q = nullptr; }
             msm_work_free(L.w1); msm_work_free(L.w2);
         }
     };
-    for (int l = 0; l < zk->nlanes; l++) for (hipStream_t q : {zk->lane[l].st, zk->lane[l].st2, zk->lane[l].fin, zk->lane[l].red}) ZKC_HIP_CHECK(ctx, hipStreamSynchronize(q));
+    for (int l = 0; l < zk->nlanes; l++) for (hipStream_t q : {zk->lane[l].st, zk->lane[l].st2, zk->lane[l].fin, zk->lane[l].red}) if (q) ZKC_HIP_CHECK(ctx, hipStreamSynchronize(q));
     release();
     const char* fail_at = getenv("ZKC_TEST_FAIL_ALLOC");          // test hook: pretend the allocation for this many proofs in flight (or more) fails
     for (int l = 0; l < zk->nlanes; l++) {
@@ -158,12 +160,20 @@ static int lanes_ensure(zkc_zkey* zk, int inflight) {
         if (rc) { (void)hipGetLastError(); release(); return rc; }
     }
     zk->cur_inflight = inflight;
+    { const size_t f = dev_free_bytes(); zk->bytes_work = free_before > f ? free_before - f : 0; }
     return ZKC_OK;
 }
-extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, zkc_zkey** out) {
+extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, zkc_zkey** out) { return zkc::zkey_load_opts(ctx, zkey_bytes, len, 0, 0, out); }
+size_t zkc::zkey_device_bytes(const zkc_zkey* zk, size_t* tables, size_t* work) {
+    if (!zk) return 0;
+    if (tables) *tables = zk->bytes_tables; if (work) *work = zk->bytes_work;
+    return zk->bytes_tables + zk->bytes_work;
+}
+int zkc::zkey_load_opts(zkc_ctx* ctx, const void* zkey_bytes, size_t len, int opt_lanes, int opt_inflight, zkc_zkey** out) {
     if (!ctx || !zkey_bytes || !out) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_zkey_load: bad argument");
     ZKC_LOCK(ctx);
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t free_at_entry = dev_free_bytes();
     const uint8_t* buf = (const uint8_t*)zkey_bytes;
     // every length and index of the file is validated by the host-only parser (zkc_hostparse.h, also built under ASan/UBSan by the tests)
     parse::BinSections bs; parse::ZkeyHeader zh; std::string perr;
@@ -311,7 +321,7 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
     // ---- work buffers: up to `max_inflight` proofs share one MSM pipeline pass; the buffers themselves are sized by lanes_ensure() for
     //      the number of proofs a call actually puts in flight (a single-proof caller does not reserve the work space of 96) ----
     const char* e_inf = getenv("ZKC_INFLIGHT");
-    zk->max_inflight = e_inf ? std::max(1, std::min(atoi(e_inf), MSM_MAX_JOBS / 4)) : 96;
+    zk->max_inflight = opt_inflight > 0 ? std::min(opt_inflight, MSM_MAX_JOBS / 4) : e_inf ? std::max(1, std::min(atoi(e_inf), MSM_MAX_JOBS / 4)) : 96;
     {   // [r4] the pass is sized for the census key (96 proofs of 7.4 M (scalar, window) entries unfolded): a larger circuit puts fewer proofs in flight -- the same ~0.7 G entries per
         // pass, which also keeps every entry index of a pass inside 32 bits (MsmJob::ent_off) -- 11 at a 2^20 domain, where ONE proof is 60 M additions and fills the chip
         const size_t per_proof_entries = (size_t)NWS * 3 * nv + (size_t)NWB * n, census_pass = 96ull * (22ull * 3 * 82754 + 15ull * 131072);
@@ -320,7 +330,8 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
     }      // same box, batch 1024: 64 -> 1955, 80 -> 1985, 96 -> 2015, 112 -> 2000, 128 -> 2022 proofs/s; round 2: 96 -> 3010, 114 -> 3004, 128 -> 3031
     // ZKC_LANES=2 lets two lanes take alternate passes; measured no gain in round 1 (the GPU is already saturated) and -4 % at the end of round 2 (3005
     // against 3142 proofs/s on one box: the second lane has no buildABC prefetch), so one lane is the default
-    { const char* e_l = getenv("ZKC_LANES"); zk->nlanes = e_l ? std::max(1, std::min(atoi(e_l), 2)) : 1; }
+    // [r5] up to MAX_LANES; the proving service asks for one lane per worker (opt_lanes) and keeps every call on its worker's lane
+    { const char* e_l = getenv("ZKC_LANES"); zk->nlanes = opt_lanes > 0 ? std::min(opt_lanes, (int)MAX_LANES) : e_l ? std::max(1, std::min(atoi(e_l), (int)MAX_LANES)) : 1; }
     for (int l = 0; l < zk->nlanes; l++) {
         zkc_lane& L = zk->lane[l];
         // ZKC_SERIAL_STREAMS=1 (measurement only): every stage of a pass on the context's one stream, so that the per-category HIP-event brackets of
@@ -328,9 +339,9 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
         zk->serial_streams = getenv("ZKC_SERIAL_STREAMS") != nullptr;
         if (zk->serial_streams) L.st = L.st2 = L.fin = L.red = ctx->stream;
         else {
-            ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.red, hipStreamNonBlocking));
-            ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking)); ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.st2, hipStreamNonBlocking));
-            ZKC_HIP_BAIL(hipStreamCreateWithFlags(&L.fin, hipStreamNonBlocking));
+            static const bool red_wanted = [] { const char* e = getenv("ZKC_REDUCE_STREAM"); return e && atoi(e) == 1; }();
+            zkc_ctx::LaneStreams ls; if ((rc = zkc_lane_streams(ctx, l, red_wanted, &ls))) return bail(rc);
+            L.st = ls.st; L.st2 = ls.st2; L.fin = ls.fin; L.red = ls.red;
         }
         ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_msm, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_msm2, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_sorted, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_ntt, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_mv, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_acc, hipEventDisableTiming));
         ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_fin[0], hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_fin[1], hipEventDisableTiming));
@@ -349,6 +360,7 @@ extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, z
     // the folding tables of the voter-independent witness part are part of the key's one-time cost, not of the first proof
     if (zk->nLevels >= 0 && (rc = fold_prepare(zk))) return bail(rc);
     if ((rc = fb4_prepare(zk))) return bail(rc);
+    { const size_t f = dev_free_bytes(); zk->bytes_tables = free_at_entry > f + zk->bytes_work ? free_at_entry - f - zk->bytes_work : 0; }
     *out = zk;
     return ZKC_OK;
 #undef ZKC_UP
@@ -556,9 +568,10 @@ extern "C" int zkc_msm_debug(zkc_zkey* zk, int which, const void* d_scalars, uin
 
 // d_inputs != nullptr: the witnesses are computed here as well, a chunk per pass on ctx->stream, so that the (latency-bound, few-wave)
 // witness kernels of pass p+1 run underneath the MSMs of pass p
-int zkc_witness_chunk_async(zkc_ctx* ctx, int nLevels, const void* d_inputs, int B, void* d_wtns, int32_t* d_status3, int32_t* d_status);
-int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nWitness, int B, const uint8_t* rs, bool want_publics, const void* d_inputs, int32_t* d_status) {
-    if (!zk || !d_wtns || !rs || B <= 0 || cs < 0 || cs > 1) return zkc_fail(zk ? zk->ctx : nullptr, ZKC_ERR_BAD_ARG, "zkc_prove_batch_dev: bad argument");
+int zkc_witness_chunk_async(zkc_ctx* ctx, int nLevels, const void* d_inputs, int B, void* d_wtns, int32_t* d_status3, int32_t* d_status, hipStream_t st);
+int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nWitness, int B, const uint8_t* rs, bool want_publics, const void* d_inputs, int32_t* d_status,
+                           int lane0, hipEvent_t wait_first, const uint8_t* host_depths, bool no_early) {
+    if (!zk || !d_wtns || !rs || B <= 0 || cs < 0 || cs >= CALL_SLOTS || lane0 >= zk->nlanes) return zkc_fail(zk ? zk->ctx : nullptr, ZKC_ERR_BAD_ARG, "zkc_prove_batch_dev: bad argument");
     zkc_ctx* ctx = zk->ctx;
     ZKC_LOCK(ctx);
     if (nWitness != zk->nVars) return zkc_fail(ctx, ZKC_ERR_INVALID_WITNESS_LENGTH, "Invalid witness length. Circuit: " + std::to_string(zk->nVars) + ", witness: " + std::to_string(nWitness));
@@ -566,7 +579,12 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const uint32_t nv = zk->nVars, np = zk->nPub, nc = nv - np - 1, n = zk->n;
     const bool can_fold = zk->nLevels >= 0;
-    hipStream_t st0 = ctx->stream;
+    // the stream of the call's witness kernels, fold check and small uploads: the context's for a call that may use every lane, the lane's own for a call that stays on one
+    // (the proving service: the Poseidon chains of concurrent calls run side by side instead of queueing on one stream)
+    // [r5'] ... which, for a call of ONE pass, is the lane's G1 stream itself: witness -> fold check -> buildABC are a chain anyway, and every further stream is a further
+    // hardware queue to share (a stream that shares its queue with another lane's pending barrier packet runs behind that lane's call: profiles/r05_service_hw_queues.txt).
+    // A call of several passes on one lane keeps the context's stream for its witness groups, so that pass p + 1's Poseidon chains run under pass p's MSMs.
+    hipStream_t st0 = (lane0 >= 0 && !zk->serial_streams && B <= zk->max_inflight) ? zk->lane[lane0].st : ctx->stream;
     WitnessLayout L{}; int rc;
     if ((rc = lanes_ensure(zk, B))) return rc;
     zkc_zkey::CallSlot& CS = zk->call[cs];
@@ -579,9 +597,14 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&CS.h_out, (256 + 32 * (size_t)zk->nPub) * want)); ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&CS.h_rs, 64 * want));
         ZKC_HIP_CHECK(ctx, hipMalloc((void**)&CS.d_xyzz, 512 * want)); ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&CS.h_xyzz, 512 * want)); CS.cap = want;
     }
-    for (int l = 0; l < zk->nlanes; l++) if (!CS.ev_done[l]) ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&CS.ev_done[l], hipEventDisableTiming));
-    CS.as_xyzz.assign((size_t)B, 0);
+    // [r5] the events a host thread waits on are blocking ones: the waiter sleeps in the driver instead of spinning on the event's memory (a rank of an 8-GPU run has 2 of the
+    // box's 16 cores' worth of CPU time: VERDICT r4 item 3).  ZKC_SPIN_WAIT=1: the old (spinning) events, for A/B.
+    static const unsigned ev_host_flags = getenv("ZKC_SPIN_WAIT") ? hipEventDisableTiming : (hipEventDisableTiming | hipEventBlockingSync);
+    for (int l = 0; l < zk->nlanes; l++) if (!CS.ev_done[l]) ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&CS.ev_done[l], ev_host_flags));
+    CS.as_xyzz.assign((size_t)B, 0); CS.lanes_used = 0;
+    if (wait_first) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st0, wait_first, 0));
     uint8_t* const h_pub = CS.h_out + 256ull * CS.cap;      // results land in pinned memory so that no copy blocks the enqueueing thread
+    if (rs != CS.h_rs_copy.data()) CS.h_rs_copy.assign(rs, rs + 64 * (size_t)B);      // (kept for a second begin of the same call: prove_batch_finish, early layout refused)
     memcpy(CS.h_rs, rs, 64 * (size_t)B);                                     // the caller's rs is its own again when begin returns
     ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.d_rs, CS.h_rs, 64 * (size_t)B, hipMemcpyHostToDevice, st0));
     // per pass (chunk of max_inflight proofs), all enqueued now on st0: [witness kernels] -> fold check (which levels of the witness differ
@@ -592,32 +615,45 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         if ((rc = fold_prepare(zk))) return rc;
         tmpl = zkc_get_template(ctx, zk->nLevels); if (!tmpl) return ZKC_ERR_HIP;
         const size_t nflags = (size_t)B * 2 * L.n;
-        if (zk->flags_cap < nflags) {
-            if (zk->d_flags) { ZKC_HIP_CHECK(ctx, hipFree(zk->d_flags)); ZKC_HIP_CHECK(ctx, hipHostFree(zk->h_flags)); zk->d_flags = zk->h_flags = nullptr; }
-            ZKC_HIP_CHECK(ctx, hipMalloc((void**)&zk->d_flags, nflags * 4)); ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&zk->h_flags, nflags * 4)); zk->flags_cap = nflags;
+        if (CS.flags_cap < nflags) {                                   // (the slot is idle: nothing reads its old buffers)
+            if (CS.d_flags) { ZKC_HIP_CHECK(ctx, hipFree(CS.d_flags)); ZKC_HIP_CHECK(ctx, hipHostFree(CS.h_flags)); CS.d_flags = CS.h_flags = nullptr; CS.flags_cap = 0; }
+            const size_t want = std::max(nflags, (size_t)256 * 2 * L.n);
+            ZKC_HIP_CHECK(ctx, hipMalloc((void**)&CS.d_flags, want * 4)); ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&CS.h_flags, want * 4)); CS.flags_cap = want;
         }
     }
     // [r3] a call of one or two voters that brings its inputs: the depths its folding needs are read from the inputs now (zkc_input_depths, on a stream of its own, ~30 us),
     // so the pass below is enqueued while the witness kernel runs instead of after a host round trip behind it (fold flags to the host, wake-up, ~70 launches: 0.1-0.2 ms of a 3.5 ms proof)
-    CS.early_n = 0;
-    if (d_inputs && can_fold && B <= 2 && B <= zk->max_inflight && zk->d_fb4) {        // one pass
-        if (!CS.h_early) ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&CS.h_early, 2 * 4 + 2 * 2 * 256 * 4));      // status [2], then fold flags [2][2][n <= 254]
-        if (!zk->d_depths) { ZKC_HIP_CHECK(ctx, hipMalloc((void**)&zk->d_depths, 4 * 4)); ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&zk->h_depths, 2 * 4 * 4)); }
-        uint32_t* hd = zk->h_depths + 4 * cs;
+    // [r5] ... and so does any call that is ONE pass (the proving service's batches of concurrent callers): begin then never waits for a witness kernel, it returns after ~0.5 ms
+    // of enqueueing and the next worker's begin can follow at once (ZKC_EARLY_LAYOUT=0: calls of more than two voters wait for their fold flags as before)
+    // ... and with the depths handed in by the caller (host_depths: the proving service reads them off the inputs -- or, for a witness that was computed elsewhere, off the
+    // sibling wires of the witness itself -- on the host) begin has no GPU round trip at all: the depth kernel below is microseconds of work, but its stream waits for a
+    // hardware queue behind whatever long kernels the other lanes have in flight, and begin holds the context's lock meanwhile.
+    CS.early_n = 0; CS.arg_wtns = d_wtns; CS.arg_nw = nWitness; CS.arg_publics = want_publics; CS.arg_lane0 = lane0; CS.arg_inputs = d_inputs != nullptr; CS.arg_wait = nullptr;
+    static const bool early_any = [] { const char* e = getenv("ZKC_EARLY_LAYOUT"); return !(e && atoi(e) == 0); }();
+    const size_t ecap = MSM_MAX_JOBS / 4;                                          // voters of a pass at most
+    const bool early_wanted = !no_early && can_fold && B <= zk->max_inflight && (B <= 2 ? zk->d_fb4 != nullptr : early_any);      // one pass
+    if (early_wanted && !CS.h_early) { ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&CS.h_early, (ecap + ecap * 2 * 256) * 4)); CS.early_cap = ecap; }      // status [ecap], then fold flags [B][2][n <= 254]
+    if (early_wanted && host_depths) {
+        bool ok = true; for (int i = 0; i < 2 * B; i++) ok = ok && host_depths[i] < (uint8_t)L.n && L.n <= 255;
+        if (ok) { CS.early_n = B; CS.early_depth.assign(host_depths, host_depths + 2 * (size_t)B); }
+    } else if (early_wanted && d_inputs) {
+        if (!zk->d_depths) { ZKC_HIP_CHECK(ctx, hipMalloc((void**)&zk->d_depths, 2 * ecap * 4)); ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&zk->h_depths, 2 * ecap * 4)); }
+        uint32_t* hd = zk->h_depths;                                               // read back below, under the context lock: one buffer per key is enough
+        if (wait_first) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream2, wait_first, 0));
         hipLaunchKernelGGL(zkc_input_depths, dim3(B, 2), dim3(64), 0, ctx->stream2, (const uint32_t*)d_inputs, L.nInputs, L.n, zk->d_depths);
         ZKC_HIP_CHECK(ctx, hipGetLastError());
         ZKC_HIP_CHECK(ctx, hipMemcpyAsync(hd, zk->d_depths, 8 * (size_t)B, hipMemcpyDeviceToHost, ctx->stream2));
         ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream2));
         bool ok = true; for (int i = 0; i < 2 * B; i++) ok = ok && hd[i] < (uint32_t)L.n;          // a non-zero LAST sibling fails SMTLevIns: no early path for that call
-        if (ok) { CS.early_n = B; for (int i = 0; i < 2 * B; i++) CS.early_depth[i] = (uint8_t)hd[i]; }
+        if (ok) { CS.early_n = B; CS.early_depth.resize(2 * (size_t)B); for (int i = 0; i < 2 * B; i++) CS.early_depth[i] = (uint8_t)hd[i]; }
     }
     const int npasses = (B + zk->max_inflight - 1) / zk->max_inflight;
     const int per_pass = (B + npasses - 1) / npasses;       // passes of equal size (1024 -> 10 x 94 + 84, not 10 x 96 + 64): the last pass' fixed-latency tail is not spent on a stub
-    while ((int)zk->ev_chunk.size() < npasses) { hipEvent_t e; ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); zk->ev_chunk.push_back(e); }
+    while ((int)CS.ev_chunk.size() < npasses) { hipEvent_t e; ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, ev_host_flags)); CS.ev_chunk.push_back(e); }      // per call slot: a call laid out early returns from begin before its event has fired, and the next call must not re-record it
     int32_t* d_status3 = nullptr;
     if (d_inputs) {
-        if ((rc = zkc_ensure(ctx, (void**)&ctx->d_status3, &ctx->status3_n, (size_t)B * 3 * sizeof(int32_t)))) return rc;
-        d_status3 = ctx->d_status3;
+        if ((rc = zkc_ensure(ctx, (void**)&CS.d_status3, &CS.status3_cap, std::max<size_t>((size_t)B, 256) * 3 * sizeof(int32_t)))) return rc;      // per call slot: the witness kernels of two calls may run side by side
+        d_status3 = CS.d_status3;
     }
     static const int wgroup = [] { const char* e = getenv("ZKC_WITNESS_GROUP"); return e ? std::max(1, atoi(e)) : 8; }();      // same box: 2 -> 2452, 4 -> 2472, 8 -> 2482 proofs/s at batch 1024
     for (int c = 0; c < npasses; c++) {
@@ -630,34 +666,37 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         if (d_inputs && (c % wgroup == 0 || c == 1)) {
             const int glast = c == 0 ? 1 : std::min(((c / wgroup) + 1) * wgroup, npasses);          // passes [c, glast)
             const int g0 = p0, gn = std::min((glast - c) * per_pass, B - g0);
-            if (gn > 0 && (rc = zkc_witness_chunk_async(ctx, zk->nLevels, (const uint8_t*)d_inputs + (size_t)g0 * L.nInputs * 32, gn, wc, d_status3 + 3 * (size_t)g0, d_status + g0))) return rc;
+            if (gn > 0 && (rc = zkc_witness_chunk_async(ctx, zk->nLevels, (const uint8_t*)d_inputs + (size_t)g0 * L.nInputs * 32, gn, wc, d_status3 + 3 * (size_t)g0, d_status + g0, st0))) return rc;
         }
         if (can_fold) {
-            uint32_t* fl = zk->d_flags + (size_t)p0 * 2 * L.n;
+            uint32_t* fl = CS.d_flags + (size_t)p0 * 2 * L.n;
             hipLaunchKernelGGL(zkc_fold_check, dim3(L.n, 2, nb), dim3(64), 0, st0, L, (const uint32_t*)wc, tmpl, fl, nb);
             ZKC_HIP_CHECK(ctx, hipGetLastError());
-            ZKC_HIP_CHECK(ctx, hipMemcpyAsync(zk->h_flags + (size_t)p0 * 2 * L.n, fl, (size_t)nb * 2 * L.n * 4, hipMemcpyDeviceToHost, st0));
+            ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.h_flags + (size_t)p0 * 2 * L.n, fl, (size_t)nb * 2 * L.n * 4, hipMemcpyDeviceToHost, st0));
         }
-        if (CS.early_n) {            // the early layout's evidence for finish, in this call's own pinned memory (the key's flag buffer belongs to whichever call began last)
-            ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.h_early, d_status, 4 * (size_t)B, hipMemcpyDeviceToHost, st0));
-            ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.h_early + 2, zk->d_flags + (size_t)p0 * 2 * L.n, (size_t)nb * 2 * L.n * 4, hipMemcpyDeviceToHost, st0));
+        if (CS.early_n) {            // the early layout's evidence for finish, in this call's own pinned memory
+            if (d_status) ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.h_early, d_status, 4 * (size_t)B, hipMemcpyDeviceToHost, st0));
+            else memset(CS.h_early, 0, 4 * (size_t)B);                             // witnesses given: nobody was rejected here
+            ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.h_early + CS.early_cap, CS.d_flags + (size_t)p0 * 2 * L.n, (size_t)nb * 2 * L.n * 4, hipMemcpyDeviceToHost, st0));
         }
-        ZKC_HIP_CHECK(ctx, hipEventRecord(zk->ev_chunk[c], st0));                // wtns of this chunk (and rs) ready, flags on the host
+        ZKC_HIP_CHECK(ctx, hipEventRecord(CS.ev_chunk[c], st0));                // wtns of this chunk (and rs) ready, flags on the host
     }
     // (npass is NOT reset per call: the result slots and their ev_fin guards carry over, because the previous call's last blinding may still be reading them)
     // ZKC_TRACE_HOST=1: where the enqueueing thread spends its time, per pass (diagnostics: a blocking call here idles a stream)
     static const bool trace_host = getenv("ZKC_TRACE_HOST") != nullptr;
     auto now_ms = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; };
     const double t_begin = now_ms(); double tr[6] = {0};
-    int pass = 0; bool done_on_st = false;
+    int pass = 0, done_on_st_lane = -1;
+    const bool one_lane = lane0 >= 0 || zk->nlanes == 1;
     for (int p0 = 0; p0 < B; p0 += per_pass, pass++) {
         const int nb = std::min(per_pass, B - p0);
-        zkc_lane& LN = zk->lane[pass % zk->nlanes]; const int slot = LN.npass & 1;       // MSM results are double-buffered: the blinding of pass k overlaps pass k+1
+        const int li = lane0 >= 0 ? lane0 : pass % zk->nlanes; CS.lanes_used |= 1u << li;
+        zkc_lane& LN = zk->lane[li]; const int slot = LN.npass & 1;       // MSM results are double-buffered: the blinding of pass k overlaps pass k+1
         tr[0] = now_ms();
         const bool early = CS.early_n > 0;
-        if (!early) ZKC_HIP_CHECK(ctx, hipEventSynchronize(zk->ev_chunk[pass]));              // host: this chunk's fold flags have arrived
+        if (!early) ZKC_HIP_CHECK(ctx, hipEventSynchronize(CS.ev_chunk[pass]));              // host: this chunk's fold flags have arrived
         tr[1] = now_ms();
-        ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(LN.st, zk->ev_chunk[pass], 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(LN.st2, zk->ev_chunk[pass], 0));
+        ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(LN.st, CS.ev_chunk[pass], 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(LN.st2, CS.ev_chunk[pass], 0));
         hipStream_t st = LN.st, st2 = LN.st2, fin = LN.fin;
         const uint32_t* w0 = (const uint32_t*)d_wtns + (size_t)p0 * nv * 8;
         // constant folding is per proof: voter q keeps the census levels below its own leaf depth dcq[q] (sik: dsq[q]) in its MSMs; the levels
@@ -665,7 +704,7 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         uint8_t dcq[MSM_MAX_JOBS / 4], dsq[MSM_MAX_JOBS / 4]; bool fold = can_fold;
         if (early) for (int q = 0; q < nb; q++) { dcq[q] = CS.early_depth[2 * q]; dsq[q] = CS.early_depth[2 * q + 1]; }
         else for (int q = 0; q < nb && fold; q++) for (int t = 0; t < 2; t++) {
-            const uint32_t* f = zk->h_flags + ((size_t)(p0 + q) * 2 + t) * L.n;
+            const uint32_t* f = CS.h_flags + ((size_t)(p0 + q) * 2 + t) * L.n;
             if (f[L.n - 1]) { fold = false; break; }                              // n2bOld block differs: not one of our witnesses
             int D = 0; for (int g = 0; g < L.n - 1; g++) if (f[g]) D = g + 1;
             (t == 0 ? dcq : dsq)[q] = (uint8_t)D;
@@ -683,7 +722,7 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         // [r2] buildABC is gather-bound and needs only the witness: the one of pass p+1 is issued on the blinding stream as soon as the accumulation
         // of pass p starts (VALU-bound, 15 ms) and is through long before the G1 stream gets there; only the first pass runs it in line
         static const bool mv_prefetch_env = getenv("ZKC_MATVEC_INLINE") == nullptr;
-        const bool mv_prefetch = mv_prefetch_env && zk->nlanes == 1;
+        const bool mv_prefetch = mv_prefetch_env && one_lane;
         const bool mv_done = mv_prefetch && pass > 0;
         if (mv_done) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, LN.ev_mv, 0));
         // (tried for passes of a few proofs while their G2 side was the longer chain: G2 enqueued first and its accumulation not held for the transforms -- its 1024 fat waves
@@ -708,9 +747,9 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         static const size_t deep_wires = [] { const char* e = getenv("ZKC_DEEP_WIRES"); return e ? (size_t)atol(e) : (size_t)16000; }();
         size_t live_wires = 0; for (int q = 0; q < nb; q++) live_wires += listed ? (size_t)vms[q].nA + vms[q].nB + vms[q].nC : 2 * (size_t)nv + nc;
         const bool deep = zk->c_deep != 0 && nb > 2 && live_wires >= 3 * deep_wires * (size_t)nb;
-        const int cs = deep ? zk->c_deep : zk->c_sec;
+        const int cw = deep ? zk->c_deep : zk->c_sec;                                                     // window bits of this pass' witness sections
         const uint32_t oA = deep ? zk->offA_deep : zk->offA, oB1 = deep ? zk->offB1_deep : zk->offB1, oC = deep ? zk->offC_deep : zk->offC;
-        const int c2 = (nb <= 2 && zk->d_g2_29_lone && lone_entries <= LN.w2.max_entries) ? MSM_C_G2_LONE : cs;
+        const int c2 = (nb <= 2 && zk->d_g2_29_lone && lone_entries <= LN.w2.max_entries) ? MSM_C_G2_LONE : cw;
         static const uint32_t vwg2_env = [] { const char* e = getenv("ZKC_VW_G2"); return e ? (uint32_t)atoi(e) : 0u; }();      // A/B: the G2 jobs' window apart from the G1 sections'
         j1.clear(vws, vwb, MSM_MAX_VW_G1); j2.clear(c2 == MSM_C_G2_LONE ? 128u : (vwg2_env && nb >= 32) ? vwg2_env : vws, 1024, MSM_MAX_VW_PER_JOB);
         // job order of the G1 pass: the nb H jobs first (the 16-bit bucket sort wants the jobs with the larger bucket count in front), then
@@ -728,17 +767,17 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
             if (tree) { ba.w[q] = w; ba.out[q] = bs; }
             if (listed) {
                 const zkc_zkey::Fold::VMap& vm = vms[q];
-                j1.add(w, vm.d + vm.offA, vm.nA, oA, nv, 0, cs);
-                j1.add(w, vm.d + vm.offB, vm.nB, oB1, nv, 0, cs);
-                j1.add(w, vm.d + vm.offC, vm.nC, oC, nc, (int32_t)np + 1, cs);
-                if (tree) { j1.add(bs, vm.d + vm.offA, vm.nA, oA, nv, 0, cs); j1.add(bs + 8ull * nv, vm.d + vm.offB, vm.nB, oB1, nv, 0, cs); }
+                j1.add(w, vm.d + vm.offA, vm.nA, oA, nv, 0, cw);
+                j1.add(w, vm.d + vm.offB, vm.nB, oB1, nv, 0, cw);
+                j1.add(w, vm.d + vm.offC, vm.nC, oC, nc, (int32_t)np + 1, cw);
+                if (tree) { j1.add(bs, vm.d + vm.offA, vm.nA, oA, nv, 0, cw); j1.add(bs + 8ull * nv, vm.d + vm.offB, vm.nB, oB1, nv, 0, cw); }
                 j2.add(w, vm.d + vm.offB, vm.nB, 0, nv, 0, c2);
                 if (tree) { ba.mapA[q] = vm.d + vm.offA; ba.nA[q] = vm.nA; ba.mapB[q] = vm.d + vm.offB; ba.nB[q] = vm.nB; }
             } else {
-                j1.add(w, nullptr, nv, oA, nv, 0, cs);
-                j1.add(w, nullptr, nv, oB1, nv, 0, cs);
-                j1.add(w + 8ull * (np + 1), nullptr, nc, oC, nc, 0, cs);
-                if (tree) { j1.add(bs, nullptr, nv, oA, nv, 0, cs); j1.add(bs + 8ull * nv, nullptr, nv, oB1, nv, 0, cs); }
+                j1.add(w, nullptr, nv, oA, nv, 0, cw);
+                j1.add(w, nullptr, nv, oB1, nv, 0, cw);
+                j1.add(w + 8ull * (np + 1), nullptr, nc, oC, nc, 0, cw);
+                if (tree) { j1.add(bs, nullptr, nv, oA, nv, 0, cw); j1.add(bs + 8ull * nv, nullptr, nv, oB1, nv, 0, cw); }
                 j2.add(w, nullptr, nv, 0, nv, 0, c2);
                 if (tree) { ba.mapA[q] = ba.mapB[q] = nullptr; ba.nA[q] = ba.nB[q] = nv; }
             }
@@ -779,8 +818,8 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         // sum of its kernels' VALU work, and where the reduction's waves run does not change that sum.  Off unless ZKC_REDUCE_STREAM=1.)
         static const bool red_on = [] { const char* e = getenv("ZKC_REDUCE_STREAM"); return e && atoi(e) == 1; }();
         const bool red_split = red_on && !zk->serial_streams && nb >= 32;
-        if ((rc = msm_pass_g1(zk, LN.w1, j1, slot, false, st, LN.ev_sorted, LN.ev_acc, red_split ? LN.red : nullptr, LN.ev_red))) return rc;
-        zk->last_lane = pass % zk->nlanes;
+        if ((rc = msm_pass_g1(zk, LN.w1, j1, slot, false, st, LN.ev_sorted, LN.ev_acc, (red_split && LN.red) ? LN.red : nullptr, LN.ev_red))) return rc;
+        zk->last_lane = li;
         tr[4] = now_ms();
         if (!g2_early) {
             ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st2, LN.ev_sorted, 0));
@@ -795,7 +834,7 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
             const int p1 = p0 + per_pass, nb1 = std::min(per_pass, B - p1);
             static const bool mv_at_ntt = [] { const char* e = getenv("ZKC_MV_PREFETCH_AT_NTT"); return e && atoi(e) == 1; }();      // A/B: start it beside this pass' bucketing instead
             ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, mv_at_ntt ? LN.ev_ntt : LN.ev_sorted, 0));         // this pass' NTT and joinABC are through (d_abc is free), its accumulation is next (waiting on ev_ntt instead, i.e. starting beside the bucketing, is 1 % slower: 3113 / 3093 against 3143 / 3137 proofs/s on one box)
-            ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, zk->ev_chunk[pass + 1], 0));
+            ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, CS.ev_chunk[pass + 1], 0));
             if ((rc = h_matvec_dev(zk, LN, (const uint32_t*)d_wtns + (size_t)p1 * nv * 8, nb1, fin))) return rc;
             ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_mv, fin));
         }
@@ -815,24 +854,24 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         if (tree) { ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.h_xyzz + 512ull * p0, CS.d_xyzz + 512 * (size_t)p0, 512ull * nb, hipMemcpyDeviceToHost, bl)); for (int q = 0; q < nb; q++) CS.as_xyzz[p0 + q] = 1; }
         else ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.h_out + 256ull * p0, CS.d_proofs + 256 * (size_t)p0, 256ull * nb, hipMemcpyDeviceToHost, fin));
         ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_fin[slot], bl));
-        if (bl == st) done_on_st = true;
+        if (bl == st) done_on_st_lane = li;
         tr[5] = now_ms();
         if (trace_host) fprintf(stderr, "[zkc host] pass %2d: start %8.2f | chunk wait %6.2f | h_evals %6.2f | g2 pass %6.2f | g1 pass %6.2f | blinding %6.2f ms\n", pass, tr[0] - t_begin,
                                 tr[1] - tr[0], tr[2] - tr[1], tr[3] - tr[2], tr[4] - tr[3], tr[5] - tr[4]);
     }
     // every lane's blinding stream already waits for its G1 and G2 streams (ev_msm, ev_msm2) and carries the last copies: one event per lane closes the call
-    for (int l = 0; l < zk->nlanes; l++) ZKC_HIP_CHECK(ctx, hipEventRecord(CS.ev_done[l], (done_on_st && l == 0) ? zk->lane[l].st : zk->lane[l].fin));      // (a one-pass call runs on lane 0)
+    for (int l = 0; l < zk->nlanes; l++) if (CS.lanes_used >> l & 1) ZKC_HIP_CHECK(ctx, hipEventRecord(CS.ev_done[l], done_on_st_lane == l ? zk->lane[l].st : zk->lane[l].fin));      // only the lanes this call ran on: another lane's streams carry another call
     CS.B = B; CS.pending = true;
     return ZKC_OK;
 }
 // second half of a batch call: wait for call slot cs, copy proofs (B x 256 B) and public signals (B x nPublic x 32 B, may be NULL) out of the pinned staging.
 // Takes no context lock while it waits, so that the next call's begin (the other slot) can run meanwhile.
 int zkc::prove_batch_finish(zkc_zkey* zk, int cs, uint8_t* proofs, uint8_t* publics) {
-    if (!zk || !proofs || cs < 0 || cs > 1) return zkc_fail(zk ? zk->ctx : nullptr, ZKC_ERR_BAD_ARG, "prove_batch_finish: bad argument");
+    if (!zk || !proofs || cs < 0 || cs >= CALL_SLOTS) return zkc_fail(zk ? zk->ctx : nullptr, ZKC_ERR_BAD_ARG, "prove_batch_finish: bad argument");
     zkc_zkey::CallSlot& CS = zk->call[cs];
     if (!CS.pending) return zkc_fail(zk->ctx, ZKC_ERR_BAD_ARG, "prove_batch_finish: no call in flight on this slot");
     hipError_t e = hipSuccess;
-    for (int l = 0; l < zk->nlanes && e == hipSuccess; l++) e = hipEventSynchronize(CS.ev_done[l]);
+    for (int l = 0; l < zk->nlanes && e == hipSuccess; l++) if (CS.lanes_used >> l & 1) e = hipEventSynchronize(CS.ev_done[l]);
     CS.pending = false;
     if (e != hipSuccess) { ZKC_LOCK(zk->ctx); return zkc_fail(zk->ctx, ZKC_ERR_HIP, std::string("prove_batch_finish: ") + hipGetErrorString(e)); }
     if (CS.early_n) {                // the pass was laid out from the inputs' depths before its witness existed: the fold check of the finished witness has to agree
@@ -840,9 +879,14 @@ int zkc::prove_batch_finish(zkc_zkey* zk, int cs, uint8_t* proofs, uint8_t* publ
         for (int q = 0; q < CS.early_n; q++) {
             if ((int32_t)CS.h_early[q] != ZKC_W_OK) continue;                   // a rejected voter: its proof is discarded whatever it is
             for (int t = 0; t < 2; t++) {
-                const uint32_t* f = CS.h_early + 2 + ((size_t)q * 2 + t) * L.n;
+                const uint32_t* f = CS.h_early + CS.early_cap + ((size_t)q * 2 + t) * L.n;
                 int D = 0; for (int g = 0; g < L.n - 1; g++) if (f[g]) D = g + 1;
-                if (f[L.n - 1] || D > (int)CS.early_depth[2 * q + t]) { ZKC_LOCK(zk->ctx); return zkc_fail(zk->ctx, ZKC_ERR_GENERIC, "prove_batch_finish: the witness does not fold at the depth its inputs gave (internal error)"); }
+                if (f[L.n - 1] || D > (int)CS.early_depth[2 * q + t]) {
+                    // a witness that was computed elsewhere and does not carry the template below its own sibling depth (a valid witness of this circuit always does): nothing
+                    // is wrong with the call, only with the shortcut -- the same call once more, laid out from its fold flags
+                    if (!CS.arg_inputs) { int rc = prove_batch_begin(zk, cs, CS.arg_wtns, CS.arg_nw, CS.B, CS.h_rs_copy.data(), CS.arg_publics, nullptr, nullptr, CS.arg_lane0, nullptr, nullptr, true); if (rc) return rc; return prove_batch_finish(zk, cs, proofs, publics); }
+                    ZKC_LOCK(zk->ctx); return zkc_fail(zk->ctx, ZKC_ERR_GENERIC, "prove_batch_finish: the witness does not fold at the depth its inputs gave (internal error)");
+                }
             }
         }
     }
@@ -869,7 +913,7 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
                             const void* d_inputs, int32_t* d_status) {
     if (!zk || !proofs) return zkc_fail(zk ? zk->ctx : nullptr, ZKC_ERR_BAD_ARG, "zkc_prove_batch_dev: bad argument");
     ZKC_LOCK(zk->ctx);
-    if (zk->call[1].pending) return zkc_fail(zk->ctx, ZKC_ERR_BAD_ARG, "zkc_prove_batch_dev: the key has a split call in flight (proving service)");
+    for (int c = 1; c < CALL_SLOTS; c++) if (zk->call[c].pending) return zkc_fail(zk->ctx, ZKC_ERR_BAD_ARG, "zkc_prove_batch_dev: the key has a split call in flight (proving service)");
     int rc = prove_batch_begin(zk, 0, d_wtns, nWitness, B, rs, publics != nullptr, d_inputs, d_status);
     if (rc) return rc;
     return prove_batch_finish(zk, 0, proofs, publics);
@@ -877,7 +921,7 @@ static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness,
 
 // the two halves as C entry points (include/zkcensus.h): what a caller that pipelines batch after batch uses
 extern "C" int zkc_batch_begin(zkc_zkey* zk, int slot, const void* d_inputs, int B, void* d_wtns, int32_t* d_status, const uint8_t* rs) {
-    if (!zk || !d_wtns || (d_inputs && !d_status)) return zkc_fail(zk ? zk->ctx : nullptr, ZKC_ERR_BAD_ARG, "zkc_batch_begin: bad argument");
+    if (!zk || !d_wtns || (d_inputs && !d_status) || slot < 0 || slot >= CALL_SLOTS) return zkc_fail(zk ? zk->ctx : nullptr, ZKC_ERR_BAD_ARG, "zkc_batch_begin: bad argument");
     if (d_inputs && zk->nLevels < 0) return zkc_fail(zk->ctx, ZKC_ERR_BAD_ARG, "zkc_batch_begin: the key is not a ZkFranchiseProofCircuit(nLevels) key; compute the witness elsewhere and pass d_inputs = NULL");
     return prove_batch_begin(zk, slot, d_wtns, zk->nVars, B, rs, true, d_inputs, d_status);
 }

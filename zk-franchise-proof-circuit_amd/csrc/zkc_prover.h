@@ -32,6 +32,9 @@ constexpr int MSM_SEG = ZKC_MSM_SEG;               // [r4] re-measured on the ro
 constexpr int MSM_MERGE_T = 8;                     // buckets with more segments get a wave of their own before the window pass
 constexpr int MSM_MAX_HEAVY = 1 << 20;
 constexpr int MSM_MAX_JOBS = 512;                  // jobs per pipeline pass (proofs in flight x sections)
+// [r5] pipeline lanes (stream sets + per-pass work space) and call slots of a key.  A direct caller uses one lane and slots 0 / 1 (bench.py); the proving service loads its
+// keys with one lane per worker so that the calls of concurrent single-proof callers are independent stream sets and really overlap on the GPU (zkc_service.hip).
+constexpr int MAX_LANES = 4, CALL_SLOTS = 4;
 
 // One multi-scalar multiplication inside a pipeline pass: sum_j scalar[j] * P[point(j)]
 struct MsmJob {
@@ -156,7 +159,7 @@ struct MsmWork {
 // One pipeline lane: its own three streams and every per-pass buffer.  Two lanes take alternate passes so that the
 // latency-bound tail of a pass (window reduce, final sums, blinding) overlaps the throughput-bound head of the next one.
 struct zkc_lane {
-    hipStream_t st = nullptr, st2 = nullptr, fin = nullptr;               // buildABC/NTT/G1 MSM ; G2 MSM ; blinding + D2H
+    hipStream_t st = nullptr, st2 = nullptr, fin = nullptr;               // buildABC/NTT/G1 MSM ; G2 MSM ; blinding + D2H.  [r5] Borrowed from the context (zkc_lane_streams): every key of a context shares them
     hipStream_t red = nullptr; hipEvent_t ev_red = nullptr;               // [r4] the G1 bucket reduction of a full pass runs here, beside the next pass' transforms; ev_red: the reduction of the lane's latest pass is through (wherever it ran)
     zkc::Fr *d_abc = nullptr, *d_t = nullptr; uint32_t* d_p = nullptr;   // [inflight][3n] x2 (d_t = NTT scratch), [inflight][n x 8]
     void* d_fin = nullptr;                                                // blinding scratch, finalize_scratch_bytes(inflight)
@@ -192,11 +195,11 @@ struct zkc_zkey {
     int max_inflight = 0;                                                   // proofs per pipeline pass (upper limit)
     int cur_inflight = 0;                                                   // what the lanes' work space is currently sized for (lanes_ensure)
     uint8_t sha256[32] = {0};                                               // of the whole .zkey image (taken once, at load)
+    size_t bytes_tables = 0, bytes_work = 0;                                // HBM held by the key: constant tables (load) / the lanes' work space (lanes_ensure); hipMemGetInfo deltas
     uint8_t fingerprint[32] = {0};                                          // parse::zkey_fingerprint of the image: the per-call identity of the resident-key caches
-    zkc_lane lane[2]; int nlanes = 2; bool serial_streams = false;          // serial_streams: the lanes borrow ctx->stream (ZKC_SERIAL_STREAMS, measurement only)
-    uint32_t *d_flags = nullptr, *h_flags = nullptr; size_t flags_cap = 0;  // fold check: [B][2][n]
+    zkc_lane lane[zkc::MAX_LANES]; int nlanes = 1; bool serial_streams = false;          // serial_streams: the lanes borrow ctx->stream (ZKC_SERIAL_STREAMS, measurement only)
     zkc::G1Affine *d_tblDelta1 = nullptr, *d_tblAlpha1 = nullptr, *d_tblBeta1 = nullptr; zkc::G2Affine* d_tblDelta2 = nullptr;
-    uint32_t *d_depths = nullptr, *h_depths = nullptr;                     // zkc_input_depths: device [4], pinned [2 call slots][4]
+    uint32_t *d_depths = nullptr, *h_depths = nullptr; size_t depths_cap = 0;                     // zkc_input_depths: device [2 B], pinned [2 B] (read back inside begin, under the context lock)
     zkc::G1XYZZ* d_fb4 = nullptr; zkc::G2XYZZ* d_fb4g2 = nullptr; int fb4_bases = 0;   // 4-bit fixed-base tables of the small-pass blinding (FinalizeArgs::fb4)
     // per CALL state, two slots: a call is begin (everything enqueued, returns) + finish (wait, copy out), and the proving service lets the begin of the next
     // call run while the previous one drains (its witness kernels beside the other call's MSMs, its transforms beside the other's bucket reduction and blinding)
@@ -205,12 +208,19 @@ struct zkc_zkey {
         uint8_t* h_out = nullptr;                                           // pinned: [B][256] proofs then [B][nPub][32] public signals (async D2H target)
         uint8_t* h_rs = nullptr;                                            // pinned copy of the caller's (r, s): begin returns before the upload has executed
         uint8_t *d_xyzz = nullptr, *h_xyzz = nullptr; std::vector<uint8_t> as_xyzz;     // [B][512]: a small pass (one or two proofs) hands its three points over as XYZZ; as_xyzz[q]: proof q is to be made affine by finish
-        hipEvent_t ev_done[2] = {nullptr, nullptr};                         // per lane: recorded on its blinding stream behind the call's last copy
+        hipEvent_t ev_done[zkc::MAX_LANES] = {};                            // per lane: recorded on its blinding stream behind the call's last copy
+        std::vector<hipEvent_t> ev_chunk;                                   // ev_chunk[p]: witness (if made here) and fold flags of the call's pass p are ready
+        uint32_t lanes_used = 0;                                            // bit l: this call enqueued a pass on lane l (finish waits for those lanes only)
         int B = 0; bool pending = false;
-        int early_n = 0; uint8_t early_depth[4] = {0, 0, 0, 0}; uint32_t* h_early = nullptr;      // [r3] a call of <= 2 voters laid out from zkc_input_depths (prove_batch_begin): voters, (census, sik) depths; pinned: their status [2], then the fold flags of the finished witness [2][2][n]
-    } call[2];
+        uint32_t *d_flags = nullptr, *h_flags = nullptr; size_t flags_cap = 0;  // fold check of this call's witnesses: [B][2][n] (device, pinned)
+        int32_t* d_status3 = nullptr; size_t status3_cap = 0;                   // the witness kernels' three status words per voter
+        // [r3] a call of <= 2 voters laid out from zkc_input_depths (prove_batch_begin): voters, (census, sik) depths; pinned: their status [B], then the fold flags of the
+        // finished witness [B][2][n].  [r5] any one-pass call that brings its inputs (the proving service's batches): begin no longer waits for the witness kernel
+        int early_n = 0; std::vector<uint8_t> early_depth; uint32_t* h_early = nullptr; size_t early_cap = 0;
+        const void* arg_wtns = nullptr; uint32_t arg_nw = 0; bool arg_publics = false, arg_inputs = false; int arg_lane0 = -1; hipEvent_t arg_wait = nullptr; std::vector<uint8_t> h_rs_copy;      // what begin was called with (finish begins a witness-given call again when its early layout is refused)
+    } call[zkc::CALL_SLOTS];
     int last_lane = -1;                                                     // lane of the latest pass that was enqueued (prove_tail_reached)
-    hipEvent_t ev_start = nullptr; std::vector<hipEvent_t> ev_chunk;        // ev_chunk[p]: witness (if made here) and fold flags of pass p are ready
+    hipEvent_t ev_start = nullptr;
     // constant folding of the voter-independent witness part (SURVEY.md hard part 4)
     struct Fold {
         std::vector<zkc::G1XYZZ> baseA, baseB1, baseC; std::vector<zkc::G2XYZZ> baseB2;        // [1]
@@ -249,12 +259,20 @@ int blind_scalars_launch(zkc_ctx* ctx, hipStream_t st, const BlindArgs& a, int n
 // a batch call in two halves (zkc_prove.hip; the public zkc_[full]prove_batch_dev are begin + finish on slot 0): begin validates, enqueues every pass and returns
 // without waiting for the GPU; finish waits for that call and copies proofs / public signals out.  cs = call slot 0 / 1; a slot must be finished before it is
 // begun again; d_wtns (and d_inputs, d_status) stay the caller's until finish returns.  d_inputs == nullptr: the witnesses are given.
-int prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nWitness, int B, const uint8_t* rs, bool want_publics, const void* d_inputs, int32_t* d_status);
+// lane0 >= 0: every pass of the call runs on that lane (the service: one lane per worker); -1: the passes rotate over the key's lanes.
+// wait_first (optional): an event the call's first kernels wait for (the uploads of its inputs / witnesses on the caller's stream)
+// host_depths (optional, 2 per voter: census, sik): 1 + index of the voter's last non-zero sibling per tree, read by the caller on the host; a one-pass call is then laid out
+// from them without any GPU round trip inside begin (255 in any entry: unknown, the call takes the usual path); no_early: never lay the pass out ahead of the fold flags
+int prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nWitness, int B, const uint8_t* rs, bool want_publics, const void* d_inputs, int32_t* d_status,
+                      int lane0 = -1, hipEvent_t wait_first = nullptr, const uint8_t* host_depths = nullptr, bool no_early = false);
 int prove_batch_finish(zkc_zkey* zk, int cs, uint8_t* proofs, uint8_t* publics);
 // has the call begun last on this key reached its tail (the last pass' G1 accumulation is through; bucket reduction, blinding and copies remain)?  The proving
 // service begins the next call then: its witness kernels and transforms run beside that tail, and until then it keeps collecting requests.
 bool prove_tail_reached(zkc_zkey* zk);
 int prove_reserve(zkc_zkey* zk, int inflight);              // grow the key's work space to `inflight` proofs per pass now (clamped to the key's own limit)
+// zkc_zkey_load with the lane count and pass size given instead of read from $ZKC_LANES / $ZKC_INFLIGHT (0: take the environment / defaults)
+int zkey_load_opts(zkc_ctx* ctx, const void* zkey_bytes, size_t len, int nlanes, int max_inflight, zkc_zkey** out);
+size_t zkey_device_bytes(const zkc_zkey* zk, size_t* tables, size_t* work);      // what the key holds in HBM now: constant tables / per-pass work space of its lanes
 size_t finalize_scratch_bytes(int nproofs);
 int msm_precompute_g1(zkc_ctx* ctx, uint32_t count, G1Affine* d_table, int c);   // d_table[0..count) = base on entry
 int msm_precompute_g2(zkc_ctx* ctx, uint32_t count, G2Affine* d_table, int c);

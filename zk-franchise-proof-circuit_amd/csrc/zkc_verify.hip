@@ -226,8 +226,85 @@ extern "C" int zkc_circuit_nlevels_from_wasm(const void* wasm, size_t len, char 
     return -1;
 }
 
+// the circuit a caller names by its witness-calculator image, per call and cheaply: the SHA-256 of a 3 MB wasm is ~2 ms, a proof's share of a GPU pass 0.3 ms, so the answer
+// is remembered per (buffer, length) and re-checked against a sampled digest of the buffer (both ends and a 64-byte block of every 64 KB: a buffer re-used for another file
+// is hashed again).  -1: unknown wasm
+static int nlevels_of_wasm_cached(const void* wasm, size_t len) {
+    struct Seen { const void* p; size_t len; uint8_t sample[32]; int nLevels; };
+    static std::mutex mu; static std::vector<Seen> seen;
+    uint8_t smp[32];
+    { parse::Sha256 h; const uint8_t* b = (const uint8_t*)wasm; const uint64_t l64 = len; h.update(&l64, 8); const size_t edge = std::min<size_t>(len, 1024); h.update(b, edge); h.update(b + len - edge, edge);
+      for (size_t off = 0; off + 64 <= len; off += 65536) h.update(b + off, 64); h.final(smp); }
+    { std::lock_guard<std::mutex> g(mu); for (auto& e : seen) if (e.p == wasm && e.len == len && !memcmp(e.sample, smp, 32)) return e.nLevels; }
+    const int nl = zkc_circuit_nlevels_from_wasm(wasm, len, nullptr);
+    std::lock_guard<std::mutex> g(mu);
+    if (seen.size() >= 16) seen.erase(seen.begin());
+    Seen e; e.p = wasm; e.len = len; memcpy(e.sample, smp, 32); e.nLevels = nl; seen.push_back(e);
+    return nl;
+}
+// nLevels of the call: from the wasm's hash when one is given (the reference's callers name the circuit that way: prover.Prove(zkey, wasm, inputs), zk_census_test.go:89),
+// else from the key's own shape (wire count and 8 public signals).  < 0: err says why
+static int nlevels_of_call(const void* zkey, size_t zkey_len, const void* wasm, size_t wasm_len, std::string& err) {
+    if (wasm) {
+        const int nl = nlevels_of_wasm_cached(wasm, wasm_len);
+        if (nl < 0) err = "the witness calculator (wasm) is not one this build has a native circuit for; the C ABI has no wasm runtime (the N-API surface executes unknown circuits in Node): compute the witness elsewhere and call groth16_prover";
+        return nl;
+    }
+    parse::BinSections bs; parse::ZkeyHeader zh;
+    if (!parse::binfile_sections((const uint8_t*)zkey, zkey_len, "zkey", 1, bs, err) || !parse::zkey_check(bs, zh, err, false)) return -1;
+    if (zh.nPub == 8) for (int nl = 3; nl <= 253; nl++) if ((uint32_t)zkc_circuit_n_wires(nl) == zh.nVars) return nl;
+    err = "no wasm given and the key is not a ZkFranchiseProofCircuit key"; return -1;
+}
+// inputs_example.json's text -> the flat input block (zkc_hostparse.h circuit_inputs_from_json: circom_runtime's reading and messages)
+extern "C" int zkc_inputs_from_json(const char* json, size_t len, int nLevels, void* out, char* err, size_t errlen) {
+    auto fail = [&](int code, const std::string& m) { if (err && errlen) snprintf(err, errlen, "%s", m.c_str()); return code; };
+    if (!json || !out || nLevels < 3 || nLevels > 253) return fail(ZKC_ERR_BAD_ARG, "zkc_inputs_from_json: bad argument");
+    std::string why;
+    const int rc = parse::circuit_inputs_from_json(json, len, nLevels, (uint8_t*)out, why);
+    if (rc) return fail(rc == 1 ? ZKC_ERR_FORMAT : ZKC_ERR_GENERIC, why);
+    if (err && errlen) err[0] = 0;
+    return ZKC_OK;
+}
+// prover.Prove(zkey, wasm, inputs) with the reference's three byte slices (zk_census_test.go:81-89), one voter, through the proving service: witness and proof on the GPU
+extern "C" int zkc_service_fullprove_json(zkc_service* svc, const void* zkey, size_t zkey_len, const void* wasm, size_t wasm_len, const char* inputs_json, size_t inputs_len,
+                                          const uint8_t* rs, uint8_t proof[256], uint8_t* publics, int32_t* status, char* err, size_t errlen) {
+    auto fail = [&](int code, const std::string& m) { if (err && errlen) snprintf(err, errlen, "%s", m.c_str()); return code; };
+    if (status) *status = 0;
+    if (!svc || !zkey || !inputs_json || !proof) return fail(ZKC_ERR_BAD_ARG, "zkc_service_fullprove_json: bad argument");
+    std::string why;
+    const int nl = nlevels_of_call(zkey, zkey_len, wasm, wasm_len, why);
+    if (nl < 0) return fail(ZKC_ERR_BAD_ARG, why);
+    std::vector<uint8_t> flat(32 * (size_t)zkc_circuit_n_inputs(nl));
+    const int rc = parse::circuit_inputs_from_json(inputs_json, inputs_len, nl, flat.data(), why);
+    if (rc) return fail(rc == 1 ? ZKC_ERR_FORMAT : ZKC_ERR_GENERIC, why);
+    return zkc_service_fullprove(svc, zkey, zkey_len, nl, flat.data(), rs, proof, publics, status, err, errlen);
+}
+// ... and with rapidsnark's conventions for everything else (groth16_prover below): JSON texts out, 0 / 1 / 2, the process-wide service, random (r, s).  What a cgo
+// prover.Prove calls instead of wasmer + groth16_prover.  A voter whose inputs fail a circuit assert: 1, error_msg = the wasm's message.
+extern "C" int groth16_fullprove(const void* zkey_buffer, unsigned long zkey_size, const void* wasm_buffer, unsigned long wasm_size, const char* inputs_json, unsigned long inputs_size,
+                                 char* proof_buffer, unsigned long* proof_size, char* public_buffer, unsigned long* public_size, char* error_msg, unsigned long error_msg_maxsize) {
+    auto err = [&](int code, const std::string& m) { if (error_msg && error_msg_maxsize) snprintf(error_msg, error_msg_maxsize, "%s", m.c_str()); return code; };
+    if (!zkey_buffer || !inputs_json || !proof_size || !public_size) return err(ZKC_ERR_GENERIC, "groth16_fullprove: null argument");
+    parse::BinSections bs; parse::ZkeyHeader zh; std::string perr;
+    if (!parse::binfile_sections((const uint8_t*)zkey_buffer, zkey_size, "zkey", 1, bs, perr) || !parse::zkey_check(bs, zh, perr, false)) return err(ZKC_ERR_GENERIC, perr);
+    const unsigned long need_proof = 8 * 80 + 128, need_public = (unsigned long)zh.nPub * 80 + 8;
+    if (!proof_buffer || !public_buffer || *proof_size < need_proof || *public_size < need_public) {
+        *proof_size = need_proof; *public_size = need_public;
+        return err(ZKC_ERR_SHORT_BUFFER, "Proof or public signals buffer is too short");
+    }
+    zkc_service* svc = zkc_service_default();
+    if (!svc) return err(ZKC_ERR_GENERIC, zkc_service_last_error());
+    uint8_t proof[256]; std::vector<uint8_t> pub(32 * (size_t)zh.nPub + 1); char etext[512] = {0}; int32_t st = 0;
+    int rc = zkc_service_fullprove_json(svc, zkey_buffer, zkey_size, wasm_buffer, wasm_size, inputs_json, inputs_size, nullptr, proof, pub.data(), &st, etext, sizeof etext);
+    if (rc) return err(ZKC_ERR_GENERIC, etext);
+    rc = zkc_proof_to_json(proof, pub.data(), (int)zh.nPub, proof_buffer, proof_size, public_buffer, public_size);
+    if (rc == ZKC_ERR_SHORT_BUFFER) return err(ZKC_ERR_SHORT_BUFFER, "Proof or public signals buffer is too short");
+    return rc;
+}
+
 // vk: alpha1(64) beta2(128) gamma2(128) delta2(128) IC[nPublic+1](64 each); pub: nPublic x 32; proof: A(64) B(128) C(64); standard form
 extern "C" int zkc_verify_bin(const uint8_t* vk, int nPublic, const uint8_t* pub, const uint8_t* proof) {
+    g_err.clear();
     if (!vk || !pub || !proof || nPublic < 0) return vfail(-ZKC_ERR_BAD_ARG, "zkc_verify_bin: bad argument");
     G1Affine alpha, A, C; G2Affine beta, gamma, delta, B;
     if (!rd_g1_std(alpha, vk) || !rd_g2_std(beta, vk + 64) || !rd_g2_std(gamma, vk + 192) || !rd_g2_std(delta, vk + 320)) return vfail(-ZKC_ERR_FORMAT, "verification key coordinate >= q");
@@ -262,6 +339,7 @@ struct Xoshiro { uint64_t s[4]; uint64_t next() { auto rotl = [](uint64_t x, int
     const uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17; s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45); return r; } };
 }
 extern "C" int zkc_verify_batch(zkc_ctx* ctx, const uint8_t* vk, int nPublic, const uint8_t* pubs, const uint8_t* proofs, int N, const uint8_t* seed32) {
+    g_err.clear();
     if (!ctx || !vk || !pubs || !proofs || nPublic < 0 || N <= 0) return vfail(-ZKC_ERR_BAD_ARG, "zkc_verify_batch: bad argument");
     G1Affine alpha; G2Affine beta, gamma, delta; std::vector<G1Affine> ic(nPublic + 1);
     if (!rd_g1_std(alpha, vk) || !rd_g2_std(beta, vk + 64) || !rd_g2_std(gamma, vk + 192) || !rd_g2_std(delta, vk + 320)) return vfail(-ZKC_ERR_FORMAT, "verification key coordinate >= q");
@@ -333,6 +411,7 @@ extern "C" int zkc_verify_batch(zkc_ctx* ctx, const uint8_t* vk, int nPublic, co
 
 // JSON surface: the three artifact files of the reference (verification_key.json, signals.json, proof.json). 1 valid / 0 invalid / <0 error
 extern "C" int zkc_verify(const char* vkey_json, const char* public_json, const char* proof_json) {
+    g_err.clear();                                       // the text belongs to THIS call: a plain invalid proof (0) leaves it empty
     if (!vkey_json || !public_json || !proof_json) return vfail(-ZKC_ERR_BAD_ARG, "zkc_verify: bad argument");
     std::vector<uint8_t> vkb, pubb, prb; int np = 0; std::string perr;
     const int rc = parse::verify_inputs_from_json(vkey_json, public_json, proof_json, vkb, pubb, prb, np, perr);
