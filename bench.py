@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # hardware queues for the HIP runtime of this process (read once, when the runtime initialises -- before torch or the library touches the GPU): the pipeline's seven streams
 # on the default four queues run 5 % slower (csrc/zkc_api.hip zkc_runtime_defaults; profiles/r05_hw_queues_ab.json)
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '24')
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (6.3 TB/s achievable)
 CATS = {0: 'witness', 1: 'buildABC_matvec', 2: 'ntt_joinABC', 3: 'msm_digits_sort', 4: 'msm_accumulate_g1', 5: 'msm_accumulate_g2', 6: 'msm_reduce',
         7: 'msm_g1_streamed'}

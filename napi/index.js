@@ -11,7 +11,7 @@
 // header (wire count), or 160 where there is no key (wtns.calculate).
 "use strict";
 // hardware queues of the HIP runtime (read when it initialises, i.e. before the addon's first call): see csrc/zkc_api.hip zkc_runtime_defaults
-if (!process.env.GPU_MAX_HW_QUEUES) process.env.GPU_MAX_HW_QUEUES = "16";
+if (!process.env.GPU_MAX_HW_QUEUES) process.env.GPU_MAX_HW_QUEUES = "24";
 const fs = require("fs");
 const path = require("path");
 const native = require("./zkcensus.node");

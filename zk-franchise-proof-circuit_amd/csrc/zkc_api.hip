@@ -119,7 +119,7 @@ static void conv_consts(std::vector<Fr>& out, const unsigned long long (&src)[N]
 // stream waits; on four queues the batch path lost 5 % (3104 -> 3267 proofs/s with 8, same box) and the proving service's lanes ran one after another instead of side by
 // side (profiles/r05_service_hw_queues.txt).  The variable is read when the HIP runtime initialises, so it is set here, at library load, unless the host has set it; a host
 // that initialises HIP before loading this library (or wants another value) sets GPU_MAX_HW_QUEUES itself -- bench.py and the N-API addon do.
-__attribute__((constructor)) static void zkc_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+__attribute__((constructor)) static void zkc_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
 
 extern "C" int zkc_ctx_create(int device, zkc_ctx** out) {
     if (!out) return zkc_fail(nullptr, ZKC_ERR_BAD_ARG, "out == NULL");

@@ -577,7 +577,11 @@ int fold_group_sums_g2(zkc_ctx* ctx, const G2Affine* tbl, const uint32_t* s, con
 static int msm_work_alloc_impl(zkc_ctx* ctx, MsmWork& w, size_t max_entries, size_t max_buckets, int max_jobs, bool g2) {
     w.max_entries = max_entries; w.max_jobs = max_jobs; w.max_buckets = max_buckets; w.xyzz_size = g2 ? sizeof(G2XYZZ) : sizeof(G1XYZZ);
     const size_t nb = max_buckets;
-    w.max_segments = max_entries / MSM_SEG_MIN + nb;    // every non-empty bucket has at most one short segment
+    // segments of a pass: a bucket of c entries is cut into ceil(c / seg) segments, seg = clamp(total / 131072, MSM_SEG_MIN, MSM_SEG) (msm_pass), so there are at most
+    // total / seg + nb of them: total / MSM_SEG for a full pass, under 131072 x 17 / 16 whenever seg is below MSM_SEG.  [r5] Rounds 1-4 sized every per-segment array for
+    // max_entries / MSM_SEG_MIN -- a full pass cut into 16-entry segments, which msm_pass never does: 4.7 GB of partial sums per lane at 64 proofs in flight where 1.4 are reachable.
+    // (32 x 8192: the half-wave-per-bucket form of a small G2 pass wants up to 32 slices for each of its <= 8192 buckets.)
+    w.max_segments = std::max<size_t>(max_entries / MSM_SEG + 1, (size_t)32 * 8192) + nb + 64;
     w.max_bins = (size_t)max_jobs << MSM_MAX_HBITS;
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.vals, max_entries * 4 + 16)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.vals2, max_entries * 4 + 16));
     ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.hist, w.max_bins * 4)); ZKC_HIP_CHECK(ctx, hipMalloc((void**)&w.bin_start, w.max_bins * 4));

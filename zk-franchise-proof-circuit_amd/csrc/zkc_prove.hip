@@ -841,18 +841,20 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         // a7 on the second stream: overlaps the next pass
         // a call that is one small pass: its blinding and its copy go on the G1 stream itself -- nothing follows that they could overlap with, and a hop to the blinding stream is
         // ~25 us of a 3.2 ms proof
-        hipStream_t bl = (tree && npasses == 1) ? st : fin;
+        // [r5] ... and so does every one-pass call that stays on its lane (the proving service): its blinding can only start when both MSM sides are through and nothing of the
+        // call follows it, so a stream of its own buys nothing and costs a hardware queue (a service of four lanes keeps 8 streams busy instead of 12)
+        hipStream_t bl = ((tree || lane0 >= 0) && npasses == 1) ? st : fin;
         if (bl == fin) { ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm, 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_red, 0)); }      // ev_msm: the G1 stream up to the copy of the public signals; ev_red: the G1 results
         // [r4] ... but the blinding scratch (LN.d_fin) is the lane's, and the pass before this one -- the last pass of the PREVIOUS call, begun on the other call slot -- blinds on
         // `fin`: without this wait its lane-per-product kernels and this call's tree kernels could write the scratch at the same time (a wrong proof for one of the two callers,
         // seen once in tests/test_gpu_service.py::test_queue_spills_over_further_device_entries under a load of mixed batch sizes).  That pass' blinding is long over when
         // this call's MSMs are through, so the wait costs nothing.
-        else if (LN.npass >= 2) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, LN.ev_fin[slot ^ 1], 0));
-        if (!tree) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(fin, LN.ev_msm2, 0));      // a small pass' piB is written on the G2 stream: piA and piC need not wait for it ...
+        else { if (LN.npass >= 2) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, LN.ev_fin[slot ^ 1], 0)); if (red_split) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, LN.ev_red, 0)); }
+        if (!tree) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(bl, LN.ev_msm2, 0));      // a small pass' piB is written on the G2 stream: piA and piC need not wait for it ...
         if ((rc = finalize_launch(ctx, bl, fa, nb))) return rc;
         if (tree) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(bl, LN.ev_msm2, 0));        // ... only the copy of the finished proof does
         if (tree) { ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.h_xyzz + 512ull * p0, CS.d_xyzz + 512 * (size_t)p0, 512ull * nb, hipMemcpyDeviceToHost, bl)); for (int q = 0; q < nb; q++) CS.as_xyzz[p0 + q] = 1; }
-        else ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.h_out + 256ull * p0, CS.d_proofs + 256 * (size_t)p0, 256ull * nb, hipMemcpyDeviceToHost, fin));
+        else ZKC_HIP_CHECK(ctx, hipMemcpyAsync(CS.h_out + 256ull * p0, CS.d_proofs + 256 * (size_t)p0, 256ull * nb, hipMemcpyDeviceToHost, bl));
         ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_fin[slot], bl));
         if (bl == st) done_on_st_lane = li;
         tr[5] = now_ms();

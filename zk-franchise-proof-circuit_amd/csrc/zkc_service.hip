@@ -73,17 +73,20 @@ struct HipBuf {     // grow-only buffer on the calling thread's current device (
 struct PinPool {
     std::mutex m; size_t slot = 0, nslots = 0, max_slots = 512; std::vector<void*> free_, chunks; std::vector<size_t> chunk_bytes;
     void* get(size_t bytes) {
-        std::lock_guard<std::mutex> g(m);
-        if (!slot) slot = (bytes + 4095) & ~(size_t)4095;
-        if (bytes > slot) return nullptr;
-        if (free_.empty()) {
-            const size_t n = std::min<size_t>(16, max_slots - nslots);
-            void* p = nullptr;
-            if (n == 0 || hipHostMalloc(&p, n * slot, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-            chunks.push_back(p); chunk_bytes.push_back(n * slot); nslots += n;
-            for (size_t i = 0; i < n; i++) free_.push_back((uint8_t*)p + i * slot);
+        size_t sl;
+        {
+            std::lock_guard<std::mutex> g(m);
+            if (!slot) slot = (bytes + 4095) & ~(size_t)4095;
+            if (bytes > slot) return nullptr;
+            if (!free_.empty()) { void* r = free_.back(); free_.pop_back(); return r; }
+            if (nslots + 2 > max_slots) return nullptr;
+            nslots += 2; sl = slot;                                  // reserved; pinned below, OUTSIDE the lock: a burst of first-time callers pins its slots side by side
         }
-        void* r = free_.back(); free_.pop_back(); return r;
+        void* p = nullptr;                                           // two slots at a time: this caller's and one for whoever comes next
+        if (hipHostMalloc(&p, 2 * sl, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); std::lock_guard<std::mutex> g(m); nslots -= 2; return nullptr; }
+        std::lock_guard<std::mutex> g(m);
+        chunks.push_back(p); chunk_bytes.push_back(2 * sl); free_.push_back((uint8_t*)p + sl);
+        return p;
     }
     void put(void* p) { if (!p) return; std::lock_guard<std::mutex> g(m); free_.push_back(p); }
     size_t bytes() { std::lock_guard<std::mutex> g(m); size_t t = 0; for (size_t b : chunk_bytes) t += b; return t; }
@@ -120,7 +123,7 @@ struct zkc_service {
     std::mutex img_mu; std::vector<std::shared_ptr<KeyImage>> images; uint64_t img_clock = 0;      // key images by (fingerprint, SHA-256): as many as the devices may hold keys, none dropped while resident
     PinPool pin;
     std::vector<std::unique_ptr<Dev>> devs; std::vector<std::unique_ptr<Worker>> workers;
-    int max_batch = 256, spill = 32, keys_per_dev = 4, workers_per_dev = 4, pass = 48, min_batch = 8; uint64_t busy_wait_us = 1000;
+    int max_batch = 256, spill = 32, keys_per_dev = 4, workers_per_dev = 4, pass = 64, min_batch = 16; uint64_t busy_wait_us = 300;
     uint64_t n_requests = 0, n_batches = 0, largest_batch = 0, key_loads = 0, key_evictions = 0, n_failed = 0, reserve_failures = 0, oom_evictions = 0;
     uint64_t us_stage = 0, us_gpu_wait = 0, us_key = 0, us_prove = 0, us_finish = 0, n_proved = 0;      // where the workers' time went (microseconds, summed over batches)
 };
