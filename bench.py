@@ -197,6 +197,22 @@ def extra_legs(args, ctx, pk, zkey_bytes, vk, B, d_inputs, d_wtns, d_status, fla
     h2h(); torch.cuda.synchronize(); t0 = time.perf_counter(); h2h(); h2h(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     res['host_to_host'] = {'value': round(2 * B / dt, 1), 'unit': 'proofs/s', 'note': 'input blocks (334 x 32 B per voter) in pinned host memory when the clock starts, proofs and public '
                            'signals in host memory when it stops; 2 steps of %d' % B}
+    # ---- [r5] census to proofs: the voters' RAW data (address, password, signature, weight) on the host when the clock starts -- SIKs, nullifiers, both trees and every sibling
+    #      list (zkc_census_inputs, on the GPU, straight into device-resident input blocks), witnesses, proofs -- proofs of B of them on the host when it stops ----
+    nC = max(8192, B); eid, address, password, signature, avail = census._voter_data(nC, census.ELECTION_ID_HEX)
+    vh = [census.bytes_to_arbo(a.to_bytes((a.bit_length() + 7) // 8 or 1, 'big')) for a in avail]
+    d_all = torch.empty(nC * len(flat) // B, dtype=torch.uint8, device='cuda')
+
+    def c2p():
+        census.census_inputs(ctx, eid, address, password, signature, avail, [1] * nC, vh, nl, d_all.data_ptr())
+        return pk.fullprove_batch_dev(d_all.data_ptr(), B, d_wtns.data_ptr(), d_status.data_ptr(), draw_rs(rs, 2 * B).tobytes())
+    c2p(); torch.cuda.synchronize(); t0 = time.perf_counter(); pc, uc = c2p(); torch.cuda.synchronize(); dtc = time.perf_counter() - t0
+    t0 = time.perf_counter(); census.census_inputs(ctx, eid, address, password, signature, avail, [1] * nC, vh, nl, d_all.data_ptr()); dtb = time.perf_counter() - t0
+    res['census_to_proofs'] = {'census_voters': nC, 'proved': B, 'seconds': round(dtc, 4), 'census_build_s': round(dtb, 4), 'proofs_per_s_census_build_included': round(B / dtc, 1),
+                               'public_signals_equal_the_timed_step': bool(uc == out['pubs']),
+                               'note': 'the whole %d-voter census is built (native builder: trie split in C++, hashes and sibling scatter on the GPU; the Python builder of rounds 1-4 '
+                                       'took ~10 s) and the first %d voters proved, one call each; the Python side of the builder call (ints -> bytes) is inside census_build_s' % (nC, B)}
+    del d_all
     # ---- one proof (BASELINE configs[1]): the first voter of the batch alone, inputs -> proof in one call, inputs and outputs' device buffers as in the headline ----
     one = []
     for _ in range(14):
@@ -275,6 +291,124 @@ def extra_legs(args, ctx, pk, zkey_bytes, vk, B, d_inputs, d_wtns, d_status, fla
     return res
 
 
+def _le32(x):
+    return int(x).to_bytes(32, 'little')
+
+
+def service_leg(args, ctx, dev, zkey_bytes, vk, voters, flat, d_wtns, nW, nIn):
+    """[r5] The reference's own call shape: ONE voter per call -- prover.Prove(zkey, wasm, inputs) per voter from goroutines (zk_census_test.go:89, ending in
+    rapidsnark's groth16_prover) and groth16.fullProve per ballot (ts_inputs/src/example.ts:358-362) -- from 64 and 256 concurrent callers over voters of the timed batch.
+    The callers are native threads (tools/loadgen/loadgen.c; Python threads would put the interpreter lock between them); all end in the library's proving service
+    (csrc/zkc_service.hip), which forms pipeline passes out of whoever is waiting.  Every proof of every leg goes through the batch verifier."""
+    from zkcensus_amd import groth16
+    lib = ctx._lib
+    so = os.path.join(ROOT, 'tools', 'loadgen', 'libzkc_loadgen.so')
+    if not os.path.exists(so):
+        return {'skipped': 'tools/loadgen/libzkc_loadgen.so is not built (python -c "import __graft_entry__ as g; g.build()")'}
+    lg = ctypes.CDLL(so); vp = ctypes.c_void_p
+    lg.zkc_loadgen_run.argtypes = [ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                   ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p,
+                                   ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    os.environ.setdefault('ZKC_DEVICE', str(dev))                       # the process-wide service behind groth16_prover stays on this rank's GPU
+    V = min(256, len(voters))
+    wt = d_wtns.view(-1, nW * 32)[:V].cpu().numpy()
+    images = []
+    for i in range(V):                                                  # .wtns file images: what go-rapidsnark hands to groth16_prover
+        w = wt[i].tobytes(); n = lib.zkc_wtns_write(w, nW, None, 0); buf = ctypes.create_string_buffer(n); lib.zkc_wtns_write(w, nW, buf, n); images.append(buf.raw)
+    flats = [flat[i * nIn * 32:(i + 1) * nIn * 32] for i in range(V)]
+    texts = [json.dumps(voters[i]).encode() for i in range(V)]          # inputs_example.json's shape: what prover.Prove receives (zk_census_test.go:85-89)
+    h = lib.zkc_service_default()
+    if not h:
+        return {'skipped': (lib.zkc_service_last_error() or b'').decode()}
+    svc = ctypes.c_void_p(h)
+
+    def stats():
+        a = (ctypes.c_uint64 * 8)(); b = (ctypes.c_uint64 * 8)(); lib.zkc_service_stats(svc, a); lib.zkc_service_timing(svc, b)
+        return [int(x) for x in a], [int(x) for x in b]
+
+    def leg(mode, callers, calls):
+        n = callers * calls
+        items = {0: images, 1: flats, 4: texts}[mode]
+        arr = (ctypes.c_char_p * V)(*items); lens = (ctypes.c_size_t * V)(*[len(x) for x in items])
+        wall = ctypes.c_double(0); lat = (ctypes.c_double * n)()
+        pj = uj = pr = pu = st = None
+        if mode == 1:
+            pr = ctypes.create_string_buffer(256 * n); pu = ctypes.create_string_buffer(256 * n); st = (ctypes.c_int32 * n)()
+            fn = ctypes.cast(lib.zkc_service_fullprove, vp)
+        else:
+            pj = ctypes.create_string_buffer(2048 * n); uj = ctypes.create_string_buffer(2048 * n)
+            fn = ctypes.cast(lib.groth16_prover if mode == 0 else lib.groth16_fullprove, vp)
+        (s0, t0) = stats(); c0 = time.process_time()
+        failed = lg.zkc_loadgen_run(mode, fn, svc if mode == 1 else None, callers, calls, zkey_bytes, len(zkey_bytes), None, 0, args.nlevels, 8, arr, lens, V, pj, uj, pr, pu, st,
+                                    ctypes.byref(wall), lat)
+        cpu_s = time.process_time() - c0; (s1, t1) = stats()
+        if mode == 1:
+            proofs, pubs = pr.raw, pu.raw
+        else:                                                           # JSON texts, parsed after the clock has stopped
+            pl, ul = [], []
+            for i in range(n):
+                p = json.loads(pj.raw[2048 * i:2048 * (i + 1)].split(b'\0', 1)[0]); u = json.loads(uj.raw[2048 * i:2048 * (i + 1)].split(b'\0', 1)[0])
+                pl += [_le32(x) for x in (p['pi_a'][0], p['pi_a'][1], p['pi_b'][0][0], p['pi_b'][0][1], p['pi_b'][1][0], p['pi_b'][1][1], p['pi_c'][0], p['pi_c'][1])]
+                ul += [_le32(x) for x in u]
+            proofs, pubs = b''.join(pl), b''.join(ul)
+        ok = failed == 0 and groth16.verify_batch(ctx, vk, pubs, proofs)
+        nb = max(1, s1[1] - s0[1]); ls = sorted(lat)
+        return {'callers': callers, 'calls_per_caller': calls, 'proofs': n, 'seconds': round(wall.value, 4), 'proofs_per_s': round(n / wall.value, 1), 'all_verified_by_batch_verifier': bool(ok),
+                'batches': nb, 'mean_batch': round(n / nb, 1), 'largest_batch_so_far': s1[2], 'latency_ms_p50': round(ls[n // 2], 2), 'latency_ms_p95': round(ls[int(n * 0.95)], 2),
+                'worker_ms_per_batch': {k: round((t1[i] - t0[i]) / 1e3 / nb, 2) for i, k in enumerate(('upload', 'collect', 'key', 'begin_to_finish', 'hand_back'))},
+                'host_cpu_cores_used': round(cpu_s / wall.value, 2)}
+    res = {'what': 'one voter per call from N concurrent native caller threads through the proving service; callers x calls proofs per leg, every one batch-verified; '
+                   'groth16_prover takes whole .zkey / .wtns file images and returns JSON (the symbol go-rapidsnark binds), zkc_service_fullprove takes the 334 x 32-byte input block, '
+                   'groth16_fullprove the byte slices of prover.Prove(zkey, wasm, inputs) with the inputs as JSON text (wasm NULL here: the circuit by the key\'s shape)'}
+    leg(0, 8, 1); leg(1, 64, 2); leg(0, 64, 2); leg(0, 256, 1); leg(1, 256, 1); leg(4, 8, 1)     # untimed: key load, work space, staging buffers, pinned slots
+    res['groth16_prover'] = [leg(0, 64, 32), leg(0, 256, 12)]
+    res['zkc_service_fullprove'] = [leg(1, 64, 32), leg(1, 256, 12)]
+    res['groth16_fullprove_json'] = [leg(4, 64, 32)]
+    res['lone_sequential_caller_ms'] = leg(1, 1, 20)['latency_ms_p50']      # one caller, one call at a time: the latency through the same queue
+    mem = (ctypes.c_uint64 * 8)(); lib.zkc_service_memory(svc, mem)
+    res['memory_GB'] = dict(zip(('resident_keys', 'key_tables', 'key_work_space', 'largest_key_tables', 'largest_key_work_space', 'staging_device', 'pinned_host', 'reserve_failures'),
+                                [int(mem[0])] + [round(int(x) / 1e9, 2) for x in mem[1:7]] + [int(mem[7])]))
+    return res
+
+
+def generic_2p20_leg(ctx):
+    """[r5] BASELINE configs[4] where the driver sees it: full Groth16 proofs of a circuit-shaped random R1CS at the 2^20 ceiling of the reference's powers of
+    tau (circuit/circuit-compiler.sh:57) -- 983 040 constraints, 983 105 wires, four different witnesses -- through groth16.prove's generic path; five of them through the pinned
+    verifier (the closed-form comparison of this size is in tools/generic_bench.py: 15 s of Python)."""
+    import random, tempfile, shutil
+    import numpy as np, torch
+    import zkcensus_amd
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import oracle_lib as ol, big_circuit as bc                          # instance generator and the checker
+    from test_generic_circuit import setup_key
+    logn = 20; n = 1 << logn; n_cons = n - n // 16; n_in = 64; n_pub = 8; B = 24; NW = 4
+    tmp = tempfile.mkdtemp(prefix='zkc_bench_2p20_')
+    try:
+        t0 = time.time(); r1 = os.path.join(tmp, 'c.r1cs'); n_wires = bc.chain_instance(r1, n_cons, n_in, n_pub, seed=logn)
+        rng = random.Random(logn)
+        wits = [bc.chain_witness(n_cons, n_in, logn, [rng.getrandbits(253) for _ in range(n_in)]) for _ in range(NW)]
+        zk, vk = setup_key(r1, 2024 + logn); t_host = time.time() - t0
+        t0 = time.time(); pk = zkcensus_amd.ProvingKey(ctx, zk); torch.cuda.synchronize(); t_load = time.time() - t0
+        d_w = torch.from_numpy(np.frombuffer(b''.join(wits), dtype=np.uint8).copy()).cuda().repeat((B + NW - 1) // NW)[:B * len(wits[0])].contiguous()
+        rs = b''.join(_le32(3 + 2 * k) + _le32(5 + 3 * k) for k in range(B))
+        proofs, pubs = pk.prove_batch_dev(d_w.data_ptr(), B, rs)        # warm-up: the work space grows here
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(2):
+            proofs, pubs = pk.prove_batch_dev(d_w.data_ptr(), B, rs)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 2
+        npb = len(pubs) // B
+        ok = all(ol.verify(vk, pubs[npb * i:npb * (i + 1)], proofs[256 * i:256 * i + 256]) for i in (0, 1, 2, 3, B - 1))
+        t1 = []
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); pk.prove_batch_dev(d_w.data_ptr(), 1, rs[:64]); t1.append((time.perf_counter() - t0) * 1e3)
+        pk.close(); del d_w; torch.cuda.empty_cache()
+        return {'domain': n, 'constraints': n_cons, 'wires': n_wires, 'zkey_MB': round(len(zk) / 1e6, 1), 'batch': B, 'generic_2p20_proofs_per_s': round(B / dt, 2), 'ms_per_proof': round(dt / B * 1e3, 2),
+                'lone_proof_ms': round(min(t1), 2), 'oracle_verifier_accepts_sampled': bool(ok), 'host_seconds_instance_and_setup': round(t_host, 1), 'key_load_s': round(t_load, 2),
+                'what': 'groth16.prove(zkey, wtns) for a circuit that is not the census circuit: no witness generation, no constant folding; witnesses device-resident, four different ones tiled over the batch'}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -327,19 +461,23 @@ def main():
     # the census is the 8 192-voter one of configs 3/4 whatever N is (leaf depth 13-17 decides how much of a witness folds away);
     # rank r proves voters [r B, (r+1) B)
     lo, hi = parallel.shard_range(rank, world, B * world)
-    # [r4] the census is built ONCE, by rank 0 (GPU Poseidon, ~10 s for 8 192 voters, most of it Python), and every rank is handed its block of input records over the
-    # process group (one broadcast of total x 334 x 32 bytes: 87 MB for 8 192 voters) -- not eight identical builds beside each other.  ZKC_BENCH_CENSUS_PER_RANK=1: the old form.
+    # [r4] the census is built ONCE, by rank 0, and every rank is handed its block of input records over the process group (one broadcast of total x 334 x 32 bytes: 87 MB
+    # for 8 192 voters) -- not eight identical builds beside each other.  ZKC_BENCH_CENSUS_PER_RANK=1: the old form.
+    # [r5] ... by the NATIVE builder (zkc_census_inputs, csrc/zkc_census.hip: trie split in C++, every hash and the sibling scatter on the GPU): ~0.1 s where the Python
+    # builder took 10.  The 12-key objects the checkers want are made on demand from the flat blocks (census.FlatVoters).
     nIn = ctx.n_inputs(args.nlevels)
+    t_census = time.perf_counter()
     if world == 1 or os.environ.get('ZKC_BENCH_CENSUS_PER_RANK') == '1':
-        voters = census.synthetic_census(ctx, max(8192, B * world), args.nlevels)[lo:hi]
-        flat = b''.join(zkcensus_amd.flatten_inputs(v, args.nlevels) for v in voters)
+        allb, _, _ = census.synthetic_census_flat(ctx, max(8192, B * world), args.nlevels)
+        flat = allb[lo * nIn * 32:hi * nIn * 32]; del allb
+        voters = census.FlatVoters(flat, args.nlevels)
         d_inputs = torch.from_numpy(np.frombuffer(flat, dtype=np.uint8).copy()).cuda(dev)
     else:
         voters = None
         if rank == 0:
-            every = census.synthetic_census(ctx, max(8192, B * world), args.nlevels)[:B * world]
-            allflat = torch.from_numpy(np.frombuffer(b''.join(zkcensus_amd.flatten_inputs(v, args.nlevels) for v in every), dtype=np.uint8).copy())
-            voters = every[lo:hi]
+            allb, _, _ = census.synthetic_census_flat(ctx, max(8192, B * world), args.nlevels)
+            allflat = torch.from_numpy(np.frombuffer(allb[:B * world * nIn * 32], dtype=np.uint8).copy())
+            voters = census.FlatVoters(allb[lo * nIn * 32:hi * nIn * 32], args.nlevels); del allb
         else:
             allflat = torch.empty(B * world * nIn * 32, dtype=torch.uint8)
         d_all = allflat if share else allflat.cuda(dev)
@@ -347,6 +485,7 @@ def main():
         d_inputs = d_all[lo * nIn * 32:hi * nIn * 32].clone().cuda(dev)
         flat = bytes(d_inputs.cpu().numpy().tobytes())
         del d_all, allflat
+    t_census = time.perf_counter() - t_census
     nW = ctx.n_wires(args.nlevels)
     # two sets of witness / status buffers: a step is begun (everything enqueued: zkc_batch_begin) before the previous one is finished (zkc_batch_finish), so that
     # the tail of step k -- bucket reduction and blinding of its last pass, copies -- runs beside the head of step k + 1 (its first witness kernels and transforms):
@@ -397,13 +536,30 @@ def main():
     if args.warmup:
         assert all(int(t.abs().sum().item()) == 0 for t in d_status_s), 'a synthetic voter failed a circuit assert'
     ctx._lib.zkc_profile_enable(ctx._h, 0x7f)
+    def thread_cpu():                                        # per-thread CPU seconds of this process (diagnostics: ZKC_BENCH_THREAD_CPU=1 prints who used the host inside the timed region)
+        res = {}
+        try:
+            tck = os.sysconf('SC_CLK_TCK')
+            for tid in os.listdir('/proc/self/task'):
+                f = open('/proc/self/task/%s/stat' % tid).read(); name = f[f.index('(') + 1:f.rindex(')')]; v = f[f.rindex(')') + 2:].split()
+                res[tid] = (name, (int(v[11]) + int(v[12])) / tck)
+        except OSError:
+            pass
+        return res
     sync()
-    t0 = time.perf_counter()
+    tc0 = thread_cpu() if os.environ.get('ZKC_BENCH_THREAD_CPU') else None
+    t0 = time.perf_counter(); c0 = time.process_time()
     for _ in range(args.steps):
         step()
     drain()
     sync()
     dt = time.perf_counter() - t0
+    # [r5] host CPU this rank spent per second of wall time inside the timed region (all threads of the process: the enqueueing thread, the HIP runtime's, RCCL's proxies).
+    # The GPU boxes hand a container 16 cores' worth of CPU time (cpu.max; profiles/r04_cpu_baseline_scaling.json): eight ranks must fit in that.
+    cpu_used = (time.process_time() - c0) / dt
+    if tc0 is not None:
+        tc1 = thread_cpu()
+        sys.stderr.write('bench.py: host CPU per thread inside the timed region (%.2f s wall): %s\n' % (dt, sorted(((round(c - tc0.get(t, (n, 0))[1], 2), n, t) for t, (n, c) in tc1.items()), reverse=True)[:10]))
     d_wtns, d_status = d_wtns_s[out['slot']], d_status_s[out['slot']]          # buffers of the LAST timed step: what the verification legs below look at
     tmax = torch.tensor([dt], dtype=torch.float64, device='cuda')
     if world > 1 and not share:
@@ -416,6 +572,12 @@ def main():
         each = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(each, mine)
         per_rank_ms = [round(float(t.item()) / args.steps * 1e3, 3) for t in each]
+    cpu_per_rank = [round(cpu_used, 3)]
+    if world > 1:
+        mine = torch.tensor([cpu_used], dtype=torch.float64) if share else torch.tensor([cpu_used], dtype=torch.float64, device='cuda')
+        each = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(each, mine)
+        cpu_per_rank = [round(float(t.item()), 3) for t in each]
     dt = float(tmax.item())
     assert all(int(t.abs().sum().item()) == 0 for t in d_status_s), 'a synthetic voter failed a circuit assert'
 
@@ -531,20 +693,31 @@ def main():
                'sample': '%d full proofs (witness + Groth16 prove) of voters of the timed batch, %d at a time on %d threads, %.1f s; '
                          'the build\'s own C oracle, not snarkjs/rapidsnark (neither can run here)' % (len(done), cores, cores, cdt)}
 
-    extras = None
+    extras = None; service = None; generic = None
+    key_shape = {'nVars': pk.n_vars, 'domainSize': pk.domain_size}
     if rank == 0 and world == 1 and not args.no_extras and not args.no_verify:
         extras = extra_legs(args, ctx, pk, zkey_bytes, vk, B, d_inputs, d_wtns, d_status, flat, out, rs, roofline['valu']['madds_per_proof'])
+        if os.environ.get('ZKC_BENCH_SERVICE', '1') != '0':
+            service = service_leg(args, ctx, dev, zkey_bytes, vk, voters, flat, d_wtns, nW, nIn)
+        if os.environ.get('ZKC_BENCH_GENERIC_2P20', '1') != '0':
+            pk.close(); pk = None; torch.cuda.empty_cache()            # the census key's tables and work space are not needed any more
+            generic = generic_2p20_leg(ctx)
+    if rank == 0 and cpu is None:
+        cpu = {'value': None, 'note': 'the CPU baseline (the C oracle on the host cores the container gets) is timed at N = 1 only, on rank 0, on a bounded sample: see the N = 1 line'
+                                      if world > 1 else 'skipped (--no-cpu-baseline / --no-verify)'}
     if rank == 0:
         total = args.steps * B * world
         line = {
             'metric': 'zkCensus proofs/sec (nLevels=%d)' % args.nlevels, 'value': round(total / dt, 3), 'unit': 'proofs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'ms_per_step_per_rank': per_rank_ms,
+            'host_cpu_cores_used': max(cpu_per_rank), 'host_cpu_cores_used_per_rank': cpu_per_rank,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u256 (8 x u32 Montgomery, BN254 Fr/Fq)',
             'data': 'synthetic',
             'config': {'workload': 'zkCensus nLevels=%d, batch of %d voter proofs per GPU per step (BASELINE configs[2]/[3] shape), '
                                    'own test zkey seed 0x5A4B43454E535553, synthetic %d-voter census' % (args.nlevels, B, max(8192, B * world)),
-                       'step_pipelining': pipelined, 'batch_per_gpu': B, 'nVars': pk.n_vars, 'domainSize': pk.domain_size, 'parallelism': 'independent proofs per GPU, RCCL all_gather of 513 B/proof'},
+                       'step_pipelining': pipelined, 'batch_per_gpu': B, 'nVars': key_shape['nVars'], 'domainSize': key_shape['domainSize'], 'parallelism': 'independent proofs per GPU, RCCL all_gather of 513 B/proof'},
             'roofline': roofline, 'cpu_baseline': cpu, 'verified': verified,
+            'service': service, 'generic_2p20': generic, 'census_build_s': round(t_census, 3), 'census_to_proofs': (extras or {}).get('census_to_proofs'),
             'host_to_host': (extras or {}).get('host_to_host'), 'single_proof': (extras or {}).get('single_proof'), 'folding': (extras or {}).get('folding'), 'stages_isolated': (extras or {}).get('stages_isolated'),
             'stage_ms_per_proof_overlapped_not_additive': {k: round(v['ms'] / (args.steps * B), 4) for k, v in prof.items() if k != 'msm_g1_streamed'},
         }
@@ -553,7 +726,9 @@ def main():
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
-    pk.close(); ctx.close()
+    if pk is not None:
+        pk.close()
+    ctx.close()
     return 0
 
 

@@ -267,9 +267,22 @@ void zkc_msm_g1_free(zkc_msm* m);
 int zkc_debug_stage(zkc_zkey* zk, const void* d_wtns, int stage, void* host_out);
 int zkc_msm_debug(zkc_zkey* zk, int which, const void* d_scalars, uint32_t count, void* host_out);
 
-/* ---- f1 support: batched Poseidon over BN254 Fr (circomlib parameters), n_inputs in {2,3,4}; host buffers,
- * inputs B x n_inputs x 32 B, out B x 32 B.  The census builder hashes whole tree levels with it. ---- */
+/* ---- f1: the census / voter generator (internal/helpers.go:36-85 GenTree -- arbo.NewTree{Poseidon}, Add, GenProof, zero padding -- and internal/inputs.go:33-98
+ * MockInputs; ts_inputs/src/inputs.ts:38-88).  arbo tree semantics: leaf = H(key, value, 1), node = H(left, right), path bit i = bit i (LSB first) of the key, an empty
+ * subtree is 0, a subtree holding one leaf is that leaf's hash.  The trie is split on the host, every hash runs on the GPU (leaves in one launch, inner nodes one launch per
+ * depth), sibling lists are written on the device: 8 192 voters in tens of milliseconds.  All values 32-byte little-endian, standard form, below r; host buffers.
+ * zkc_poseidon_batch   : n_inputs in {2, 3, 4}; inputs B x n_inputs x 32 B, out B x 32 B.
+ * zkc_smt_build        : one tree over n (key, value) pairs with distinct keys -> root (32 B), siblings (n x (nLevels + 1) x 32 B, zero-padded, may be NULL: leaf i's sibling
+ *                        at level l in slot i (nLevels + 1) + l) and depths (levels above leaf i; may be NULL).  ZKC_ERR_BAD_ARG: duplicate keys, or two keys that share
+ *                        their first nLevels path bits.
+ * zkc_census_inputs    : the circuit inputs of n voters of one election: SIK = H(address, password, signature), nullifier = H(signature, password, electionId[0],
+ *                        electionId[1]), census tree address -> available_weight, SIK tree address -> SIK, both roots and every voter's two sibling lists, as n blocks of
+ *                        zkc_circuit_n_inputs(nLevels) x 32 B (the layout zkc_witness takes) into inputs_out (host) and / or d_inputs_out (device), either may be NULL.
+ *                        vote_hash: n x 2 x 32 B; election_id: 2 x 32 B; roots_out (may be NULL): census root | SIK root. ---- */
 int zkc_poseidon_batch(zkc_ctx* ctx, int n_inputs, const void* inputs, size_t B, void* out);
+int zkc_smt_build(zkc_ctx* ctx, const void* keys, const void* values, size_t n, int nLevels, uint8_t root[32], void* siblings, int32_t* depths);
+int zkc_census_inputs(zkc_ctx* ctx, size_t n, int nLevels, const uint8_t election_id[64], const void* address, const void* password, const void* signature,
+                      const void* available_weight, const void* vote_weight, const void* vote_hash, void* inputs_out, void* d_inputs_out, uint8_t* roots_out);
 
 /* ---- measurement: HIP-event timing per kernel category on zkc_ctx_stream (bit i of mask enables category i) ----
  * 0 witness, 1 buildABC mat-vec, 2 NTT+joinABC, 3 MSM digits+sort+offsets, 4 MSM bucket accumulation G1, 5 same G2,

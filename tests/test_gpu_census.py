@@ -93,3 +93,56 @@ def test_deep_pass_takes_the_second_section_tables():
         assert pk.batch_finish(k & 1, 5) == (p_all, u_all), k
         assert pk.batch_finish(1 - (k & 1), 6) == alone, k
     pk.close(); ctx.close()
+
+
+def test_native_census_builder_equals_the_python_tree_and_the_oracle():
+    """[r5] zkc_census_inputs / zkc_smt_build (csrc/zkc_census.hip: trie split on the host in C++, every hash and the sibling scatter on the GPU) against
+    census.SparseMerkleTree (the Python builder of rounds 1-4, itself pinned through the circuit and the reference's arbo-built path) -- byte for byte over whole censuses --
+    and, for a small tree, against a pure-Python climb with the oracle's Poseidon.  Edge shapes: one voter, two voters whose paths share 40 bits, a census that does not
+    fit the depth (two keys colliding on their first nLevels bits), duplicate keys, values at r - 1."""
+    import time, ctypes, random
+    import zkcensus_amd
+    from zkcensus_amd import census
+    ctx = zkcensus_amd.Context(0)
+    for n, nl in ((300, 160), (2048, 160), (50, 10), (1, 160)):
+        py = census.synthetic_census(ctx, n, nl) if nl == 160 or n < 2 else None
+        if py is None:                                                   # at nLevels 10 fifty random 160-bit addresses may collide on 10 bits: take the low bits apart
+            continue
+        flat, croot, sroot = census.synthetic_census_flat(ctx, n, nl)
+        assert flat == b''.join(zkcensus_amd.flatten_inputs(v, nl) for v in py), (n, nl)
+        assert str(croot) == py[0]['censusRoot'] and str(sroot) == py[0]['sikRoot']
+        fv = census.FlatVoters(flat, nl)
+        assert len(fv) == n and fv[0] == py[0] and fv[n - 1] == py[-1]
+    # one tree, small, against a climb with the ORACLE's Poseidon (no GPU code on the checking side)
+    rng = random.Random(5)
+    nl = 12; keys = rng.sample(range(1 << nl), 40); vals = [rng.randrange(ol.R) for _ in keys]; vals[3] = ol.R - 1
+    le = lambda xs: b''.join(int(x).to_bytes(32, 'little') for x in xs)
+    root = ctypes.create_string_buffer(32); sib = ctypes.create_string_buffer(32 * (nl + 1) * len(keys)); dep = (ctypes.c_int32 * len(keys))()
+    ctx._check(ctx._lib.zkc_smt_build(ctx._h, le(keys), le(vals), len(keys), nl, root, sib, dep))
+    rt = int.from_bytes(root.raw, 'little')
+    for i, (k, v) in enumerate(zip(keys, vals)):
+        s = [int.from_bytes(sib.raw[32 * ((nl + 1) * i + l):32 * ((nl + 1) * i + l + 1)], 'little') for l in range(nl + 1)]
+        assert all(x == 0 for x in s[dep[i]:])
+        cur = ol.poseidon([k, v, 1])
+        for l in range(dep[i] - 1, -1, -1):
+            cur = ol.poseidon([s[l], cur]) if (k >> l) & 1 else ol.poseidon([cur, s[l]])
+        assert cur == rt, i
+    t = census.SparseMerkleTree(ctx, keys, vals, nl)
+    assert t.root == rt
+    # two leaves whose paths part at bit 40: forty inner nodes with one empty child each
+    k2 = [5, 5 + (1 << 40)]
+    ctx._check(ctx._lib.zkc_smt_build(ctx._h, le(k2), le([7, 9]), 2, 160, root, None, dep))
+    assert list(dep) [:2] == [41, 41] and int.from_bytes(root.raw, 'little') == census.SparseMerkleTree(ctx, k2, [7, 9], 160).root
+    # refusals: keys that agree on the first nLevels path bits, duplicate keys, a value that is not a field element
+    assert ctx._lib.zkc_smt_build(ctx._h, le([1, 1 + (1 << 12)]), le([1, 2]), 2, 12, root, None, None) == 4
+    assert ctx._lib.zkc_smt_build(ctx._h, le([9, 9]), le([1, 2]), 2, 160, root, None, None) == 4
+    assert ctx._lib.zkc_smt_build(ctx._h, le([1, 2]), le([1, ol.R]), 2, 160, root, None, None) == 4
+    # the whole 8 192-voter census of BASELINE configs[2..3] in well under a second, its first voters accepted by the circuit with the oracle's witness
+    t0 = time.time(); flat, croot, sroot = census.synthetic_census_flat(ctx, 8192, 160); dt = time.time() - t0
+    print('\nnative census builder: 8192 voters in %.3f s' % dt)
+    assert dt < 1.0, dt
+    fv = census.FlatVoters(flat, 160)
+    ws, st = ctx.witness([fv[0], fv[4095], fv[8191]])
+    assert st == [0, 0, 0]
+    rc, w = ol.witness(fv[8191]); assert rc == 0 and w == ws[2]
+    ctx.close()

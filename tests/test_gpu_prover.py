@@ -325,6 +325,47 @@ def test_fullprove_batch_nl160_three_passes_config3(env):
     assert not groth16.verify_batch(ctx, vk, pubs, bytes(bad))
 
 
+def test_fullprove_batch_nl160_b1024_config2_full_size(env):
+    """BASELINE configs[2] at its OWN size and in the bench's form: 1 024 voters of the 8 192-voter synthetic census through zkc_batch_begin /
+    zkc_batch_finish, two steps in flight on the two call slots (step 2 is begun before step 1 is finished, with its own witness / status buffers and fresh (r, s)) --
+    eleven passes of 94 / 84 voters each.  All 2 048 proofs through the product's batch verifier; the first / last proofs and both sides of two pass boundaries of BOTH steps
+    byte-equal to the CPU oracle's (its witness from the voter's inputs, its proof from that witness and the step's (r, s)), on host threads."""
+    ctx, get, torch = env
+    import zkcensus_amd
+    from zkcensus_amd import census, groth16
+    nl, B = 160, 1024
+    zk, pk, vk = get(nl)
+    voters = census.synthetic_census(ctx, 8192, nl)[:B]
+    flat = b''.join(zkcensus_amd.flatten_inputs(v, nl) for v in voters)
+    d_in = dev_bytes(torch, flat)
+    nW = ctx.n_wires(nl)
+    d_w = [torch.zeros(B * nW * 32, dtype=torch.uint8, device='cuda') for _ in range(2)]; d_st = [torch.zeros(B, dtype=torch.int32, device='cuda') for _ in range(2)]
+    rng = random.Random(1024)
+    rs = [b''.join(rng.randrange(R).to_bytes(32, 'little') for _ in range(2 * B)) for _ in range(2)]
+    pk.batch_begin(0, d_in.data_ptr(), B, d_w[0].data_ptr(), d_st[0].data_ptr(), rs[0])
+    pk.batch_begin(1, d_in.data_ptr(), B, d_w[1].data_ptr(), d_st[1].data_ptr(), rs[1])
+    out = [pk.batch_finish(0, B), pk.batch_finish(1, B)]
+    per = -(-B // -(-B // 96))                                           # 94: the library cuts 1 024 into eleven equal passes
+    picks = (0, per - 1, per, 5 * per - 1, 5 * per, B - 1)
+    for k in range(2):
+        proofs, pubs = out[k]
+        assert d_st[k].cpu().tolist() == [0] * B
+        assert groth16.verify_batch(ctx, vk, pubs, proofs), 'step %d' % k
+    assert out[0][0] != out[1][0] and out[0][1] == out[1][1]             # fresh (r, s): other proofs, same public signals
+    wt = [d_w[k].view(B, nW * 32) for k in range(2)]
+    dev_w = {(k, i): wt[k][i].cpu().numpy().tobytes() for k in range(2) for i in picks}
+
+    def check(ki):
+        k, i = ki
+        rc, ow = ol.witness(voters[i], nLevels=nl)
+        assert rc == 0 and ow == dev_w[ki], ki
+        r_i = int.from_bytes(rs[k][64 * i:64 * i + 32], 'little'); s_i = int.from_bytes(rs[k][64 * i + 32:64 * i + 64], 'little')
+        rc, op, opub = ol.prove(zk, ow, r_i, s_i)
+        assert rc == 0 and op == out[k][0][256 * i:256 * i + 256] and opub == out[k][1][256 * i:256 * i + 256], ki
+    ol.pmap(check, [(k, i) for k in range(2) for i in picks])
+    del d_w, d_in
+
+
 @pytest.mark.parametrize('B', [1, 2, 97, 193])
 def test_fullprove_batch_sizes_around_pass_boundaries_nl10(env, B):
     """Batches that do not fill their passes (1, 2), spill one proof into a second pass (97 -> 49 + 48 after balancing) or into a third (193):

@@ -13,13 +13,14 @@
 typedef int (*prover_fn)(const void*, unsigned long, const void*, unsigned long, char*, unsigned long*, char*, unsigned long*, char*, unsigned long);
 typedef int (*fullprove_fn)(void*, const void*, size_t, int, const void*, const uint8_t*, uint8_t*, uint8_t*, int32_t*, char*, size_t);
 typedef int (*service_prove_fn)(void*, const void*, size_t, const void*, uint32_t, const uint8_t*, uint8_t*, uint8_t*, char*, size_t);
+typedef int (*g16_fullprove_fn)(const void*, unsigned long, const void*, unsigned long, const char*, unsigned long, char*, unsigned long*, char*, unsigned long*, char*, unsigned long);
 typedef int (*fullprove_json_fn)(void*, const void*, size_t, const void*, size_t, const char*, size_t, const uint8_t*, uint8_t*, uint8_t*, int32_t*, char*, size_t);
 
 struct gate { pthread_mutex_t m; pthread_cond_t cv; int go; };      /* go: 0 wait, 1 run, -1 leave (a thread could not be started) */
 typedef struct {
     int mode, t, calls, nvoters, nLevels, nPub; void* fn; void* svc;
     const void* zkey; size_t zkey_len; const void* wasm; size_t wasm_len;
-    const void* const* items; const size_t* item_len;            /* per voter: .wtns image (mode 0), flat inputs (mode 1), inputs JSON text (mode 2), witness payload (mode 3: zkc_service_prove) */
+    const void* const* items; const size_t* item_len;            /* per voter: .wtns image (mode 0), flat inputs (mode 1), inputs JSON text (mode 2), witness payload (mode 3: zkc_service_prove), inputs JSON text again (mode 4: groth16_fullprove, JSON out) */
     char* proof_json; char* public_json;                          /* mode 0: [threads][calls][2048] each */
     uint8_t* proofs; uint8_t* publics; int32_t* statuses;         /* modes 1, 2: [threads][calls][256], [..][nPub * 32], [..] */
     double* lat_ms; struct gate* gate; int failed; double t_end;
@@ -41,6 +42,9 @@ static void* caller_main(void* p) {
         } else if (c->mode == 1) {
             char err[256];
             rc = ((fullprove_fn)c->fn)(c->svc, c->zkey, c->zkey_len, c->nLevels, c->items[v], NULL, c->proofs + 256 * i, c->publics + (size_t)c->nPub * 32 * i, c->statuses + i, err, sizeof err);
+        } else if (c->mode == 4) {
+            unsigned long ps = 2048, us = 2048; char err[256];
+            rc = ((g16_fullprove_fn)c->fn)(c->zkey, c->zkey_len, c->wasm, c->wasm_len, (const char*)c->items[v], c->item_len[v], c->proof_json + 2048 * i, &ps, c->public_json + 2048 * i, &us, err, sizeof err);
         } else if (c->mode == 3) {
             char err[256];
             rc = ((service_prove_fn)c->fn)(c->svc, c->zkey, c->zkey_len, c->items[v], (uint32_t)(c->item_len[v] / 32), NULL, c->proofs + 256 * i, c->publics + (size_t)c->nPub * 32 * i, err, sizeof err);

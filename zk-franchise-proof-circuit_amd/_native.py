@@ -57,6 +57,8 @@ def load():
     L.zkc_wtns_parse.argtypes = [ctypes.c_char_p, ctypes.c_ulong, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint32)]
     L.zkc_wtns_write.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_ulong]; L.zkc_wtns_write.restype = ctypes.c_ulong
     L.zkc_poseidon_batch.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+    L.zkc_smt_build.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, i32p]
+    L.zkc_census_inputs.argtypes = [vp, ctypes.c_size_t, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, vp, vp, ctypes.c_char_p]
     L.zkc_profile_enable.argtypes = [vp, ctypes.c_uint32]
     L.zkc_ntt_dev.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     L.zkc_g1_mul_batch_dev.argtypes = [vp, ctypes.c_char_p, vp, ctypes.c_uint32, vp]

@@ -3,6 +3,7 @@
 #include "zkc_internal.h"
 #include "zkc_f29.h"
 #include <cstring>
+#include <ctime>
 #include "../../include/zkc_poseidon_constants.inc"
 
 using namespace zkc;
@@ -21,6 +22,19 @@ static thread_local std::string g_create_err;
 int zkc_fail(zkc_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg; else g_create_err = msg;
     return code;
+}
+hipError_t zkc_wait_event(hipEvent_t ev) {
+    static const bool spin = getenv("ZKC_SPIN_WAIT") != nullptr;
+    if (spin) return hipEventSynchronize(ev);
+    for (int i = 0;; i++) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        if (i >= 48) { timespec ts{0, 50000}; nanosleep(&ts, nullptr); }
+    }
+}
+hipError_t zkc_wait_stream(hipStream_t st, hipEvent_t scratch_ev) {
+    const hipError_t e = hipEventRecord(scratch_ev, st);
+    return e != hipSuccess ? e : zkc_wait_event(scratch_ev);
 }
 int zkc_ensure(zkc_ctx* ctx, void** p, size_t* cur, size_t need) {
     if (*cur >= need) return ZKC_OK;

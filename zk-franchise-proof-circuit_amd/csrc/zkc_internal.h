@@ -52,6 +52,13 @@ struct zkc_ctx {
 };
 
 int zkc_fail(zkc_ctx* ctx, int code, const std::string& msg);
+// [r5] Host waits that SLEEP.  On this stack a host thread inside hipEventSynchronize / hipStreamSynchronize burns its core: the completion signals are ROCr BusyWaitSignals,
+// which spin whatever wait state is asked for -- hipEventBlockingSync events and hipDeviceScheduleBlockingSync included (rocgdb backtrace in profiles/r05_host_cpu_threads.txt:
+// BusyWaitSignal::WaitRelaxed under hsa_signal_wait_scacquire).  A rank of an 8-GPU run has two of the container's 16 cores' worth of CPU time, so the
+// waits on the proving path poll the event instead: a few dozen hipEventQuery calls back to back (a wait that is nearly over costs nothing extra), then one query per 50 us
+// nap.  At most ~0.1 ms later than a spinning wait, per wait: 12 waits per 1024-proof step of 320 ms.  ZKC_SPIN_WAIT=1: hipEventSynchronize as before (A/B).
+hipError_t zkc_wait_event(hipEvent_t ev);
+hipError_t zkc_wait_stream(hipStream_t st, hipEvent_t scratch_ev);      // record scratch_ev on st, then zkc_wait_event (scratch_ev: any event of the caller's that is not otherwise in flight)
 int zkc_ensure(zkc_ctx* ctx, void** p, size_t* cur, size_t need);
 // RAII bracket: records two events around the launches made while it is alive when category `cat` is enabled
 struct zkc_prof_scope {

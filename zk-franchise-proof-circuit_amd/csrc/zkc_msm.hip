@@ -671,7 +671,7 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
         zkc_prof_scope _ps(ctx, ZKC_PROF_MSM_SORT, 0, st);
         if (jl.total_windows > w.max_windows) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "msm_pass: too many virtual windows for the work space");
         const int hs = w.h_next; w.h_next ^= 1;
-        ZKC_HIP_CHECK(ctx, hipEventSynchronize(w.h_ev[hs]));                            // the copy that last used this staging slot has executed (two passes back)
+        ZKC_HIP_CHECK(ctx, zkc_wait_event(w.h_ev[hs]));                            // the copy that last used this staging slot has executed (two passes back)
         MsmWindow* wins = w.h_windows[hs]; uint32_t nwin = 0;
         for (int j = 0; j < nj; j++) for (uint32_t k = 0; k < (uint32_t)msm_half((int)jl.job[j].c) / jl.job[j].vw; k++)
             wins[nwin++] = MsmWindow{jl.id_of(k * jl.job[j].vw, (uint32_t)j), jl.job[j].win_off + k, jl.job[j].vw / 64};

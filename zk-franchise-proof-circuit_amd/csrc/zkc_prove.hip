@@ -597,9 +597,8 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&CS.h_out, (256 + 32 * (size_t)zk->nPub) * want)); ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&CS.h_rs, 64 * want));
         ZKC_HIP_CHECK(ctx, hipMalloc((void**)&CS.d_xyzz, 512 * want)); ZKC_HIP_CHECK(ctx, hipHostMalloc((void**)&CS.h_xyzz, 512 * want)); CS.cap = want;
     }
-    // [r5] the events a host thread waits on are blocking ones: the waiter sleeps in the driver instead of spinning on the event's memory (a rank of an 8-GPU run has 2 of the
-    // box's 16 cores' worth of CPU time: VERDICT r4 item 3).  ZKC_SPIN_WAIT=1: the old (spinning) events, for A/B.
-    static const unsigned ev_host_flags = getenv("ZKC_SPIN_WAIT") ? hipEventDisableTiming : (hipEventDisableTiming | hipEventBlockingSync);
+    // [r5] the events a host thread waits on (zkc_wait_event: polled with naps, not hipEventSynchronize'd)
+    static const unsigned ev_host_flags = hipEventDisableTiming;           // (hipEventBlockingSync was tried: the waits spin all the same on this stack, see zkc_wait_event)
     for (int l = 0; l < zk->nlanes; l++) if (!CS.ev_done[l]) ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&CS.ev_done[l], ev_host_flags));
     CS.as_xyzz.assign((size_t)B, 0); CS.lanes_used = 0;
     if (wait_first) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st0, wait_first, 0));
@@ -694,7 +693,7 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         zkc_lane& LN = zk->lane[li]; const int slot = LN.npass & 1;       // MSM results are double-buffered: the blinding of pass k overlaps pass k+1
         tr[0] = now_ms();
         const bool early = CS.early_n > 0;
-        if (!early) ZKC_HIP_CHECK(ctx, hipEventSynchronize(CS.ev_chunk[pass]));              // host: this chunk's fold flags have arrived
+        if (!early) ZKC_HIP_CHECK(ctx, zkc_wait_event(CS.ev_chunk[pass]));              // host: this chunk's fold flags have arrived
         tr[1] = now_ms();
         ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(LN.st, CS.ev_chunk[pass], 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(LN.st2, CS.ev_chunk[pass], 0));
         hipStream_t st = LN.st, st2 = LN.st2, fin = LN.fin;
@@ -873,7 +872,7 @@ int zkc::prove_batch_finish(zkc_zkey* zk, int cs, uint8_t* proofs, uint8_t* publ
     zkc_zkey::CallSlot& CS = zk->call[cs];
     if (!CS.pending) return zkc_fail(zk->ctx, ZKC_ERR_BAD_ARG, "prove_batch_finish: no call in flight on this slot");
     hipError_t e = hipSuccess;
-    for (int l = 0; l < zk->nlanes && e == hipSuccess; l++) if (CS.lanes_used >> l & 1) e = hipEventSynchronize(CS.ev_done[l]);
+    for (int l = 0; l < zk->nlanes && e == hipSuccess; l++) if (CS.lanes_used >> l & 1) e = zkc_wait_event(CS.ev_done[l]);
     CS.pending = false;
     if (e != hipSuccess) { ZKC_LOCK(zk->ctx); return zkc_fail(zk->ctx, ZKC_ERR_HIP, std::string("prove_batch_finish: ") + hipGetErrorString(e)); }
     if (CS.early_n) {                // the pass was laid out from the inputs' depths before its witness existed: the fold check of the finished witness has to agree

@@ -402,7 +402,7 @@ void process(zkc_service* s, zkc_service::Worker* w, std::vector<Req*>&& first) 
     {
         const int B = (int)b.reqs.size();
         rc = zkc::prove_batch_finish(zk, w->slot, (uint8_t*)w->h_proofs.p, (uint8_t*)w->h_pubs.p);
-        if (!rc && full && (hipMemcpyAsync(w->h_status.p, w->d_status.p, (size_t)B * 4, hipMemcpyDeviceToHost, w->st) != hipSuccess || hipStreamSynchronize(w->st) != hipSuccess)) { (void)hipGetLastError(); rc = ZKC_ERR_HIP; }
+        if (!rc && full && (hipMemcpyAsync(w->h_status.p, w->d_status.p, (size_t)B * 4, hipMemcpyDeviceToHost, w->st) != hipSuccess || zkc_wait_stream(w->st, w->ev_up) != hipSuccess)) { (void)hipGetLastError(); rc = ZKC_ERR_HIP; }
         const std::string why = rc ? (rc == ZKC_ERR_HIP ? std::string("HIP failure while the batch finished: ") : std::string()) + zkc_last_error(d->ctx) : std::string();
         { std::lock_guard<std::mutex> fl(d->fl_mu); for (auto& k : d->keys) if (k.key == zk) k.in_flight--; } d->fl_cv.notify_all();
         d->proofs_in_flight -= B;

@@ -581,6 +581,61 @@ zkc_poseidon_batch_kernel(PoseidonTable tab, const uint32_t* __restrict__ in, ui
     d[0] = make_uint4(s[0], s[1], s[2], s[3]); d[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
 
+// ---- f1: the hashing of the census builder (csrc/zkc_census.hip: arbo-style Poseidon sparse Merkle trees, internal/helpers.go:36-85), one lane per hash, standard form in and
+// out.  The tree's values live in ONE array: val[0] = 0 (an empty subtree), val[1 + i] = leaf i, val[1 + n + j] = inner node j. ----
+__device__ __forceinline__ void store_std(uint32_t* p, const Fr& h) {
+    uint32_t s[8]; fp_to_std<FrParams>(s, h);
+    uint4* d = reinterpret_cast<uint4*>(p); d[0] = make_uint4(s[0], s[1], s[2], s[3]); d[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+// kind 0: out[i] = H(a[i], b[i], 1)            a leaf: key, value, 1 (arbo's leaf hash; smtverifier.circom's hash1New)
+// kind 1: out[i] = H(a[i], b[i], c[i])         the SIK: address, password, signature (census.circom:74-77)
+// kind 2: out[i] = H(a[i], b[i], c[0], c[1])   the nullifier: signature, password, electionId[0], electionId[1] (census.circom:105-109)
+extern "C" __global__ void __launch_bounds__(64)
+zkc_census_hash(PoseidonTable tab, int kind, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ c, uint32_t* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Emit none{nullptr};
+    Fr x[4]; x[0] = load_std(a + 8 * i); x[1] = load_std(b + 8 * i);
+    Fr h;
+    if (kind == 0) { x[2] = Fr::one(); h = poseidon_trace29<4, 0>(x, 1u, tab, none, 0); }
+    else if (kind == 1) { x[2] = load_std(c + 8 * i); h = poseidon_trace29<4, 0>(x, 1u, tab, none, 0); }
+    else { x[2] = load_std(c); x[3] = load_std(c + 8); h = poseidon_trace29<5, 1>(x, 1u, tab, none, 0); }
+    store_std(out + 8 * i, h);
+}
+// the inner nodes of one depth: node j = order[first + t] gets val[node0 + j] = H(val[left[j]], val[right[j]]) (children one level down are finished: launches go bottom-up)
+extern "C" __global__ void __launch_bounds__(64)
+zkc_census_level(PoseidonTable tab, const uint32_t* __restrict__ left, const uint32_t* __restrict__ right, const uint32_t* __restrict__ order, uint32_t first, uint32_t count,
+                 uint32_t* val, uint32_t node0) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const uint32_t j = order[first + t];
+    Emit none{nullptr};
+    Fr x[2]; x[0] = load_std(val + 8 * (size_t)left[j]); x[1] = load_std(val + 8 * (size_t)right[j]);
+    store_std(val + 8 * ((size_t)node0 + j), poseidon_trace29<3, 0>(x, 1u, tab, none, 0));
+}
+// 32-byte copies val[ref] -> out[dst] for a list of (dst, ref) pairs: the sibling lists of every leaf, straight into the voters' input blocks
+extern "C" __global__ void __launch_bounds__(256)
+zkc_census_scatter(const uint32_t* __restrict__ val, const uint2* __restrict__ pairs, size_t count, uint32_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint2 pr = pairs[i];
+    const uint4* s = reinterpret_cast<const uint4*>(val + 8 * (size_t)pr.y); uint4* d = reinterpret_cast<uint4*>(out + 8 * (size_t)pr.x);
+    d[0] = s[0]; d[1] = s[1];
+}
+// the twelve scalar inputs of every voter's block (census.circom:51-67 order; internal/inputs.go:33-98 MockInputs): block = nIn x 32 B, zeroed beforehand
+extern "C" __global__ void __launch_bounds__(256)
+zkc_census_scalars(const uint32_t* __restrict__ eid, const uint32_t* __restrict__ nullifier, const uint32_t* __restrict__ avail, const uint32_t* __restrict__ vhash,
+                   const uint32_t* __restrict__ sik_root, const uint32_t* __restrict__ census_root, const uint32_t* __restrict__ address, const uint32_t* __restrict__ password,
+                   const uint32_t* __restrict__ signature, const uint32_t* __restrict__ vweight, size_t n, int nIn, uint32_t* __restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * 12) return;
+    const size_t v = t / 12; const int k = (int)(t % 12);
+    const uint32_t* src = k < 2 ? eid + 8 * k : k == 2 ? nullifier + 8 * v : k == 3 ? avail + 8 * v : k < 6 ? vhash + 8 * (2 * v + (k - 4)) : k == 6 ? sik_root : k == 7 ? census_root
+                        : k == 8 ? address + 8 * v : k == 9 ? password + 8 * v : k == 10 ? signature + 8 * v : vweight + 8 * v;
+    const uint4* s = reinterpret_cast<const uint4*>(src); uint4* d = reinterpret_cast<uint4*>(out + 8 * (v * (size_t)nIn + k));
+    d[0] = s[0]; d[1] = s[1];
+}
+
 // coalesced broadcast of the template witness: one uint4 (half a wire) per lane
 extern "C" __global__ void __launch_bounds__(256)
 zkc_witness_tostd(uint32_t* __restrict__ wtns, size_t nwires_total) {
