@@ -22,35 +22,18 @@ const INPUT_KEYS = ["electionId", "nullifier", "availableWeight", "voteHash", "s
   "signature", "voteWeight", "censusSiblings", "sikSiblings"];
 const LIB = process.env.ZKCENSUS_LIB || path.join(__dirname, "..", "zk-franchise-proof-circuit_amd", "libzkcensus.so");
 
-// 32-byte little-endian image of x mod r, through one hex conversion (a per-byte BigInt loop cost 0.4 ms per voter: more than the voter's share of a GPU pass)
+// 32-byte little-endian image of x mod r (the blinding scalars of opts.r / opts.s), through one hex conversion
 function le32(x) {
   let v = BigInt(x); if (v < 0n || v >= R) v = ((v % R) + R) % R;
   return Buffer.from(v.toString(16).padStart(64, "0"), "hex").reverse();
 }
-// the 12-key input object -> (12 + 2 (nLevels + 1)) x 32 bytes, in place in one buffer.  Zero siblings (most of a padded list) are skipped: converting every "0" through BigInt
-// cost 0.2 ms per voter, a fifth of a 64-voter burst's wall time
+// the 12-key input object -> (12 + 2 (nLevels + 1)) x 32 bytes.  [r5] ONE implementation for every host: the library's zkc_inputs_from_json (include/zkcensus.h) reads the object
+// the way circom_runtime 0.1.22's witness calculator does -- any key order, decimal / "0x" strings, integer literals and BigInts, nested arrays flattened, reduction mod r,
+// "Signal <k> not found", "Too many values for input signal <k>", "Not all inputs have been set. Only <a> out of <b>" -- plus zero padding of short sibling lists; the cgo host
+// passes the file image of inputs_example.json to the same function (zk_census_test.go:85-89).  JSON.stringify of 334 short strings is ~30 us.
 function flatten(input, nLevels) {
-  const out = Buffer.alloc(32 * (12 + 2 * (nLevels + 1)));
-  let o = 0;
-  const put = (x) => {
-    if (x === "0" || x === 0 || x === 0n) { o += 32; return; }
-    let v = BigInt(x); if (v < 0n || v >= R) v = ((v % R) + R) % R;
-    const h = v.toString(16), b = Buffer.from(h.length & 1 ? "0" + h : h, "hex");
-    for (let i = 0, k = b.length - 1; k >= 0; i++, k--) out[o + i] = b[k];
-    o += 32;
-  };
-  for (const k of INPUT_KEYS) {
-    if (!(k in input)) throw new Error(`Error: Signal not found.\n(input ${k})`);
-    const v = input[k];
-    if (k.endsWith("Siblings")) {
-      const n = v.length;
-      if (n > nLevels + 1) throw new Error(`Too many values for input signal ${k}`);
-      for (let i = 0; i < n; i++) put(v[i]);
-      o += 32 * (nLevels + 1 - n);
-    } else if (Array.isArray(v)) for (const x of v) put(x);
-    else put(v);
-  }
-  return out;
+  if (input === null || typeof input !== "object") throw new Error("the circuit inputs must be an object");
+  return native.flattenJson(JSON.stringify(input, (k, v) => (typeof v === "bigint" ? v.toString() : v)), nLevels, LIB);
 }
 // a path is read once per (path, size, mtime): snarkjs re-reads the 55 MB .zkey on every fullProve, which here would cost more than the proof
 const fileCache = new Map();
@@ -126,12 +109,26 @@ const groth16 = {
   async fullProveBatch(inputs, wasmFile, zkeyFile, opts) {
     const c = await circuitOf(wasmFile, zkeyFile, opts);
     if (c.calc) {                 // a circuit without a native witness generator: witnesses one by one in Node, proofs coalesced by the library's proving service
-      return Promise.all(inputs.map(async (x, i) => {
-        try {
-          const o = opts && opts.rs ? { r: opts.rs[i][0], s: opts.rs[i][1] } : null;
-          return toJson(await native.proveRaw(readArtifact(zkeyFile), wtnsImage(await c.calc.calculate(x), c.calc.prime), blind(o, "r"), blind(o, "s"), LIB));
-        } catch (e) { return e instanceof Error ? e : new Error(String(e)); }
-      }));
+      // the key image is read ONCE (a Buffer / {type: "mem"} artifact is copied by readArtifact: one copy per voter was 56 GB of host memory for a census of 1 024 and a new
+      // (pointer, length) -- a new SHA-256 over the whole key -- per request), and the voters go through in chunks: witnesses of a chunk are computed (main thread, Node's
+      // WebAssembly) and submitted, the next chunk's witnesses run while the GPU proves
+      const zk = readArtifact(zkeyFile), out = new Array(inputs.length), CHUNK = 64;
+      let pending = [];
+      for (let i0 = 0; i0 < inputs.length; i0 += CHUNK) {
+        const chunk = [];
+        for (let i = i0; i < Math.min(inputs.length, i0 + CHUNK); i++) {
+          chunk.push((async () => {
+            try {
+              const o = opts && opts.rs ? { r: opts.rs[i][0], s: opts.rs[i][1] } : null;
+              out[i] = toJson(await native.proveRaw(zk, wtnsImage(await c.calc.calculate(inputs[i]), c.calc.prime), blind(o, "r"), blind(o, "s"), LIB));
+            } catch (e) { out[i] = e instanceof Error ? e : new Error(String(e)); }
+          })());
+        }
+        await Promise.all(pending);                              // at most two chunks of witnesses and proofs alive at once
+        pending = chunk;
+      }
+      await Promise.all(pending);
+      return out;
     }
     const nLevels = c.nLevels;
     const devs = Buffer.alloc(4 * ((opts && opts.devices) || [0]).length);

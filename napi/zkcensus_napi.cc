@@ -43,6 +43,7 @@ struct Api {
     int (*submit_prove)(void*, const void*, size_t, const void*, uint32_t, const uint8_t*, uint8_t*, uint8_t*, done_fn, void*) = nullptr;
     int (*header_info)(const void*, size_t, uint32_t*, uint32_t*, uint32_t*) = nullptr;
     const char* (*status_text)(int, int32_t) = nullptr;
+    int (*inputs_from_json)(const char*, size_t, int, void*, char*, size_t) = nullptr;
     std::string err;
 } g;
 std::mutex g_mu;                       // guards everything below and every use of the shared context / key
@@ -63,7 +64,7 @@ bool load_api(const std::string& hint) {               // caller holds g_mu
     SYM(pool_create, "zkc_pool_create") SYM(pool_destroy, "zkc_pool_destroy") SYM(pool_err, "zkc_pool_last_error") SYM(pool_zkey_load, "zkc_pool_zkey_load")
     SYM(pool_zkey, "zkc_pool_zkey") SYM(pool_fullprove, "zkc_pool_fullprove_batch")
     SYM(service_default, "zkc_service_default") SYM(service_err, "zkc_service_last_error") SYM(submit_fullprove, "zkc_service_submit_fullprove")
-    SYM(submit_prove, "zkc_service_submit_prove") SYM(header_info, "zkc_zkey_header_info") SYM(status_text, "zkc_witness_status_text")
+    SYM(submit_prove, "zkc_service_submit_prove") SYM(header_info, "zkc_zkey_header_info") SYM(status_text, "zkc_witness_status_text") SYM(inputs_from_json, "zkc_inputs_from_json")
 #undef SYM
     g.h = h;
     return true;
@@ -283,6 +284,20 @@ napi_value StatusText(napi_env env, napi_callback_info info) {
     const std::string t = assert_text(nl, st);
     napi_value out; napi_create_string_utf8(env, t.c_str(), t.size(), &out); return out;
 }
+// flattenJson(inputsJson: string, nLevels, libPath) -> Buffer: the 12-key input object, as JSON text, -> the flat block of the C ABI (zkc_inputs_from_json: the ONE reading of the
+// reference's inputs schema -- key order, zero padding of sibling lists, reduction mod r, circom_runtime's messages -- shared with the cgo and Python hosts)
+napi_value FlattenJson(napi_env env, napi_callback_info info) {
+    size_t argc = 3; napi_value a[3]; napi_get_cb_info(env, info, &argc, a, nullptr, nullptr);
+    { std::lock_guard<std::mutex> guard(g_mu); if (!load_api(str_arg(env, a[2]))) { napi_throw_error(env, nullptr, g.err.c_str()); return nullptr; } }
+    int32_t nl = 0; napi_get_value_int32(env, a[1], &nl);
+    const int ni = g.n_inputs(nl);
+    if (ni <= 0) { napi_throw_error(env, nullptr, "bad nLevels"); return nullptr; }
+    const std::string js = str_arg(env, a[0]);
+    void* data = nullptr; napi_value buf; napi_create_buffer(env, (size_t)ni * 32, &data, &buf);
+    char err[256] = {0};
+    if (g.inputs_from_json(js.data(), js.size(), nl, data, err, sizeof err)) { napi_throw_error(env, nullptr, err); return nullptr; }
+    return buf;
+}
 // decimals(buf: Buffer) -> string[]: every 32-byte little-endian word of buf as a decimal string (what snarkjs' proof.json / public.json hold).  In C++ because
 // BigInt("0x..").toString() costs Node 4 us per value -- 16 values per proof, on the main thread, after the GPU is done: a tenth of a 256-voter burst
 napi_value Decimals(napi_env env, napi_callback_info info) {
@@ -322,7 +337,7 @@ napi_value Init(napi_env env, napi_value exports) {
     napi_create_threadsafe_function(env, nullptr, nullptr, name, 0, 1, nullptr, nullptr, nullptr, settle_js, &g_tsfn);
     napi_unref_threadsafe_function(env, g_tsfn);
 #define EXPORT(name, fn) napi_create_function(env, name, NAPI_AUTO_LENGTH, fn, nullptr, &f); napi_set_named_property(env, exports, name, f);
-    EXPORT("fullProveRaw", FullProveRaw) EXPORT("fullProveBatchRaw", FullProveBatchRaw) EXPORT("proveRaw", ProveRaw) EXPORT("witnessRaw", WitnessRaw) EXPORT("circuitFromWasm", CircuitFromWasm) EXPORT("verifyJson", VerifyJson) EXPORT("statusText", StatusText) EXPORT("zkeyInfo", ZkeyInfo) EXPORT("decimals", Decimals)
+    EXPORT("flattenJson", FlattenJson) EXPORT("fullProveRaw", FullProveRaw) EXPORT("fullProveBatchRaw", FullProveBatchRaw) EXPORT("proveRaw", ProveRaw) EXPORT("witnessRaw", WitnessRaw) EXPORT("circuitFromWasm", CircuitFromWasm) EXPORT("verifyJson", VerifyJson) EXPORT("statusText", StatusText) EXPORT("zkeyInfo", ZkeyInfo) EXPORT("decimals", Decimals)
 #undef EXPORT
     return exports;
 }

@@ -116,6 +116,28 @@ int main() {
         v2[rnd() % v2.size()] = (char)rnd(); p2[rnd() % p2.size()] = (char)rnd(); if (it & 1) s2[rnd() % s2.size()] = (char)rnd();
         (void)verify_inputs_from_json(v2, s2, p2, a, b, c, np, err);
     }
+    // ---- [r5] the strict JSON reader and the circuit-inputs reader (zkc_json.h, circuit_inputs_from_json): truncations, mutations, deep nesting, long numbers ----
+    {
+        std::string in = "{\"electionId\":[\"1\",\"2\"],\"nullifier\":\"3\",\"availableWeight\":\"4\",\"voteHash\":[\"5\",\"6\"],\"sikRoot\":\"7\",\"censusRoot\":\"8\",\"address\":\"0x9\",\"password\":-10,"
+                         "\"signature\":\"21888242871839275222246405745257275088548364400416034343698204186575808495618\",\"voteWeight\":1,\"censusSiblings\":[\"1\",[\"2\",\"3\"]],\"sikSiblings\":[]}";
+        std::vector<uint8_t> blk(32 * (12 + 2 * 11)); std::string e;
+        CHECK(circuit_inputs_from_json(in.data(), in.size(), 10, blk.data(), e) == 0);
+        CHECK(blk[32 * 8] == 9 && blk[32 * 10] == 1 && blk[32 * 11] == 1 && blk[32 * 12] == 1 && blk[32 * 14] == 3);      // hex, r + 1 = 1, number, nested list
+        { uint32_t w[8]; memcpy(w, blk.data() + 32 * 9, 32); CHECK(w[0] == kFrP[0] - 10 && w[7] == kFrP[7]); }            // -10 = r - 10
+        for (size_t n = 0; n < in.size(); n++) CHECK(circuit_inputs_from_json(in.data(), n, 10, blk.data(), e) != 0);
+        for (int it = 0; it < 30000; it++) {
+            std::string m = in; const int k = 1 + (int)(rnd() % 3);
+            for (int j = 0; j < k; j++) { const size_t at = rnd() % m.size(); if (rnd() & 1) m[at] = (char)rnd(); else m.insert(at, 1, "[]{}\",:\\0-e."[rnd() % 13]); }
+            (void)circuit_inputs_from_json(m.data(), m.size(), 10, blk.data(), e);
+        }
+        std::string deep(100000, '['); CHECK(circuit_inputs_from_json(deep.data(), deep.size(), 10, blk.data(), e) == 1);
+        std::string longnum = "{\"voteWeight\":" + std::string(200000, '7') + "}"; CHECK(circuit_inputs_from_json(longnum.data(), longnum.size(), 10, blk.data(), e) == 2);      // parses; the other signals are missing
+        zkc::json::Value v; std::string je;
+        const char* okdoc = "{\"a\":[1,2.5e3,-0,true,false,null,\"\\u00e9\\ud83d\\ude00\\n\"]}";
+        CHECK(zkc::json::parse(okdoc, strlen(okdoc), v, je) && v.o.size() == 1 && v.o[0].second.a.size() == 7 && v.o[0].second.a[6].s == "\xc3\xa9\xf0\x9f\x98\x80\n");
+        const char* bad[] = {"", " ", "{", "}", "[1,]", "{\"a\":1,}", "{a:1}", "01", "1.", ".5", "-", "+1", "1e", "\"\\x\"", "\"\t\"", "nul", "tru", "[1 2]", "{\"a\" 1}", "[1]]", "NaN", "Infinity", "'a'", "\"\xff\"", "\"\xc0\x80\"", "\"\xed\xa0\x80\""};
+        for (const char* b : bad) { zkc::json::Value x; CHECK(!zkc::json::parse(b, strlen(b), x, je)); }
+    }
     { uint8_t d[32]; sha256("abc", 3, d); CHECK(hex_of(d, 32) == "ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad");
       std::string m(1000, 'a'); sha256(m.data(), m.size(), d); CHECK(hex_of(d, 32) == "41edece42d63e8d9bf515a9ba6932e1c20cbc9f5a5d134645adb5db1b9737ea3"); }
     // the SHA-extension rounds against the portable ones: every length around the block boundaries, split updates

@@ -47,3 +47,25 @@ def test_c_program_proves_through_a_device_pool(tmp_path):
     for i in range(n):
         if i != 3:
             assert ol.verify(vk, pubs[256 * i:256 * i + 256], proofs[256 * i:256 * i + 256]), i
+
+
+@pytest.mark.gpu
+def test_c_program_proves_from_the_reference_inputs_file_image(tmp_path):
+    """[r5] prover.Prove(zkey, wasm, inputs []byte) as the reference calls it (zk_census_test.go:81-93): the C program hands groth16_fullprove the FILE IMAGE of
+    tests/golden/ref/inputs_example.json (the reference's own fixture) and of the nLevels-160 test key, and gets proof.json / public.json texts back -- which must carry the
+    reference's own public signals (signals.json) and pass the pinned verifier under the key's verification key."""
+    from zkcensus_amd import setup
+    _, zp, vp = setup.ensure_test_artifacts(160)
+    pj, uj = tmp_path / 'proof.json', tmp_path / 'public.json'
+    try:
+        r = subprocess.run([build(tmp_path), LIB, 'json', zp, os.path.join(ol.ROOT, 'tests', 'golden', 'ref', 'inputs_example.json'), str(pj), str(uj)], capture_output=True, text=True, timeout=600)
+    except OSError as e:
+        pytest.skip('cannot start a child program from this process: %s' % e)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1]) == {'rc': 0, 'size_query_rc': 2, 'damaged_inputs_rc': 1, 'damaged_inputs_message_is_set': True}
+    proof = json.load(open(pj)); pub = json.load(open(uj))
+    assert pub == json.load(open(os.path.join(ol.ROOT, 'tests', 'golden', 'ref', 'signals.json')))
+    assert proof['protocol'] == 'groth16' and proof['curve'] == 'bn128'
+    le = lambda x: int(x).to_bytes(32, 'little')
+    pb = le(proof['pi_a'][0]) + le(proof['pi_a'][1]) + le(proof['pi_b'][0][0]) + le(proof['pi_b'][0][1]) + le(proof['pi_b'][1][0]) + le(proof['pi_b'][1][1]) + le(proof['pi_c'][0]) + le(proof['pi_c'][1])
+    assert ol.verify(json.load(open(vp)), b''.join(le(x) for x in pub), pb)

@@ -345,3 +345,88 @@ def test_soak_of_mixed_batch_sizes_on_two_keys(capsys):
         sys.argv = old
     out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
     assert rc == 0 and out['all_valid'] and out['proofs'] > 500 and out['batches'] > 50 and out['key_loads'] == 2, out
+
+
+def test_six_keys_cycling_are_loaded_once_each_and_memory_is_reported(monkeypatch):
+    """[r5] ADVICE r4 (medium, twice) + VERDICT r4 item 8.  Six keys of the nLevels-10 circuit (six ceremonies: the reference keeps a key per environment and depth,
+    circuit/circuit-compiler.sh:15,82) cycle through one device that may hold eight: round 4 kept at most FOUR key images whatever the devices held, so the fifth key pushed a
+    resident key's image out and its next caller loaded it a second time beside an unreachable copy.  Now: key_loads == number of keys however long they cycle, every proof
+    valid under ITS key, and zkc_service_memory says what the keys hold.  Then the same service is told its device is out of memory while it holds >= 3 keys
+    (ZKC_TEST_FAIL_KEY_LOADS): the next new key evicts idle keys until its load succeeds instead of failing the batch."""
+    import tempfile
+    import zkcensus_amd
+    from zkcensus_amd import setup
+    nl, NK = 10, 6
+    monkeypatch.setenv('ZKC_SERVICE_KEYS', '8')
+    svc = zkcensus_amd.ProvingService([0])
+    monkeypatch.delenv('ZKC_SERVICE_KEYS')
+    keys = []
+    with tempfile.TemporaryDirectory() as d:
+        for k in range(NK + 2):
+            _, zp, vp = setup.ensure_test_artifacts(nl, seed=1000 + k, directory=os.path.join(d, str(k)))
+            keys.append((open(zp, 'rb').read(), json.load(open(vp))))
+    voters = _voters(8, nl, 3)
+    out = []
+    for rnd in range(4):                                                 # four rounds over six keys, several callers per key and round
+        def caller(j):
+            k = j % NK
+            p, u, s = svc.fullprove(keys[k][0], voters[j % 8], nLevels=nl)
+            assert s == 0
+            out.append((k, p, u))
+        th = [threading.Thread(target=caller, args=(j,)) for j in range(3 * NK)]
+        for t in th: t.start()
+        for t in th: t.join()
+        assert svc.stats()['key_loads'] == NK, (rnd, svc.stats())      # each key once, in the first round; never again
+    assert svc.timing()['key_evictions'] == 0
+    for k, p, u in out[::5]:
+        assert ol.verify(keys[k][1], u, p) and not ol.verify(keys[(k + 1) % NK][1], u, p)
+    mem = svc.memory()
+    assert mem['resident_keys'] == NK and mem['table_bytes'] > 0 and mem['work_bytes'] > 0 and mem['reserve_failures'] == 0, mem
+    # an nLevels-10 key: ~0.1 GB of tables (the figure of the FIRST key of a device also holds what the device context allocates once, e.g. the hardware queues' rings:
+    # the numbers are hipMemGetInfo deltas around the load), lanes' work space dominated by the 65 536 buckets per H job whatever the circuit's size
+    assert mem['largest_key_table_bytes'] < 2e9 and mem['largest_key_work_bytes'] < 8e9 and mem['table_bytes'] < 3e9, mem
+    # out of memory with idle keys resident: evict and retry
+    monkeypatch.setenv('ZKC_TEST_FAIL_KEY_LOADS', '3')
+    p, u, s = svc.fullprove(keys[NK][0], voters[0], nLevels=nl)
+    monkeypatch.delenv('ZKC_TEST_FAIL_KEY_LOADS')
+    assert s == 0 and ol.verify(keys[NK][1], u, p)
+    st = svc.stats(); ev = svc.timing()['key_evictions']
+    assert st['failed'] == 0 and ev >= NK - 2 and svc.memory()['resident_keys'] <= 3, (st, ev, svc.memory())
+    # ... and the survivors still prove (a key that was evicted is loaded again, once)
+    p, u, s = svc.fullprove(keys[0][0], voters[1], nLevels=nl)
+    assert s == 0 and ol.verify(keys[0][1], u, p)
+    svc.close()
+
+
+def test_four_nl160_keys_stay_under_the_stated_bound(monkeypatch):
+    """[r5] VERDICT r4 item 8: what a resident key costs, measured where the driver sees it.  Four nLevels-160 keys (four ceremonies) on one device with the service's defaults
+    (4 lanes x 64-proof passes): each key's constant tables are ~3.1 GB; the first keys reserve their lanes' work space at once (~37 GB each) while the card is less than half
+    full, later ones grow on demand.  INTEGRATION.md section 5 states the bound: 4 keys <= 4 x (3.5 + 40) GB = 174 GB of the card's 288."""
+    import tempfile
+    import zkcensus_amd
+    from zkcensus_amd import setup
+    from census_gen import random_voter
+    nl = 160
+    svc = zkcensus_amd.ProvingService([0])
+    rng = random.Random(8)
+    v = random_voter(rng, ol.poseidon, nLevels=nl, depth_c=12, depth_s=11)
+    seen = []
+    r1, zp0, vp0 = setup.ensure_test_artifacts(nl)                       # the circuit's .r1cs is the same for every ceremony: only the setup runs again (~8 s of C++ each)
+    lib = zkcensus_amd._native.load()
+    with tempfile.TemporaryDirectory() as d:
+        for k in range(4):
+            zp, vp = (zp0, vp0) if k == 0 else (os.path.join(d, '%d.zkey' % k), os.path.join(d, '%d.vkey.json' % k))
+            if k:
+                err = ctypes.create_string_buffer(512)
+                assert lib.zkc_setup_from_r1cs(r1.encode(), 500 + k, zp.encode(), vp.encode(), err, 512) == 0, err.value
+            zk = open(zp, 'rb').read(); vk = json.load(open(vp))
+            p, u, s = svc.fullprove(zk, v, nLevels=nl)
+            assert s == 0 and ol.verify(vk, u, p)
+            seen.append(svc.memory())
+            del zk
+    mem = seen[-1]
+    print('\n[four nLevels-160 keys] ' + '; '.join('%d keys: tables %.1f GB, work %.1f GB' % (m['resident_keys'], m['table_bytes'] / 1e9, m['work_bytes'] / 1e9) for m in seen))
+    assert mem['resident_keys'] == 4 and svc.stats()['key_loads'] == 4 and svc.timing()['key_evictions'] == 0
+    assert 2.5e9 < mem['largest_key_table_bytes'] < 3.5e9, mem
+    assert mem['largest_key_work_bytes'] < 40e9 and mem['table_bytes'] + mem['work_bytes'] < 174e9, mem
+    svc.close()

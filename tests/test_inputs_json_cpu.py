@@ -1,0 +1,138 @@
+"""CPU: the circuit inputs as the reference hands them over -- the TEXT of inputs_example.json (zk_census_test.go:85-89: prover.Prove's third argument; internal/inputs.go:14-31
+is the schema) -- read by the library's one implementation, zkc_inputs_from_json (include/zkcensus.h, csrc/zkc_hostparse.h), which the Python, N-API and cgo hosts all call.
+
+Pinned against the oracle's flattening (tests/oracle_lib.py flat_inputs: the block whose witnesses equal the reference wasm's, tests/golden/witness_vectors.json) for every
+golden voter, positive and negative; error texts = circom_runtime 0.1.22's (witness_calculator.js _doCalculateWitness), the same ones the N-API host throws."""
+import ctypes, json, os, random, shutil, subprocess
+import pytest
+import oracle_lib as ol
+
+GOLD = json.load(open(os.path.join(ol.ROOT, 'tests', 'golden', 'witness_vectors.json')))
+
+
+def _lib():
+    import zkcensus_amd
+    from zkcensus_amd import _native
+    return _native.load()
+
+
+def _flat(text, nl=160):
+    lib = _lib()
+    out = ctypes.create_string_buffer(32 * (12 + 2 * (nl + 1))); err = ctypes.create_string_buffer(256)
+    if isinstance(text, str):
+        text = text.encode()
+    rc = lib.zkc_inputs_from_json(text, len(text), nl, out, err, 256)
+    return rc, out.raw, err.value.decode()
+
+
+def _vectors():
+    vs = []
+    for key in ('vectors', 'negative', 'negatives', 'rejected'):
+        for v in GOLD.get(key, []) if isinstance(GOLD, dict) else []:
+            if isinstance(v, dict) and 'input' in v:
+                vs.append(v['input'])
+    if not vs:                                                         # whatever the fixture's layout: every dict that looks like a 12-key input object
+        def walk(o):
+            if isinstance(o, dict):
+                if 'censusSiblings' in o and 'nullifier' in o:
+                    vs.append(o)
+                else:
+                    for x in o.values(): walk(x)
+            elif isinstance(o, list):
+                for x in o: walk(x)
+        walk(GOLD)
+    return vs
+
+
+def test_every_golden_voter_flattens_like_the_oracle():
+    vs = _vectors()
+    assert len(vs) >= 60, len(vs)                                       # 30 accepted + 42 rejected voters of the reference wasm
+    import zkcensus_amd
+    for v in vs:
+        nl = len(v['censusSiblings']) - 1 if len(v['censusSiblings']) in (11, 161, 254) else 160
+        rc, flat, err = _flat(json.dumps(v), nl)
+        assert rc == 0, err
+        assert flat == ol.flat_inputs(v, nl) == zkcensus_amd.flatten_inputs(v, nl)
+    # the reference's own file image, byte for byte as prover.Prove receives it
+    text = open(os.path.join(ol.ROOT, 'tests', 'golden', 'ref', 'inputs_example.json'), 'rb').read()
+    rc, flat, err = _flat(text)
+    assert rc == 0 and flat == ol.flat_inputs(json.loads(text))
+
+
+def test_any_key_order_value_forms_and_padding():
+    ex = json.load(open(os.path.join(ol.ROOT, 'tests', 'golden', 'ref', 'inputs_example.json')))
+    want = ol.flat_inputs(ex)
+    rng = random.Random(3)
+    keys = list(ex); rng.shuffle(keys)
+    shuffled = {k: ex[k] for k in keys}
+    assert _flat(json.dumps(shuffled))[1] == want
+    # integers as JSON numbers of any length (not rounded through a double), hex strings, negative values (mod r), nested lists, short sibling lists, whitespace
+    forms = dict(ex)
+    forms['nullifier'] = int(ex['nullifier'])                           # a 77-digit integer literal
+    forms['address'] = hex(int(ex['address']))
+    forms['voteWeight'] = str(int(ex['voteWeight']) - ol.R)             # negative: reduced mod r
+    forms['password'] = str(int(ex['password']) + 5 * ol.R)             # above r: reduced
+    forms['electionId'] = [[ex['electionId'][0]], [ex['electionId'][1]]]
+    n = max(i + 1 for i, s in enumerate(ex['censusSiblings']) if s != '0')
+    forms['censusSiblings'] = ex['censusSiblings'][:n]
+    forms['sikSiblings'] = []
+    ex0 = dict(ex, sikSiblings=['0'] * 161)
+    rc, flat, err = _flat('  \n' + json.dumps(forms, indent=2) + '\n')
+    assert rc == 0 and flat == ol.flat_inputs(ex0), err
+    assert _flat(json.dumps(dict(ex, voteWeight=True)))[1] == ol.flat_inputs(dict(ex, voteWeight='1'))      # BigInt(true) = 1n
+    # a repeated name: the last one stands, as JSON.parse has it
+    t = json.dumps(ex)[:-1] + ', "voteWeight": "7"}'
+    assert _flat(t)[1] == ol.flat_inputs(dict(ex, voteWeight='7'))
+    # nLevels 10: eleven siblings per list
+    small = dict(ex, censusSiblings=ex['censusSiblings'][:11], sikSiblings=ex['sikSiblings'][:11])
+    assert _flat(json.dumps(small), 10)[1] == ol.flat_inputs(small, 10)
+
+
+def test_circom_runtime_messages_and_json_errors():
+    ex = json.load(open(os.path.join(ol.ROOT, 'tests', 'golden', 'ref', 'inputs_example.json')))
+    def err_of(obj, nl=160):
+        rc, _, e = _flat(obj if isinstance(obj, (str, bytes)) else json.dumps(obj), nl)
+        return rc, e
+    miss = dict(ex); del miss['nullifier']
+    assert err_of(miss) == (1, 'Not all inputs have been set. Only 333 out of 334')
+    assert err_of(dict(ex, foo='1')) == (1, 'Signal foo not found\n')
+    assert err_of(dict(ex, censusSiblings=['1'] * 162)) == (1, 'Too many values for input signal censusSiblings\n')
+    assert err_of(dict(ex, electionId=['1', '2', '3'])) == (1, 'Too many values for input signal electionId\n')
+    assert err_of(dict(ex, electionId=['1'])) == (1, 'Not enough values for input signal electionId\n')
+    assert err_of(dict(ex, voteWeight='12x')) == (1, 'Cannot convert 12x to a BigInt')
+    assert err_of(dict(ex, voteWeight=1.5)) == (1, 'Cannot convert 1.5 to a BigInt')
+    assert err_of(dict(ex, voteWeight=None)) == (1, 'Cannot convert null to a BigInt')
+    assert err_of(dict(ex, voteWeight='-0x5'))[0] == 1
+    # the text must be JSON, and an object: ZKC_ERR_FORMAT (5)
+    good = json.dumps(ex)
+    for bad in (good[:-1], good + ' x', good.replace('"nullifier"', 'nullifier', 1), good.replace(',', ',,', 1), '[1, 2]', '"str"', '', '{"a": 01}', '{"a": "\\x"}', good.replace('{', '{ /* c */', 1),
+                '{"voteWeight": NaN}', b'\xef\xbb\xbf' + good.encode(), good.encode().replace(b'"address"', b'"addr\xff"', 1)):
+        rc, e = err_of(bad)
+        assert rc == 5 and e.startswith('JSON'), (bad[:40], rc, e)
+    assert err_of('{' + '"a": [' * 100 + ']' * 100 + '}')[0] == 5      # nested too deeply
+    lib = _lib()
+    assert lib.zkc_inputs_from_json(b'{}', 2, 2, ctypes.create_string_buffer(64), None, 0) == 4      # bad nLevels
+    assert lib.zkc_inputs_from_json(None, 0, 160, ctypes.create_string_buffer(64), None, 0) == 4
+
+
+def test_the_node_host_goes_through_the_same_function():
+    """napi/index.js flatten = JSON.stringify + zkc_inputs_from_json: same bytes as the Python host for the reference's example, same messages."""
+    node = shutil.which('node'); addon = os.path.join(ol.ROOT, 'napi', 'zkcensus.node')
+    if not node or not os.path.exists(addon):
+        pytest.skip('node or the built addon is not available')
+    js = r'''
+const { flatten } = require("./napi/index.js"); const crypto = require("crypto");
+const inp = require("./tests/golden/ref/inputs_example.json");
+const out = { flat: crypto.createHash("sha256").update(flatten(inp, 160)).digest("hex"), errs: [] };
+const tries = [Object.assign({}, inp, { foo: "1" }), (() => { const y = Object.assign({}, inp); delete y.sikRoot; return y; })(), Object.assign({}, inp, { sikSiblings: Array(200).fill("0") }),
+               Object.assign({}, inp, { address: "zz" }), Object.assign({}, inp, { nullifier: BigInt(inp.nullifier) })];
+for (const t of tries) { try { flatten(t, 160); out.errs.push(null); } catch (e) { out.errs.push(e.message); } }
+console.log(JSON.stringify(out));
+'''
+    r = subprocess.run([node, '-e', js], cwd=ol.ROOT, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1500:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    import hashlib
+    ex = json.load(open(os.path.join(ol.ROOT, 'tests', 'golden', 'ref', 'inputs_example.json')))
+    assert j['flat'] == hashlib.sha256(ol.flat_inputs(ex)).hexdigest()
+    assert j['errs'] == ['Signal foo not found\n', 'Not all inputs have been set. Only 333 out of 334', 'Too many values for input signal sikSiblings\n', 'Cannot convert zz to a BigInt', None]

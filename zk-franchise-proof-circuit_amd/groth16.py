@@ -20,7 +20,15 @@ from .inputs import R_MOD
 _ctx = None
 _keys = collections.OrderedDict()      # sha256 of the .zkey image -> ProvingKey; at most MAX_RESIDENT_KEYS stay in HBM
 _path_digest = {}                       # (path, mtime_ns, size) -> sha256, so that an unchanged file is not re-read per proof
-MAX_RESIDENT_KEYS = int(os.environ.get("ZKC_SERVICE_KEYS", "4"))      # [r4] as many as the proving service keeps per device
+def _max_resident_keys():
+    """As many as the proving service keeps per device ($ZKC_SERVICE_KEYS), clamped the way the C side clamps it (1 .. 64; anything that is not a number: 4)."""
+    try:
+        return max(1, min(int(os.environ.get("ZKC_SERVICE_KEYS", "4")), 64))
+    except ValueError:
+        return 4
+
+
+MAX_RESIDENT_KEYS = _max_resident_keys()
 
 
 def _context(device=None):

@@ -31,19 +31,22 @@ def hex_to_ff(h):
 
 
 def flatten_inputs(inp, nLevels=160):
-    """12-key input object -> nInputs x 32-byte little-endian block (values reduced mod r, as circom_runtime does)."""
-    out = []
-    for k in INPUT_KEYS:
-        v = inp[k]
-        if k.endswith('Siblings'):
-            v = list(v)
-            if len(v) > nLevels + 1:
-                raise ValueError('%s: too many values for input signal (%d > %d)' % (k, len(v), nLevels + 1))
-            v = v + ['0'] * (nLevels + 1 - len(v))
-        if isinstance(v, (list, tuple)):
-            out.extend(int(x) % R_MOD for x in v)
-        else:
-            out.append(int(v) % R_MOD)
-    if len(out) != 12 + 2 * (nLevels + 1):
-        raise ValueError('Not all inputs have been set: %d of %d' % (len(out), 12 + 2 * (nLevels + 1)))
-    return b''.join(x.to_bytes(32, 'little') for x in out)
+    """12-key input object (or the JSON text of one: bytes / str) -> nInputs x 32-byte little-endian block.  [r5] ONE implementation for every host: the library's
+    zkc_inputs_from_json (include/zkcensus.h; host only, no GPU needed), which reads the object the way circom_runtime's witness calculator does -- any key order, decimal /
+    "0x" strings and integers, reduction mod r, "Signal <k> not found", "Too many values for input signal <k>", "Not all inputs have been set" -- and pads short sibling lists
+    with zeros.  The N-API host (napi/index.js flatten) and the cgo host (prover.Prove's inputs []byte, zk_census_test.go:85-89) go through the same function.
+    ValueError carries circom_runtime's message."""
+    import ctypes, json
+    from . import _native
+    lib = _native.load()
+    if isinstance(inp, (bytes, bytearray)):
+        text = bytes(inp)
+    elif isinstance(inp, str):
+        text = inp.encode()
+    else:
+        text = json.dumps({k: v for k, v in inp.items()}, default=lambda o: str(int(o))).encode()
+    out = ctypes.create_string_buffer(32 * (12 + 2 * (nLevels + 1))); err = ctypes.create_string_buffer(256)
+    rc = lib.zkc_inputs_from_json(text, len(text), nLevels, out, err, 256)
+    if rc:
+        raise ValueError(err.value.decode())
+    return out.raw
