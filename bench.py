@@ -366,7 +366,7 @@ def service_leg(args, ctx, dev, zkey_bytes, vk, voters, flat, d_wtns, nW, nIn):
     res['groth16_fullprove_json'] = [leg(4, 64, 32)]
     res['lone_sequential_caller_ms'] = leg(1, 1, 20)['latency_ms_p50']      # one caller, one call at a time: the latency through the same queue
     mem = (ctypes.c_uint64 * 8)(); lib.zkc_service_memory(svc, mem)
-    res['memory_GB'] = dict(zip(('resident_keys', 'key_tables', 'key_work_space', 'largest_key_tables', 'largest_key_work_space', 'staging_device', 'pinned_host', 'reserve_failures'),
+    res['memory_GB'] = dict(zip(('resident_keys', 'key_tables', 'lanes_work_space_shared_by_the_keys', 'largest_key_tables', 'largest_device_work_space', 'staging_device', 'pinned_host', 'reserve_failures'),
                                 [int(mem[0])] + [round(int(x) / 1e9, 2) for x in mem[1:7]] + [int(mem[7])]))
     return res
 
@@ -630,8 +630,8 @@ def main():
     # ---- verify what was timed: the proofs of the LAST timed step ----
     verified = None
     vk = json.load(open(vkey_path))
-    inflight = int(os.environ.get('ZKC_INFLIGHT', '96'))
-    npass = -(-B // inflight); per = -(-B // npass)                       # the library cuts a batch into equal passes of at most `inflight` proofs
+    inflight = pk.pass_size
+    npass = -(-B // inflight); per = -(-B // npass)                       # the library cuts a batch into equal passes of at most `inflight` proofs (zkc_zkey_pass_info)
     sample = sorted({i for i in (0, 1, per - 1, per, 2 * per - 1, 2 * per, B // 2, (npass - 1) * per - 1, (npass - 1) * per, B - 2, B - 1) if 0 <= i < B})
     if not args.no_verify:
         ok_batch = groth16.verify_batch(ctx, vk, out['pubs'], out['proofs'])                  # all B proofs of the step, product batch verifier
@@ -694,7 +694,7 @@ def main():
                          'the build\'s own C oracle, not snarkjs/rapidsnark (neither can run here)' % (len(done), cores, cores, cdt)}
 
     extras = None; service = None; generic = None
-    key_shape = {'nVars': pk.n_vars, 'domainSize': pk.domain_size}
+    key_shape = {'nVars': pk.n_vars, 'domainSize': pk.domain_size, 'pass_size': pk.pass_size, 'lanes': pk.lanes}
     if rank == 0 and world == 1 and not args.no_extras and not args.no_verify:
         extras = extra_legs(args, ctx, pk, zkey_bytes, vk, B, d_inputs, d_wtns, d_status, flat, out, rs, roofline['valu']['madds_per_proof'])
         if os.environ.get('ZKC_BENCH_SERVICE', '1') != '0':
@@ -715,7 +715,7 @@ def main():
             'data': 'synthetic',
             'config': {'workload': 'zkCensus nLevels=%d, batch of %d voter proofs per GPU per step (BASELINE configs[2]/[3] shape), '
                                    'own test zkey seed 0x5A4B43454E535553, synthetic %d-voter census' % (args.nlevels, B, max(8192, B * world)),
-                       'step_pipelining': pipelined, 'batch_per_gpu': B, 'nVars': key_shape['nVars'], 'domainSize': key_shape['domainSize'], 'parallelism': 'independent proofs per GPU, RCCL all_gather of 513 B/proof'},
+                       'step_pipelining': pipelined, 'batch_per_gpu': B, 'pass_size': key_shape['pass_size'], 'lanes': key_shape['lanes'], 'nVars': key_shape['nVars'], 'domainSize': key_shape['domainSize'], 'parallelism': 'independent proofs per GPU, RCCL all_gather of 513 B/proof'},
             'roofline': roofline, 'cpu_baseline': cpu, 'verified': verified,
             'service': service, 'generic_2p20': generic, 'census_build_s': round(t_census, 3), 'census_to_proofs': (extras or {}).get('census_to_proofs'),
             'host_to_host': (extras or {}).get('host_to_host'), 'single_proof': (extras or {}).get('single_proof'), 'folding': (extras or {}).get('folding'), 'stages_isolated': (extras or {}).get('stages_isolated'),

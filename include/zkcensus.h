@@ -94,6 +94,7 @@ int zkc_witness_dev(zkc_ctx* ctx, int nLevels, const void* d_inputs, int B, void
 int  zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, zkc_zkey** out);
 void zkc_zkey_free(zkc_zkey* zk);
 int  zkc_zkey_info(const zkc_zkey* zk, uint32_t* nVars, uint32_t* nPublic, uint32_t* domainSize);
+int  zkc_zkey_pass_info(const zkc_zkey* zk, int* pass_size, int* lanes);      /* proofs per pipeline pass (a batch call of B voters is cut into ceil(B / pass_size) equal passes) and pipeline lanes the passes rotate over */
 int  zkc_zkey_header_info(const void* zkey_bytes, size_t len, uint32_t* nVars, uint32_t* nPublic, uint32_t* domainSize);   /* from the file image alone: host only, nothing is loaded */
 int  zkc_zkey_sha256(const zkc_zkey* zk, uint8_t out[32]);      /* of the .zkey image it was loaded from (circuits-info.md:5 publishes this hash) */
 /* cheap identity of a .zkey image for resident-key caches: a SAMPLED hash (SHA-256 over the header, the IC points, the ends of every section and a
@@ -114,9 +115,10 @@ int zkc_prove_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, const uin
                   uint8_t proof[256], uint8_t* public_out);
 
 /* batch form: B witnesses resident in HBM (B x nWitness x 32 B), rs = B x 64 B (r || s per proof), outputs on the host:
- * proofs B x 256 B, publics B x nPublic x 32 B (may be NULL).  Up to ZKC_INFLIGHT (default 96) proofs share one MSM
- * pipeline pass; the work space grows with the number of proofs a call puts in flight (a single-proof caller reserves that of one
- * proof, not of 96).  Mirrors what a rapidsnark / snarkjs caller would loop over (zk_census_test.go:89 per voter). */
+ * proofs B x 256 B, publics B x nPublic x 32 B (may be NULL).  Up to ZKC_INFLIGHT (default 64 for a census key, 96 otherwise) proofs share one MSM
+ * pipeline pass and the passes of a call rotate over ZKC_LANES pipeline lanes (default 4 for a census key; zkc_zkey_pass_info); the work space belongs to the
+ * CONTEXT, is shared by its keys and grows with what calls put in flight (a single-proof caller touches one lane with room for four proofs, 0.6 GB at nLevels 160; a
+ * 1 024-voter call four lanes of 64, 37 GB).  Mirrors what a rapidsnark / snarkjs caller would loop over (zk_census_test.go:89 per voter). */
 int zkc_prove_batch_dev(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, int B, const uint8_t* rs, uint8_t* proofs, uint8_t* publics);
 
 /* groth16.fullProve (ts_inputs/src/example.ts:358-362) for a batch, everything on the device: B input blocks (zkc_circuit_n_inputs x 32 B
@@ -193,8 +195,9 @@ int zkc_service_stats(zkc_service* svc, uint64_t out[8]);
  * $ZKC_SERVICE_KEYS keys resident, default 4, least recently used out first; the reference has one key per environment and depth, circuit/circuit-compiler.sh:15,82) */
 int zkc_service_timing(zkc_service* svc, uint64_t out[8]);
 /* what the service holds in memory NOW (bytes): out[0] resident keys over all devices, [1] their constant tables (pre-shifted bases, matrices, twiddles, folding tables),
- * [2] their lanes' per-pass work space, [3] / [4] the same two for the largest key, [5] the workers' device staging (inputs, witnesses), [6] pinned host memory (staging +
- * witness slots), [7] work-space reservations that failed so far (such a key grows on demand instead).  INTEGRATION.md section 5 has the figures per key at nLevels 160. */
+ * [2] the per-pass work space of the devices' pipeline lanes -- ONE set per device, shared by every key resident on it -- [3] the largest key's tables, [4] the largest device's
+ * work space, [5] the workers' device staging (inputs, witnesses), [6] pinned host memory (staging + witness slots), [7] work-space reservations that failed so far (the lanes
+ * then grow on demand).  INTEGRATION.md section 1 has the figures at nLevels 160. */
 int zkc_service_memory(zkc_service* svc, uint64_t out[8]);
 
 /* ---- the rapidsnark entry point (go-rapidsnark prover.h `groth16_prover`, reached from prover.Prove at

@@ -274,7 +274,7 @@ def test_optional_pipeline_modes_give_identical_proofs(env):
     ref = pk.prove_batch_dev(d_w.data_ptr(), B, rs)
     old = {k: os.environ.get(k) for k in ('ZKC_LANES', 'ZKC_INFLIGHT')}
     try:
-        for lanes, inflight in (('2', '8'), ('1', '3'), ('2', '32')):
+        for lanes, inflight in (('2', '8'), ('1', '3'), ('2', '32'), ('4', '5'), ('3', '96')):
             os.environ['ZKC_LANES'] = lanes; os.environ['ZKC_INFLIGHT'] = inflight
             pk2 = zkcensus_amd.ProvingKey(ctx, zk)
             try:
@@ -289,8 +289,8 @@ def test_optional_pipeline_modes_give_identical_proofs(env):
 
 def test_fullprove_batch_nl160_three_passes_config3(env):
     """BASELINE configs[2] regime at a size the oracle can follow: zkc_fullprove_batch_dev at nLevels = 160 over B = 200 voters of the
-    8 192-voter synthetic census (three pipeline passes of 67, 67 and 66 voters: 65 536-bucket H jobs, pass boundaries inside the
-    batch).  Every proof goes through the product's batch verifier, the pass-boundary proofs through the oracle's pairing verifier,
+    8 192-voter synthetic census (four pipeline passes of 50 voters, one on each of the key's lanes -- three of 67, 67, 66 until round 5 --: 65 536-bucket H jobs, pass
+    boundaries inside the batch).  Every proof goes through the product's batch verifier, the pass-boundary proofs through the oracle's pairing verifier,
     and two of them (first of pass 2, last of the batch) are re-proved by the CPU oracle from the device witness: identical bytes."""
     ctx, get, torch = env
     import zkcensus_amd
@@ -307,10 +307,11 @@ def test_fullprove_batch_nl160_three_passes_config3(env):
     proofs, pubs = pk.fullprove_batch_dev(d_in.data_ptr(), B, d_w.data_ptr(), d_st.data_ptr(), rs)
     assert d_st.cpu().tolist() == [0] * B
     assert groth16.verify_batch(ctx, vk, pubs, proofs)
-    for i in (0, 66, 67, 95, 96, 133, 134, B - 1):
+    per = -(-B // -(-B // pk.pass_size))                                 # proofs per pass (zkc_zkey_pass_info)
+    for i in sorted({0, per - 1, per, 2 * per - 1, 2 * per, 66, 67, 133, 134, B - 1}):
         assert ol.verify(vk, pubs[256 * i:256 * i + 256], proofs[256 * i:256 * i + 256]), i
     wt = d_w.view(B, nW * 32)
-    dev_w = {i: wt[i].cpu().numpy().tobytes() for i in (67, B - 1)}
+    dev_w = {i: wt[i].cpu().numpy().tobytes() for i in (per, B - 1)}
 
     def check(i):
         w = dev_w[i]
@@ -319,7 +320,7 @@ def test_fullprove_batch_nl160_three_passes_config3(env):
         r_i = int.from_bytes(rs[64 * i:64 * i + 32], 'little'); s_i = int.from_bytes(rs[64 * i + 32:64 * i + 64], 'little')
         rc, op, opub = ol.prove(zk, w, r_i, s_i)
         assert rc == 0 and op == proofs[256 * i:256 * i + 256] and opub == pubs[256 * i:256 * i + 256], i
-    ol.pmap(check, (67, B - 1))
+    ol.pmap(check, (per, B - 1))
     # a tampered proof in the middle of the batch is caught by the batch verifier
     bad = bytearray(proofs); bad[256 * 100 + 5] ^= 1
     assert not groth16.verify_batch(ctx, vk, pubs, bytes(bad))
@@ -328,7 +329,7 @@ def test_fullprove_batch_nl160_three_passes_config3(env):
 def test_fullprove_batch_nl160_b1024_config2_full_size(env):
     """BASELINE configs[2] at its OWN size and in the bench's form: 1 024 voters of the 8 192-voter synthetic census through zkc_batch_begin /
     zkc_batch_finish, two steps in flight on the two call slots (step 2 is begun before step 1 is finished, with its own witness / status buffers and fresh (r, s)) --
-    eleven passes of 94 / 84 voters each.  All 2 048 proofs through the product's batch verifier; the first / last proofs and both sides of two pass boundaries of BOTH steps
+    sixteen passes of 64 voters rotating over the key's four pipeline lanes.  All 2 048 proofs through the product's batch verifier; the first / last proofs and both sides of two pass boundaries of BOTH steps
     byte-equal to the CPU oracle's (its witness from the voter's inputs, its proof from that witness and the step's (r, s)), on host threads."""
     ctx, get, torch = env
     import zkcensus_amd
@@ -345,7 +346,7 @@ def test_fullprove_batch_nl160_b1024_config2_full_size(env):
     pk.batch_begin(0, d_in.data_ptr(), B, d_w[0].data_ptr(), d_st[0].data_ptr(), rs[0])
     pk.batch_begin(1, d_in.data_ptr(), B, d_w[1].data_ptr(), d_st[1].data_ptr(), rs[1])
     out = [pk.batch_finish(0, B), pk.batch_finish(1, B)]
-    per = -(-B // -(-B // 96))                                           # 94: the library cuts 1 024 into eleven equal passes
+    per = -(-B // -(-B // pk.pass_size))                                 # 64: the library cuts 1 024 into sixteen equal passes (zkc_zkey_pass_info) rotating over pk.lanes lanes
     picks = (0, per - 1, per, 5 * per - 1, 5 * per, B - 1)
     for k in range(2):
         proofs, pubs = out[k]

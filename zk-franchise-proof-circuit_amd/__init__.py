@@ -81,6 +81,9 @@ class ProvingKey:
         a, b, c = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
         self._lib.zkc_zkey_info(h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
         self.n_vars, self.n_public, self.domain_size = a.value, b.value, c.value
+        ps, ln = ctypes.c_int(), ctypes.c_int()
+        self._lib.zkc_zkey_pass_info(h, ctypes.byref(ps), ctypes.byref(ln))
+        self.pass_size, self.lanes = ps.value, ln.value          # a batch call of B voters runs as ceil(B / pass_size) equal passes over `lanes` pipeline lanes
 
     def close(self):
         if getattr(self, '_h', None):
@@ -247,7 +250,7 @@ class ProvingService:
     def memory(self):
         out = (ctypes.c_uint64 * 8)()
         self._lib.zkc_service_memory(self._h, out)
-        return dict(zip(('resident_keys', 'table_bytes', 'work_bytes', 'largest_key_table_bytes', 'largest_key_work_bytes', 'staging_device_bytes', 'pinned_host_bytes', 'reserve_failures'),
+        return dict(zip(('resident_keys', 'table_bytes', 'work_bytes', 'largest_key_table_bytes', 'largest_device_work_bytes', 'staging_device_bytes', 'pinned_host_bytes', 'reserve_failures'),
                         [int(x) for x in out]))
 
     def close(self):

@@ -40,6 +40,7 @@ def load():
     L.zkc_zkey_load.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(vp)]
     L.zkc_zkey_free.argtypes = [vp]; L.zkc_zkey_free.restype = None
     L.zkc_zkey_info.argtypes = [vp, u32p, u32p, u32p]
+    L.zkc_zkey_pass_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     L.zkc_witness_status_text.argtypes = [ctypes.c_int, ctypes.c_int32]; L.zkc_witness_status_text.restype = ctypes.c_char_p
     L.zkc_prove.argtypes = [vp, ctypes.c_char_p, ctypes.c_uint32, u8p, u8p, ctypes.c_char_p, ctypes.c_char_p]
     L.zkc_prove_dev.argtypes = [vp, vp, ctypes.c_uint32, u8p, u8p, ctypes.c_char_p, ctypes.c_char_p]

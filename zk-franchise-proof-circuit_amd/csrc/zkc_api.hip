@@ -36,6 +36,7 @@ hipError_t zkc_wait_stream(hipStream_t st, hipEvent_t scratch_ev) {
     const hipError_t e = hipEventRecord(scratch_ev, st);
     return e != hipSuccess ? e : zkc_wait_event(scratch_ev);
 }
+void zkc_ctx_lanes_destroy(zkc_ctx* ctx);      // zkc_prove.hip
 int zkc_ensure(zkc_ctx* ctx, void** p, size_t* cur, size_t need) {
     if (*cur >= need) return ZKC_OK;
     if (*p) { ZKC_HIP_CHECK(ctx, hipFree(*p)); *p = nullptr; *cur = 0; }
@@ -209,7 +210,9 @@ extern "C" void zkc_ctx_destroy(zkc_ctx* ctx) {
     if (ctx->d_status3) (void)hipFree(ctx->d_status3);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_prof_entries) (void)hipFree(ctx->d_prof_entries);
-    for (auto& ls : ctx->lane_streams) for (hipStream_t q : {ls.st, ls.st2, ls.fin, ls.red}) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+    for (auto& ls : ctx->lane_streams) for (hipStream_t q : {ls.st, ls.st2, ls.fin, ls.red}) if (q) (void)hipStreamSynchronize(q);
+    zkc_ctx_lanes_destroy(ctx);
+    for (auto& ls : ctx->lane_streams) for (hipStream_t q : {ls.st, ls.st2, ls.fin, ls.red}) if (q) (void)hipStreamDestroy(q);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->fin_stream) (void)hipStreamDestroy(ctx->fin_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

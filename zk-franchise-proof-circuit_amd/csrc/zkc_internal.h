@@ -34,6 +34,11 @@ struct zkc_ctx {
     // device resource -- each takes a hardware queue (or a share of one: GPU_MAX_HW_QUEUES), and a stream that shares its queue with another stream's barrier packet waits
     // behind it -- so four resident keys must not mean four times the streams.  Created on first use (zkc_lane_streams), destroyed with the context.
     struct LaneStreams { hipStream_t st = nullptr, st2 = nullptr, fin = nullptr, red = nullptr; } lane_streams[4];
+    // ... and so do the lanes themselves -- the per-pass work space (transform vectors, MSM entry lists, bucket and segment arrays, partial sums: ~0.15 GB per proof in flight at
+    // nLevels 160) and the events that order a lane's streams: zkc_lane[MAX_LANES] (zkc_prover.h), made on first use and grown to the largest need any key of the context has
+    // shown (zkc_prove.hip lane_ensure).  Calls on one lane are ordered by its streams whatever key they prove with, so four resident keys cost four sets of TABLES, not four
+    // work spaces (round 4 and the first half of round 5: 37 GB of work space per service key).
+    struct zkc_lane* lanes = nullptr;
     std::string err;
     zkc::PoseidonTable ptab{};            // device pointers
     void* d_ptab_mem = nullptr;

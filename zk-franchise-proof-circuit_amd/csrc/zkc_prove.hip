@@ -105,75 +105,112 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     if (zk->h_depths) (void)hipHostFree(zk->h_depths);
     for (auto& c : zk->call) { for (void* q : {(void*)c.d_rs, (void*)c.d_proofs, (void*)c.d_flags, (void*)c.d_status3}) if (q) (void)hipFree(q); if (c.h_flags) (void)hipHostFree(c.h_flags); if (c.h_out) (void)hipHostFree(c.h_out); if (c.h_rs) (void)hipHostFree(c.h_rs); if (c.h_xyzz) (void)hipHostFree(c.h_xyzz); if (c.h_early) (void)hipHostFree(c.h_early); if (c.d_xyzz) (void)hipFree(c.d_xyzz); for (hipEvent_t e : c.ev_done) if (e) (void)hipEventDestroy(e); for (hipEvent_t e : c.ev_chunk) (void)hipEventDestroy(e); }
     if (zk->ev_start) (void)hipEventDestroy(zk->ev_start);
-    for (auto& L : zk->lane) {
-        for (hipStream_t q : {L.st, L.st2, L.fin, L.red}) if (q) (void)hipStreamSynchronize(q);      // (the streams are the context's: zkc_lane_streams)
-        if (L.ev_red) (void)hipEventDestroy(L.ev_red);
-        for (void* q : {(void*)L.d_abc, (void*)L.d_t, (void*)L.d_p, L.d_fin, (void*)L.d_bs}) if (q) (void)hipFree(q);
-        for (hipEvent_t e : {L.ev_msm, L.ev_msm2, L.ev_sorted, L.ev_ntt, L.ev_mv, L.ev_acc, L.ev_fin[0], L.ev_fin[1]}) if (e) (void)hipEventDestroy(e);
-        msm_work_free(L.w1); msm_work_free(L.w2);
-    }
+    if (zk->ctx->lanes) for (int l = 0; l < zk->nlanes; l++) for (hipStream_t q : {zk->ctx->lanes[l].st, zk->ctx->lanes[l].st2, zk->ctx->lanes[l].fin, zk->ctx->lanes[l].red}) if (q) (void)hipStreamSynchronize(q);      // (lanes, streams and work space are the context's and stay)
     delete zk;
 }
 
 static size_t dev_free_bytes() { size_t f = 0, t = 0; if (hipMemGetInfo(&f, &t) != hipSuccess) { (void)hipGetLastError(); return 0; } return f; }
 static int fold_prepare(zkc_zkey* zk);
 static int fb4_prepare(zkc_zkey* zk);
-// (Re)allocates the per-pass work space of every lane for `inflight` proofs per pass (grow only).  The caller holds the context lock and no
-// pass is in flight.  Footprint per proof in flight at nLevels = 160: abc + NTT scratch 2 x 12 MiB, p 4 MiB, MSM entries ~25 MB, partial sums.
-static int lanes_ensure(zkc_zkey* zk, int inflight) {
-    inflight = std::max(1, std::min(inflight, zk->max_inflight));
-    if (inflight <= zk->cur_inflight) return ZKC_OK;
-    // grow in two steps only: a caller of one to four proofs at a time reserves four proofs' work space (0.25 GB at nLevels = 160), anything larger the full pass
-    // (96 proofs, 6 GB of the card's 288): every growth frees and re-allocates the whole work space, which a burst of growing batches (the proving service
-    // under a rising load) would otherwise pay five or six times, hundreds of milliseconds each
-    inflight = inflight <= 4 ? 4 : zk->max_inflight;
-    inflight = std::min(inflight, zk->max_inflight);
-    zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n, nv = zk->nVars; int rc;
-    const int NWS = msm_nw(zk->c_sec), NWB = msm_nw(zk->c_h);
+// ---- the pipeline lanes: the CONTEXT's (zkc_ctx::lanes), shared by every key of the context ----
+// what one lane must hold for `inflight` proofs of this key per pass
+struct LaneNeed { size_t abc, p, fin, bs, e1, b1, e2, b2; int j1, j2; };
+static LaneNeed lane_need(const zkc_zkey* zk, int inflight) {
+    const uint32_t n = zk->n, nv = zk->nVars; const int NWS = msm_nw(zk->c_sec), NWB = msm_nw(zk->c_h);
     const size_t per_proof_entries = (size_t)NWS * 3 * nv + (size_t)NWB * n;
     const size_t per_proof_buckets = 3 * (size_t)msm_half(std::max(zk->c_sec, zk->c_deep)) + msm_half(zk->c_h);      // (a deep pass has fewer entries and more buckets)
-    // the old work space goes first (a key at nLevels = 160 with 96 proofs in flight holds ~6 GB): from here until every allocation has succeeded the key
-    // has NO work space, and says so (cur_inflight = 0), so a failure leaves a key that re-allocates on its next call instead of launching on freed buffers
-    zk->cur_inflight = 0;
-    const size_t free_before = dev_free_bytes() + zk->bytes_work;               // as if the old work space were gone already
-    auto release = [&]() {
-        zk->bytes_work = 0;
-        for (int l = 0; l < zk->nlanes; l++) {
-            zkc_lane& L = zk->lane[l];
-            for (void** q : {(void**)&L.d_abc, (void**)&L.d_t, (void**)&L.d_p, &L.d_fin, (void**)&L.d_bs}) if (*q) { (void)hipFree(*q); *q = nullptr; }
-            msm_work_free(L.w1); msm_work_free(L.w2);
-        }
-    };
-    for (int l = 0; l < zk->nlanes; l++) for (hipStream_t q : {zk->lane[l].st, zk->lane[l].st2, zk->lane[l].fin, zk->lane[l].red}) if (q) ZKC_HIP_CHECK(ctx, hipStreamSynchronize(q));
-    release();
-    const char* fail_at = getenv("ZKC_TEST_FAIL_ALLOC");          // test hook: pretend the allocation for this many proofs in flight (or more) fails
-    for (int l = 0; l < zk->nlanes; l++) {
-        zkc_lane& L = zk->lane[l];
-        rc = (fail_at && inflight >= atoi(fail_at)) ? zkc_fail(ctx, ZKC_ERR_HIP, "lanes_ensure: allocation failure injected by ZKC_TEST_FAIL_ALLOC") : ZKC_OK;
-        if (!rc) rc = dmalloc(ctx, &L.d_abc, 3 * (size_t)n * inflight);
-        if (!rc) rc = dmalloc(ctx, &L.d_t, 3 * (size_t)n * inflight);
-        if (!rc) rc = dmalloc(ctx, &L.d_p, 8 * (size_t)n * inflight);
-        if (!rc && hipMalloc(&L.d_fin, finalize_scratch_bytes(inflight)) != hipSuccess) rc = zkc_fail(ctx, ZKC_ERR_HIP, "lanes_ensure: hipMalloc failed (blinding scratch)");
-        if (!rc) rc = dmalloc(ctx, &L.d_bs, 2 * 2 * 8 * (size_t)nv);
-        if (!rc) rc = msm_work_alloc(ctx, L.w1, per_proof_entries * inflight, per_proof_buckets * inflight, 4 * inflight, false);
-        if (!rc) rc = msm_work_alloc(ctx, L.w2, (size_t)NWS * nv * inflight, (size_t)msm_half(std::max(zk->c_sec, zk->c_deep)) * inflight, inflight, true);
-        if (rc) { (void)hipGetLastError(); release(); return rc; }
+    LaneNeed nd; nd.abc = 3 * (size_t)n * inflight; nd.p = 8 * (size_t)n * inflight; nd.fin = finalize_scratch_bytes(inflight); nd.bs = 2 * 2 * 8 * (size_t)nv;
+    nd.e1 = per_proof_entries * inflight; nd.b1 = per_proof_buckets * inflight; nd.j1 = 4 * inflight;
+    nd.e2 = (size_t)NWS * nv * inflight; nd.b2 = (size_t)msm_half(std::max(zk->c_sec, zk->c_deep)) * inflight; nd.j2 = inflight;
+    return nd;
+}
+static bool lane_holds(const zkc_lane& L, const LaneNeed& nd) {
+    return L.cap_abc >= nd.abc && L.cap_p >= nd.p && L.cap_fin >= nd.fin && L.cap_bs >= nd.bs && L.w1.max_entries >= nd.e1 && L.w1.max_buckets >= nd.b1 && L.w1.max_jobs >= nd.j1 &&
+           L.w2.max_entries >= nd.e2 && L.w2.max_buckets >= nd.b2 && L.w2.max_jobs >= nd.j2;
+}
+static void lane_release(zkc_lane& L) {      // the buffers only: streams, events and the pass counter stay
+    for (void** q : {(void**)&L.d_abc, (void**)&L.d_t, (void**)&L.d_p, &L.d_fin, (void**)&L.d_bs}) if (*q) { (void)hipFree(*q); *q = nullptr; }
+    msm_work_free(L.w1); msm_work_free(L.w2);
+    L.cap_abc = L.cap_p = L.cap_fin = L.cap_bs = 0; L.bytes = 0;
+}
+static zkc_lane* ctx_lanes(zkc_ctx* ctx) { if (!ctx->lanes) ctx->lanes = new zkc_lane[MAX_LANES]; return ctx->lanes; }
+static size_t ctx_work_bytes(const zkc_ctx* ctx) { size_t t = 0; if (ctx->lanes) for (int l = 0; l < MAX_LANES; l++) t += ctx->lanes[l].bytes; return t; }
+void zkc_ctx_lanes_destroy(zkc_ctx* ctx) {
+    if (!ctx->lanes) return;
+    for (int l = 0; l < MAX_LANES; l++) {
+        zkc_lane& L = ctx->lanes[l];
+        lane_release(L);
+        for (hipEvent_t e : {L.ev_msm, L.ev_msm2, L.ev_sorted, L.ev_ntt, L.ev_mv, L.ev_acc, L.ev_fin[0], L.ev_fin[1], L.ev_red}) if (e) (void)hipEventDestroy(e);
     }
-    zk->cur_inflight = inflight;
-    { const size_t f = dev_free_bytes(); zk->bytes_work = free_before > f ? free_before - f : 0; }
+    delete[] ctx->lanes; ctx->lanes = nullptr;
+}
+// streams and events of lane l, once per context
+static int lane_init(zkc_ctx* ctx, int l) {
+    zkc_lane& L = ctx_lanes(ctx)[l];
+    if (L.made) return ZKC_OK;
+    static const bool red_wanted = [] { const char* e = getenv("ZKC_REDUCE_STREAM"); return e && atoi(e) == 1; }();
+    zkc_ctx::LaneStreams ls; int rc = zkc_lane_streams(ctx, l, red_wanted, &ls); if (rc) return rc;
+    L.st = ls.st; L.st2 = ls.st2; L.fin = ls.fin; L.red = ls.red;
+    for (hipEvent_t* e : {&L.ev_msm, &L.ev_msm2, &L.ev_sorted, &L.ev_ntt, &L.ev_mv, &L.ev_acc, &L.ev_fin[0], &L.ev_fin[1], &L.ev_red}) if (!*e) ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    L.made = true; return ZKC_OK;
+}
+// the streams a pass of THIS key runs on in lane L: the lane's own, or -- a key loaded with ZKC_SERIAL_STREAMS=1 (measurement only: every stage of a pass on the context's one
+// stream, so that the per-category HIP-event brackets of zkc_profile_* are ISOLATED kernel times; the pipeline's overlap is gone, the proofs are the same bytes) -- ctx->stream
+struct LaneSt { hipStream_t st, st2, fin, red; };
+static LaneSt lane_st(const zkc_zkey* zk, const zkc_lane& L) { hipStream_t c = zk->ctx->stream; return zk->serial_streams ? LaneSt{c, c, c, c} : LaneSt{L.st, L.st2, L.fin, L.red}; }
+// Grows lane l of the key's context until it holds `inflight` proofs of this key per pass (grow only, never below what another key of the context asked for).  The caller holds
+// the context lock.  Footprint per proof in flight at nLevels = 160: abc + NTT scratch 2 x 12 MiB, p 4 MiB, MSM entries 59 MB, bucket / segment arrays and partial sums ~60 MB.
+static int lane_ensure(zkc_zkey* zk, int l, int inflight) {
+    zkc_ctx* ctx = zk->ctx; int rc;
+    if ((rc = lane_init(ctx, l))) return rc;
+    zkc_lane& L = ctx->lanes[l];
+    inflight = std::max(1, std::min(inflight, zk->max_inflight));
+    if (lane_holds(L, lane_need(zk, inflight))) return ZKC_OK;
+    // grow in two steps only: a caller of one to four proofs at a time reserves four proofs' work space (0.6 GB at nLevels = 160), anything larger the full pass (14 GB for 96
+    // proofs): every growth frees and re-allocates the lane, which a burst of growing batches would otherwise pay five or six times, hundreds of milliseconds each
+    inflight = std::min(inflight <= 4 ? 4 : zk->max_inflight, zk->max_inflight);
+    LaneNeed nd = lane_need(zk, inflight);
+    nd.abc = std::max(nd.abc, L.cap_abc); nd.p = std::max(nd.p, L.cap_p); nd.fin = std::max(nd.fin, L.cap_fin); nd.bs = std::max(nd.bs, L.cap_bs);      // what other keys of the context needed stays
+    nd.e1 = std::max(nd.e1, L.w1.max_entries); nd.b1 = std::max(nd.b1, L.w1.max_buckets); nd.j1 = std::max(nd.j1, L.w1.max_jobs);
+    nd.e2 = std::max(nd.e2, L.w2.max_entries); nd.b2 = std::max(nd.b2, L.w2.max_buckets); nd.j2 = std::max(nd.j2, L.w2.max_jobs);
+    // the old work space goes first: from here until every allocation has succeeded the lane has NO work space and says so (capacities zero), so a failure leaves a lane that
+    // re-allocates on its next call instead of launching on freed buffers
+    for (hipStream_t q : {L.st, L.st2, L.fin, L.red}) if (q) ZKC_HIP_CHECK(ctx, hipStreamSynchronize(q));
+    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    lane_release(L);
+    const size_t free_before = dev_free_bytes();
+    const char* fail_at = getenv("ZKC_TEST_FAIL_ALLOC");          // test hook: pretend the allocation for this many proofs in flight (or more) fails
+    rc = (fail_at && inflight >= atoi(fail_at)) ? zkc_fail(ctx, ZKC_ERR_HIP, "lanes_ensure: allocation failure injected by ZKC_TEST_FAIL_ALLOC") : ZKC_OK;
+    if (!rc) rc = dmalloc(ctx, &L.d_abc, nd.abc);
+    if (!rc) rc = dmalloc(ctx, &L.d_t, nd.abc);
+    if (!rc) rc = dmalloc(ctx, &L.d_p, nd.p);
+    if (!rc && hipMalloc(&L.d_fin, nd.fin) != hipSuccess) rc = zkc_fail(ctx, ZKC_ERR_HIP, "lanes_ensure: hipMalloc failed (blinding scratch)");
+    if (!rc) rc = dmalloc(ctx, &L.d_bs, nd.bs);
+    if (!rc) rc = msm_work_alloc(ctx, L.w1, nd.e1, nd.b1, nd.j1, false);
+    if (!rc) rc = msm_work_alloc(ctx, L.w2, nd.e2, nd.b2, nd.j2, true);
+    if (rc) { (void)hipGetLastError(); lane_release(L); return rc; }
+    L.cap_abc = nd.abc; L.cap_p = nd.p; L.cap_fin = nd.fin; L.cap_bs = nd.bs;
+    { const size_t f = dev_free_bytes(); L.bytes = free_before > f ? free_before - f : 0; }
+    return ZKC_OK;
+}
+// lanes [first, first + count) of the key's context, each for `inflight` proofs per pass
+static int lanes_ensure(zkc_zkey* zk, int inflight, int first = 0, int count = -1) {
+    if (count < 0) count = zk->nlanes - first;
+    for (int l = first; l < first + count && l < zk->nlanes; l++) { const int rc = lane_ensure(zk, l, inflight); if (rc) return rc; }
     return ZKC_OK;
 }
 extern "C" int zkc_zkey_load(zkc_ctx* ctx, const void* zkey_bytes, size_t len, zkc_zkey** out) { return zkc::zkey_load_opts(ctx, zkey_bytes, len, 0, 0, out); }
 size_t zkc::zkey_device_bytes(const zkc_zkey* zk, size_t* tables, size_t* work) {
     if (!zk) return 0;
-    if (tables) *tables = zk->bytes_tables; if (work) *work = zk->bytes_work;
-    return zk->bytes_tables + zk->bytes_work;
+    const size_t w = ctx_work_bytes(zk->ctx);
+    if (tables) *tables = zk->bytes_tables; if (work) *work = w;
+    return zk->bytes_tables + w;
 }
 int zkc::zkey_load_opts(zkc_ctx* ctx, const void* zkey_bytes, size_t len, int opt_lanes, int opt_inflight, zkc_zkey** out) {
     if (!ctx || !zkey_bytes || !out) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_zkey_load: bad argument");
     ZKC_LOCK(ctx);
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    const size_t free_at_entry = dev_free_bytes();
+    const size_t free_at_entry = dev_free_bytes(), work_at_entry = ctx_work_bytes(ctx);
     const uint8_t* buf = (const uint8_t*)zkey_bytes;
     // every length and index of the file is validated by the host-only parser (zkc_hostparse.h, also built under ASan/UBSan by the tests)
     parse::BinSections bs; parse::ZkeyHeader zh; std::string perr;
@@ -321,7 +358,8 @@ int zkc::zkey_load_opts(zkc_ctx* ctx, const void* zkey_bytes, size_t len, int op
     // ---- work buffers: up to `max_inflight` proofs share one MSM pipeline pass; the buffers themselves are sized by lanes_ensure() for
     //      the number of proofs a call actually puts in flight (a single-proof caller does not reserve the work space of 96) ----
     const char* e_inf = getenv("ZKC_INFLIGHT");
-    zk->max_inflight = opt_inflight > 0 ? std::min(opt_inflight, MSM_MAX_JOBS / 4) : e_inf ? std::max(1, std::min(atoi(e_inf), MSM_MAX_JOBS / 4)) : 96;
+    // [r5] a census key: passes of 64 proofs over four lanes (below); any other key: 96 (cut down by its size, next block) on one lane as before
+    zk->max_inflight = opt_inflight > 0 ? std::min(opt_inflight, MSM_MAX_JOBS / 4) : e_inf ? std::max(1, std::min(atoi(e_inf), MSM_MAX_JOBS / 4)) : zk->nLevels >= 0 ? 64 : 96;
     {   // [r4] the pass is sized for the census key (96 proofs of 7.4 M (scalar, window) entries unfolded): a larger circuit puts fewer proofs in flight -- the same ~0.7 G entries per
         // pass, which also keeps every entry index of a pass inside 32 bits (MsmJob::ent_off) -- 11 at a 2^20 domain, where ONE proof is 60 M additions and fills the chip
         const size_t per_proof_entries = (size_t)NWS * 3 * nv + (size_t)NWB * n, census_pass = 96ull * (22ull * 3 * 82754 + 15ull * 131072);
@@ -331,23 +369,14 @@ int zkc::zkey_load_opts(zkc_ctx* ctx, const void* zkey_bytes, size_t len, int op
     // ZKC_LANES=2 lets two lanes take alternate passes; measured no gain in round 1 (the GPU is already saturated) and -4 % at the end of round 2 (3005
     // against 3142 proofs/s on one box: the second lane has no buildABC prefetch), so one lane is the default
     // [r5] up to MAX_LANES; the proving service asks for one lane per worker (opt_lanes) and keeps every call on its worker's lane
-    { const char* e_l = getenv("ZKC_LANES"); zk->nlanes = opt_lanes > 0 ? std::min(opt_lanes, (int)MAX_LANES) : e_l ? std::max(1, std::min(atoi(e_l), (int)MAX_LANES)) : 1; }
-    for (int l = 0; l < zk->nlanes; l++) {
-        zkc_lane& L = zk->lane[l];
-        // ZKC_SERIAL_STREAMS=1 (measurement only): every stage of a pass on the context's one stream, so that the per-category HIP-event brackets of
-        // zkc_profile_* are ISOLATED kernel times (bench.py's per-stage roofline); the pipeline's overlap is gone, the proofs are the same bytes
-        zk->serial_streams = getenv("ZKC_SERIAL_STREAMS") != nullptr;
-        if (zk->serial_streams) L.st = L.st2 = L.fin = L.red = ctx->stream;
-        else {
-            static const bool red_wanted = [] { const char* e = getenv("ZKC_REDUCE_STREAM"); return e && atoi(e) == 1; }();
-            zkc_ctx::LaneStreams ls; if ((rc = zkc_lane_streams(ctx, l, red_wanted, &ls))) return bail(rc);
-            L.st = ls.st; L.st2 = ls.st2; L.fin = ls.fin; L.red = ls.red;
-        }
-        ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_msm, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_msm2, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_sorted, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_ntt, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_mv, hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_acc, hipEventDisableTiming));
-        ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_fin[0], hipEventDisableTiming)); ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_fin[1], hipEventDisableTiming));
-        ZKC_HIP_BAIL(hipEventCreateWithFlags(&L.ev_red, hipEventDisableTiming));
-    }
-    if ((rc = lanes_ensure(zk, 1))) return bail(rc);
+    // [r5''] ... and, for a census key, the default of the batch entry points too: four lanes of 64-proof passes, the passes of a call rotating over them.  With every stream on
+    // a hardware queue of its own (GPU_MAX_HW_QUEUES, zkc_api.hip) and the lanes made only when a call reaches them, the overlap that rounds 1-4 could not find is there:
+    // alternating on one box, (1 lane, 96) 3243 / 3235 proofs/s, (4, 96) 3291, (4, 64) 3314 / 3308 (+2.2 %), (4, 48) 3251, (3, 64) 3179, (2, 96) 3146 / 3155.  A lone proof
+    // still touches lane 0 only (0.6 GB); a 1 024-voter call all four (37 GB; ZKC_LANES=1 ZKC_INFLIGHT=96: 14 GB and the old shape).
+    { const char* e_l = getenv("ZKC_LANES"); zk->nlanes = opt_lanes > 0 ? std::min(opt_lanes, (int)MAX_LANES) : e_l ? std::max(1, std::min(atoi(e_l), (int)MAX_LANES)) : zk->nLevels >= 0 ? (int)MAX_LANES : 1; }
+    zk->serial_streams = getenv("ZKC_SERIAL_STREAMS") != nullptr;          // (lane_st)
+    // the lanes are the context's: lane 0 is made (or found) now with room for a lone caller, the others when a call first lands on them
+    if ((rc = lanes_ensure(zk, 1, 0, 1))) return bail(rc);
     {   // fixed-base tables for the blinding step (delta1, alpha1, beta1 in G1; delta2 in G2)
         FixedBase<Fq> td(zk->delta1), ta(zk->alpha1), tb(zk->beta1); FixedBase<Fq2> t2(zk->delta2);
         if ((rc = dmalloc(ctx, &zk->d_tblDelta1, td.tab.size())) || (rc = dmalloc(ctx, &zk->d_tblAlpha1, ta.tab.size())) ||
@@ -360,7 +389,7 @@ int zkc::zkey_load_opts(zkc_ctx* ctx, const void* zkey_bytes, size_t len, int op
     // the folding tables of the voter-independent witness part are part of the key's one-time cost, not of the first proof
     if (zk->nLevels >= 0 && (rc = fold_prepare(zk))) return bail(rc);
     if ((rc = fb4_prepare(zk))) return bail(rc);
-    { const size_t f = dev_free_bytes(); zk->bytes_tables = free_at_entry > f + zk->bytes_work ? free_at_entry - f - zk->bytes_work : 0; }
+    { const size_t f = dev_free_bytes(), grown = ctx_work_bytes(ctx) > work_at_entry ? ctx_work_bytes(ctx) - work_at_entry : 0; zk->bytes_tables = free_at_entry > f + grown ? free_at_entry - f - grown : 0; }
     *out = zk;
     return ZKC_OK;
 #undef ZKC_UP
@@ -373,7 +402,12 @@ int zkc::prove_reserve(zkc_zkey* zk, int inflight) {
     if (!zk) return ZKC_ERR_BAD_ARG;
     ZKC_LOCK(zk->ctx);
     ZKC_HIP_CHECK(zk->ctx, hipSetDevice(zk->ctx->device));
-    return lanes_ensure(zk, inflight);
+    return lanes_ensure(zk, inflight);      // every lane of the key
+}
+extern "C" int zkc_zkey_pass_info(const zkc_zkey* zk, int* pass_size, int* lanes) {
+    if (!zk) return ZKC_ERR_BAD_ARG;
+    if (pass_size) *pass_size = zk->max_inflight; if (lanes) *lanes = zk->nlanes;
+    return ZKC_OK;
 }
 extern "C" int zkc_zkey_info(const zkc_zkey* zk, uint32_t* nVars, uint32_t* nPublic, uint32_t* domainSize) {
     if (!zk) return ZKC_ERR_BAD_ARG;
@@ -515,8 +549,8 @@ static int h_matvec_dev(zkc_zkey* zk, zkc_lane& L, const uint32_t* d_wtns0, int 
 }
 // stages a2..a4 for `nb` proofs: leaves (A'B' - C') on the odd coset in d_p[q] (standard form), q < nb.  with_matvec = false: buildABC has been
 // run already (on another stream; L.st has been made to wait for it)
-static int h_evals_dev(zkc_zkey* zk, zkc_lane& L, const uint32_t* d_wtns0, int nb, bool with_matvec = true) {
-    zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n; hipStream_t st = L.st;
+static int h_evals_dev(zkc_zkey* zk, zkc_lane& L, hipStream_t st, const uint32_t* d_wtns0, int nb, bool with_matvec = true) {
+    zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n;
     if (with_matvec) { int rc0 = h_matvec_dev(zk, L, d_wtns0, nb, st); if (rc0) return rc0; }
     zkc_prof_scope _pn(ctx, ZKC_PROF_NTT, (uint64_t)nb * (6ull * 2 * n * 32 + 4ull * n * 32), st);   // 6 transforms r+w, joinABC
     int rc;
@@ -534,33 +568,37 @@ static int h_evals_dev(zkc_zkey* zk, zkc_lane& L, const uint32_t* d_wtns0, int n
 
 extern "C" int zkc_debug_stage(zkc_zkey* zk, const void* d_wtns, int stage, void* host_out) {
     if (!zk || !d_wtns || !host_out) return ZKC_ERR_BAD_ARG;
-    zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n; zkc_lane& L0 = zk->lane[0];
+    zkc_ctx* ctx = zk->ctx; const uint32_t n = zk->n;
     ZKC_LOCK(ctx);
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device)); ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    { int rc0 = lanes_ensure(zk, 1, 0, 1); if (rc0) return rc0; }
+    zkc_lane& L0 = ctx->lanes[0]; const hipStream_t st0 = lane_st(zk, L0).st;
     if (stage == 0) {
-        matvec_launch(zk, L0, (const uint32_t*)d_wtns, 1, L0.st);
+        matvec_launch(zk, L0, (const uint32_t*)d_wtns, 1, st0);
         ZKC_HIP_CHECK(ctx, hipGetLastError());
-        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(host_out, L0.d_abc, 96ull * n, hipMemcpyDeviceToHost, L0.st));
+        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(host_out, L0.d_abc, 96ull * n, hipMemcpyDeviceToHost, st0));
     } else {
-        int rc = h_evals_dev(zk, L0, (const uint32_t*)d_wtns, 1); if (rc) return rc;
-        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(host_out, L0.d_p, 32ull * n, hipMemcpyDeviceToHost, L0.st));
+        int rc = h_evals_dev(zk, L0, st0, (const uint32_t*)d_wtns, 1); if (rc) return rc;
+        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(host_out, L0.d_p, 32ull * n, hipMemcpyDeviceToHost, st0));
     }
-    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(L0.st));
+    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(st0));
     return ZKC_OK;
 }
 
 extern "C" int zkc_msm_debug(zkc_zkey* zk, int which, const void* d_scalars, uint32_t count, void* host_out) {
     if (!zk || !d_scalars || !host_out || which < 0 || which > 4) return ZKC_ERR_BAD_ARG;
-    zkc_ctx* ctx = zk->ctx; zkc_lane& L0 = zk->lane[0];
+    zkc_ctx* ctx = zk->ctx;
     ZKC_LOCK(ctx);
     ZKC_HIP_CHECK(ctx, hipSetDevice(ctx->device)); ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    { int rc0 = lanes_ensure(zk, 1, 0, 1); if (rc0) return rc0; }
+    zkc_lane& L0 = ctx->lanes[0]; const hipStream_t st_l0 = lane_st(zk, L0).st;
     const uint32_t full = which == 3 ? zk->nVars - zk->nPub - 1 : which == 4 ? zk->n : zk->nVars;
     if (count != full) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "zkc_msm_debug: count must equal the section size");
     static thread_local MsmJobList jl; jl.clear(256, 1024, which == 2 ? (uint32_t)MSM_MAX_VW_PER_JOB : (uint32_t)MSM_MAX_VW_G1);
     const uint32_t offs[5] = {zk->offA, zk->offB1, 0, zk->offC, zk->offH};
     jl.add((const uint32_t*)d_scalars, nullptr, count, offs[which], full, 0, which == 4 ? zk->c_h : zk->c_sec);
-    int rc = which == 2 ? msm_pass_g2(zk, L0.w2, jl, 0, true, L0.st) : msm_pass_g1(zk, L0.w1, jl, 0, true, L0.st); if (rc) return rc;
-    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(L0.st));
+    int rc = which == 2 ? msm_pass_g2(zk, L0.w2, jl, 0, true, st_l0) : msm_pass_g1(zk, L0.w1, jl, 0, true, st_l0); if (rc) return rc;
+    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(st_l0));
     if (which == 2) g2_to_std((uint8_t*)host_out, xyzz_to_affine(*(G2XYZZ*)L0.w2.h_results));
     else g1_to_std((uint8_t*)host_out, xyzz_to_affine(*(G1XYZZ*)L0.w1.h_results));
     return ZKC_OK;
@@ -584,9 +622,14 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
     // [r5'] ... which, for a call of ONE pass, is the lane's G1 stream itself: witness -> fold check -> buildABC are a chain anyway, and every further stream is a further
     // hardware queue to share (a stream that shares its queue with another lane's pending barrier packet runs behind that lane's call: profiles/r05_service_hw_queues.txt).
     // A call of several passes on one lane keeps the context's stream for its witness groups, so that pass p + 1's Poseidon chains run under pass p's MSMs.
-    hipStream_t st0 = (lane0 >= 0 && !zk->serial_streams && B <= zk->max_inflight) ? zk->lane[lane0].st : ctx->stream;
     WitnessLayout L{}; int rc;
-    if ((rc = lanes_ensure(zk, B))) return rc;
+    // the lanes this call lands on -- its one lane, or as many of the key's lanes as it has passes -- hold a pass of this key (they are the context's: grown here if another,
+    // smaller key shaped them, or if this is the first call that needs them)
+    {
+        const int npasses0 = (B + zk->max_inflight - 1) / zk->max_inflight, per0 = (B + npasses0 - 1) / npasses0;
+        if ((rc = lanes_ensure(zk, per0, lane0 >= 0 ? lane0 : 0, lane0 >= 0 ? 1 : std::min(zk->nlanes, npasses0)))) return rc;
+    }
+    hipStream_t st0 = (lane0 >= 0 && !zk->serial_streams && B <= zk->max_inflight) ? ctx->lanes[lane0].st : ctx->stream;
     zkc_zkey::CallSlot& CS = zk->call[cs];
     if (CS.pending) return zkc_fail(ctx, ZKC_ERR_BAD_ARG, "prove_batch_begin: this call slot has a call in flight (finish it first)");
     if (CS.cap < (size_t)B) {                                    // the slot is idle (finished), so its buffers are nobody's
@@ -690,13 +733,13 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
     for (int p0 = 0; p0 < B; p0 += per_pass, pass++) {
         const int nb = std::min(per_pass, B - p0);
         const int li = lane0 >= 0 ? lane0 : pass % zk->nlanes; CS.lanes_used |= 1u << li;
-        zkc_lane& LN = zk->lane[li]; const int slot = LN.npass & 1;       // MSM results are double-buffered: the blinding of pass k overlaps pass k+1
+        zkc_lane& LN = ctx->lanes[li]; const LaneSt LS = lane_st(zk, LN); const int slot = LN.npass & 1;       // MSM results are double-buffered: the blinding of pass k overlaps pass k+1
         tr[0] = now_ms();
         const bool early = CS.early_n > 0;
         if (!early) ZKC_HIP_CHECK(ctx, zkc_wait_event(CS.ev_chunk[pass]));              // host: this chunk's fold flags have arrived
         tr[1] = now_ms();
-        ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(LN.st, CS.ev_chunk[pass], 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(LN.st2, CS.ev_chunk[pass], 0));
-        hipStream_t st = LN.st, st2 = LN.st2, fin = LN.fin;
+        ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(LS.st, CS.ev_chunk[pass], 0)); ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(LS.st2, CS.ev_chunk[pass], 0));
+        hipStream_t st = LS.st, st2 = LS.st2, fin = LS.fin;
         const uint32_t* w0 = (const uint32_t*)d_wtns + (size_t)p0 * nv * 8;
         // constant folding is per proof: voter q keeps the census levels below its own leaf depth dcq[q] (sik: dsq[q]) in its MSMs; the levels
         // above are the template's and come back as a constant in the blinding kernel.  One foreign witness (n2bOld block differs) unfolds the pass.
@@ -726,7 +769,7 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         if (mv_done) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, LN.ev_mv, 0));
         // (tried for passes of a few proofs while their G2 side was the longer chain: G2 enqueued first and its accumulation not held for the transforms -- its 1024 fat waves
         // then slowed buildABC and the first transform kernel threefold; with the 8-bit-window G2 table the G1 side is the longer one and goes first again)
-        if ((rc = h_evals_dev(zk, LN, w0, nb, !mv_done))) return rc;
+        if ((rc = h_evals_dev(zk, LN, st, w0, nb, !mv_done))) return rc;
         ZKC_HIP_CHECK(ctx, hipEventRecord(LN.ev_ntt, st));
         tr[2] = now_ms();
         static thread_local MsmJobList j1, j2;     // 6 KB each: kept off the stack frame of a C-ABI entry point
@@ -817,7 +860,7 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         // sum of its kernels' VALU work, and where the reduction's waves run does not change that sum.  Off unless ZKC_REDUCE_STREAM=1.)
         static const bool red_on = [] { const char* e = getenv("ZKC_REDUCE_STREAM"); return e && atoi(e) == 1; }();
         const bool red_split = red_on && !zk->serial_streams && nb >= 32;
-        if ((rc = msm_pass_g1(zk, LN.w1, j1, slot, false, st, LN.ev_sorted, LN.ev_acc, (red_split && LN.red) ? LN.red : nullptr, LN.ev_red))) return rc;
+        if ((rc = msm_pass_g1(zk, LN.w1, j1, slot, false, st, LN.ev_sorted, LN.ev_acc, (red_split && LS.red) ? LS.red : nullptr, LN.ev_red))) return rc;
         zk->last_lane = li;
         tr[4] = now_ms();
         if (!g2_early) {
@@ -861,7 +904,7 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
                                 tr[1] - tr[0], tr[2] - tr[1], tr[3] - tr[2], tr[4] - tr[3], tr[5] - tr[4]);
     }
     // every lane's blinding stream already waits for its G1 and G2 streams (ev_msm, ev_msm2) and carries the last copies: one event per lane closes the call
-    for (int l = 0; l < zk->nlanes; l++) if (CS.lanes_used >> l & 1) ZKC_HIP_CHECK(ctx, hipEventRecord(CS.ev_done[l], done_on_st_lane == l ? zk->lane[l].st : zk->lane[l].fin));      // only the lanes this call ran on: another lane's streams carry another call
+    for (int l = 0; l < zk->nlanes; l++) if (CS.lanes_used >> l & 1) { const LaneSt ls = lane_st(zk, ctx->lanes[l]); ZKC_HIP_CHECK(ctx, hipEventRecord(CS.ev_done[l], done_on_st_lane == l ? ls.st : ls.fin)); }      // only the lanes this call ran on: another lane's streams carry another call
     CS.B = B; CS.pending = true;
     return ZKC_OK;
 }
@@ -904,7 +947,8 @@ int zkc::prove_batch_finish(zkc_zkey* zk, int cs, uint8_t* proofs, uint8_t* publ
 }
 bool zkc::prove_tail_reached(zkc_zkey* zk) {
     if (!zk || zk->last_lane < 0) return true;
-    const hipError_t e = hipEventQuery(zk->lane[zk->last_lane].ev_acc);
+    if (!zk->ctx->lanes) return true;
+    const hipError_t e = hipEventQuery(zk->ctx->lanes[zk->last_lane].ev_acc);
     if (e == hipErrorNotReady) return false;
     if (e != hipSuccess) (void)hipGetLastError();
     return true;

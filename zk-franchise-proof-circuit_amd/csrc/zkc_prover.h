@@ -165,6 +165,7 @@ struct zkc_lane {
     void* d_fin = nullptr;                                                // blinding scratch, finalize_scratch_bytes(inflight)
     uint32_t* d_bs = nullptr;                                             // [2 proofs][2 sections][nVars x 8]: the blinded scalars of a small pass (zkc_blind_scalars)
     zkc::MsmWork w1, w2;                                                  // G1 and G2 pipelines
+    size_t cap_abc = 0, cap_p = 0, cap_fin = 0, cap_bs = 0, bytes = 0; bool made = false;      // capacities (elements of d_abc / d_t, words of d_p, bytes of d_fin, words of d_bs), HBM held (hipMemGetInfo delta), events and streams created
     hipEvent_t ev_msm = nullptr, ev_msm2 = nullptr, ev_sorted = nullptr, ev_ntt = nullptr, ev_mv = nullptr, ev_acc = nullptr, ev_fin[2] = {nullptr, nullptr}; int npass = 0;      // ev_acc: the G1 accumulation of the lane's latest pass is through      // ev_ntt: buildABC/NTT/joinABC of the pass are through      // ev_fin[slot]: blinding of the pass that used result slot `slot`
 };
 
@@ -193,11 +194,10 @@ struct zkc_zkey {
     int c_h = zkc::MSM_C_BIG;                                                    // [r4] window bits of the H section of THIS key (17 for a census key, else by the domain size)
     int c_sec = zkc::MSM_C_SMALL;                                                // [r4] window bits of the witness sections A, B1, C, B2 of THIS key (zkc_zkey_load: 12, or 17 for sections of 2^16 wires and more)
     int max_inflight = 0;                                                   // proofs per pipeline pass (upper limit)
-    int cur_inflight = 0;                                                   // what the lanes' work space is currently sized for (lanes_ensure)
     uint8_t sha256[32] = {0};                                               // of the whole .zkey image (taken once, at load)
-    size_t bytes_tables = 0, bytes_work = 0;                                // HBM held by the key: constant tables (load) / the lanes' work space (lanes_ensure); hipMemGetInfo deltas
+    size_t bytes_tables = 0;                                                // HBM held by the key's constant tables (hipMemGetInfo delta around the load; the lanes' work space is the context's)
     uint8_t fingerprint[32] = {0};                                          // parse::zkey_fingerprint of the image: the per-call identity of the resident-key caches
-    zkc_lane lane[zkc::MAX_LANES]; int nlanes = 1; bool serial_streams = false;          // serial_streams: the lanes borrow ctx->stream (ZKC_SERIAL_STREAMS, measurement only)
+    int nlanes = 1; bool serial_streams = false;          // lanes of the context this key's passes may use (zkc_ctx::lanes); serial_streams: every stage on ctx->stream instead of the lane's streams (ZKC_SERIAL_STREAMS, measurement only)
     zkc::G1Affine *d_tblDelta1 = nullptr, *d_tblAlpha1 = nullptr, *d_tblBeta1 = nullptr; zkc::G2Affine* d_tblDelta2 = nullptr;
     uint32_t *d_depths = nullptr, *h_depths = nullptr; size_t depths_cap = 0;                     // zkc_input_depths: device [2 B], pinned [2 B] (read back inside begin, under the context lock)
     zkc::G1XYZZ* d_fb4 = nullptr; zkc::G2XYZZ* d_fb4g2 = nullptr; int fb4_bases = 0;   // 4-bit fixed-base tables of the small-pass blinding (FinalizeArgs::fb4)
@@ -272,7 +272,7 @@ bool prove_tail_reached(zkc_zkey* zk);
 int prove_reserve(zkc_zkey* zk, int inflight);              // grow the key's work space to `inflight` proofs per pass now (clamped to the key's own limit)
 // zkc_zkey_load with the lane count and pass size given instead of read from $ZKC_LANES / $ZKC_INFLIGHT (0: take the environment / defaults)
 int zkey_load_opts(zkc_ctx* ctx, const void* zkey_bytes, size_t len, int nlanes, int max_inflight, zkc_zkey** out);
-size_t zkey_device_bytes(const zkc_zkey* zk, size_t* tables, size_t* work);      // what the key holds in HBM now: constant tables / per-pass work space of its lanes
+size_t zkey_device_bytes(const zkc_zkey* zk, size_t* tables, size_t* work);      // HBM now: the key's constant tables / the per-pass work space of its context's lanes (shared by every key of the context)
 size_t finalize_scratch_bytes(int nproofs);
 int msm_precompute_g1(zkc_ctx* ctx, uint32_t count, G1Affine* d_table, int c);   // d_table[0..count) = base on entry
 int msm_precompute_g2(zkc_ctx* ctx, uint32_t count, G2Affine* d_table, int c);

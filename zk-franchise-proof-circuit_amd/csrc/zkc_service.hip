@@ -264,14 +264,12 @@ int ensure_key(zkc_service* s, zkc_service::Dev* d, const std::shared_ptr<KeyIma
             if (!evict_lru(s, d)) break;                                       // an idle key's tables and work space for this one, then once more
             { std::lock_guard<std::mutex> g(s->mu); s->oom_evictions++; }
         }
-        // the work space of a full pass at once: a key behind the service is there for concurrent callers, and growing from four proofs to a pass in the middle of the
-        // first burst stalled the device for ~0.5 s (free + re-allocation of GBs).  [r5] Only while the card is less than half full (a device that already holds several keys'
-        // work space lets the next key grow on demand); a failed reserve is counted, not fatal.  ZKC_SERVICE_RESERVE=0: always on demand, as the direct entry points do.
+        // the work space of a full pass on every lane at once: a key behind the service is there for concurrent callers, and growing a lane from four proofs to a pass in the
+        // middle of the first burst stalled the device for ~0.5 s (free + re-allocation of GBs).  [r5] The lanes are the CONTEXT's (zkc_prove.hip lane_ensure): the first key of
+        // a device pays for them (~37 GB at nLevels 160 with four lanes of 64 proofs), later keys of the same shape find them there; a failed reserve is counted, not fatal
+        // (the lanes then grow on demand).  ZKC_SERVICE_RESERVE=0: always on demand, as the direct entry points do.
         static const bool reserve = [] { const char* e = getenv("ZKC_SERVICE_RESERVE"); return !(e && atoi(e) == 0); }();
-        if (!rc && reserve) {
-            size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); fr = tot = 0; }
-            if (fr > tot / 2 && zkc::prove_reserve(key, 1 << 20) != ZKC_OK) { (void)zkc_last_error(d->ctx); std::lock_guard<std::mutex> g(s->mu); s->reserve_failures++; }
-        }
+        if (!rc && reserve && zkc::prove_reserve(key, 1 << 20) != ZKC_OK) { (void)zkc_last_error(d->ctx); std::lock_guard<std::mutex> g(s->mu); s->reserve_failures++; }
         if (!rc) { std::lock_guard<std::mutex> fl(d->fl_mu); zkc_service::KeySlot k; k.img = img; k.key = key; k.last_use = ++d->use_clock; d->keys.push_back(k); }
         std::lock_guard<std::mutex> g(s->mu); s->key_loads++;
         if (!rc) { d->resident.push_back(img); *out = key; }
@@ -590,18 +588,21 @@ extern "C" int zkc_service_timing(zkc_service* s, uint64_t out[8]) {
     out[0] = s->us_stage; out[1] = s->us_gpu_wait; out[2] = s->us_key; out[3] = s->us_prove; out[4] = s->us_finish; out[5] = s->n_proved; out[6] = s->n_batches; out[7] = s->key_evictions;
     return ZKC_OK;
 }
-// HBM and pinned host memory the service holds now: out[0] resident keys (all devices), [1] their constant tables, [2] their lanes' work space, [3] / [4] the same two for the
-// largest key, [5] the workers' device staging, [6] pinned host memory (workers' staging + witness slots), [7] work-space reservations that failed (the key then grows on demand)
+// HBM and pinned host memory the service holds now: out[0] resident keys (all devices), [1] their constant tables, [2] the lanes' work space of the devices' contexts (ONE per
+// device, shared by its keys), [3] the largest key's tables, [4] the largest device's work space, [5] the workers' device staging, [6] pinned host memory (workers' staging +
+// witness slots), [7] work-space reservations that failed (the lanes then grow on demand)
 extern "C" int zkc_service_memory(zkc_service* s, uint64_t out[8]) {
     if (!s || !out) return ZKC_ERR_BAD_ARG;
     for (int i = 0; i < 8; i++) out[i] = 0;
     for (auto& d : s->devs) {
         std::lock_guard<std::mutex> fl(d->fl_mu);
+        size_t dev_work = 0;
         for (auto& k : d->keys) {
             size_t t = 0, wk = 0; zkc::zkey_device_bytes(k.key, &t, &wk);
-            out[0]++; out[1] += t; out[2] += wk;
-            if (t + wk > out[3] + out[4]) { out[3] = t; out[4] = wk; }
+            out[0]++; out[1] += t; dev_work = std::max(dev_work, wk);
+            if (t > out[3]) out[3] = t;
         }
+        out[2] += dev_work; if (dev_work > out[4]) out[4] = dev_work;
     }
     for (auto& w : s->workers) { for (HipBuf* hb : {&w->d_in, &w->d_wtns, &w->d_status}) out[5] += hb->sz; for (HipBuf* hb : {&w->h_in, &w->h_wtns, &w->h_proofs, &w->h_pubs, &w->h_status}) out[6] += hb->sz; }
     out[6] += s->pin.bytes();
