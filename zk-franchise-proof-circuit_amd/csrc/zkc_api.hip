@@ -2,8 +2,11 @@
 // CPU fallback here -- without a working HIP device every call fails with ZKC_ERR_HIP.
 #include "zkc_internal.h"
 #include "zkc_f29.h"
+#include <array>
 #include <cstring>
 #include <ctime>
+#include <map>
+#include <mutex>
 #include "../../include/zkc_poseidon_constants.inc"
 
 using namespace zkc;
@@ -210,21 +213,28 @@ extern "C" void zkc_ctx_destroy(zkc_ctx* ctx) {
     if (ctx->d_status3) (void)hipFree(ctx->d_status3);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_prof_entries) (void)hipFree(ctx->d_prof_entries);
-    for (auto& ls : ctx->lane_streams) for (hipStream_t q : {ls.st, ls.st2, ls.fin, ls.red}) if (q) (void)hipStreamSynchronize(q);
+    for (auto& ls : ctx->lane_streams) for (hipStream_t q : {ls.st, ls.st2, ls.fin, ls.red}) if (q) (void)hipStreamSynchronize(q);      // (the streams are the DEVICE's and stay: zkc_lane_streams)
     zkc_ctx_lanes_destroy(ctx);
-    for (auto& ls : ctx->lane_streams) for (hipStream_t q : {ls.st, ls.st2, ls.fin, ls.red}) if (q) (void)hipStreamDestroy(q);
+    if (ctx->ev_acc_chain) (void)hipEventDestroy(ctx->ev_acc_chain);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->fin_stream) (void)hipStreamDestroy(ctx->fin_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 // the three streams of lane l of this context (buildABC / NTT / G1 MSM ; G2 MSM ; blinding + D2H), created on first use; with_red: the optional bucket-reduction stream too
+// [r5'] ... of this DEVICE: every context of the process on one device gets the same twelve streams (made once, kept for the life of the process).  A host that holds a
+// context of its own beside the proving service's -- bench.py does, so does any process that both batch-proves and serves single calls -- would otherwise run 2 x 12 lane
+// streams, and past ~24 busy hardware queues the service's lanes queue behind one another again whatever GPU_MAX_HW_QUEUES says (measured with 32 and 48: the service legs
+// of bench.py at 1 250-1 600 proofs/s instead of 2 800-3 100; profiles/r05_service_layout_sweeps.json).  Sharing a stream between contexts only adds ordering: each context
+// still has its own lanes' work space, events and lock.
 int zkc_lane_streams(zkc_ctx* ctx, int l, bool with_red, zkc_ctx::LaneStreams* out) {
     if (!ctx || l < 0 || l >= 4 || !out) return ZKC_ERR_BAD_ARG;
-    zkc_ctx::LaneStreams& ls = ctx->lane_streams[l];
+    static std::mutex mu; static std::map<int, std::array<zkc_ctx::LaneStreams, 4>> by_device;
+    std::lock_guard<std::mutex> g(mu);
+    zkc_ctx::LaneStreams& ls = by_device[ctx->device][l];
     for (hipStream_t* q : {&ls.st, &ls.st2, &ls.fin}) if (!*q) ZKC_HIP_CHECK(ctx, hipStreamCreateWithFlags(q, hipStreamNonBlocking));
     if (with_red && !ls.red) ZKC_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ls.red, hipStreamNonBlocking));
-    *out = ls; return ZKC_OK;
+    ctx->lane_streams[l] = ls; *out = ls; return ZKC_OK;
 }
 extern "C" const char* zkc_last_error(const zkc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 extern "C" void* zkc_ctx_stream(zkc_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }

@@ -32,13 +32,19 @@ struct zkc_ctx {
     hipStream_t fin_stream = nullptr;     // blinding kernel + proof D2H, overlapping the next pipeline pass
     // [r5] the stream sets of the pipeline lanes belong to the CONTEXT, not to a key: every key of the context runs its lane l on the same three streams.  Streams are a
     // device resource -- each takes a hardware queue (or a share of one: GPU_MAX_HW_QUEUES), and a stream that shares its queue with another stream's barrier packet waits
-    // behind it -- so four resident keys must not mean four times the streams.  Created on first use (zkc_lane_streams), destroyed with the context.
+    // behind it -- so four resident keys must not mean four times the streams.  Created on first use (zkc_lane_streams); [r5'] they are in fact the DEVICE's, shared by every
+    // context of the process on that device and kept for the life of the process: these are this context's copies of the handles.
     struct LaneStreams { hipStream_t st = nullptr, st2 = nullptr, fin = nullptr, red = nullptr; } lane_streams[4];
     // ... and so do the lanes themselves -- the per-pass work space (transform vectors, MSM entry lists, bucket and segment arrays, partial sums: ~0.15 GB per proof in flight at
     // nLevels 160) and the events that order a lane's streams: zkc_lane[MAX_LANES] (zkc_prover.h), made on first use and grown to the largest need any key of the context has
     // shown (zkc_prove.hip lane_ensure).  Calls on one lane are ordered by its streams whatever key they prove with, so four resident keys cost four sets of TABLES, not four
     // work spaces (round 4 and the first half of round 5: 37 GB of work space per service key).
     struct zkc_lane* lanes = nullptr;
+    // [r5] the G1 accumulations of a context run ONE AT A TIME, whatever lanes they are launched on: each waits for the one enqueued before it (ev_acc_chain; begins are
+    // serialised by the context lock, so the chain follows the enqueue order and has no cycle).  The kernel saturates the chip's vector issue by itself (VALU-busy 1.00):
+    // two of them side by side finish no earlier than one after the other, keep 2 x 3 waves per SIMD of registers away from the latency-bound kernels the lanes exist to
+    // overlap, and double every launch's duration -- which is also what the roofline line divides by.  ZKC_ACC_CHAIN=0: let them overlap (A/B).
+    hipEvent_t ev_acc_chain = nullptr; bool acc_chain_armed = false;
     std::string err;
     zkc::PoseidonTable ptab{};            // device pointers
     void* d_ptab_mem = nullptr;

@@ -694,6 +694,12 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
     XYZZ<F>* wres = reinterpret_cast<XYZZ<F>*>(w.wres);
     XYZZ<F>* results = reinterpret_cast<XYZZ<F>*>(w.results) + (size_t)slot * w.max_jobs;
     if (wait_before_acc) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, wait_before_acc, 0));      // hold the (VALU-bound) accumulation until the other stream reaches its memory-bound phase
+    static const bool acc_chain_on = [] { const char* e = getenv("ZKC_ACC_CHAIN"); return !(e && atoi(e) == 0); }();
+    const bool acc_chain = !kG2 && acc_chain_on && total >= ((size_t)1 << 22);       // (a lone proof's 0.2 ms accumulation is not worth an event)
+    if (acc_chain) {
+        if (!ctx->ev_acc_chain) ZKC_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_acc_chain, hipEventDisableTiming));
+        if (ctx->acc_chain_armed) ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->ev_acc_chain, 0));
+    }
     {
         zkc_prof_scope _ps(ctx, kG2 ? ZKC_PROF_MSM_ACC_G2 : ZKC_PROF_MSM_ACC_G1, alg_bytes, st);
         if (!kG2 && ((ctx->prof.mask >> ZKC_PROF_MSM_ACC_G1) & 1)) ctx->prof.bytes[ZKC_PROF_MSM_G1_STREAMED] += streamed_bytes;
@@ -715,10 +721,12 @@ static int msm_pass(zkc_zkey* zk, MsmWork& w, const Affine<F>* table, const MsmJ
             hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate29_g2<1>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
                                g2_table29, (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.bcnt, w.segoff, w.seg2bucket, w.perm, nb, reinterpret_cast<XYZZ<Fq2>*>(partial), (uint32_t)w.max_segments);
           }
-        } else    // G1: same layout, field type with the inlined product.  160 VGPRs = 3 waves per SIMD; capped at 128 (4 waves) the accumulator spills and the kernel is 3.6x slower
+        } else {  // G1: same layout, field type with the inlined product.  160 VGPRs = 3 waves per SIMD; capped at 128 (4 waves) the accumulator spills and the kernel is 3.6x slower
             hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_msm_accumulate29<2>), dim3((unsigned)((seg_bound + 127) / 128)), dim3(128), 0, st,
                                reinterpret_cast<const Affine<Fq>*>(table), (const MsmJobList*)w.d_jobs, w.vals2, w.off, w.bcnt, w.segoff, w.seg2bucket, w.perm, nb,
                                reinterpret_cast<XYZZ<Fq>*>(partial), (uint32_t)w.max_segments);
+            if (acc_chain) { ZKC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_acc_chain, st)); ctx->acc_chain_armed = true; }      // the next G1 accumulation of this context, on whatever lane, starts behind this one
+        }
         ZKC_LAUNCH_CHECK(ctx, "zkc_msm_accumulate");
         if (ev_acc) ZKC_HIP_CHECK(ctx, hipEventRecord(ev_acc, st));                 // the long kernel of the pass is through: what follows (bucket reduction, blinding) is the latency-bound tail
     }
