@@ -590,7 +590,7 @@ def main():
     d = prof[dom]
     achieved = d['alg_bytes'] / (d['ms'] * 1e-3) / 1e9 if d['ms'] > 0 else 0.0
     traffic, traffic_src = None, None
-    for pmc_file in ('r04_pmc_hbm_traffic.json', 'r03_pmc_hbm_traffic.json', 'r02_pmc_hbm_traffic.json', 'r01_pmc_hbm_traffic.json'):
+    for pmc_file in ('r05_pmc_hbm_traffic.json', 'r04_pmc_hbm_traffic.json', 'r03_pmc_hbm_traffic.json', 'r02_pmc_hbm_traffic.json', 'r01_pmc_hbm_traffic.json'):
         try:      # HBM bytes per launch of the same kernel/geometry from the committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
             pm = json.load(open(os.path.join(ROOT, 'profiles', pmc_file)))
             traffic = int(pm.get('hbm_bytes_per_launch', pm['hbm_bytes_per_launch_uncorrected']))

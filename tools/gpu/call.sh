@@ -19,7 +19,7 @@ R="$GRAFT_REPO_ROOT"; [ -n "$R" ] || R="$(cd "$(dirname "$0")/../.." && pwd)"
 cd "$R"; RUN=${1:-run}; shift; O="$R/gpurun_out/$RUN"; mkdir -p "$O"
 log() { echo "$*" | tee -a "$O/steps.log"; }
 killed() { [ "$1" = 124 ] || [ "$1" = 137 ]; }
-PMC_BENCH="python3 $R/bench.py --batch 96 --steps 1 --warmup 0 --no-cpu-baseline --no-verify"
+PMC_BENCH="python3 $R/bench.py --batch 64 --steps 1 --warmup 0 --no-cpu-baseline --no-verify"
 for step in "$@"; do
   name=${step%%:*}; arg=${step#*:}; [ "$arg" = "$step" ] && arg=""
   cd "$R"

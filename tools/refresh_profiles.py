@@ -24,7 +24,7 @@ ks = glob.glob(os.path.join(run, 'prof', '**', '*_kernel_stats.csv'), recursive=
 if ks:
     shutil.copy(ks[0], os.path.join(P, tag + '_bench_b1024_kernel_stats.csv'))
 if os.path.isdir(os.path.join(run, 'pmc_fetch')) and os.path.isdir(os.path.join(run, 'pmc_write')):
-    subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'pmc_summary.py'), os.path.join(run, 'pmc_fetch'), os.path.join(run, 'pmc_write'), '96', os.path.join(P, tag + '_pmc_hbm_traffic.json')])
+    subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'pmc_summary.py'), os.path.join(run, 'pmc_fetch'), os.path.join(run, 'pmc_write'), '64', os.path.join(P, tag + '_pmc_hbm_traffic.json')])
 want = {'SQ_BUSY_CYCLES', 'SQ_ACTIVE_INST_VALU', 'SQ_INSTS_VALU', 'GRBM_GUI_ACTIVE', 'SQ_WAVES'}
 for f in glob.glob(os.path.join(run, 'pmc_sq', '**', '*counter_collection.csv'), recursive=True):
     names = {ln.split(',')[15].strip('"') for ln in open(f) if ln.count(',') > 16}
