@@ -19,6 +19,11 @@ sys.path.insert(0, ROOT)
 # hardware queues for the HIP runtime of this process (read once, when the runtime initialises -- before torch or the library touches the GPU): the pipeline's seven streams
 # on the default four queues run 5 % slower (csrc/zkc_api.hip zkc_runtime_defaults; profiles/r05_hw_queues_ab.json)
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '24')
+# the host side of a step is a few kilobytes of numpy / torch bookkeeping: one thread each.  Left alone, OpenBLAS starts 64 threads at import and torch's intra-op pool one per
+# schedulable core (256 on the GPU boxes) -- and eight ranks share 16 cores' worth of CPU time (profiles/r04_cpu_baseline_scaling.json); a parallel region that wakes 256 threads to add
+# up 1 024 status words costs more than the step's enqueueing.  (The CPU baseline leg and the batch verifier use their own threads, not these pools.)
+for _v in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
+    os.environ.setdefault(_v, '1')
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (6.3 TB/s achievable)
 CATS = {0: 'witness', 1: 'buildABC_matvec', 2: 'ntt_joinABC', 3: 'msm_digits_sort', 4: 'msm_accumulate_g1', 5: 'msm_accumulate_g2', 6: 'msm_reduce',
         7: 'msm_g1_streamed'}
@@ -423,6 +428,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
+    torch.set_num_threads(1)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
     # ZKC_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box only): ranks share the visible devices and gather over gloo, because RCCL refuses two
