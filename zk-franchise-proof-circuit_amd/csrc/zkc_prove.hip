@@ -846,7 +846,9 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         // Passes of fewer than 32 proofs keep the hold: a lone proof's G2 kernels (1024 waves of 400 registers) slowed buildABC and the first transform kernel threefold when they were
         // not held (round 3), and the twelve-proof passes of a 2^20-domain key run 140 proofs/s held against 136 early (their bucketing phase is 9 ms long: room for the G2 accumulation).
         static const bool g2_hold_env = getenv("ZKC_G2_ACC_HOLD") != nullptr, g2_early_env = getenv("ZKC_G2_ACC_EARLY") != nullptr;
-        const bool g2_acc_with_sort = g2_hold_env || (nb < 32 && !g2_early_env);
+        // [r5] ... and with the passes of a call rotating over four lanes the hold is right again for full passes: the G2 accumulation of lane k then lands beside lane k's own
+        // bucketing instead of beside another lane's transforms (alternating on one box: 3380 / 3386 proofs/s held, 3363 / 3363 started with the pass: +0.6 %)
+        const bool g2_acc_with_sort = g2_hold_env || ((nb < 32 || !one_lane) && !g2_early_env);
         if (g2_early) {
             if ((rc = msm_pass_g2(zk, LN.w2, j2, slot, false, st2, g2_acc_with_sort ? LN.ev_ntt : nullptr))) return rc;
             if (tree && (rc = finalize_tree_g2_launch(ctx, st2, fa, nb))) return rc;
