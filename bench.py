@@ -33,8 +33,8 @@ R_MOD = 218882428718392752222464057452572750885483644004160343436982041865758084
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=int(os.environ.get('ZKC_BATCH', '1024')), help='voter proofs per GPU per step')
     ap.add_argument('--nlevels', type=int, default=160)
     ap.add_argument('--no-cpu-baseline', action='store_true')

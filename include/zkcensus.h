@@ -268,6 +268,7 @@ void zkc_msm_g1_free(zkc_msm* m);
  * zkc_msm_debug  : one MSM over zkey section which (0=A 1=B1 2=B2 3=C 4=H) with caller scalars (device, standard form);
  *                  host_out = affine point in standard form (64 B, or 128 B for B2). */
 int zkc_debug_stage(zkc_zkey* zk, const void* d_wtns, int stage, void* host_out);
+unsigned long long zkc_debug_early_retries(void);      /* calls of given witnesses that were laid out from their sibling wires, refused by the fold check and proved again from their fold flags (process-wide) */
 int zkc_msm_debug(zkc_zkey* zk, int which, const void* d_scalars, uint32_t count, void* host_out);
 
 /* ---- f1: the census / voter generator (internal/helpers.go:36-85 GenTree -- arbo.NewTree{Poseidon}, Add, GenProof, zero padding -- and internal/inputs.go:33-98

@@ -431,3 +431,62 @@ def test_four_nl160_keys_stay_under_the_stated_bound(monkeypatch):
     assert 2.5e9 < mem['largest_key_table_bytes'] < 3.5e9, mem
     assert mem['work_bytes'] < 40e9 and seen[0]['work_bytes'] == mem['work_bytes'] and mem['table_bytes'] + mem['work_bytes'] < 55e9, mem      # the lanes' work space is the device's: the second to fourth key added tables only
     svc.close()
+
+
+def test_host_side_pass_layout_falls_back_for_witnesses_and_inputs_it_cannot_trust():
+    """[r5] The service lays a one-pass call out from depths it reads on the HOST -- the sibling lists of the inputs, or the sibling wires of a witness computed elsewhere
+    (csrc/zkc_service.hip depths_of; prove_batch_begin host_depths) -- so that begin never waits for the GPU.  The shortcut must be invisible:
+      * a FOREIGN witness that does not carry the voter-independent template below its own sibling depth (a tampered wire deep in a tree, a tampered old-key block) is proved
+        again from its fold flags (prove_batch_finish) and gives the ORACLE's bytes for that witness -- the oracle never folds -- while its neighbours in the same batch, which
+        do fold, give theirs;
+      * a voter whose LAST sibling is not zero (SMTLevIns, status 5 / 7) has no depth: its call takes the usual path, it is rejected alone, its neighbours are proved."""
+    import zkcensus_amd
+    from zkcensus_amd import setup
+    nl = 10
+    _, zkey_path, vkey_path = setup.ensure_test_artifacts(nl)
+    zk = open(zkey_path, 'rb').read()
+    voters = _voters(12, nl, 19)
+    rng = random.Random(23)
+    rs = [rng.randrange(ol.R).to_bytes(32, 'little') + rng.randrange(ol.R).to_bytes(32, 'little') for _ in voters]
+    wit = []
+    for v in voters:
+        rc, w = ol.witness(v, nl); assert rc == 0; wit.append(bytearray(w))
+    L_census = 13 + 2 * nl                                               # first wire of the census verifier block (zkc_device.h WitnessLayout)
+    nW = len(wit[0]) // 32
+    lvl9 = 261 + 244 + 8 * 245 + 1                                       # WitnessLayout::lvl_off(9) at n = 11: level 9 of a tree, far below every voter's leaf (depths 2-7)
+    wit[3][32 * (L_census + lvl9 + 20):32 * (L_census + lvl9 + 21)] = (12345).to_bytes(32, 'little')      # a hash-internal wire of that level: differs from the template there
+    wit[7][32 * (nW - 40):32 * (nW - 40) + 32] = (777).to_bytes(32, 'little')                          # the sik verifier's tail (not a foldable group): no fold flag changes
+    lib = zkcensus_amd._native.load(); retries0 = lib.zkc_debug_early_retries()
+    svc = zkcensus_amd.ProvingService([0])
+    out = [None] * len(voters)
+
+    def caller(i):
+        out[i] = svc.prove(zk, bytes(wit[i]), rs=rs[i])
+    th = [threading.Thread(target=caller, args=(i,)) for i in range(len(voters))]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert svc.stats()['failed'] == 0
+    assert lib.zkc_debug_early_retries() > retries0, 'the tampered witness should have been refused by the fold check and proved again'
+
+    def check(i):
+        rc, p, u = ol.prove(zk, bytes(wit[i]), int.from_bytes(rs[i][:32], 'little'), int.from_bytes(rs[i][32:], 'little'))
+        assert rc == 0 and out[i] == (p, u), 'witness %d' % i
+    ol.pmap(check, range(len(voters)))
+    vk = json.load(open(vkey_path))
+    assert ol.verify(vk, out[0][1], out[0][0]) and not ol.verify(vk, out[3][1], out[3][0])         # the tampered witness is no witness: its proof is the oracle's and does not verify
+    # inputs path: a voter with a non-zero last sibling among good ones
+    bad = dict(voters[5]); sib = list(bad['censusSiblings']); sib[nl] = '5'; bad['censusSiblings'] = sib
+    group = [voters[0], bad, voters[1], voters[2]]
+    res = [None] * 4
+
+    def fcaller(i):
+        res[i] = svc.fullprove(zk, group[i], nLevels=nl, rs=rs[i])
+    th = [threading.Thread(target=fcaller, args=(i,)) for i in range(4)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert res[1][2] == 5 and [r[2] for i, r in enumerate(res) if i != 1] == [0, 0, 0]
+    for i, v in ((0, voters[0]), (2, voters[1]), (3, voters[2])):
+        rc, w = ol.witness(v, nl)
+        rc, p, u = ol.prove(zk, w, int.from_bytes(rs[i][:32], 'little'), int.from_bytes(rs[i][32:], 'little'))
+        assert (res[i][0], res[i][1]) == (p, u), i
+    svc.close()

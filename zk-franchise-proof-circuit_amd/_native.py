@@ -47,6 +47,7 @@ def load():
     L.zkc_prove_batch_dev.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
     L.zkc_fullprove_batch_dev.argtypes = [vp, vp, ctypes.c_int, vp, vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
     L.zkc_debug_stage.argtypes = [vp, vp, ctypes.c_int, ctypes.c_char_p]
+    L.zkc_debug_early_retries.argtypes = []; L.zkc_debug_early_retries.restype = ctypes.c_ulonglong
     L.zkc_msm_debug.argtypes = [vp, ctypes.c_int, vp, ctypes.c_uint32, ctypes.c_char_p]
     ulp = ctypes.POINTER(ctypes.c_ulong)
     L.groth16_prover.argtypes = [ctypes.c_char_p, ctypes.c_ulong, ctypes.c_char_p, ctypes.c_ulong, ctypes.c_char_p, ulp, ctypes.c_char_p, ulp, ctypes.c_char_p, ctypes.c_ulong]

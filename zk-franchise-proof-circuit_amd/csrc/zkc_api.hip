@@ -26,13 +26,16 @@ int zkc_fail(zkc_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg; else g_create_err = msg;
     return code;
 }
-hipError_t zkc_wait_event(hipEvent_t ev) {
+hipError_t zkc_wait_event(hipEvent_t ev, unsigned spin_us) {
     static const bool spin = getenv("ZKC_SPIN_WAIT") != nullptr;
     if (spin) return hipEventSynchronize(ev);
+    timespec t0; if (spin_us) clock_gettime(CLOCK_MONOTONIC, &t0);
     for (int i = 0;; i++) {
         const hipError_t e = hipEventQuery(ev);
         if (e != hipErrorNotReady) return e;
-        if (i >= 48) { timespec ts{0, 50000}; nanosleep(&ts, nullptr); }
+        if (i < 48) continue;
+        if (spin_us) { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); if ((t.tv_sec - t0.tv_sec) * 1000000ll + (t.tv_nsec - t0.tv_nsec) / 1000 < (long long)spin_us) continue; spin_us = 0; }
+        timespec ts{0, 50000}; nanosleep(&ts, nullptr);
     }
 }
 hipError_t zkc_wait_stream(hipStream_t st, hipEvent_t scratch_ev) {

@@ -68,7 +68,7 @@ int zkc_fail(zkc_ctx* ctx, int code, const std::string& msg);
 // BusyWaitSignal::WaitRelaxed under hsa_signal_wait_scacquire).  A rank of an 8-GPU run has two of the container's 16 cores' worth of CPU time, so the
 // waits on the proving path poll the event instead: a few dozen hipEventQuery calls back to back (a wait that is nearly over costs nothing extra), then one query per 50 us
 // nap.  At most ~0.1 ms later than a spinning wait, per wait: 12 waits per 1024-proof step of 320 ms.  ZKC_SPIN_WAIT=1: hipEventSynchronize as before (A/B).
-hipError_t zkc_wait_event(hipEvent_t ev);
+hipError_t zkc_wait_event(hipEvent_t ev, unsigned spin_us = 0);        // spin_us: keep polling back to back for that long before the naps start (a lone caller's 3 ms proof: the nap would add 2 % to its latency)
 hipError_t zkc_wait_stream(hipStream_t st, hipEvent_t scratch_ev);      // record scratch_ev on st, then zkc_wait_event (scratch_ev: any event of the caller's that is not otherwise in flight)
 int zkc_ensure(zkc_ctx* ctx, void** p, size_t* cur, size_t need);
 // RAII bracket: records two events around the launches made while it is alive when category `cat` is enabled

@@ -13,6 +13,7 @@
 #include <ctime>
 #include <cstdio>
 #include <algorithm>
+#include <atomic>
 
 using namespace zkc;
 
@@ -910,6 +911,8 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
     CS.B = B; CS.pending = true;
     return ZKC_OK;
 }
+static std::atomic<unsigned long long> g_early_retries{0};
+extern "C" unsigned long long zkc_debug_early_retries(void) { return g_early_retries.load(); }
 // second half of a batch call: wait for call slot cs, copy proofs (B x 256 B) and public signals (B x nPublic x 32 B, may be NULL) out of the pinned staging.
 // Takes no context lock while it waits, so that the next call's begin (the other slot) can run meanwhile.
 int zkc::prove_batch_finish(zkc_zkey* zk, int cs, uint8_t* proofs, uint8_t* publics) {
@@ -917,7 +920,7 @@ int zkc::prove_batch_finish(zkc_zkey* zk, int cs, uint8_t* proofs, uint8_t* publ
     zkc_zkey::CallSlot& CS = zk->call[cs];
     if (!CS.pending) return zkc_fail(zk->ctx, ZKC_ERR_BAD_ARG, "prove_batch_finish: no call in flight on this slot");
     hipError_t e = hipSuccess;
-    for (int l = 0; l < zk->nlanes && e == hipSuccess; l++) if (CS.lanes_used >> l & 1) e = zkc_wait_event(CS.ev_done[l]);
+    for (int l = 0; l < zk->nlanes && e == hipSuccess; l++) if (CS.lanes_used >> l & 1) e = zkc_wait_event(CS.ev_done[l], CS.B <= 2 ? 6000u : 0u);      // a call of one or two proofs is somebody's latency: poll through it
     CS.pending = false;
     if (e != hipSuccess) { ZKC_LOCK(zk->ctx); return zkc_fail(zk->ctx, ZKC_ERR_HIP, std::string("prove_batch_finish: ") + hipGetErrorString(e)); }
     if (CS.early_n) {                // the pass was laid out from the inputs' depths before its witness existed: the fold check of the finished witness has to agree
@@ -930,7 +933,7 @@ int zkc::prove_batch_finish(zkc_zkey* zk, int cs, uint8_t* proofs, uint8_t* publ
                 if (f[L.n - 1] || D > (int)CS.early_depth[2 * q + t]) {
                     // a witness that was computed elsewhere and does not carry the template below its own sibling depth (a valid witness of this circuit always does): nothing
                     // is wrong with the call, only with the shortcut -- the same call once more, laid out from its fold flags
-                    if (!CS.arg_inputs) { int rc = prove_batch_begin(zk, cs, CS.arg_wtns, CS.arg_nw, CS.B, CS.h_rs_copy.data(), CS.arg_publics, nullptr, nullptr, CS.arg_lane0, nullptr, nullptr, true); if (rc) return rc; return prove_batch_finish(zk, cs, proofs, publics); }
+                    if (!CS.arg_inputs) { g_early_retries++; int rc = prove_batch_begin(zk, cs, CS.arg_wtns, CS.arg_nw, CS.B, CS.h_rs_copy.data(), CS.arg_publics, nullptr, nullptr, CS.arg_lane0, nullptr, nullptr, true); if (rc) return rc; return prove_batch_finish(zk, cs, proofs, publics); }
                     ZKC_LOCK(zk->ctx); return zkc_fail(zk->ctx, ZKC_ERR_GENERIC, "prove_batch_finish: the witness does not fold at the depth its inputs gave (internal error)");
                 }
             }
