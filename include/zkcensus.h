@@ -155,14 +155,14 @@ int  zkc_pool_fullprove_batch(zkc_pool* pool, const void* inputs, int B, const u
 
 /* ---- the reference's own call shape, one voter per call, made fast: a submission queue behind the single-proof entry points.
  * prover.Prove is called per voter, from a loop or from goroutines (zk_census_test.go:89), groth16.fullProve per ballot
- * (ts_inputs/src/example.ts:358-362).  A service owns a pair of worker threads per GPU; callers enqueue one voter each and a worker proves
- * whatever has accumulated in ONE pipeline pass sequence (zkc_fullprove_batch_dev / zkc_prove_batch_dev): a lone caller is served at once,
- * concurrent callers share passes (64 concurrent callers reach most of the batch rate instead of 64 x the single-proof latency).
+ * (ts_inputs/src/example.ts:358-362).  A service owns one worker thread per pipeline lane of a GPU ($ZKC_SERVICE_WORKERS, default 4; passes of up to $ZKC_SERVICE_PASS = 64
+ * proofs); callers enqueue one voter each and the workers form pipeline passes out of whoever is waiting: a lone caller is served at once, concurrent callers share passes
+ * (64 concurrent callers: 2 800-3 000 proofs/s on one MI355X, 256: 3 100-3 300 -- the rate of a 1 024-voter batch call -- instead of 64 x the single-proof latency).
  * Devices: hip_devices[n], or n = 0: $ZKC_DEVICE ("2", "0,1,2,3", "all"), unset = every visible device; a device is brought up (context, key
  * tables) only when the queue is long enough to pay for it, and loads its key before it takes requests.  A device keeps up to $ZKC_SERVICE_KEYS keys resident
- * (default 4, ~2 GB of tables each at nLevels 160; least recently used out first): callers with different keys -- one per environment and depth,
+ * (default 4, ~2.5 GB of tables each at nLevels 160, ONE 37 GB set of lane work space per device shared by them; least recently used out first): callers with different keys -- one per environment and depth,
  * circuit/circuit-compiler.sh:15,82 -- share a GPU without reloads, each batch of one key.  Key identity: the service keeps its own copy of
- * every .zkey image it has seen (at most four); a request finds its image through zkc_zkey_fingerprint (a SAMPLED hash) and, the first time a given caller
+ * every .zkey image its devices may hold; a request finds its image through zkc_zkey_fingerprint (a SAMPLED hash) and, the first time a given caller
  * buffer (pointer, length) shows up, through the SHA-256 of the whole image -- so the caller's .zkey buffer need only stay valid during the call itself.
  * The blocking calls return the voter's own result: ZKC_OK, ZKC_ERR_WITNESS (status = ZKC_W_*: that voter failed a circuit assert; other
  * callers of the same pass are not affected), or an error with text in err.  rs = r || s (64 B) or NULL (drawn uniform in Fr).

@@ -2,26 +2,27 @@
 //
 // The reference proves one voter per call: prover.Prove(zkey, wasm, inputs) in a loop or from goroutines (zk_census_test.go:89, reaching
 // rapidsnark's groth16_prover through cgo) and groth16.fullProve(inputs, wasm, zkey) per ballot (ts_inputs/src/example.ts:358-362).  A GPU pipeline
-// pass proves up to 96 voters in the time two single proofs take, so behind those entry points sits a submission queue: callers enqueue
-// (inputs | witness, r, s) and one pair of worker threads per GPU drains whatever has accumulated -- group commit, no timer: a lone caller is
-// served at once with a batch of one, callers that arrive while the GPU is busy share its next pass -- into one zkc_fullprove_batch_dev /
-// zkc_prove_batch_dev call, and every caller gets its own proof, status and error back.  Two workers per device: while one holds the GPU the
-// other collects and uploads the next batch and tops it up until the GPU is free.  Devices: an explicit list, $ZKC_DEVICE ("2", "0,1,2,3", "all")
-// or, unset, every visible device -- but a device is only brought up (context + 1 GB of key tables, 0.6 s) when the queue is long enough to pay for
-// it, so a sequential caller stays on the first one; and a device that is brought up loads its key from the service's OWN copy of the image BEFORE it takes
-// any request, so nobody waits behind a key load that a warm device could have served meanwhile.
-// [r4] A device keeps SEVERAL keys resident (least recently used out first, $ZKC_SERVICE_KEYS of them, default 4: the reference has a key per environment and per depth,
-// circuit/circuit-compiler.sh:15,82, and 288 GB hold dozens): requests for different keys alternate on one GPU without a reload, each batch still of one key.  A key is freed
-// only by a worker that holds the device's GPU lock, after it has left the routing table and its last call in flight has finished.
-// Key identity: the service keeps a copy of every .zkey image it has seen (at most four), found per call through the sampled fingerprint and confirmed, the
-// first time a given caller buffer (pointer, length) shows up, by the SHA-256 of the whole image: two images that differ only in unsampled bytes are two keys.
-// [r5] One worker per pipeline LANE of the key (default four per GPU; $ZKC_SERVICE_WORKERS, passes of up to $ZKC_SERVICE_PASS proofs): every worker owns a call slot and a lane --
-// streams and work space of its own -- so the calls of concurrent callers are independent on the GPU and overlap in full (round 4: two workers on ONE lane, whose calls
-// could only overlap tail on head: 58-71 % of the batch rate from 64 callers).  One worker per device at a time COLLECTS: it takes what is queued, waits -- on a condition
-// variable, woken by every arrival -- while requests keep coming (briefly when the device is idle, up to ~1 ms when other calls keep it busy), uploads as it goes, then hands
-// the collector role on and begins its call.  A one-pass call is laid out from its inputs (zkc_prove.hip, early layout), so begin returns after ~0.5 ms of enqueueing and
-// never holds the device lock for the length of a witness kernel.  Witnesses (2.6 MB each, the groth16_prover shape) are copied into pinned slots by the CALLERS' threads,
-// in parallel, and go up without a host-side wait.
+// pass proves 64 voters in the time four single proofs take, so behind those entry points sits a submission queue: callers enqueue (inputs | witness, r, s), the workers of
+// a GPU form pipeline passes out of whoever is waiting -- group commit, no timer: a lone caller is served at once with a batch of one, callers that arrive while the GPU is busy
+// share a coming pass -- and every caller gets its own proof, status and error back.
+// Workers: one per pipeline LANE of the device (default four per GPU; $ZKC_SERVICE_WORKERS, passes of up to $ZKC_SERVICE_PASS = 64 proofs).  Worker k owns call slot k of the key
+// and lane k of the device -- streams and work space of its own -- so the calls of concurrent callers are independent on the GPU and overlap in full.  (Round 4: two workers on
+// ONE lane, whose calls could only overlap tail on head: 58-71 % of the batch rate from 64 callers.  And lanes only overlap once every busy stream has a hardware queue of its
+// own: GPU_MAX_HW_QUEUES, zkc_api.hip.)  One worker per device at a time COLLECTS: it takes its share of what is queued (everything the device's callers have outstanding divided
+// by the workers, at least $ZKC_SERVICE_MIN_BATCH = 16), waits -- on a condition variable, woken by every arrival of its class -- while requests keep coming (three quiet 50 us
+// waits on an idle device, two quiet 100 us waits or $ZKC_SERVICE_BUSY_WAIT_US = 300 on a busy one), uploads on its lane's stream as it goes, hands the collector role on and
+// begins its call.  A one-pass call is laid out from sibling depths read on the HOST (off the inputs, or off the sibling wires of a given witness), so begin is ~0.4 ms of
+// enqueueing and never waits for the GPU.  Witnesses (2.6 MB each, the groth16_prover shape) are copied into pinned slots by the CALLERS' threads, side by side.
+// Devices: an explicit list, $ZKC_DEVICE ("2", "0,1,2,3", "all") or, unset, every visible device -- but a device is only brought up (context, ~2.5 GB of key tables, 0.6 s,
+// the lanes' work space) when the queue is long enough to pay for it, so a sequential caller stays on the first one; and a device that is brought up loads its key from the
+// service's OWN copy of the image BEFORE it takes any request, so nobody waits behind a key load that a warm device could have served meanwhile.
+// Keys: a device keeps SEVERAL resident (least recently used out first, $ZKC_SERVICE_KEYS of them, default 4: the reference has a key per environment and per depth,
+// circuit/circuit-compiler.sh:15,82): requests for different keys alternate on one GPU without a reload, each batch still of one key; the lanes' work space is the device
+// context's and shared by them (zkc_prove.hip lane_ensure).  A key is freed only by a worker that holds the device's GPU lock, after it has left the routing table and its
+// last call in flight has finished; a key load that fails for want of memory evicts idle keys and tries again.
+// Key identity: the service keeps a copy of every .zkey image its devices may hold (never dropping one that is resident or in a request), found per call through the sampled
+// fingerprint and confirmed, the first time a given caller buffer (pointer, length) shows up, by the SHA-256 of the whole image: two images that differ only in unsampled
+// bytes are two keys.
 // Host code over the public batch entry points; launches no kernel of its own.
 #include "zkc_prover.h"
 #include "zkc_hostparse.h"
