@@ -127,6 +127,9 @@ class FlatVoters:
     def __len__(self):
         return len(self.flat) // (32 * self.nIn)
 
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
     def __getitem__(self, i):
         if isinstance(i, slice):
             return [self[k] for k in range(*i.indices(len(self)))]
@@ -140,15 +143,17 @@ class FlatVoters:
 
 
 def synthetic_census(ctx, n_voters, nLevels=160, election_id_hex=ELECTION_ID_HEX):
-    """deterministic census of n_voters; returns the list of 12-key circuit input objects
-    (decimal strings, siblings zero-padded to nLevels+1 like internal/inputs.go:52,72)."""
-    eid = bytes_to_arbo(bytes.fromhex(election_id_hex))
-    u32 = lambda i: int(i).to_bytes(4, 'little')
-    address = [int.from_bytes(hashlib.sha256(b'addr' + u32(i)).digest()[:20], 'little') for i in range(n_voters)]
-    password = [int.from_bytes(hashlib.sha256(b'pw' + u32(i)).digest()[:11], 'big') % R_MOD for i in range(n_voters)]
-    signature = [int.from_bytes(hashlib.sha256(b'sigA' + u32(i)).digest() + hashlib.sha256(b'sigB' + u32(i)).digest(), 'big') % R_MOD
-                 for i in range(n_voters)]
-    avail = [1 + (i % 100) for i in range(n_voters)]
+    """deterministic census of n_voters as a sequence of 12-key circuit input objects (decimal strings, siblings zero-padded to nLevels + 1 like
+    internal/inputs.go:52,72).  [r5] Built by the native builder (zkc_census_inputs); the objects are made on demand from its flat blocks (FlatVoters: indexing and slicing give
+    dicts / lists of dicts, `.flat` the blocks themselves).  synthetic_census_py is the Python builder of rounds 1-4, kept as the cross-check
+    (tests/test_gpu_census.py: byte-equal over whole censuses)."""
+    flat, _, _ = synthetic_census_flat(ctx, n_voters, nLevels, election_id_hex)
+    return FlatVoters(flat, nLevels)
+
+
+def synthetic_census_py(ctx, n_voters, nLevels=160, election_id_hex=ELECTION_ID_HEX):
+    """The same census through SparseMerkleTree above (Python lists, one batched GPU Poseidon call per tree level): ten seconds for 8 192 voters."""
+    eid, address, password, signature, avail = _voter_data(n_voters, election_id_hex)
     sik = poseidon_batch(ctx, list(zip(address, password, signature)))                     # census.circom:74-77
     nullifier = poseidon_batch(ctx, [(s, p, int(eid[0]), int(eid[1])) for s, p in zip(signature, password)])   # :105-109
     census = SparseMerkleTree(ctx, address, avail, nLevels)

@@ -135,11 +135,6 @@ void finish(zkc_service* s, Req* r, int rc, int32_t status, const std::string& e
 
 // ---- dispatch (all under svc->mu) ----
 bool any_dev_has(zkc_service* s, const KeyImage* img) { for (auto& d : s->devs) if (d->has(img) || d->loading.get() == img) return true; return false; }
-// the requests worker w takes now, up to `cap` of one class in arrival order:
-//   its device holds keys             -> the class of the first queued request for any of them (arrival order: two resident keys take turns);
-//   else, no device holds or is loading the head's key (the very first request, or a new key)
-//                                     -> the head's class: this worker will load the key with those requests in hand (somebody has to);
-//   else                              -> nothing: other devices serve that key (if the queue grows past `spill`, dispatch brings this device up FIRST, without requests)
 // how many requests a batch on device d should take when `have` are in hand already: everything the device's callers have outstanding -- in hand, queued, in the calls in
 // flight -- shared out over the device's workers, and at least min_batch.  Sixty-four callers that come back from one call together would otherwise go into ONE call again,
 // and a single call in flight leaves its latency-bound phases (witness chains, bucket reductions, blinding) uncovered; four calls of sixteen drift apart and cover one another.
@@ -147,6 +142,11 @@ size_t batch_target(zkc_service* s, zkc_service::Dev* d, size_t have) {
     const size_t all = have + s->q.size() + (size_t)std::max(0, d->proofs_in_flight.load());
     return std::max<size_t>((size_t)s->min_batch, (all + (size_t)s->workers_per_dev - 1) / (size_t)s->workers_per_dev);
 }
+// the requests worker w takes now, up to `cap` of one class in arrival order:
+//   its device holds keys             -> the class of the first queued request for any of them (arrival order: two resident keys take turns);
+//   else, no device holds or is loading the head's key (the very first request, or a new key)
+//                                     -> the head's class: this worker will load the key with those requests in hand (somebody has to);
+//   else                              -> nothing: other devices serve that key (if the queue grows past `spill`, dispatch brings this device up FIRST, without requests)
 std::vector<Req*> grab(zkc_service* s, zkc_service::Worker* w, size_t cap, const Req* like = nullptr) {
     std::vector<Req*> out;
     if (s->q.empty() || cap == 0) return out;
