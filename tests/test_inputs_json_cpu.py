@@ -83,6 +83,10 @@ def test_any_key_order_value_forms_and_padding():
     # a repeated name: the last one stands, as JSON.parse has it
     t = json.dumps(ex)[:-1] + ', "voteWeight": "7"}'
     assert _flat(t)[1] == ol.flat_inputs(dict(ex, voteWeight='7'))
+    # the decimal fast path (at most 77 digits: chunks of nineteen, then a few subtractions of r) and the digit loop behind it agree with Python on the edges
+    for x in (0, 1, ol.R - 1, ol.R, ol.R + 1, 5 * ol.R - 1, 10 ** 77 - 1, 10 ** 76, 2 ** 256 - 1, 2 ** 256, 10 ** 78 + 7, 10 ** 200 + 3, int('9' * 19), int('9' * 20), int('1' + '0' * 57)):
+        for form in (str(x), '000' + str(x), ' ' + str(x) + '\n'):
+            assert _flat(json.dumps(dict(ex, address=form)))[1] == ol.flat_inputs(dict(ex, address=str(x))), (x, form)
     # nLevels 10: eleven siblings per list
     small = dict(ex, censusSiblings=ex['censusSiblings'][:11], sikSiblings=ex['sikSiblings'][:11])
     assert _flat(json.dumps(small), 10)[1] == ol.flat_inputs(small, 10)
