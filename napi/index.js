@@ -49,10 +49,17 @@ function readArtifact(f) {
     fileCache.set(f, { key, data });
     return data;
   }
-  if (f && f.type === "mem") return Buffer.from(f.data);
-  return Buffer.from(f);
+  // in-memory artifacts are NOT copied (Buffer.from(buffer) copies: 55 MB of key per fullProve call) and the same source object yields the same Buffer object every time,
+  // so that the per-image caches -- here and in the library, which keys its SHA-256 check on (pointer, length) -- hit
+  const src = f && f.type === "mem" ? f.data : f;
+  if (Buffer.isBuffer(src)) return src;
+  let view = memViews.get(src);
+  if (!view) { view = ArrayBuffer.isView(src) ? Buffer.from(src.buffer, src.byteOffset, src.byteLength) : Buffer.from(src); if (src && typeof src === "object") memViews.set(src, view); }
+  return view;
 }
+const memViews = new WeakMap();
 const { WasmWitnessCalculator, wtnsImage } = require("./wasm_witness.js");
+const wasmInfo = new WeakMap();                                 // wasm image (Buffer object) -> {nLevels, sha256}
 const wasmCache = new Map();                                  // sha256 of a wasm this build executes -> its compiled calculator (at most four)
 // which witness generator a call takes: {nLevels, calc}.  calc === null: the native HIP generator of ZkFranchiseProofCircuit(nLevels); else the caller's wasm, executed here
 async function circuitOf(wasmFile, zkeyFile, opts) {
@@ -68,7 +75,10 @@ async function circuitOf(wasmFile, zkeyFile, opts) {
     return { nLevels: k.nLevels, calc: null };
   }
   const code = readArtifact(wasmFile);
-  const c = native.circuitFromWasm(code, LIB);
+  // the circuit a wasm image stands for, remembered per image OBJECT: a path yields the same cached Buffer while the file is unchanged (readArtifact), so Promise.all over a
+  // census hashes the 3 MB witness calculator once, not once per ballot (2 ms each on the main thread: 500 proofs/s at best)
+  let c = wasmInfo.get(code);
+  if (!c) { c = native.circuitFromWasm(code, LIB); wasmInfo.set(code, c); }
   if (c.nLevels >= 0 && !(opts && opts.forceWasm)) {
     if (want && want !== c.nLevels) throw new Error(`wasm file is the nLevels=${c.nLevels} circuit but nLevels=${want} was requested`);
     return { nLevels: c.nLevels, calc: null };
