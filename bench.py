@@ -625,8 +625,19 @@ def main():
            'note': 'VALU issue bound: capacity = lane-operations/s a dependency-free loop with the kernel\'s own instruction mix sustains on this part '
                    '(tools/probe/rate_probe.hip, profiles/r02_rate_probe.txt) / VALU instructions of one mixed addition (profiles/r02_accumulate_isa_histogram.txt); '
                    'rocprofv3 SQ counters of the kernel are in profiles/r02_pmc_sq_accumulate.json.  This, not HBM, limits the kernel; box-to-box clock differences move frac by a few percent'}
+    # [r5] the whole pipeline against the chip's vector issue: VALU-busy cycles per SIMD of ONE pass, summed over every kernel (rocprofv3 SQ counters, committed:
+    # profiles/r05_kernel_valu_busy_table.json), per proof, times the measured proofs/s, over the clock the accumulation kernel sustains (2.15 GHz, profiles/r02_power_clock_trace.json)
+    pipeline_valu = None
+    try:
+        kb = json.load(open(os.path.join(ROOT, 'profiles', 'r05_kernel_valu_busy_table.json')))
+        per_proof = kb['pass_valu_busy_Mcycles_per_simd'] * 1e6 / kb.get('proofs_in_pass', 64)
+        pipeline_valu = {'valu_busy_cycles_per_simd_per_proof': round(per_proof), 'proofs_per_s_if_every_issue_slot_were_used_at_2.15_GHz': round(2.15e9 / per_proof, 1),
+                         'frac_of_issue_slots_used': round(args.steps * B / dt * per_proof / 2.15e9, 4), 'source': 'profiles/r05_kernel_valu_busy_table.json (one pass, every kernel, additive)',
+                         'note': 'at N = 1; what is left of the chip is this fraction short of 1: the pipeline as a whole, not one kernel, is at the vector-issue ceiling'}
+    except Exception:
+        pass
     roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': round(achieved, 3), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'valu': alu,
-                'frac': round(achieved / HBM_PEAK_GBPS, 6), 'traffic': traffic, 'traffic_source': traffic_src,
+                'frac': round(achieved / HBM_PEAK_GBPS, 6), 'pipeline_valu': pipeline_valu, 'traffic': traffic, 'traffic_source': traffic_src,
                 'avg_launch_ms': round(d['ms'] / max(1, d['launches']), 4), 'alg_bytes_per_launch': d['alg_bytes'] // max(1, d['launches']),
                 'streamed_pair_bytes_per_launch': prof['msm_g1_streamed']['alg_bytes'] // max(1, d['launches']),
                 'note': 'achieved = algorithmic bytes (whole A,B1,C,H sections, SURVEY.md 8d) / kernel time; constant folding streams only streamed_pair_bytes. '

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """The ADDITIVE per-kernel view of one pipeline pass (the wall-duration CSV of rocprofv3 --kernel-trace misranks kernels that idle beside
 the accumulation on another stream).  Input: the counter_collection.csv of
-    rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES -- python3 bench.py --batch 96 --steps 1 --warmup 0 --no-cpu-baseline --no-verify
-(tools/gpu/call.sh ... pmc:sq:...).  Per kernel, summed over the launches of the one 96-proof pass:
+    rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES -- python3 bench.py --batch 64 --steps 1 --warmup 0 --no-cpu-baseline --no-verify
+(tools/gpu/call.sh ... pmc:sq:...).  Per kernel, summed over the launches of the one 64-proof pass:
     valu_busy_Mcycles_per_simd = SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs   (the counter is in quad-cycles, summed over the chip)
     share                      = that / the sum over all zkc kernels     -- VALU work adds up across streams, wall durations do not
     gui_active_Mcycles         = GRBM_GUI_ACTIVE / 8 XCDs               (wall cycles while the kernel was resident: inflated by whatever ran beside it)
@@ -30,10 +30,10 @@ tot = sum(r['valu_busy_Mcycles_per_simd'] for r in rows if r['phase'] == 'pass')
 for r in rows:
     r['share_of_pass'] = round(r['valu_busy_Mcycles_per_simd'] / tot, 4) if r['phase'] == 'pass' else None
 rows.sort(key=lambda r: (r['phase'] != 'pass', -r['valu_busy_Mcycles_per_simd']))
-json.dump({'command': 'rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES -- python3 bench.py --batch 96 --steps 1 --warmup 0 --no-cpu-baseline --no-verify',
+json.dump({'command': 'rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES -- python3 bench.py --batch 64 --steps 1 --warmup 0 --no-cpu-baseline --no-verify',
            'commit': commit, 'units': __doc__.split('Per kernel')[1].split('usage')[0].strip(), 'pass_valu_busy_Mcycles_per_simd': round(tot, 2),
            'pass_valu_busy_ms_at_2.15_GHz': round(tot / 2.15, 2), 'kernels': rows}, open(dst, 'w'), indent=1)
 for r in rows:
     if r['phase'] == 'pass' and r['share_of_pass'] >= 0.002:
         print('%-44s %3d launches  %8.3f Mcyc  %5.1f %%' % (r['kernel'][:44], r['launches'], r['valu_busy_Mcycles_per_simd'], 100 * r['share_of_pass']))
-print('one 96-proof pass: %.2f M VALU-busy cycles per SIMD = %.2f ms at 2.15 GHz' % (tot, tot / 2.15))
+print('one 64-proof pass: %.2f M VALU-busy cycles per SIMD = %.2f ms at 2.15 GHz' % (tot, tot / 2.15))
