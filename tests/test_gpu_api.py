@@ -141,3 +141,59 @@ def test_key_and_context_lifecycle_returns_device_memory():
     for _ in range(8):
         last = cycle()
     assert first - last < 64 << 20, 'device memory shrank by %.1f MB over nine load/free cycles' % ((first - last) / 1e6)
+
+
+def test_groth16_fullprove_takes_the_reference_argument_shapes():
+    """[r5] prover.Prove(zkey, wasm, inputs) in one call (include/zkcensus.h groth16_fullprove; zk_census_test.go:81-93): file images and JSON text in, proof.json / public.json
+    texts out, rapidsnark's return codes.  nLevels 10 key, circuit named by the key's own shape (wasm NULL); an unknown wasm is refused; a voter who fails a circuit assert and a
+    damaged inputs object come back as 1 with the wasm's / circom_runtime's message; the size query is answered without proving."""
+    import ctypes, json, random, sys, os
+    import zkcensus_amd
+    from zkcensus_amd import setup, _native
+    sys.path.insert(0, os.path.join(ol.ROOT, 'tools'))
+    from census_gen import random_voter
+    lib = _native.load()
+    nl = 10
+    _, zp, vp = setup.ensure_test_artifacts(nl)
+    zk = open(zp, 'rb').read(); vk = json.load(open(vp))
+    v = random_voter(random.Random(77), ol.poseidon, nLevels=nl, depth_c=5, depth_s=3)
+    text = json.dumps(v).encode()
+
+    def call(wasm, js, psz=2048, usz=2048):
+        pb, ub, eb = ctypes.create_string_buffer(max(psz, 1)), ctypes.create_string_buffer(max(usz, 1)), ctypes.create_string_buffer(512)
+        ps, us = ctypes.c_ulong(psz), ctypes.c_ulong(usz)
+        rc = lib.groth16_fullprove(zk, len(zk), wasm, len(wasm) if wasm else 0, js, len(js), pb, ctypes.byref(ps), ub, ctypes.byref(us), eb, 512)
+        return rc, pb.value, ub.value, eb.value.decode(), ps.value, us.value
+    rc, pj, uj, err, ps, us = call(None, text)
+    assert rc == 0, err
+    proof, pub = json.loads(pj), json.loads(uj)
+    rcw, w = ol.witness(v, nl); assert rcw == 0
+    assert [int(x) for x in pub] == [int.from_bytes(w[32 * (1 + k):32 * (2 + k)], 'little') for k in range(8)]
+    le = lambda x: int(x).to_bytes(32, 'little')
+    pbin = le(proof['pi_a'][0]) + le(proof['pi_a'][1]) + le(proof['pi_b'][0][0]) + le(proof['pi_b'][0][1]) + le(proof['pi_b'][1][0]) + le(proof['pi_b'][1][1]) + le(proof['pi_c'][0]) + le(proof['pi_c'][1])
+    assert ol.verify(vk, b''.join(le(x) for x in pub), pbin)
+    assert ps == len(pj) + 1 and us == len(uj) + 1                      # sizes written back include the terminating NUL, as rapidsnark's do
+    # size query: nothing proved, sizes that hold any proof of this shape
+    rc, _, _, err, ps, us = call(None, text, 10, 10)
+    assert rc == 2 and ps >= len(pj) + 1 and us >= len(uj) + 1
+    # an unknown witness calculator: refused (the C ABI has no wasm runtime), with a message that says what to do
+    rc, _, _, err, _, _ = call(b'\0asm\x01\0\0\0' + b'x' * 64, text)
+    assert rc == 1 and 'no wasm runtime' in err
+    # a voter who fails census.circom:72 (weight): the wasm's own message, nothing proved for him
+    badv = dict(v, voteWeight=str(int(v['availableWeight']) + 1))
+    rc, _, _, err, _, _ = call(None, json.dumps(badv).encode())
+    assert rc == 1 and err.startswith('Assert Failed.'), err
+    # a damaged document, an unknown signal
+    rc, _, _, err, _, _ = call(None, text[:-5])
+    assert rc == 1 and err.startswith('JSON'), err
+    rc, _, _, err, _, _ = call(None, json.dumps(dict(v, extra='1')).encode())
+    assert rc == 1 and err == 'Signal extra not found\n'
+    # the binary form through an explicit service, with injected (r, s): bytes equal the oracle's
+    svc = zkcensus_amd.ProvingService([0])
+    p = ctypes.create_string_buffer(256); u = ctypes.create_string_buffer(256); st = ctypes.c_int32(0); eb = ctypes.create_string_buffer(256)
+    rs = (12345).to_bytes(32, 'little') + (67890).to_bytes(32, 'little')
+    rc = lib.zkc_service_fullprove_json(svc._h, zk, len(zk), None, 0, text, len(text), rs, p, u, ctypes.byref(st), eb, 256)
+    assert rc == 0 and st.value == 0, eb.value
+    rco, op, ou = ol.prove(zk, w, 12345, 67890)
+    assert rco == 0 and (p.raw, u.raw) == (op, ou)
+    svc.close()
