@@ -31,6 +31,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <set>
@@ -69,29 +70,30 @@ struct HipBuf {     // grow-only buffer on the calling thread's current device (
     }
     void release() { if (p) { if (host) (void)hipHostFree(p); else (void)hipFree(p); } p = nullptr; sz = 0; }
 };
-// pinned host slots for witnesses on their way up (one size class: the first witness seen; larger ones go through the worker's own staging).  The copy from the caller's
+// pinned host slots for witnesses on their way up, by size class (the witness size rounded up to 256 KB: a process that proves for several circuits -- the census circuit beside
+// whatever a caller's own wasm computes -- keeps a free list per class; 2 GB in all, beyond that a witness goes through the worker's own staging).  The copy from the caller's
 // pageable buffer -- 2.6 MB at nLevels 160, ~0.3 ms -- is made by the CALLER's thread inside submit, so sixty-four callers copy side by side instead of one worker copying for all
 struct PinPool {
-    std::mutex m; size_t slot = 0, nslots = 0, max_slots = 512; std::vector<void*> free_, chunks; std::vector<size_t> chunk_bytes;
+    std::mutex m; size_t total = 0, max_total = (size_t)2 << 30; std::map<size_t, std::vector<void*>> free_; std::map<void*, size_t> cls_of; std::vector<void*> chunks;
+    static size_t cls(size_t bytes) { return (bytes + 262143) & ~(size_t)262143; }
     void* get(size_t bytes) {
-        size_t sl;
+        const size_t sl = cls(bytes);
         {
             std::lock_guard<std::mutex> g(m);
-            if (!slot) slot = (bytes + 4095) & ~(size_t)4095;
-            if (bytes > slot) return nullptr;
-            if (!free_.empty()) { void* r = free_.back(); free_.pop_back(); return r; }
-            if (nslots + 2 > max_slots) return nullptr;
-            nslots += 2; sl = slot;                                  // reserved; pinned below, OUTSIDE the lock: a burst of first-time callers pins its slots side by side
+            auto& fl = free_[sl];
+            if (!fl.empty()) { void* r = fl.back(); fl.pop_back(); return r; }
+            if (total + 2 * sl > max_total) return nullptr;
+            total += 2 * sl;                                         // reserved; pinned below, OUTSIDE the lock: a burst of first-time callers pins its slots side by side
         }
         void* p = nullptr;                                           // two slots at a time: this caller's and one for whoever comes next
-        if (hipHostMalloc(&p, 2 * sl, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); std::lock_guard<std::mutex> g(m); nslots -= 2; return nullptr; }
+        if (hipHostMalloc(&p, 2 * sl, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); std::lock_guard<std::mutex> g(m); total -= 2 * sl; return nullptr; }
         std::lock_guard<std::mutex> g(m);
-        chunks.push_back(p); chunk_bytes.push_back(2 * sl); free_.push_back((uint8_t*)p + sl);
+        chunks.push_back(p); cls_of[p] = sl; cls_of[(uint8_t*)p + sl] = sl; free_[sl].push_back((uint8_t*)p + sl);
         return p;
     }
-    void put(void* p) { if (!p) return; std::lock_guard<std::mutex> g(m); free_.push_back(p); }
-    size_t bytes() { std::lock_guard<std::mutex> g(m); size_t t = 0; for (size_t b : chunk_bytes) t += b; return t; }
-    void release() { for (void* p : chunks) (void)hipHostFree(p); chunks.clear(); chunk_bytes.clear(); free_.clear(); nslots = 0; }
+    void put(void* p) { if (!p) return; std::lock_guard<std::mutex> g(m); free_[cls_of[p]].push_back(p); }
+    size_t bytes() { std::lock_guard<std::mutex> g(m); return total; }
+    void release() { for (void* p : chunks) (void)hipHostFree(p); chunks.clear(); cls_of.clear(); free_.clear(); total = 0; }
 };
 }  // namespace
 
