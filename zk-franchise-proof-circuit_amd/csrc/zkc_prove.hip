@@ -105,7 +105,6 @@ extern "C" void zkc_zkey_free(zkc_zkey* zk) {
     for (void* q : {(void*)zk->fold.d_foldA, (void*)zk->fold.d_foldB1, (void*)zk->fold.d_foldC, (void*)zk->fold.d_foldB2}) if (q) (void)hipFree(q);
     if (zk->h_depths) (void)hipHostFree(zk->h_depths);
     for (auto& c : zk->call) { for (void* q : {(void*)c.d_rs, (void*)c.d_proofs, (void*)c.d_flags, (void*)c.d_status3}) if (q) (void)hipFree(q); if (c.h_flags) (void)hipHostFree(c.h_flags); if (c.h_out) (void)hipHostFree(c.h_out); if (c.h_rs) (void)hipHostFree(c.h_rs); if (c.h_xyzz) (void)hipHostFree(c.h_xyzz); if (c.h_early) (void)hipHostFree(c.h_early); if (c.d_xyzz) (void)hipFree(c.d_xyzz); for (hipEvent_t e : c.ev_done) if (e) (void)hipEventDestroy(e); for (hipEvent_t e : c.ev_chunk) (void)hipEventDestroy(e); }
-    if (zk->ev_start) (void)hipEventDestroy(zk->ev_start);
     if (zk->ctx->lanes) for (int l = 0; l < zk->nlanes; l++) for (hipStream_t q : {zk->ctx->lanes[l].st, zk->ctx->lanes[l].st2, zk->ctx->lanes[l].fin, zk->ctx->lanes[l].red}) if (q) (void)hipStreamSynchronize(q);      // (lanes, streams and work space are the context's and stay)
     delete zk;
 }
@@ -385,7 +384,6 @@ int zkc::zkey_load_opts(zkc_ctx* ctx, const void* zkey_bytes, size_t len, int op
         ZKC_UP(zk->d_tblDelta1, td.tab.data(), td.tab.size() * sizeof(G1Affine)); ZKC_UP(zk->d_tblAlpha1, ta.tab.data(), ta.tab.size() * sizeof(G1Affine));
         ZKC_UP(zk->d_tblBeta1, tb.tab.data(), tb.tab.size() * sizeof(G1Affine)); ZKC_UP(zk->d_tblDelta2, t2.tab.data(), t2.tab.size() * sizeof(G2Affine));
     }
-    ZKC_HIP_BAIL(hipEventCreateWithFlags(&zk->ev_start, hipEventDisableTiming));
     ZKC_HIP_BAIL(hipStreamSynchronize(ctx->stream));
     // the folding tables of the voter-independent witness part are part of the key's one-time cost, not of the first proof
     if (zk->nLevels >= 0 && (rc = fold_prepare(zk))) return bail(rc);
@@ -864,7 +862,6 @@ int zkc::prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nW
         static const bool red_on = [] { const char* e = getenv("ZKC_REDUCE_STREAM"); return e && atoi(e) == 1; }();
         const bool red_split = red_on && !zk->serial_streams && nb >= 32;
         if ((rc = msm_pass_g1(zk, LN.w1, j1, slot, false, st, LN.ev_sorted, LN.ev_acc, (red_split && LS.red) ? LS.red : nullptr, LN.ev_red))) return rc;
-        zk->last_lane = li;
         tr[4] = now_ms();
         if (!g2_early) {
             ZKC_HIP_CHECK(ctx, hipStreamWaitEvent(st2, LN.ev_sorted, 0));
@@ -949,14 +946,6 @@ int zkc::prove_batch_finish(zkc_zkey* zk, int cs, uint8_t* proofs, uint8_t* publ
     }
     if (publics) memcpy(publics, CS.h_out + 256ull * CS.cap, 32ull * zk->nPub * CS.B);
     return ZKC_OK;
-}
-bool zkc::prove_tail_reached(zkc_zkey* zk) {
-    if (!zk || zk->last_lane < 0) return true;
-    if (!zk->ctx->lanes) return true;
-    const hipError_t e = hipEventQuery(zk->ctx->lanes[zk->last_lane].ev_acc);
-    if (e == hipErrorNotReady) return false;
-    if (e != hipSuccess) (void)hipGetLastError();
-    return true;
 }
 // the synchronous form: begin + finish on slot 0 under the context lock
 static int prove_batch_impl(zkc_zkey* zk, const void* d_wtns, uint32_t nWitness, int B, const uint8_t* rs, uint8_t* proofs, uint8_t* publics,

@@ -219,8 +219,6 @@ struct zkc_zkey {
         int early_n = 0; std::vector<uint8_t> early_depth; uint32_t* h_early = nullptr; size_t early_cap = 0;
         const void* arg_wtns = nullptr; uint32_t arg_nw = 0; bool arg_publics = false, arg_inputs = false; int arg_lane0 = -1; hipEvent_t arg_wait = nullptr; std::vector<uint8_t> h_rs_copy;      // what begin was called with (finish begins a witness-given call again when its early layout is refused)
     } call[zkc::CALL_SLOTS];
-    int last_lane = -1;                                                     // lane of the latest pass that was enqueued (prove_tail_reached)
-    hipEvent_t ev_start = nullptr;
     // constant folding of the voter-independent witness part (SURVEY.md hard part 4)
     struct Fold {
         std::vector<zkc::G1XYZZ> baseA, baseB1, baseC; std::vector<zkc::G2XYZZ> baseB2;        // [1]
@@ -266,9 +264,6 @@ int blind_scalars_launch(zkc_ctx* ctx, hipStream_t st, const BlindArgs& a, int n
 int prove_batch_begin(zkc_zkey* zk, int cs, const void* d_wtns, uint32_t nWitness, int B, const uint8_t* rs, bool want_publics, const void* d_inputs, int32_t* d_status,
                       int lane0 = -1, hipEvent_t wait_first = nullptr, const uint8_t* host_depths = nullptr, bool no_early = false);
 int prove_batch_finish(zkc_zkey* zk, int cs, uint8_t* proofs, uint8_t* publics);
-// has the call begun last on this key reached its tail (the last pass' G1 accumulation is through; bucket reduction, blinding and copies remain)?  The proving
-// service begins the next call then: its witness kernels and transforms run beside that tail, and until then it keeps collecting requests.
-bool prove_tail_reached(zkc_zkey* zk);
 int prove_reserve(zkc_zkey* zk, int inflight);              // grow the key's work space to `inflight` proofs per pass now (clamped to the key's own limit)
 // zkc_zkey_load with the lane count and pass size given instead of read from $ZKC_LANES / $ZKC_INFLIGHT (0: take the environment / defaults)
 int zkey_load_opts(zkc_ctx* ctx, const void* zkey_bytes, size_t len, int nlanes, int max_inflight, zkc_zkey** out);
