@@ -245,6 +245,12 @@ const char* zkc_verify_last_error(void);
  * .wtns = iden3 binfile "wtns" v2 (section 1: n8, prime, nWitness; section 2: nWitness x 32 B LE). */
 int zkc_proof_to_json(const uint8_t proof[256], const uint8_t* pub, int nPublic, char* proof_buf, unsigned long* proof_size,
                       char* public_buf, unsigned long* public_size);
+/* The way back (prover.ParseProof, zk_census_test.go:118, and the vkey []byte of (*Proof).Verify, :122): the JSON texts -> the binary forms zkc_verify_bin /
+ * zkc_verify_batch take, under the same strict reading as zkc_verify.  zkc_proof_from_json: *nPublic in = room in pub (32 B each), out = signals in the document;
+ * 1 = parsed, 0 = well-formed documents with a value that is no encoding (json.Unmarshal takes it, no verifier will), <0 = -ZKC_ERR_FORMAT (a document Unmarshal
+ * refuses) / -ZKC_ERR_SHORT_BUFFER / -ZKC_ERR_BAD_ARG, text in zkc_verify_last_error().  zkc_vkey_from_json: *vk_size in = room, out = 448 + 64 (nPublic + 1). */
+int zkc_proof_from_json(const char* proof_json, const char* public_json, uint8_t proof[256], uint8_t* pub, int* nPublic);
+int zkc_vkey_from_json(const char* vkey_json, uint8_t* vk, unsigned long* vk_size, int* nPublic);
 int zkc_wtns_parse(const void* wtns_bytes, unsigned long size, const uint8_t** payload, uint32_t* nWitness);
 unsigned long zkc_wtns_write(const void* payload, uint32_t nWitness, void* out, unsigned long out_size);   /* returns bytes needed/written */
 

@@ -116,3 +116,46 @@ def test_shapes_of_well_formed_documents():
     # escapes and unicode inside strings are JSON's business: an escaped digit is the digit
     assert _verify(VK, PUB.replace('"1', '"\\u0031', 1) if '"1' in PUB else PUB, PR) == 1
     assert _verify('﻿' + VK, PUB, PR) == -5                                           # a byte order mark is not JSON
+
+
+def test_parse_proof_and_vkey_codecs_round_trip_the_reference_triple():
+    """[r5] zkc_proof_from_json = prover.ParseProof (zk_census_test.go:118) and zkc_vkey_from_json = the vkey []byte of (*Proof).Verify (:122) at the C ABI: the reference's
+    committed triple goes JSON -> binary -> zkc_verify_bin (valid) and binary -> zkc_proof_to_json -> the same values; buffers too small report the size; what
+    json.Unmarshal refuses is -ZKC_ERR_FORMAT; a value that is no encoding is 0 (Unmarshal takes it, Verify would not)."""
+    from zkcensus_amd import groth16
+    lib = _lib()
+    o_vk, o_pub, o_pr = json.loads(VK), json.loads(PUB), json.loads(PR)
+    prb, pubb = groth16.proof_from_json(PR, PUB)
+    le = lambda x: int(x).to_bytes(32, 'little')
+    assert prb == b''.join(le(x) for x in (o_pr['pi_a'][0], o_pr['pi_a'][1], o_pr['pi_b'][0][0], o_pr['pi_b'][0][1], o_pr['pi_b'][1][0], o_pr['pi_b'][1][1], o_pr['pi_c'][0], o_pr['pi_c'][1]))
+    assert pubb == b''.join(le(x) for x in o_pub)
+    vkb = groth16.vk_to_bytes(VK)
+    assert len(vkb) == 448 + 64 * (len(o_pub) + 1) and vkb[:32] == le(o_vk['vk_alpha_1'][0]) and vkb[-32:] == le(o_vk['IC'][-1][1])
+    assert vkb == groth16.vk_to_bytes(o_vk)
+    assert lib.zkc_verify_bin(vkb, len(o_pub), pubb, prb) == 1
+    # and back: the texts zkc_proof_to_json writes hold the same values as the reference's files
+    pj, uj = ctypes.create_string_buffer(2048), ctypes.create_string_buffer(2048); ps, us = ctypes.c_ulong(2048), ctypes.c_ulong(2048)
+    assert lib.zkc_proof_to_json(prb, pubb, len(o_pub), pj, ctypes.byref(ps), uj, ctypes.byref(us)) == 0
+    assert _val(json.loads(uj.value)) == _val(o_pub) and all(_val(json.loads(pj.value)[k]) == _val(o_pr[k]) for k in ('pi_a', 'pi_b', 'pi_c'))
+    assert groth16.proof_from_json(pj.value, uj.value) == (prb, pubb)
+    # sizes
+    n = ctypes.c_int(3); out = ctypes.create_string_buffer(256); pub = ctypes.create_string_buffer(32 * 8)
+    assert lib.zkc_proof_from_json(PR.encode(), PUB.encode(), out, pub, ctypes.byref(n)) == -2 and n.value == len(o_pub)
+    sz = ctypes.c_ulong(10); k = ctypes.c_int(0)
+    assert lib.zkc_vkey_from_json(VK.encode(), ctypes.create_string_buffer(10), ctypes.byref(sz), ctypes.byref(k)) == -2 and sz.value == len(vkb) and k.value == len(o_pub)
+    # malformed / wrong shapes / non-encodings
+    n = ctypes.c_int(8)
+    assert lib.zkc_proof_from_json(PR[:-2].encode(), PUB.encode(), out, pub, ctypes.byref(n)) == -5 and b'proof' in lib.zkc_verify_last_error()
+    n = ctypes.c_int(8)
+    assert lib.zkc_proof_from_json(PR.encode(), b'["1", 2]', out, pub, ctypes.byref(n)) == -5
+    n = ctypes.c_int(8)
+    assert lib.zkc_proof_from_json(json.dumps(dict(o_pr, pi_a=o_pr['pi_a'][:2])).encode(), PUB.encode(), out, pub, ctypes.byref(n)) == -5
+    n = ctypes.c_int(8)
+    assert lib.zkc_proof_from_json(json.dumps(dict(o_pr, pi_a=['abc', '1', '1'])).encode(), PUB.encode(), out, pub, ctypes.byref(n)) == 0 and n.value == len(o_pub)
+    n = ctypes.c_int(8)
+    assert lib.zkc_proof_from_json(json.dumps(dict(o_pr, pi_c=[o_pr['pi_c'][0], o_pr['pi_c'][1], '2'])).encode(), PUB.encode(), out, pub, ctypes.byref(n)) == 0
+    sz = ctypes.c_ulong(4096)
+    assert lib.zkc_vkey_from_json(VK[1:].encode(), ctypes.create_string_buffer(4096), ctypes.byref(sz), None) == -5
+    sz = ctypes.c_ulong(4096)
+    assert lib.zkc_vkey_from_json(json.dumps({k: v for k, v in o_vk.items() if k != 'IC'}).encode(), ctypes.create_string_buffer(4096), ctypes.byref(sz), None) == -5
+    assert lib.zkc_proof_from_json(None, PUB.encode(), out, pub, ctypes.byref(n)) == -4

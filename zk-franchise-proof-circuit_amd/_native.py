@@ -56,6 +56,8 @@ def load():
     L.zkc_verify_batch.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
     L.zkc_verify_last_error.restype = ctypes.c_char_p
     L.zkc_proof_to_json.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ulp, ctypes.c_char_p, ulp]
+    L.zkc_proof_from_json.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+    L.zkc_vkey_from_json.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ulp, ctypes.POINTER(ctypes.c_int)]
     L.zkc_wtns_parse.argtypes = [ctypes.c_char_p, ctypes.c_ulong, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint32)]
     L.zkc_wtns_write.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_ulong]; L.zkc_wtns_write.restype = ctypes.c_ulong
     L.zkc_poseidon_batch.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]

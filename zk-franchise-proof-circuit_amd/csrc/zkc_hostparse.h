@@ -135,39 +135,59 @@ inline bool scheme_ok(const json::Value& doc, const char* what, std::string& err
     if (c && (c->type != json::Value::String || (c->s != "bn128" && c->s != "bn254" && c->s != "BN128" && c->s != "BN254" && c->s != "altbn128"))) { err = std::string(what) + ": curve is not \"bn128\""; return false; }
     return true;
 }
+// proof.json + signals.json texts -> proof (256 B) and public signals (np x 32 B), what prover.ParseProof reads (zk_census_test.go:118): both PARSED as JSON
+// (zkc_json.h), shapes exactly the reference's.  returns 1 ok, 0 = well-formed documents whose VALUES are no valid encoding (json.Unmarshal takes them, no verifier
+// does), -1 = a malformed document (err set)
+inline int proof_from_json(const std::string& pj, const std::string& pr, std::vector<uint8_t>& pubb, std::vector<uint8_t>& prb, int& nPublic, std::string& err) {
+    json::Value jp, jr; std::string perr;
+    if (!json::parse(pj.data(), pj.size(), jp, perr)) { err = "public signals: " + perr; return -1; }
+    if (!json::parse(pr.data(), pr.size(), jr, perr)) { err = "proof: " + perr; return -1; }
+    if (jr.type != json::Value::Object) { err = "proof JSON: expected an object"; return -1; }
+    if (jp.type != json::Value::Array) { err = "public signals JSON: expected an array of decimal strings"; return -1; }
+    for (auto& x : jp.a) if (x.type != json::Value::String) { err = "public signals JSON: expected an array of decimal strings"; return -1; }
+    if (!scheme_ok(jr, "proof JSON", err)) return -1;
+    const json::Value *pa = jr.find("pi_a"), *pb = jr.find("pi_b"), *pc = jr.find("pi_c");
+    if (!pa || !pb || !pc) { err = "proof JSON: missing member"; return -1; }
+    const size_t np = jp.a.size();
+    if (np > 4096) { err = "public signals JSON: too many signals"; return -1; }
+    pubb.assign(32 * np + 1, 0); prb.assign(256, 0); nPublic = (int)np;
+    const int ra = put_g1_json(*pa, prb.data()), rb = put_g2_json(*pb, prb.data() + 64), rc = put_g1_json(*pc, prb.data() + 192);
+    if (ra < 0 || rb < 0 || rc < 0) { err = "proof JSON: pi_a / pi_c must be three decimal strings, pi_b three pairs"; return -1; }
+    for (size_t i = 0; i < np; i++) { uint32_t s[8]; if (!dec_to_std(jp.a[i].s, s)) return 0; memcpy(pubb.data() + 32 * i, s, 32); }
+    if (ra == 0 || rb == 0 || rc == 0) return 0;
+    return 1;
+}
+// verification_key.json text -> the binary layout of zkc_verify_bin (alpha1 beta2 gamma2 delta2 IC[nIC]); 1 ok, -1 malformed (err set)
+inline int vkey_from_json(const std::string& vk, std::vector<uint8_t>& vkb, int& nIC, std::string& err) {
+    json::Value jv; std::string perr;
+    if (!json::parse(vk.data(), vk.size(), jv, perr)) { err = "verification key: " + perr; return -1; }
+    if (jv.type != json::Value::Object) { err = "verification key JSON: expected an object"; return -1; }
+    if (!scheme_ok(jv, "verification key JSON", err)) return -1;
+    const json::Value *a1 = jv.find("vk_alpha_1"), *b2 = jv.find("vk_beta_2"), *g2 = jv.find("vk_gamma_2"), *d2 = jv.find("vk_delta_2"), *ic = jv.find("IC"), *npub = jv.find("nPublic");
+    if (!a1 || !b2 || !g2 || !d2 || !ic) { err = "verification key JSON: missing member"; return -1; }
+    if (ic->type != json::Value::Array || ic->a.empty() || ic->a.size() > 4097) { err = "verification key: IC length does not match the public signals"; return -1; }
+    const size_t n = ic->a.size();
+    if (npub && (npub->type != json::Value::Number || npub->s != std::to_string(n - 1))) { err = "verification key: nPublic does not match the public signals"; return -1; }
+    vkb.assign(448 + 64 * n, 0);
+    if (put_g1_json(*a1, vkb.data()) != 1 || put_g2_json(*b2, vkb.data() + 64) != 1 || put_g2_json(*g2, vkb.data() + 192) != 1 || put_g2_json(*d2, vkb.data() + 320) != 1) {
+        err = "verification key JSON: bad point"; return -1;
+    }
+    for (size_t i = 0; i < n; i++) if (put_g1_json(ic->a[i], vkb.data() + 448 + 64 * i) != 1) { err = "verification key JSON: bad IC point"; return -1; }
+    nIC = (int)n;
+    return 1;
+}
 // verification_key.json + signals.json + proof.json texts -> the binary layouts of zkc_verify_bin.  [r5] The three are PARSED as JSON (zkc_json.h) and must have the
 // reference's shapes exactly: round 4 collected quoted strings and ignored everything between them, so a document with stray tokens, a damaged member name or a missing
 // comma still verified where prover.ParseProof's json.Unmarshal (zk_census_test.go:118) and snarkjs's JSON.parse refuse it.
 // returns 1 ok, 0 = well-formed documents whose VALUES are no valid encoding (an invalid proof), -1 = a malformed document (err set)
 inline int verify_inputs_from_json(const std::string& vk, const std::string& pj, const std::string& pr, std::vector<uint8_t>& vkb, std::vector<uint8_t>& pubb,
                                    std::vector<uint8_t>& prb, int& nPublic, std::string& err) {
-    json::Value jv, jp, jr; std::string perr;
-    if (!json::parse(vk.data(), vk.size(), jv, perr)) { err = "verification key: " + perr; return -1; }
-    if (!json::parse(pj.data(), pj.size(), jp, perr)) { err = "public signals: " + perr; return -1; }
-    if (!json::parse(pr.data(), pr.size(), jr, perr)) { err = "proof: " + perr; return -1; }
-    if (jv.type != json::Value::Object) { err = "verification key JSON: expected an object"; return -1; }
-    if (jr.type != json::Value::Object) { err = "proof JSON: expected an object"; return -1; }
-    if (jp.type != json::Value::Array) { err = "public signals JSON: expected an array of decimal strings"; return -1; }
-    for (auto& x : jp.a) if (x.type != json::Value::String) { err = "public signals JSON: expected an array of decimal strings"; return -1; }
-    if (!scheme_ok(jv, "verification key JSON", err) || !scheme_ok(jr, "proof JSON", err)) return -1;
-    const json::Value *a1 = jv.find("vk_alpha_1"), *b2 = jv.find("vk_beta_2"), *g2 = jv.find("vk_gamma_2"), *d2 = jv.find("vk_delta_2"), *ic = jv.find("IC"), *npub = jv.find("nPublic");
-    const json::Value *pa = jr.find("pi_a"), *pb = jr.find("pi_b"), *pc = jr.find("pi_c");
-    if (!a1 || !b2 || !g2 || !d2 || !ic) { err = "verification key JSON: missing member"; return -1; }
-    if (!pa || !pb || !pc) { err = "proof JSON: missing member"; return -1; }
-    const size_t np = jp.a.size();
-    if (ic->type != json::Value::Array || np > 4096 || ic->a.size() != np + 1) { err = "verification key: IC length does not match the public signals"; return -1; }
-    if (npub && (npub->type != json::Value::Number || npub->s != std::to_string(np))) { err = "verification key: nPublic does not match the public signals"; return -1; }
-    vkb.assign(448 + 64 * (np + 1), 0); pubb.assign(32 * np + 1, 0); prb.assign(256, 0);
-    if (put_g1_json(*a1, vkb.data()) != 1 || put_g2_json(*b2, vkb.data() + 64) != 1 || put_g2_json(*g2, vkb.data() + 192) != 1 || put_g2_json(*d2, vkb.data() + 320) != 1) {
-        err = "verification key JSON: bad point"; return -1;
-    }
-    for (size_t i = 0; i <= np; i++) if (put_g1_json(ic->a[i], vkb.data() + 448 + 64 * i) != 1) { err = "verification key JSON: bad IC point"; return -1; }
-    nPublic = (int)np;
-    const int ra = put_g1_json(*pa, prb.data()), rb = put_g2_json(*pb, prb.data() + 64), rc = put_g1_json(*pc, prb.data() + 192);
-    if (ra < 0 || rb < 0 || rc < 0) { err = "proof JSON: pi_a / pi_c must be three decimal strings, pi_b three pairs"; return -1; }
-    for (size_t i = 0; i < np; i++) { uint32_t s[8]; if (!dec_to_std(jp.a[i].s, s)) return 0; memcpy(pubb.data() + 32 * i, s, 32); }
-    if (ra == 0 || rb == 0 || rc == 0) return 0;
-    return 1;
+    int nIC = 0;
+    if (vkey_from_json(vk, vkb, nIC, err) < 0) return -1;
+    const int rp = proof_from_json(pj, pr, pubb, prb, nPublic, err);
+    if (rp < 0) return -1;
+    if (nIC != nPublic + 1) { err = "verification key: IC length does not match the public signals"; return -1; }
+    return rp;
 }
 
 // ---- circuit inputs as the reference hands them over: the text of inputs_example.json (zk_census_test.go:85-89, prover.Prove's third argument; internal/inputs.go:14-31

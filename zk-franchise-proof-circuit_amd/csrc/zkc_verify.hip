@@ -420,6 +420,34 @@ extern "C" int zkc_verify(const char* vkey_json, const char* public_json, const 
     return zkc_verify_bin(vkb.data(), np, pubb.data(), prb.data());
 }
 
+// prover.ParseProof (zk_census_test.go:118) at the C ABI: proof.json + signals.json texts -> the binary forms every other entry point takes.  1 parsed / 0 well-formed
+// documents with a value that is no encoding / <0 = -ZKC_ERR_* (text in zkc_verify_last_error)
+extern "C" int zkc_proof_from_json(const char* proof_json, const char* public_json, uint8_t proof[256], uint8_t* pub, int* nPublic) {
+    g_err.clear();
+    if (!proof_json || !public_json || !nPublic) return vfail(-ZKC_ERR_BAD_ARG, "zkc_proof_from_json: bad argument");
+    std::vector<uint8_t> pubb, prb; int np = 0; std::string perr;
+    const int rc = parse::proof_from_json(public_json, proof_json, pubb, prb, np, perr);
+    if (rc < 0) return vfail(-ZKC_ERR_FORMAT, perr);
+    const int cap = *nPublic; *nPublic = np;
+    if (rc == 0) return 0;
+    if ((np && !pub) || cap < np) return vfail(-ZKC_ERR_SHORT_BUFFER, "zkc_proof_from_json: room for fewer public signals than the document holds");
+    if (proof) memcpy(proof, prb.data(), 256);
+    if (np) memcpy(pub, pubb.data(), 32ull * np);
+    return 1;
+}
+// verification_key.json text -> the layout zkc_verify_bin / zkc_verify_batch take.  1 parsed / <0 = -ZKC_ERR_*; *vk_size: in = room, out = 448 + 64 (nPublic + 1)
+extern "C" int zkc_vkey_from_json(const char* vkey_json, uint8_t* vk, unsigned long* vk_size, int* nPublic) {
+    g_err.clear();
+    if (!vkey_json || !vk_size) return vfail(-ZKC_ERR_BAD_ARG, "zkc_vkey_from_json: bad argument");
+    std::vector<uint8_t> vkb; int nIC = 0; std::string perr;
+    if (parse::vkey_from_json(vkey_json, vkb, nIC, perr) < 0) return vfail(-ZKC_ERR_FORMAT, perr);
+    const unsigned long room = *vk_size; *vk_size = (unsigned long)vkb.size();
+    if (nPublic) *nPublic = nIC - 1;
+    if (!vk || room < vkb.size()) return vfail(-ZKC_ERR_SHORT_BUFFER, "zkc_vkey_from_json: buffer too small (size written back)");
+    memcpy(vk, vkb.data(), vkb.size());
+    return 1;
+}
+
 // proof 256 B + public signals -> the JSON texts snarkjs / rapidsnark emit (a8); returns needed size when the buffer is short
 extern "C" int zkc_proof_to_json(const uint8_t proof[256], const uint8_t* pub, int nPublic, char* proof_buf, unsigned long* proof_size,
                                  char* public_buf, unsigned long* public_size) {

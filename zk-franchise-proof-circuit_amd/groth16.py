@@ -177,11 +177,32 @@ def verify(vk, public_signals, proof):
 
 
 def vk_to_bytes(vk):
-    """verification_key.json object -> the binary layout of zkc_verify_bin / zkc_verify_batch (standard form, little endian)."""
-    le = lambda d: int(d).to_bytes(32, 'little')
-    g1 = lambda p: le(p[0]) + le(p[1])
-    g2 = lambda p: le(p[0][0]) + le(p[0][1]) + le(p[1][0]) + le(p[1][1])
-    return g1(vk['vk_alpha_1']) + g2(vk['vk_beta_2']) + g2(vk['vk_gamma_2']) + g2(vk['vk_delta_2']) + b''.join(g1(p) for p in vk['IC'])
+    """verification_key.json (object or text) -> the binary layout of zkc_verify_bin / zkc_verify_batch (standard form, little endian), read by the library's
+    strict parser (zkc_vkey_from_json)."""
+    lib = _native.load()
+    text = vk.encode() if isinstance(vk, str) else bytes(vk) if isinstance(vk, (bytes, bytearray)) else json.dumps(vk).encode()
+    size = ctypes.c_ulong(0)
+    rc = lib.zkc_vkey_from_json(text, None, ctypes.byref(size), None)
+    if rc == -2:                                         # ZKC_ERR_SHORT_BUFFER: the size was written back
+        buf = ctypes.create_string_buffer(size.value)
+        rc = lib.zkc_vkey_from_json(text, buf, ctypes.byref(size), None)
+    if rc != 1:
+        raise _native.ZkcError(-rc, (lib.zkc_verify_last_error() or b'').decode())
+    return buf.raw[:size.value]
+
+
+def proof_from_json(proof, public_signals):
+    """prover.ParseProof (zk_census_test.go:118): proof.json / signals.json (objects or texts) -> (256-byte proof, nPublic x 32-byte signals), the forms
+    verify_batch and the binary entry points take.  Raises on a document json.Unmarshal would refuse; ValueError on a value that is no encoding."""
+    lib = _native.load()
+    t = lambda x: x.encode() if isinstance(x, str) else bytes(x) if isinstance(x, (bytes, bytearray)) else json.dumps(x).encode()
+    n = ctypes.c_int(4096); pr = ctypes.create_string_buffer(256); pub = ctypes.create_string_buffer(32 * 4096)
+    rc = lib.zkc_proof_from_json(t(proof), t(public_signals), pr, pub, ctypes.byref(n))
+    if rc < 0:
+        raise _native.ZkcError(-rc, (lib.zkc_verify_last_error() or b'').decode())
+    if rc == 0:
+        raise ValueError('proof / public signals hold a value that is no field or point encoding')
+    return pr.raw, pub.raw[:32 * n.value]
 
 
 def verify_batch(ctx, vk, publics, proofs, seed=None):
