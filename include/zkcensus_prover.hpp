@@ -40,7 +40,7 @@ inline std::string dec(const uint8_t le[32]) {                     // (*big.Int)
     return std::string(out.rbegin(), out.rend());
 }
 inline Big big_u64(uint64_t v) { Big b{}; memcpy(b.data(), &v, 8); return b; }
-// new(big.Int).SetBytes(b) mod r for a big-endian byte string of any length (a 65-byte signature is 520 bits): double-and-add over the bits, 4 x 64-bit limbs
+// new(big.Int).SetBytes(b) mod r for a big-endian byte string of any length (a 64-byte signature is 512 bits): double-and-add over the bits, 4 x 64-bit limbs
 inline Big mod_r_be(const uint8_t* p, size_t n) {
     static const uint64_t R[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
     uint64_t a[4] = {0, 0, 0, 0};
@@ -164,13 +164,13 @@ struct circuitInputs {
         return s + "}";
     }
 };
-// internal/inputs.go:33-98 MockInputs.  An account is a random 20-byte address and a random 65-byte signature here: deriving them (secp256k1, vocdoni's SIK payload)
+// internal/inputs.go:33-98 MockInputs.  An account is a random 20-byte address and a random 64-byte signature (the SIK signature without its recovery byte, ts_inputs/src/inputs.ts:6-13) here: deriving them (secp256k1, vocdoni's SIK payload)
 // is the node's business, and the circuit sees only the field elements.  Everything from there on follows the reference: password "password123", weight 10 of which
 // 5 are spent, SIK = H(address, password, signature), nullifier = H(signature, password, electionId), one tree each of nKeys leaves, siblings padded to nLevels + 1.
 // (The reference ignores nKeys and builds 10-leaf trees; 10 is what its only caller passes.)
 inline circuitInputs MockInputs(int nLevels, int nKeys) {
     zkc_ctx* ctx = detail::context();
-    std::random_device rd; uint8_t address[20], signature[65];
+    std::random_device rd; uint8_t address[20], signature[64];
     for (auto& b : address) b = (uint8_t)rd();
     for (auto& b : signature) b = (uint8_t)rd();
     const char* password = "password123";

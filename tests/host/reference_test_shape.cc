@@ -12,6 +12,7 @@
 #include <iterator>
 #include <map>
 #include <string>
+#include <vector>
 #include "zkcensus_prover.hpp"
 
 using namespace zkcensus;
@@ -99,7 +100,25 @@ static void Test_bytesRoundTrip() {
     if (enc.second != pubSignals) throw Fatal("signals.json does not survive ParseProof -> Bytes");
 }
 
+// not in the reference: the encodings of internal/helpers.go:16-34 on the raw client values of ts_inputs/src/example.ts:340-346, printed as JSON for the test to compare
+// with the reference's inputs_example.json (the same voter)
+static std::vector<uint8_t> unhex(const std::string& h) {
+    std::vector<uint8_t> out; for (size_t i = 0; i + 1 < h.size(); i += 2) out.push_back((uint8_t)strtol(h.substr(i, 2).c_str(), nullptr, 16)); return out;
+}
+static void Print_encodings() {
+    const auto eid = unhex("7faeab7a7d250527d614e952ae8e446825bd1124c6def410844c7c383d1519a6"), addr = unhex("032234DBb3B6dA8c11DDdc26338867C769e66B00"),
+               pw = unhex("70617373776f7264313233"),
+               sig = unhex("7b6cac3c3b64d0b7fc10f0f6d4b8baf2548f246a748d25d8825becc1e2fa3c6e0a2654b042be487f0a352bc2c0577cde1440373197b4d93e09fc7502b61e9632");
+    const auto e = internal::BytesToArbo(eid.data(), eid.size());
+    const uint8_t weight[1] = {10}; const auto vh = internal::BytesToArbo(weight, 1);
+    Big a{}; memcpy(a.data(), addr.data(), addr.size());
+    printf("{\"electionId\":[\"%s\",\"%s\"],\"voteHash\":[\"%s\",\"%s\"],\"address\":\"%s\",\"password\":\"%s\",\"signature\":\"%s\"}\n",
+           detail::dec(e[0].data()).c_str(), detail::dec(e[1].data()).c_str(), detail::dec(vh[0].data()).c_str(), detail::dec(vh[1].data()).c_str(), detail::dec(a.data()).c_str(),
+           detail::dec(internal::BigToFF(pw.data(), pw.size()).data()).c_str(), detail::dec(internal::BigToFF(sig.data(), sig.size()).data()).c_str());
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "Print_encodings") { Print_encodings(); return 0; }
     // `go test -run <name>`: one test by name, or all three in file order
     const std::map<std::string, void (*)()> tests = {{"Test_genInputs", Test_genInputs}, {"Test_genProof", Test_genProof}, {"Test_verifyProof", Test_verifyProof},
                                                        {"Test_bytesRoundTrip", Test_bytesRoundTrip}};

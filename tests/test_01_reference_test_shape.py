@@ -59,6 +59,10 @@ def test_verify_and_bytes_on_the_reference_triple(tmp_path):
     (d / 'proof.json').write_text(open(os.path.join(REF, 'proof.json')).read()[:-1])
     r = run(exe, tmp_path, 'Test_verifyProof')
     assert r.returncode == 1 and 'parsing proof' in r.stdout
+    # internal/helpers.go:16-34 on example.ts:340-346's raw client values = the reference's inputs_example.json (the same voter)
+    enc = json.loads(run(exe, tmp_path, 'Print_encodings').stdout)
+    ref_inputs = json.load(open(os.path.join(REF, 'inputs_example.json')))
+    assert enc == {k: ref_inputs[k] for k in ('electionId', 'voteHash', 'address', 'password', 'signature')}
     # getEnvVars: the reference's own refusals and its path scheme
     r = run(exe, tmp_path, 'Test_verifyProof', NLEVELS=9)
     assert r.returncode == 1 and 'the number of levels must be 10 at least to support the current key length' in r.stdout
