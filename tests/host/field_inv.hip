@@ -1,4 +1,4 @@
-// Host check of the two field inversions of libzkcensus (csrc/zkc_field.h): fp_inv (square and multiply, what the device uses lane-parallel) against fp_inv_gcd (binary Euclid,
+// Host check of the field products and the two field inversions of libzkcensus (csrc/zkc_field.h): fp_inv (square and multiply, what the device uses lane-parallel) against fp_inv_gcd (binary Euclid,
 // what prove_batch_finish uses to make the points of a small pass affine), in Fq, Fr and Fq2, on edge values and random ones; and xyzz_to_affine_gcd against xyzz_to_affine.
 //   hipcc --offload-arch=gfx950 -std=c++17 -O2 -I zk-franchise-proof-circuit_amd/csrc -I include tests/host/field_inv.hip -o field_inv && ./field_inv
 #include "zkc_curve.h"
@@ -21,8 +21,23 @@ template <class P> static int check(const char* name) {
     printf("%s: %d mismatches\n", name, bad);
     return bad;
 }
+// the host product over 4 x 64-bit limbs (fp_mul_host64, what operator* is on the host) against the 8 x 32-bit CIOS the header started with and the radix-2^29 form the GPU runs
+template <class P> static int check_mul(const char* name) {
+    std::mt19937_64 g(19); int bad = 0;
+    for (int it = 0; it < 200000; it++) {
+        uint32_t a[8], b[8], r0[8], r1[8], r2[8];
+        for (int i = 0; i < 8; i++) { a[i] = (uint32_t)g(); b[i] = (uint32_t)g(); }
+        a[7] &= 0x3fffffff; b[7] &= 0x3fffffff;                                         // any residues below 2^254 > p: the routines take operands below 2p
+        if (it < 64) for (int i = 0; i < 8; i++) { a[i] = (it & 1) ? P::p[i] : (it & 2) ? 0xffffffffu >> (i == 7 ? 2 : 0) : 0; b[i] = (it & 4) ? P::p[i] : (it & 8) ? (i == 0) : b[i]; }
+        if (it < 64 && (it & 16)) a[0] -= 1;
+        fp_mul_limbs<P>(r0, a, b); fp_mul_host64<P>(r1, a, b); fp_mul_r29<P>(r2, a, b);
+        for (int i = 0; i < 8; i++) if (r0[i] != r1[i] || r0[i] != r2[i]) { bad++; break; }
+    }
+    printf("%s products: %d mismatches\n", name, bad);
+    return bad;
+}
 int main() {
-    int bad = check<FqParams>("Fq") + check<FrParams>("Fr");
+    int bad = check<FqParams>("Fq") + check<FrParams>("Fr") + check_mul<FqParams>("Fq") + check_mul<FrParams>("Fr");
     std::mt19937_64 g(11);
     for (int it = 0; it < 300; it++) {
         uint32_t s[4][8]; for (auto& r : s) { for (int i = 0; i < 8; i++) r[i] = (uint32_t)g(); r[7] &= 0x1fffffff; }

@@ -1,0 +1,158 @@
+// zkc_pairing_host.h -- the BN254 pairing of the CPU verifier (a9 / f4; host only, included by zkc_verify.hip).
+//
+// What go-rapidsnark's verifier does behind (*Proof).Verify (zk_census_test.go:122) and snarkjs behind groth16.verify, restated: optimal ate Miller loop over 6x + 2
+// with the two Frobenius steps, homogeneous projective line functions (no inversions), lines multiplied in sparsely, several pairs sharing ONE accumulator (one squaring
+// per bit whatever the number of pairs), G2 points "prepared" into their line coefficients (a verification key's gamma and delta once per key), and a final
+// exponentiation split into the easy part and the Fuentes-Castaneda hard part over three powers of x.  Rounds 1-4 ran the plain ate loop over 6x^2 with affine lines
+// (one Fq2 inversion per step), dense Fq12 products and a 1268-bit square-and-multiply final exponentiation: 30 ms per proof on the GPU boxes' hosts.
+//
+// Tower: Fq2 = Fq[u]/(u^2 + 1), Fq6 = Fq2[v]/(v^3 - xi), Fq12 = Fq6[w]/(w^2 - v), xi = 9 + u; the twist is y^2 = x^3 + 3/xi (D type), a line lives in the
+// coefficients of w^0, w^1, w^3.  The value final_exp() returns is the reduced pairing raised to 2x(6x^2 + 3x + 1) -- exactly what libff / ffjavascript compute and
+// what verification_key.json carries as vk_alphabeta_12, which pins all of this (tests/test_oracle_pinning.py through zkc_pairing_bin).
+#pragma once
+#include <array>
+#include <cstring>
+#include <vector>
+#include "zkc_curve.h"
+
+namespace zkc { namespace pairing {
+
+inline Fq2 mul_xi(const Fq2& a) {                                    // (9 + u) a
+    const Fq t0 = fp_dbl(fp_dbl(fp_dbl(a.c0))) + a.c0, t1 = fp_dbl(fp_dbl(fp_dbl(a.c1))) + a.c1;
+    return {t0 - a.c1, t1 + a.c0};
+}
+inline Fq2 conj2(const Fq2& a) { return {a.c0, fp_neg(a.c1)}; }
+inline Fq2 scale2(const Fq2& a, const Fq& s) { return {a.c0 * s, a.c1 * s}; }
+inline Fq2 fq2_pow(const Fq2& a, const uint32_t* e, int nbits) { Fq2 r = Fq2::one(); for (int i = nbits - 1; i >= 0; i--) { r = fp_sqr(r); if ((e[i >> 5] >> (i & 31)) & 1) r = r * a; } return r; }
+
+struct Fq6 { Fq2 a0, a1, a2; };
+struct Fq12 { Fq6 a, b; };
+inline Fq6 operator+(const Fq6& x, const Fq6& y) { return {x.a0 + y.a0, x.a1 + y.a1, x.a2 + y.a2}; }
+inline Fq6 operator-(const Fq6& x, const Fq6& y) { return {x.a0 - y.a0, x.a1 - y.a1, x.a2 - y.a2}; }
+inline Fq6 neg6(const Fq6& x) { return {fp_neg(x.a0), fp_neg(x.a1), fp_neg(x.a2)}; }
+inline Fq6 mul_v(const Fq6& x) { return {mul_xi(x.a2), x.a0, x.a1}; }
+inline Fq6 operator*(const Fq6& x, const Fq6& y) {                   // Karatsuba: 6 products in Fq2
+    const Fq2 v0 = x.a0 * y.a0, v1 = x.a1 * y.a1, v2 = x.a2 * y.a2;
+    return {v0 + mul_xi((x.a1 + x.a2) * (y.a1 + y.a2) - v1 - v2), (x.a0 + x.a1) * (y.a0 + y.a1) - v0 - v1 + mul_xi(v2), (x.a0 + x.a2) * (y.a0 + y.a2) - v0 - v2 + v1};
+}
+inline Fq6 mul_by_01(const Fq6& x, const Fq2& b0, const Fq2& b1) {  // x (b0 + b1 v): 5 products
+    const Fq2 v0 = x.a0 * b0, v1 = x.a1 * b1;
+    return {v0 + mul_xi((x.a1 + x.a2) * b1 - v1), (x.a0 + x.a1) * (b0 + b1) - v0 - v1, (x.a0 + x.a2) * b0 - v0 + v1};
+}
+inline Fq6 mul_by_fq2(const Fq6& x, const Fq2& b) { return {x.a0 * b, x.a1 * b, x.a2 * b}; }
+inline Fq6 inv6(const Fq6& x) {
+    const Fq2 c0 = fp_sqr(x.a0) - mul_xi(x.a1 * x.a2), c1 = mul_xi(fp_sqr(x.a2)) - x.a0 * x.a1, c2 = fp_sqr(x.a1) - x.a0 * x.a2;
+    const Fq2 t = fp_inv_gcd(mul_xi(x.a2 * c1 + x.a1 * c2) + x.a0 * c0);
+    return {c0 * t, c1 * t, c2 * t};
+}
+inline Fq12 one12() { Fq12 r{}; r.a.a0 = Fq2::one(); r.a.a1 = r.a.a2 = r.b.a0 = r.b.a1 = r.b.a2 = Fq2::zero(); return r; }
+inline Fq12 operator*(const Fq12& x, const Fq12& y) {                // Karatsuba: 3 products in Fq6
+    const Fq6 aa = x.a * y.a, bb = x.b * y.b;
+    return {aa + mul_v(bb), (x.a + x.b) * (y.a + y.b) - aa - bb};
+}
+inline Fq12 sqr12(const Fq12& x) {                                   // complex squaring: 2 products in Fq6
+    const Fq6 ab = x.a * x.b;
+    return {(x.a + x.b) * (x.a + mul_v(x.b)) - ab - mul_v(ab), ab + ab};
+}
+inline Fq12 conj12(const Fq12& x) { return {x.a, neg6(x.b)}; }      // x^(q^6); the inverse inside the cyclotomic subgroup
+inline Fq12 inv12(const Fq12& x) { const Fq6 t = inv6(x.a * x.a - mul_v(x.b * x.b)); return {x.a * t, neg6(x.b * t)}; }
+inline bool is_one12(const Fq12& x) { const Fq12 o = one12(); return memcmp(&x, &o, sizeof o) == 0; }
+// f (c0 + d0 w + d1 w^3): the product with a line, 13 products in Fq2 instead of 18
+inline Fq12 mul_by_034(const Fq12& f, const Fq2& c0, const Fq2& d0, const Fq2& d1) {
+    const Fq6 a = mul_by_fq2(f.a, c0), b = mul_by_01(f.b, d0, d1), e = mul_by_01(f.a + f.b, c0 + d0, d1);
+    return {a + mul_v(b), e - a - b};
+}
+
+// ---- constants derived once: xi^((q-1)/6) and its powers (Frobenius on Fq12 and on the twist), the twist's b, 1/2 ----
+struct Consts {
+    Fq2 g1[6], g3[6]; Fq g2[6];          // gk[i] = xi^(i (q^k - 1) / 6): w^i -> gk[i] w^i under x -> x^(q^k) (coefficients conjugated for odd k); g2 lies in Fq
+    Fq2 twist_b; Fq half;
+    Fq2 psi_x, psi_y, psi2_x, psi2_y;     // pi(Q) = (conj(x) psi_x, conj(y) psi_y); pi^2(Q) = (x psi2_x, y psi2_y)
+};
+inline const Consts& consts() {
+    static const Consts C = [] {
+        Consts c;
+        uint32_t e6[8]; { uint32_t qm1[8]; for (int i = 0; i < 8; i++) qm1[i] = FqParams::p[i]; qm1[0] -= 1;
+                          uint64_t rem = 0; for (int i = 7; i >= 0; i--) { const uint64_t cur = (rem << 32) | qm1[i]; e6[i] = (uint32_t)(cur / 6); rem = cur % 6; } }
+        const Fq2 xi{fp_from_u32<FqParams>(9), Fq::one()};
+        const Fq2 g = fq2_pow(xi, e6, 254);
+        c.g1[0] = Fq2::one(); for (int i = 1; i < 6; i++) c.g1[i] = c.g1[i - 1] * g;
+        for (int i = 0; i < 6; i++) { const Fq2 n = c.g1[i] * conj2(c.g1[i]); c.g2[i] = n.c0; c.g3[i] = scale2(c.g1[i], n.c0); }      // q^2 - 1 = (q - 1)(q + 1), q^3 - 1 = (q - 1)(q^2 + q + 1)
+        c.twist_b = scale2(fp_inv_gcd(xi), fp_from_u32<FqParams>(3));
+        c.half = fp_inv_gcd(fp_from_u32<FqParams>(2));
+        c.psi_x = c.g1[2]; c.psi_y = c.g1[3];                                       // xi^((q-1)/3), xi^((q-1)/2)
+        c.psi2_x = {c.g2[2], Fq::zero()}; c.psi2_y = {c.g2[3], Fq::zero()};
+        return c;
+    }();
+    return C;
+}
+inline Fq12 frobenius(const Fq12& f, int k) {                       // f^(q^k), k = 1, 2, 3
+    const Consts& C = consts();
+    const Fq2* c[6] = {&f.a.a0, &f.b.a0, &f.a.a1, &f.b.a1, &f.a.a2, &f.b.a2};       // coefficients of w^0 .. w^5
+    Fq2 o[6];
+    for (int i = 0; i < 6; i++) {
+        const Fq2 x = (k & 1) ? conj2(*c[i]) : *c[i];
+        o[i] = k == 1 ? x * C.g1[i] : k == 2 ? scale2(x, C.g2[i]) : x * C.g3[i];
+    }
+    return {{o[0], o[2], o[4]}, {o[1], o[3], o[5]}};
+}
+
+// ---- Miller loop ----
+typedef std::array<Fq2, 3> LineCoeffs;                               // (c, d0, d1): the line is c yP + d0 xP w + d1 w^3
+struct G2Prepared { std::vector<LineCoeffs> lines; bool inf = true; };
+static const uint64_t ATE_LOOP[2] = {0x9d797039be763ba8ull, 0x1ull};  // 6x + 2 = 29793968203157093288, x = 4965661367192848881; 65 bits
+// Q -> the coefficients of every line of its Miller loop, in loop order (Costello-Lange-Naehrig homogeneous formulas, as arkworks' bn / gnark lay them out)
+inline G2Prepared prepare_g2(const G2Affine& Q) {
+    G2Prepared out; if (Q.is_inf()) return out;
+    out.inf = false; out.lines.reserve(104);
+    const Consts& C = consts();
+    Fq2 X = Q.x, Y = Q.y, Z = Fq2::one();
+    auto dbl = [&] {
+        const Fq2 a = scale2(X * Y, C.half), b = fp_sqr(Y), c = fp_sqr(Z), c3 = fp_dbl(c) + c, e = C.twist_b * c3, f = fp_dbl(e) + e, g = scale2(b + f, C.half),
+                  h = fp_sqr(Y + Z) - (b + c), i = e - b, j = fp_sqr(X), e2 = fp_sqr(e);
+        X = a * (b - f); Y = fp_sqr(g) - (fp_dbl(e2) + e2); Z = b * h;
+        out.lines.push_back({fp_neg(h), fp_dbl(j) + j, i});
+    };
+    auto add = [&](const Fq2& xq, const Fq2& yq) {
+        const Fq2 theta = Y - yq * Z, lambda = X - xq * Z, c = fp_sqr(theta), d = fp_sqr(lambda), e = lambda * d, f = Z * c, g = X * d, h = e + f - fp_dbl(g);
+        const Fq2 j = theta * xq - lambda * yq;
+        X = lambda * h; Y = theta * (g - h) - e * Y; Z = Z * e;
+        out.lines.push_back({lambda, fp_neg(theta), j});
+    };
+    for (int i = 63; i >= 0; i--) { dbl(); if ((ATE_LOOP[i >> 6] >> (i & 63)) & 1) add(Q.x, Q.y); }
+    add(conj2(Q.x) * C.psi_x, conj2(Q.y) * C.psi_y);                               // + pi(Q)
+    add(Q.x * C.psi2_x, fp_neg(Q.y * C.psi2_y));                                   // - pi^2(Q)
+    return out;
+}
+struct Pair { G1Affine P; const G2Prepared* Q; };
+// prod_k f_{6x+2, Q_k}(P_k) with its Frobenius lines, all pairs on one accumulator.  Pairs with P or Q at infinity contribute 1.
+inline Fq12 multi_miller(const Pair* pairs, size_t n) {
+    std::vector<const Pair*> live; for (size_t k = 0; k < n; k++) if (!pairs[k].P.is_inf() && !pairs[k].Q->inf) live.push_back(&pairs[k]);
+    Fq12 f = one12(); size_t idx = 0;
+    auto ell = [&] { for (const Pair* p : live) { const LineCoeffs& l = p->Q->lines[idx]; f = mul_by_034(f, scale2(l[0], p->P.y), scale2(l[1], p->P.x), l[2]); } idx++; };
+    if (live.empty()) return f;
+    for (int i = 63; i >= 0; i--) { if (i != 63) f = sqr12(f); ell(); if ((ATE_LOOP[i >> 6] >> (i & 63)) & 1) ell(); }
+    ell(); ell();
+    return f;
+}
+inline Fq12 miller(const G1Affine& P, const G2Affine& Q) { const G2Prepared q = prepare_g2(Q); const Pair p{P, &q}; return multi_miller(&p, 1); }
+
+// ---- final exponentiation: f -> f^((q^12 - 1)/r * 2x(6x^2 + 3x + 1)) ----
+inline Fq12 exp_by_neg_x(const Fq12& f) {                            // f^(-x) inside the cyclotomic subgroup
+    static const uint64_t X = 4965661367192848881ull;
+    Fq12 r = f;
+    for (int i = 61; i >= 0; i--) { r = sqr12(r); if ((X >> i) & 1) r = r * f; }   // bit 62 is the top one
+    return conj12(r);
+}
+inline Fq12 final_exp(const Fq12& f) {
+    Fq12 r = conj12(f) * inv12(f);                                   // f^(q^6 - 1)
+    r = frobenius(r, 2) * r;                                         // ^(q^2 + 1): r is in the cyclotomic subgroup from here on
+    // Fuentes-Castaneda, Knapp, Rodriguez-Henriquez: lambda_0 + lambda_1 q + lambda_2 q^2 + lambda_3 q^3 with
+    // lambda_0 = 1 + 6x + 12x^2 + 12x^3, lambda_1 = 4x + 6x^2 + 12x^3, lambda_2 = 6x + 6x^2 + 12x^3, lambda_3 = lambda_1 - 1
+    const Fq12 y0 = exp_by_neg_x(r), y1 = sqr12(y0), y2 = sqr12(y1), y3n = y2 * y1, y4 = exp_by_neg_x(y3n), y5 = sqr12(y4), y6n = exp_by_neg_x(y5);
+    const Fq12 y3 = conj12(y3n), y6 = conj12(y6n);
+    const Fq12 y7 = y6 * y4, y8 = y7 * y3, y9 = y8 * y1, y10 = y8 * y4, y11 = y10 * r;
+    const Fq12 y13 = frobenius(y9, 1) * y11, y14 = frobenius(y8, 2) * y13, y15 = frobenius(conj12(r) * y9, 3);
+    return y15 * y14;
+}
+}}  // namespace zkc::pairing

@@ -3,8 +3,7 @@
 //
 // Mirrors go-rapidsnark/verifier VerifyGroth16 behind dvote's proof.Verify (zk_census_test.go:122) and snarkjs
 // groth16.verify: vk_x = IC0 + sum s_i IC_{i+1};  e(-A, B) e(alpha, beta) e(vk_x, gamma) e(C, delta) == 1.
-// The pairing is the plain ate pairing over T = 6x^2 with affine line functions and a straight final exponentiation:
-// verification is a handful of milliseconds per proof and is not on the throughput path.
+// The pairing lives in zkc_pairing_host.h (optimal ate, projective sparse lines, shared accumulator, prepared G2 points, cyclotomic final exponentiation).
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -14,135 +13,35 @@
 #include <algorithm>
 #include "zkc_prover.h"
 #include "zkc_hostparse.h"
+#include "zkc_pairing_host.h"
 #include <sys/random.h>
 #include <cerrno>
 #include <mutex>
+#include <memory>
+#include <array>
 
 using namespace zkc;
+using namespace zkc::pairing;
 
 namespace {
 
-// ---------------- Fq6 = Fq2[v]/(v^3 - xi), Fq12 = Fq6[w]/(w^2 - v), xi = 9 + u ----------------
-Fq2 mul_xi(const Fq2& a) {
-    Fq t0 = fp_dbl(fp_dbl(fp_dbl(a.c0))) + a.c0, t1 = fp_dbl(fp_dbl(fp_dbl(a.c1))) + a.c1;   // 9a
-    return {t0 - a.c1, t1 + a.c0};
-}
-struct Fq6 { Fq2 a0, a1, a2; };
-struct Fq12 { Fq6 a, b; };
-Fq6 operator+(const Fq6& x, const Fq6& y) { return {x.a0 + y.a0, x.a1 + y.a1, x.a2 + y.a2}; }
-Fq6 operator-(const Fq6& x, const Fq6& y) { return {x.a0 - y.a0, x.a1 - y.a1, x.a2 - y.a2}; }
-Fq6 neg6(const Fq6& x) { return {fp_neg(x.a0), fp_neg(x.a1), fp_neg(x.a2)}; }
-Fq6 operator*(const Fq6& x, const Fq6& y) {
-    return {x.a0 * y.a0 + mul_xi(x.a1 * y.a2 + x.a2 * y.a1), x.a0 * y.a1 + x.a1 * y.a0 + mul_xi(x.a2 * y.a2), x.a0 * y.a2 + x.a1 * y.a1 + x.a2 * y.a0};
-}
-Fq6 mul_v(const Fq6& x) { return {mul_xi(x.a2), x.a0, x.a1}; }
-Fq6 inv6(const Fq6& x) {
-    Fq2 c0 = fp_sqr(x.a0) - mul_xi(x.a1 * x.a2), c1 = mul_xi(fp_sqr(x.a2)) - x.a0 * x.a1, c2 = fp_sqr(x.a1) - x.a0 * x.a2;
-    Fq2 t = fp_inv(mul_xi(x.a2 * c1 + x.a1 * c2) + x.a0 * c0);
-    return {c0 * t, c1 * t, c2 * t};
-}
-Fq12 one12() { Fq12 r{}; r.a.a0 = Fq2::one(); r.a.a1 = r.a.a2 = r.b.a0 = r.b.a1 = r.b.a2 = Fq2::zero(); return r; }
-Fq12 operator*(const Fq12& x, const Fq12& y) { return {x.a * y.a + mul_v(x.b * y.b), x.a * y.b + x.b * y.a}; }
-Fq12 conj12(const Fq12& x) { return {x.a, neg6(x.b)}; }
-Fq12 inv12(const Fq12& x) { Fq6 t = inv6(x.a * x.a - mul_v(x.b * x.b)); return {x.a * t, neg6(x.b * t)}; }
-bool is_one12(const Fq12& x) { Fq12 o = one12(); return memcmp(&x, &o, sizeof o) == 0; }
-
-// line through twist points with slope lam evaluated at P in G1:  yP + (-lam xP) w + (lam xT - yT) w^3
-Fq12 line_eval(const Fq2& lam, const Fq2& xT, const Fq2& yT, const G1Affine& P) {
-    Fq12 l{}; l.a.a0 = {P.y, Fq::zero()}; l.a.a1 = l.a.a2 = l.b.a2 = Fq2::zero();
-    l.b.a0 = fp_neg(lam * Fq2{P.x, Fq::zero()}); l.b.a1 = lam * xT - yT;
-    return l;
-}
-Fq12 miller(const G1Affine& P, const G2Affine& Q) {
-    static const uint64_t T[2] = {0xf83e9682e87cfd46ull, 0x6f4d8248eeb859fbull};   // 6 x^2, x = 4965661367192848881
-    Fq12 f = one12();
-    if (P.is_inf() || Q.is_inf()) return f;
-    Fq2 xR = Q.x, yR = Q.y; bool rinf = false;
-    for (int i = 125; i >= 0; i--) {
-        f = f * f;
-        if (!rinf) {
-            Fq2 x2 = fp_sqr(xR), lam = (fp_dbl(x2) + x2) * fp_inv(fp_dbl(yR));
-            f = f * line_eval(lam, xR, yR, P);
-            Fq2 x3 = fp_sqr(lam) - fp_dbl(xR), y3 = lam * (xR - x3) - yR;
-            xR = x3; yR = y3;
-        }
-        if ((T[i >> 6] >> (i & 63)) & 1) {
-            if (rinf) { xR = Q.x; yR = Q.y; rinf = false; continue; }
-            Fq2 dx = Q.x - xR;
-            if (dx.is_zero()) {
-                if ((Q.y - yR).is_zero()) {                              // R == Q: the chord is the tangent (only small-order points get here)
-                    Fq2 x2 = fp_sqr(xR), lam = (fp_dbl(x2) + x2) * fp_inv(fp_dbl(yR));
-                    f = f * line_eval(lam, xR, yR, P);
-                    Fq2 x3 = fp_sqr(lam) - fp_dbl(xR), y3 = lam * (xR - x3) - yR;
-                    xR = x3; yR = y3;
-                } else rinf = true;                                      // R == -Q: vertical line, killed by the final exponentiation
-                continue;
-            }
-            Fq2 lam = (Q.y - yR) * fp_inv(dx);
-            f = f * line_eval(lam, xR, yR, P);
-            Fq2 x3 = fp_sqr(lam) - xR - Q.x, y3 = lam * (xR - x3) - yR;
-            xR = x3; yR = y3;
-        }
-    }
-    return f;
-}
-Fq12 final_exp(const Fq12& f) {          // (q^12 - 1)/r = (q^6 - 1) * ((q^6 + 1)/r); f^(q^6) = conj(f)
-    static const uint64_t E[20] = {
-        0x5250a54036e3f812ull, 0xa5635f1596789051ull, 0xd1138bf54d5bd1d4ull, 0xa8ce2533be36c7a2ull, 0x94f69f6b84e09bf6ull,
-        0x42ad1f5e50ef3644ull, 0x0fcc420e48c3454cull, 0x758e4408ecc9952cull, 0xc901bf1887c6042cull, 0xa733cd65b14bb3b5ull,
-        0xdf6d76bdcf51b0d8ull, 0xca64c0fd82eb59e1ull, 0x1d2e5726e39276a1ull, 0xc2d1ea74a391cae9ull, 0x07409206c82d647eull,
-        0x051c6d1aa5afdd17ull, 0xb37f601919667af5ull, 0x150e578c5084015bull, 0xfbdea556c23998e4ull, 0x000fd14cc52f5b83ull};
-    Fq12 b = conj12(f) * inv12(f), r = one12();
-    for (int k = 1267; k >= 0; k--) { r = r * r; if ((E[k >> 6] >> (k & 63)) & 1) r = r * b; }
-    return r;
-}
-// ---- the pairing value snarkjs stores in verification_key.json as vk_alphabeta_12 (artifacts/zkCensus/dev/160/verification_key.json:52) ----
-// ffjavascript/wasmcurves follow libff's alt_bn128: optimal ate Miller loop over 6x + 2 with the two Frobenius line steps, then a final
-// exponentiation whose last chunk (Fuentes-Castaneda et al.) yields the reduced pairing raised to 2x(6x^2 + 3x + 1).  Pinned by
-// tests/test_oracle_pinning.py against the reference's own verification key (alpha, beta -> vk_alphabeta_12).
-Fq2 fq2_pow(const Fq2& a, const uint32_t* e, int nbits) { Fq2 r = Fq2::one(); for (int i = nbits - 1; i >= 0; i--) { r = fp_sqr(r); if ((e[i >> 5] >> (i & 31)) & 1) r = r * a; } return r; }
-Fq2 fq2_conj(const Fq2& a) { return {a.c0, fp_neg(a.c1)}; }
-Fq12 miller_optimal_ate(const G1Affine& P, const G2Affine& Q) {
-    Fq12 f = one12();
-    if (P.is_inf() || Q.is_inf()) return f;
-    static const uint64_t S[2] = {0x9d797039be763ba8ull, 0x1ull};             // 6x + 2 = 29793968203157093288
-    Fq2 xR = Q.x, yR = Q.y;
-    auto dbl = [&]() { Fq2 x2 = fp_sqr(xR), lam = (fp_dbl(x2) + x2) * fp_inv(fp_dbl(yR)); f = f * line_eval(lam, xR, yR, P);
-                       Fq2 x3 = fp_sqr(lam) - fp_dbl(xR), y3 = lam * (xR - x3) - yR; xR = x3; yR = y3; };
-    auto add = [&](const Fq2& xq, const Fq2& yq) { Fq2 lam = (yq - yR) * fp_inv(xq - xR); f = f * line_eval(lam, xR, yR, P);
-                                                   Fq2 x3 = fp_sqr(lam) - xR - xq, y3 = lam * (xR - x3) - yR; xR = x3; yR = y3; };
-    for (int i = 63; i >= 0; i--) { f = f * f; dbl(); if ((S[i >> 6] >> (i & 63)) & 1) add(Q.x, Q.y); }
-    // pi(Q) = (conj(x) xi^((q-1)/3), conj(y) xi^((q-1)/2)); pi^2(Q) = (x N(g12), y N(g13)) with the norms of those constants
-    uint32_t e3[8], e2[8];
-    { uint32_t qm1[8]; for (int i = 0; i < 8; i++) qm1[i] = FqParams::p[i]; qm1[0] -= 1;
-      uint64_t rem = 0; for (int i = 7; i >= 0; i--) { uint64_t cur = (rem << 32) | qm1[i]; e3[i] = (uint32_t)(cur / 3); rem = cur % 3; }
-      for (int i = 0; i < 8; i++) e2[i] = (qm1[i] >> 1) | (i < 7 ? qm1[i + 1] << 31 : 0); }
-    const Fq2 xi{fp_from_u32<FqParams>(9), Fq::one()};
-    const Fq2 g12 = fq2_pow(xi, e3, 254), g13 = fq2_pow(xi, e2, 254);
-    const Fq2 x1 = fq2_conj(Q.x) * g12, y1 = fq2_conj(Q.y) * g13;
-    const Fq2 x2 = Q.x * (g12 * fq2_conj(g12)), y2 = fp_neg(Q.y * (g13 * fq2_conj(g13)));
-    add(x1, y1); add(x2, y2);
-    return f;
-}
-Fq12 pairing_snarkjs(const G1Affine& P, const G2Affine& Q) {
-    const Fq12 e = final_exp(miller_optimal_ate(P, Q));
-    // m = 2x(6x^2 + 3x + 1), x = 4965661367192848881
-    static const uint64_t M[3] = {0x2e5d4e223ddedaf4ull, 0x1ea96b02d9d9e38dull, 0x3bec47df15e307c8ull};      // 190 bits
-    Fq12 r = one12();
-    for (int k = 189; k >= 0; k--) { r = r * r; if ((M[k >> 6] >> (k & 63)) & 1) r = r * e; }
-    return r;
-}
+// e(P, Q) as snarkjs stores it in verification_key.json as vk_alphabeta_12 (artifacts/zkCensus/dev/160/verification_key.json:52): ffjavascript / wasmcurves follow
+// libff's alt_bn128, whose final exponentiation ends in the Fuentes-Castaneda chunk and so yields the reduced pairing raised to 2x(6x^2 + 3x + 1) -- which is what
+// pairing::final_exp returns.  Pinned by tests/test_oracle_pinning.py against the reference's own verification key (alpha, beta -> vk_alphabeta_12).
+Fq12 pairing_snarkjs(const G1Affine& P, const G2Affine& Q) { return final_exp(miller(P, Q)); }
 bool g1_on_curve(const G1Affine& a) { return a.is_inf() || fp_sqr(a.y) == fp_sqr(a.x) * a.x + fp_from_u32<FqParams>(3); }
 bool g2_on_curve(const G2Affine& a) {
     if (a.is_inf()) return true;
     static const Fq2 B = Fq2{fp_from_u32<FqParams>(3), Fq::zero()} * fp_inv(Fq2{fp_from_u32<FqParams>(9), Fq::one()});
     return fp_sqr(a.y) == fp_sqr(a.x) * a.x + B;
 }
-bool g2_in_subgroup(const G2Affine& a) {            // on the twist and [r]a = infinity
+bool g2_in_subgroup(const G2Affine& a) {            // on the twist and [r]a = infinity (the definition; mixed additions, no leading zero steps)
     if (!g2_on_curve(a)) return false;
     if (a.is_inf()) return true;
-    uint32_t rord[8]; for (int q = 0; q < 8; q++) rord[q] = FrParams::p[q];
-    return xyzz_mul(G2XYZZ::from_affine(a), rord).is_inf();
+    int top = 255; while (!((FrParams::p[top >> 5] >> (top & 31)) & 1)) top--;
+    G2XYZZ acc = G2XYZZ::from_affine(a);
+    for (int i = top - 1; i >= 0; i--) { acc = xyzz_dbl(acc); if ((FrParams::p[i >> 5] >> (i & 31)) & 1) acc = xyzz_add_affine(acc, a); }
+    return acc.is_inf();
 }
 bool rd_fq_std(Fq& o, const uint8_t* p) { uint32_t s[8]; memcpy(s, p, 32); if (!fp_std_lt_p<FqParams>(s)) return false; o = fp_from_std<FqParams>(s); return true; }
 bool rd_g1_std(G1Affine& o, const uint8_t* p) { return rd_fq_std(o.x, p) && rd_fq_std(o.y, p + 32); }
@@ -302,28 +201,71 @@ extern "C" int groth16_fullprove(const void* zkey_buffer, unsigned long zkey_siz
     return rc;
 }
 
+// ---- a verification key made ready once: points read and checked (on the curve, G2 points in the order-r subgroup), gamma and delta prepared into their line
+// coefficients, the Miller value of (alpha, beta) computed.  A node verifies every ballot of an election under ONE key (zk_census_test.go:103-124 per vote), so the
+// latest few keys are kept by their bytes; the three [r]Q checks and three preparations were a third of a verification. ----
+namespace {
+struct VkReady {
+    std::vector<uint8_t> bytes; int nPublic = 0;
+    G1Affine alpha; G2Affine beta, gamma, delta; std::vector<G1Affine> ic;
+    G2Prepared pgamma, pdelta, pbeta; Fq12 m_alpha_beta;
+};
+std::mutex g_vk_mu; std::vector<std::shared_ptr<const VkReady>> g_vk_ready;      // most recent first, at most 8
+std::shared_ptr<const VkReady> vk_ready(const uint8_t* vk, int nPublic, int* code) {
+    const size_t len = 448 + 64 * ((size_t)nPublic + 1);
+    {
+        std::lock_guard<std::mutex> g(g_vk_mu);
+        for (size_t i = 0; i < g_vk_ready.size(); i++)
+            if (g_vk_ready[i]->bytes.size() == len && !memcmp(g_vk_ready[i]->bytes.data(), vk, len)) {
+                auto hit = g_vk_ready[i];
+                if (i) { g_vk_ready.erase(g_vk_ready.begin() + (long)i); g_vk_ready.insert(g_vk_ready.begin(), hit); }
+                return hit;
+            }
+    }
+    auto r = std::make_shared<VkReady>(); r->bytes.assign(vk, vk + len); r->nPublic = nPublic; r->ic.resize((size_t)nPublic + 1);
+    if (!rd_g1_std(r->alpha, vk) || !rd_g2_std(r->beta, vk + 64) || !rd_g2_std(r->gamma, vk + 192) || !rd_g2_std(r->delta, vk + 320)) { *code = vfail(-ZKC_ERR_FORMAT, "verification key coordinate >= q"); return nullptr; }
+    if (!g1_on_curve(r->alpha) || !g2_in_subgroup(r->beta) || !g2_in_subgroup(r->gamma) || !g2_in_subgroup(r->delta)) { *code = vfail(-ZKC_ERR_FORMAT, "verification key point not on the curve / not in the order-r subgroup"); return nullptr; }
+    for (int j = 0; j <= nPublic; j++) if (!rd_g1_std(r->ic[j], vk + 448 + 64 * (size_t)j) || !g1_on_curve(r->ic[j])) { *code = vfail(-ZKC_ERR_FORMAT, "IC point invalid"); return nullptr; }
+    r->pgamma = prepare_g2(r->gamma); r->pdelta = prepare_g2(r->delta); r->pbeta = prepare_g2(r->beta);
+    const Pair ab{r->alpha, &r->pbeta}; r->m_alpha_beta = multi_miller(&ab, 1);
+    std::lock_guard<std::mutex> g(g_vk_mu);
+    g_vk_ready.insert(g_vk_ready.begin(), r); if (g_vk_ready.size() > 8) g_vk_ready.pop_back();
+    return r;
+}
+// sum_j k_j P_j over a handful of points (the public-input combination vk_x): one doubling chain shared by all scalars, mixed additions
+G1XYZZ g1_sum_of_products(const G1Affine* pts, const uint32_t (*k)[8], int n) {
+    int top = -1;
+    for (int b = 255; b >= 0 && top < 0; b--) for (int j = 0; j < n; j++) if ((k[j][b >> 5] >> (b & 31)) & 1) { top = b; break; }
+    G1XYZZ acc = G1XYZZ::inf();
+    for (int b = top; b >= 0; b--) {
+        acc = xyzz_dbl(acc);
+        for (int j = 0; j < n; j++) if ((k[j][b >> 5] >> (b & 31)) & 1) acc = xyzz_add_affine(acc, pts[j]);
+    }
+    return acc;
+}
+}  // namespace
+
 // vk: alpha1(64) beta2(128) gamma2(128) delta2(128) IC[nPublic+1](64 each); pub: nPublic x 32; proof: A(64) B(128) C(64); standard form
 extern "C" int zkc_verify_bin(const uint8_t* vk, int nPublic, const uint8_t* pub, const uint8_t* proof) {
     g_err.clear();
-    if (!vk || !pub || !proof || nPublic < 0) return vfail(-ZKC_ERR_BAD_ARG, "zkc_verify_bin: bad argument");
-    G1Affine alpha, A, C; G2Affine beta, gamma, delta, B;
-    if (!rd_g1_std(alpha, vk) || !rd_g2_std(beta, vk + 64) || !rd_g2_std(gamma, vk + 192) || !rd_g2_std(delta, vk + 320)) return vfail(-ZKC_ERR_FORMAT, "verification key coordinate >= q");
-    if (!g1_on_curve(alpha) || !g2_in_subgroup(beta) || !g2_in_subgroup(gamma) || !g2_in_subgroup(delta)) return vfail(-ZKC_ERR_FORMAT, "verification key point not on the curve / not in the order-r subgroup");
+    if (!vk || !pub || !proof || nPublic < 0 || nPublic > 4096) return vfail(-ZKC_ERR_BAD_ARG, "zkc_verify_bin: bad argument");
+    int code = 0;
+    const std::shared_ptr<const VkReady> V = vk_ready(vk, nPublic, &code);
+    if (!V) return code;
+    G1Affine A, C; G2Affine B;
     if (!rd_g1_std(A, proof) || !rd_g2_std(B, proof + 64) || !rd_g1_std(C, proof + 192)) return 0;
     // B must lie in the order-r subgroup of the twist (G2 has a cofactor): go-rapidsnark's bn256 unmarshalling and this library's batch verifier
     // reject such points too, so the two entry points agree on crafted proofs
     if (!g1_on_curve(A) || !g1_on_curve(C) || !g2_in_subgroup(B)) return 0;
-    G1Affine ic; if (!rd_g1_std(ic, vk + 448) || !g1_on_curve(ic)) return vfail(-ZKC_ERR_FORMAT, "IC point invalid");
-    G1XYZZ acc = G1XYZZ::from_affine(ic);
+    std::vector<std::array<uint32_t, 8>> k((size_t)nPublic);
     for (int i = 0; i < nPublic; i++) {
-        uint32_t k[8]; memcpy(k, pub + 32 * i, 32);
-        if (!fp_std_lt_p<FrParams>(k)) return 0;                                   // snarkjs: public input not in field -> invalid
-        if (!rd_g1_std(ic, vk + 448 + 64 * (i + 1)) || !g1_on_curve(ic)) return vfail(-ZKC_ERR_FORMAT, "IC point invalid");
-        acc = xyzz_add(acc, xyzz_mul(G1XYZZ::from_affine(ic), k));
+        memcpy(k[i].data(), pub + 32 * i, 32);
+        if (!fp_std_lt_p<FrParams>(k[i].data())) return 0;                         // snarkjs: public input not in field -> invalid
     }
-    const G1Affine vkx = xyzz_to_affine(acc);
-    Fq12 f = miller(affine_neg(A), B) * miller(alpha, beta) * miller(vkx, gamma) * miller(C, delta);
-    return is_one12(final_exp(f)) ? 1 : 0;
+    const G1Affine vkx = xyzz_to_affine_gcd(xyzz_add_affine(g1_sum_of_products(V->ic.data() + 1, (const uint32_t (*)[8])k.data(), nPublic), V->ic[0]));
+    const G2Prepared pB = prepare_g2(B);
+    const Pair pairs[3] = {{affine_neg(A), &pB}, {vkx, &V->pgamma}, {C, &V->pdelta}};
+    return is_one12(final_exp(multi_miller(pairs, 3) * V->m_alpha_beta)) ? 1 : 0;
 }
 
 // ---- f4: batch verification (the step on the other side of the path, zk_census_test.go:103-124 run per vote) ----
@@ -341,10 +283,11 @@ struct Xoshiro { uint64_t s[4]; uint64_t next() { auto rotl = [](uint64_t x, int
 extern "C" int zkc_verify_batch(zkc_ctx* ctx, const uint8_t* vk, int nPublic, const uint8_t* pubs, const uint8_t* proofs, int N, const uint8_t* seed32) {
     g_err.clear();
     if (!ctx || !vk || !pubs || !proofs || nPublic < 0 || N <= 0) return vfail(-ZKC_ERR_BAD_ARG, "zkc_verify_batch: bad argument");
-    G1Affine alpha; G2Affine beta, gamma, delta; std::vector<G1Affine> ic(nPublic + 1);
-    if (!rd_g1_std(alpha, vk) || !rd_g2_std(beta, vk + 64) || !rd_g2_std(gamma, vk + 192) || !rd_g2_std(delta, vk + 320)) return vfail(-ZKC_ERR_FORMAT, "verification key coordinate >= q");
-    for (int j = 0; j <= nPublic; j++) if (!rd_g1_std(ic[j], vk + 448 + 64 * (size_t)j) || !g1_on_curve(ic[j])) return vfail(-ZKC_ERR_FORMAT, "IC point invalid");
-    if (!g1_on_curve(alpha) || !g2_in_subgroup(beta) || !g2_in_subgroup(gamma) || !g2_in_subgroup(delta)) return vfail(-ZKC_ERR_FORMAT, "verification key point not on the curve / not in the order-r subgroup");
+    if (nPublic > 4096) return vfail(-ZKC_ERR_BAD_ARG, "zkc_verify_batch: bad argument");
+    int code = 0;
+    const std::shared_ptr<const VkReady> V = vk_ready(vk, nPublic, &code);
+    if (!V) return code;
+    const std::vector<G1Affine>& ic = V->ic;
     Xoshiro rng;
     if (seed32) memcpy(rng.s, seed32, 32); else { std::random_device rd; for (auto& x : rng.s) x = ((uint64_t)rd() << 32) | rd(); }
     if (!(rng.s[0] | rng.s[1] | rng.s[2] | rng.s[3])) rng.s[0] = 1;
@@ -385,26 +328,35 @@ extern "C" int zkc_verify_batch(zkc_ctx* ctx, const uint8_t* vk, int nPublic, co
         if (rc) return vfail(rc > 0 ? -rc : -ZKC_ERR_GENERIC, std::string("zkc_verify_batch: ") + zkc_last_error(ctx));
     }
     // ---- vk_x side: (sum rho) IC0 + sum_j (sum_i rho_i x_ij) IC_j ----
-    uint32_t k[8]; fp_to_std<FrParams>(k, rsum);
-    G1XYZZ vx = xyzz_mul(G1XYZZ::from_affine(ic[0]), k);
-    const G1Affine ralpha = xyzz_to_affine(xyzz_mul(G1XYZZ::from_affine(alpha), k));
-    for (int j = 0; j < nPublic; j++) { fp_to_std<FrParams>(k, xsum[j]); vx = xyzz_add(vx, xyzz_mul(G1XYZZ::from_affine(ic[j + 1]), k)); }
-    // ---- Miller loops on host threads (and the subgroup check of every B_i) ----
-    const unsigned nthr = std::max(1u, std::min({std::thread::hardware_concurrency(), 32u, (unsigned)N}));
+    std::vector<std::array<uint32_t, 8>> ks((size_t)nPublic + 1);
+    fp_to_std<FrParams>(ks[0].data(), rsum);
+    for (int j = 0; j < nPublic; j++) fp_to_std<FrParams>(ks[j + 1].data(), xsum[j]);
+    const G1XYZZ vx = g1_sum_of_products(ic.data(), (const uint32_t (*)[8])ks.data(), nPublic + 1);
+    const G1Affine ralpha = xyzz_to_affine_gcd(g1_sum_of_products(&V->alpha, (const uint32_t (*)[8])ks.data(), 1));
+    // ---- Miller loops on host threads (and the subgroup check of every B_i): a thread's pairs share one accumulator, sixteen at a time ----
+    const unsigned nthr = std::max(1u, std::min({std::thread::hardware_concurrency(), 32u, ((unsigned)N + 7) / 8}));
     std::vector<Fq12> part(nthr, one12()); std::vector<int> bad(nthr, 0);
     auto work = [&](unsigned t) {
-        uint32_t rord[8]; for (int q = 0; q < 8; q++) rord[q] = FrParams::p[q];
-        Fq12 f = one12();
-        for (int i = (int)t; i < N; i += (int)nthr) {
-            if (!Bs[i].is_inf() && !xyzz_mul(G2XYZZ::from_affine(Bs[i]), rord).is_inf()) { bad[t] = 1; return; }
-            f = f * miller(affine_neg(xyzz_to_affine(gout[i])), Bs[i]);
+        constexpr int CH = 16;
+        const int lo = (int)((size_t)N * t / nthr), hi = (int)((size_t)N * (t + 1) / nthr);
+        Fq12 f = one12(); G2Prepared prep[CH]; Pair pairs[CH];
+        for (int i0 = lo; i0 < hi; i0 += CH) {
+            const int n = std::min(CH, hi - i0);
+            for (int k = 0; k < n; k++) {
+                const int i = i0 + k;
+                if (!g2_in_subgroup(Bs[i])) { bad[t] = 1; return; }
+                prep[k] = prepare_g2(Bs[i]);
+                pairs[k] = {affine_neg(xyzz_to_affine_gcd(gout[i])), &prep[k]};
+            }
+            f = f * multi_miller(pairs, (size_t)n);
         }
         part[t] = f;
     };
     std::vector<std::thread> th; for (unsigned t = 1; t < nthr; t++) th.emplace_back(work, t);
     work(0); for (auto& x : th) x.join();
     for (unsigned t = 0; t < nthr; t++) if (bad[t]) return 0;
-    Fq12 f = miller(ralpha, beta) * miller(xyzz_to_affine(vx), gamma) * miller(xyzz_to_affine(gout[N]), delta);
+    const Pair tail[3] = {{ralpha, &V->pbeta}, {xyzz_to_affine_gcd(vx), &V->pgamma}, {xyzz_to_affine_gcd(gout[N]), &V->pdelta}};
+    Fq12 f = multi_miller(tail, 3);
     for (unsigned t = 0; t < nthr; t++) f = f * part[t];
     return is_one12(final_exp(f)) ? 1 : 0;
 }
