@@ -54,6 +54,24 @@ inline Fq12 sqr12(const Fq12& x) {                                   // complex 
     const Fq6 ab = x.a * x.b;
     return {(x.a + x.b) * (x.a + mul_v(x.b)) - ab - mul_v(ab), ab + ab};
 }
+// squaring inside the cyclotomic subgroup (Granger-Scott: Fq12 as three Fq4 = Fq2[y]/(y^2 - xi) squarings, 6 products in Fq2 instead of 12); valid for x with
+// x^(q^4 - q^2 + 1) = 1, which everything after the easy part of the final exponentiation satisfies
+inline Fq12 cyclotomic_sqr(const Fq12& x) {
+    const Fq2 &r0 = x.a.a0, &r4 = x.a.a1, &r3 = x.a.a2, &r2 = x.b.a0, &r1 = x.b.a1, &r5 = x.b.a2;
+    auto sq4 = [](const Fq2& a, const Fq2& b, Fq2& t0, Fq2& t1) {      // (a + b y)^2 = t0 + t1 y
+        const Fq2 ab = a * b;
+        t0 = (a + b) * (mul_xi(b) + a) - ab - mul_xi(ab); t1 = fp_dbl(ab);
+    };
+    Fq2 t0, t1, t2, t3, t4, t5;
+    sq4(r0, r1, t0, t1); sq4(r2, r3, t2, t3); sq4(r4, r5, t4, t5);
+    auto three_minus_two = [](const Fq2& t, const Fq2& z) { return fp_dbl(t - z) + t; };      // 3t - 2z
+    auto three_plus_two = [](const Fq2& t, const Fq2& z) { return fp_dbl(t + z) + t; };       // 3t + 2z
+    Fq12 o;
+    o.a.a0 = three_minus_two(t0, r0); o.b.a1 = three_plus_two(t1, r1);
+    o.b.a0 = three_plus_two(mul_xi(t5), r2); o.a.a2 = three_minus_two(t4, r3);
+    o.a.a1 = three_minus_two(t2, r4); o.b.a2 = three_plus_two(t3, r5);
+    return o;
+}
 inline Fq12 conj12(const Fq12& x) { return {x.a, neg6(x.b)}; }      // x^(q^6); the inverse inside the cyclotomic subgroup
 inline Fq12 inv12(const Fq12& x) { const Fq6 t = inv6(x.a * x.a - mul_v(x.b * x.b)); return {x.a * t, neg6(x.b * t)}; }
 inline bool is_one12(const Fq12& x) { const Fq12 o = one12(); return memcmp(&x, &o, sizeof o) == 0; }
@@ -97,15 +115,60 @@ inline Fq12 frobenius(const Fq12& f, int k) {                       // f^(q^k), 
     return {{o[0], o[2], o[4]}, {o[1], o[3], o[5]}};
 }
 
+// ---- curve and subgroup membership ----
+inline bool g1_on_curve(const G1Affine& a) { return a.is_inf() || fp_sqr(a.y) == fp_sqr(a.x) * a.x + fp_from_u32<FqParams>(3); }
+inline bool g2_on_curve(const G2Affine& a) {
+    if (a.is_inf()) return true;
+    return fp_sqr(a.y) == fp_sqr(a.x) * a.x + consts().twist_b;
+}
+// membership in G2, the order-r subgroup of the twist, by definition: [r]a = infinity.  Kept as the cross-check of the one below (tests/host/pairing_host.hip)
+inline bool g2_in_subgroup_by_order(const G2Affine& a) {
+    if (!g2_on_curve(a)) return false;
+    if (a.is_inf()) return true;
+    int top = 255; while (!((FrParams::p[top >> 5] >> (top & 31)) & 1)) top--;
+    G2XYZZ acc = G2XYZZ::from_affine(a);
+    for (int i = top - 1; i >= 0; i--) { acc = xyzz_dbl(acc); if ((FrParams::p[i >> 5] >> (i & 31)) & 1) acc = xyzz_add_affine(acc, a); }
+    return acc.is_inf();
+}
+// ... at half the work: psi(a) == [6x^2]a, psi the untwist-Frobenius-twist map.  psi satisfies X^2 - tX + q = 0 on the whole twist, so psi(a) = [u]a gives
+// [u^2 - tu + q]a = 0, and with u = t - 1 = 6x^2 that scalar is q - 6x^2 = r: a has order r (or is infinity), and the points of order dividing r in E'(Fq2) are exactly
+// G2 (r divides the group order once).  Conversely psi acts on G2 as multiplication by q = t - 1 mod r.  A 127-bit scalar instead of a 254-bit one.
+inline bool g2_in_subgroup(const G2Affine& a) {
+    if (!g2_on_curve(a)) return false;
+    if (a.is_inf()) return true;
+    static const uint64_t T[2] = {0xf83e9682e87cfd46ull, 0x6f4d8248eeb859fbull};   // 6 x^2, x = 4965661367192848881; bit 126 is the top one
+    G2XYZZ acc = G2XYZZ::from_affine(a);
+    for (int i = 125; i >= 0; i--) { acc = xyzz_dbl(acc); if ((T[i >> 6] >> (i & 63)) & 1) acc = xyzz_add_affine(acc, a); }
+    if (acc.is_inf()) return false;
+    const Consts& C = consts();
+    return acc.X == conj2(a.x) * C.psi_x * acc.ZZ && acc.Y == conj2(a.y) * C.psi_y * acc.ZZZ;
+}
+
 // ---- Miller loop ----
 typedef std::array<Fq2, 3> LineCoeffs;                               // (c, d0, d1): the line is c yP + d0 xP w + d1 w^3
 struct G2Prepared { std::vector<LineCoeffs> lines; bool inf = true; };
-static const uint64_t ATE_LOOP[2] = {0x9d797039be763ba8ull, 0x1ull};  // 6x + 2 = 29793968203157093288, x = 4965661367192848881; 65 bits
+// 6x + 2 = 29793968203157093288 (x = 4965661367192848881, 65 bits) in signed digits: the non-adjacent form, its top "1 0 -1" folded back to "1 1" so that the loop
+// keeps 64 doublings -- 24 additions instead of the 36 set bits.  digit[64] = 1 is the starting point R = Q.
+struct AteLoop { int8_t digit[65]; };
+inline const AteLoop& ate_loop() {
+    static const AteLoop L = [] {
+        AteLoop l{}; const unsigned __int128 value = ((unsigned __int128)1 << 64) | 0x9d797039be763ba8ull;
+        int8_t d[68] = {0}; int len = 0;
+        for (unsigned __int128 n = value; n; n >>= 1, len++)
+            if (n & 1) { if ((n & 3) == 1) { d[len] = 1; n -= 1; } else { d[len] = -1; n += 1; } }
+        if (len == 66 && d[65] == 1 && d[64] == 0 && d[63] == -1) { d[65] = 0; d[64] = 1; d[63] = 1; len = 65; }      // 2^65 - 2^63 = 2^64 + 2^63
+        __int128 back = 0; for (int i = len - 1; i >= 0; i--) back = 2 * back + d[i];
+        if (len != 65 || d[64] != 1 || back != (__int128)value) { for (int i = 0; i < 65; i++) d[i] = (int8_t)((value >> i) & 1); }   // plain binary (never taken for this constant)
+        for (int i = 0; i < 65; i++) l.digit[i] = d[i];
+        return l;
+    }();
+    return L;
+}
 // Q -> the coefficients of every line of its Miller loop, in loop order (Costello-Lange-Naehrig homogeneous formulas, as arkworks' bn / gnark lay them out)
 inline G2Prepared prepare_g2(const G2Affine& Q) {
     G2Prepared out; if (Q.is_inf()) return out;
-    out.inf = false; out.lines.reserve(104);
-    const Consts& C = consts();
+    out.inf = false; out.lines.reserve(96);
+    const Consts& C = consts(); const AteLoop& L = ate_loop();
     Fq2 X = Q.x, Y = Q.y, Z = Fq2::one();
     auto dbl = [&] {
         const Fq2 a = scale2(X * Y, C.half), b = fp_sqr(Y), c = fp_sqr(Z), c3 = fp_dbl(c) + c, e = C.twist_b * c3, f = fp_dbl(e) + e, g = scale2(b + f, C.half),
@@ -119,7 +182,8 @@ inline G2Prepared prepare_g2(const G2Affine& Q) {
         X = lambda * h; Y = theta * (g - h) - e * Y; Z = Z * e;
         out.lines.push_back({lambda, fp_neg(theta), j});
     };
-    for (int i = 63; i >= 0; i--) { dbl(); if ((ATE_LOOP[i >> 6] >> (i & 63)) & 1) add(Q.x, Q.y); }
+    const Fq2 nQy = fp_neg(Q.y);
+    for (int i = 63; i >= 0; i--) { dbl(); if (L.digit[i] > 0) add(Q.x, Q.y); else if (L.digit[i] < 0) add(Q.x, nQy); }
     add(conj2(Q.x) * C.psi_x, conj2(Q.y) * C.psi_y);                               // + pi(Q)
     add(Q.x * C.psi2_x, fp_neg(Q.y * C.psi2_y));                                   // - pi^2(Q)
     return out;
@@ -131,7 +195,8 @@ inline Fq12 multi_miller(const Pair* pairs, size_t n) {
     Fq12 f = one12(); size_t idx = 0;
     auto ell = [&] { for (const Pair* p : live) { const LineCoeffs& l = p->Q->lines[idx]; f = mul_by_034(f, scale2(l[0], p->P.y), scale2(l[1], p->P.x), l[2]); } idx++; };
     if (live.empty()) return f;
-    for (int i = 63; i >= 0; i--) { if (i != 63) f = sqr12(f); ell(); if ((ATE_LOOP[i >> 6] >> (i & 63)) & 1) ell(); }
+    const AteLoop& L = ate_loop();
+    for (int i = 63; i >= 0; i--) { if (i != 63) f = sqr12(f); ell(); if (L.digit[i]) ell(); }
     ell(); ell();
     return f;
 }
@@ -141,7 +206,7 @@ inline Fq12 miller(const G1Affine& P, const G2Affine& Q) { const G2Prepared q = 
 inline Fq12 exp_by_neg_x(const Fq12& f) {                            // f^(-x) inside the cyclotomic subgroup
     static const uint64_t X = 4965661367192848881ull;
     Fq12 r = f;
-    for (int i = 61; i >= 0; i--) { r = sqr12(r); if ((X >> i) & 1) r = r * f; }   // bit 62 is the top one
+    for (int i = 61; i >= 0; i--) { r = cyclotomic_sqr(r); if ((X >> i) & 1) r = r * f; }   // bit 62 is the top one
     return conj12(r);
 }
 inline Fq12 final_exp(const Fq12& f) {
@@ -149,7 +214,7 @@ inline Fq12 final_exp(const Fq12& f) {
     r = frobenius(r, 2) * r;                                         // ^(q^2 + 1): r is in the cyclotomic subgroup from here on
     // Fuentes-Castaneda, Knapp, Rodriguez-Henriquez: lambda_0 + lambda_1 q + lambda_2 q^2 + lambda_3 q^3 with
     // lambda_0 = 1 + 6x + 12x^2 + 12x^3, lambda_1 = 4x + 6x^2 + 12x^3, lambda_2 = 6x + 6x^2 + 12x^3, lambda_3 = lambda_1 - 1
-    const Fq12 y0 = exp_by_neg_x(r), y1 = sqr12(y0), y2 = sqr12(y1), y3n = y2 * y1, y4 = exp_by_neg_x(y3n), y5 = sqr12(y4), y6n = exp_by_neg_x(y5);
+    const Fq12 y0 = exp_by_neg_x(r), y1 = cyclotomic_sqr(y0), y2 = cyclotomic_sqr(y1), y3n = y2 * y1, y4 = exp_by_neg_x(y3n), y5 = cyclotomic_sqr(y4), y6n = exp_by_neg_x(y5);
     const Fq12 y3 = conj12(y3n), y6 = conj12(y6n);
     const Fq12 y7 = y6 * y4, y8 = y7 * y3, y9 = y8 * y1, y10 = y8 * y4, y11 = y10 * r;
     const Fq12 y13 = frobenius(y9, 1) * y11, y14 = frobenius(y8, 2) * y13, y15 = frobenius(conj12(r) * y9, 3);

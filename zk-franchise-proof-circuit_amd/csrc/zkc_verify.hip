@@ -29,20 +29,6 @@ namespace {
 // libff's alt_bn128, whose final exponentiation ends in the Fuentes-Castaneda chunk and so yields the reduced pairing raised to 2x(6x^2 + 3x + 1) -- which is what
 // pairing::final_exp returns.  Pinned by tests/test_oracle_pinning.py against the reference's own verification key (alpha, beta -> vk_alphabeta_12).
 Fq12 pairing_snarkjs(const G1Affine& P, const G2Affine& Q) { return final_exp(miller(P, Q)); }
-bool g1_on_curve(const G1Affine& a) { return a.is_inf() || fp_sqr(a.y) == fp_sqr(a.x) * a.x + fp_from_u32<FqParams>(3); }
-bool g2_on_curve(const G2Affine& a) {
-    if (a.is_inf()) return true;
-    static const Fq2 B = Fq2{fp_from_u32<FqParams>(3), Fq::zero()} * fp_inv(Fq2{fp_from_u32<FqParams>(9), Fq::one()});
-    return fp_sqr(a.y) == fp_sqr(a.x) * a.x + B;
-}
-bool g2_in_subgroup(const G2Affine& a) {            // on the twist and [r]a = infinity (the definition; mixed additions, no leading zero steps)
-    if (!g2_on_curve(a)) return false;
-    if (a.is_inf()) return true;
-    int top = 255; while (!((FrParams::p[top >> 5] >> (top & 31)) & 1)) top--;
-    G2XYZZ acc = G2XYZZ::from_affine(a);
-    for (int i = top - 1; i >= 0; i--) { acc = xyzz_dbl(acc); if ((FrParams::p[i >> 5] >> (i & 31)) & 1) acc = xyzz_add_affine(acc, a); }
-    return acc.is_inf();
-}
 bool rd_fq_std(Fq& o, const uint8_t* p) { uint32_t s[8]; memcpy(s, p, 32); if (!fp_std_lt_p<FqParams>(s)) return false; o = fp_from_std<FqParams>(s); return true; }
 bool rd_g1_std(G1Affine& o, const uint8_t* p) { return rd_fq_std(o.x, p) && rd_fq_std(o.y, p + 32); }
 bool rd_g2_std(G2Affine& o, const uint8_t* p) { return rd_fq_std(o.x.c0, p) && rd_fq_std(o.x.c1, p + 32) && rd_fq_std(o.y.c0, p + 64) && rd_fq_std(o.y.c1, p + 96); }
@@ -209,6 +195,7 @@ struct VkReady {
     std::vector<uint8_t> bytes; int nPublic = 0;
     G1Affine alpha; G2Affine beta, gamma, delta; std::vector<G1Affine> ic;
     G2Prepared pgamma, pdelta, pbeta; Fq12 m_alpha_beta;
+    std::vector<G1Affine> ic_mult;                 // k IC_j for k = 1..15, j = 1..nPublic (row j - 1): the public-input combination takes one addition per 4 bits of a signal
 };
 std::mutex g_vk_mu; std::vector<std::shared_ptr<const VkReady>> g_vk_ready;      // most recent first, at most 8
 std::shared_ptr<const VkReady> vk_ready(const uint8_t* vk, int nPublic, int* code) {
@@ -228,6 +215,13 @@ std::shared_ptr<const VkReady> vk_ready(const uint8_t* vk, int nPublic, int* cod
     for (int j = 0; j <= nPublic; j++) if (!rd_g1_std(r->ic[j], vk + 448 + 64 * (size_t)j) || !g1_on_curve(r->ic[j])) { *code = vfail(-ZKC_ERR_FORMAT, "IC point invalid"); return nullptr; }
     r->pgamma = prepare_g2(r->gamma); r->pdelta = prepare_g2(r->delta); r->pbeta = prepare_g2(r->beta);
     const Pair ab{r->alpha, &r->pbeta}; r->m_alpha_beta = multi_miller(&ab, 1);
+    if (nPublic <= 64) {
+        r->ic_mult.resize(15 * (size_t)nPublic);
+        for (int j = 0; j < nPublic; j++) {
+            G1XYZZ m = G1XYZZ::from_affine(r->ic[j + 1]);
+            for (int k = 0; k < 15; k++) { r->ic_mult[15 * (size_t)j + k] = xyzz_to_affine_gcd(m); m = xyzz_add_affine(m, r->ic[j + 1]); }
+        }
+    }
     std::lock_guard<std::mutex> g(g_vk_mu);
     g_vk_ready.insert(g_vk_ready.begin(), r); if (g_vk_ready.size() > 8) g_vk_ready.pop_back();
     return r;
@@ -262,7 +256,14 @@ extern "C" int zkc_verify_bin(const uint8_t* vk, int nPublic, const uint8_t* pub
         memcpy(k[i].data(), pub + 32 * i, 32);
         if (!fp_std_lt_p<FrParams>(k[i].data())) return 0;                         // snarkjs: public input not in field -> invalid
     }
-    const G1Affine vkx = xyzz_to_affine_gcd(xyzz_add_affine(g1_sum_of_products(V->ic.data() + 1, (const uint32_t (*)[8])k.data(), nPublic), V->ic[0]));
+    G1XYZZ sum = G1XYZZ::inf();
+    if (!V->ic_mult.empty()) {
+        for (int w = 63; w >= 0; w--) {
+            if (!sum.is_inf()) for (int d = 0; d < 4; d++) sum = xyzz_dbl(sum);
+            for (int j = 0; j < nPublic; j++) { const uint32_t dg = (k[j][w >> 3] >> (4 * (w & 7))) & 15u; if (dg) sum = xyzz_add_affine(sum, V->ic_mult[15 * (size_t)j + dg - 1]); }
+        }
+    } else sum = g1_sum_of_products(V->ic.data() + 1, (const uint32_t (*)[8])k.data(), nPublic);
+    const G1Affine vkx = xyzz_to_affine_gcd(xyzz_add_affine(sum, V->ic[0]));
     const G2Prepared pB = prepare_g2(B);
     const Pair pairs[3] = {{affine_neg(A), &pB}, {vkx, &V->pgamma}, {C, &V->pdelta}};
     return is_one12(final_exp(multi_miller(pairs, 3) * V->m_alpha_beta)) ? 1 : 0;
