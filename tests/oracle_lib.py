@@ -204,3 +204,30 @@ def status_of_wasm_message(msg):
     line, inner = int(frames[-1][1]), frames[0][0]
     return {(72, 'ZkFranchiseProofCircuit'): 1, (90, 'SMTLevIns'): 7, (90, 'ForceEqualIfEnabled'): 2, (103, 'SMTLevIns'): 5,
             (103, 'ForceEqualIfEnabled'): 3, (114, 'ForceEqualIfEnabled'): 4}[(line, inner)]
+
+
+def twist_point_outside_g2(start=1):
+    """A point on the twist y^2 = x^3 + 3/(9 + u) over Fq2 that is (almost surely) NOT in the order-r subgroup G2: the first x = x0 + u, x0 >= start, whose right-hand side
+    is a square.  Returns ((x0, x1), (y0, y1)) as integers.  Used to check that the verifiers refuse a proof whose B leaves G2 (the twist has a cofactor)."""
+    q = Q
+    def f2mul(a, b): return ((a[0] * b[0] - a[1] * b[1]) % q, (a[0] * b[1] + a[1] * b[0]) % q)
+    def f2pow(a, e):
+        r = (1, 0)
+        while e:
+            if e & 1: r = f2mul(r, a)
+            a = f2mul(a, a); e >>= 1
+        return r
+    def f2inv(a):
+        n = pow(a[0] * a[0] + a[1] * a[1], -1, q); return (a[0] * n % q, -a[1] * n % q)
+    def f2sqrt(a):                                         # q = 3 mod 4: complex method
+        if a == (0, 0): return a
+        a1 = f2pow(a, (q - 3) // 4); alpha = f2mul(f2mul(a1, a1), a); x0 = f2mul(a1, a)
+        if alpha == (q - 1, 0): return f2mul((0, 1), x0)
+        b = f2pow(((1 + alpha[0]) % q, alpha[1]), (q - 1) // 2); return f2mul(b, x0)
+    Btw = f2mul((3, 0), f2inv((9, 1)))
+    for x0 in range(start, start + 200):
+        x = (x0, 1); rhs = f2mul(f2mul(x, x), x); rhs = ((rhs[0] + Btw[0]) % q, (rhs[1] + Btw[1]) % q)
+        y = f2sqrt(rhs)
+        if f2mul(y, y) == rhs:
+            return (x, y)
+    raise AssertionError('no twist point found')

@@ -29,6 +29,16 @@ def test_batch_verify_matches_single_verdicts():
     single = [ol.verify(vk, pubs[32 * npub * i:32 * npub * (i + 1)], proofs[256 * i:256 * (i + 1)]) for i in range(N)]
     assert all(single)
     seed = bytes(range(32))
+    for path in ('0', '1'):            # the Miller loops on host threads, then on the GPU (zkc_pairing_dev.hip; by default from 128 proofs on): the same verdict on every case below
+        os.environ['ZKC_VERIFY_BATCH_GPU'] = path
+        try:
+            _verdicts(ctx, groth16, vk, pubs, proofs, seed, npub)
+        finally:
+            del os.environ['ZKC_VERIFY_BATCH_GPU']
+    pk.close(); ctx.close()
+
+
+def _verdicts(ctx, groth16, vk, pubs, proofs, seed, npub):
     assert groth16.verify_batch(ctx, vk, pubs, proofs, seed) is True
     assert groth16.verify_batch(ctx, vk, pubs, proofs) is True                       # weights from the OS
     assert groth16.verify_batch(ctx, vk, pubs[:32 * npub], proofs[:256], seed) is True   # N = 1
@@ -56,4 +66,9 @@ def test_batch_verify_matches_single_verdicts():
     q = ol.Q
     y = int.from_bytes(proofs[32:64], 'little')
     assert groth16.verify_batch(ctx, vk, pubs, with_patch(proofs, 32, ((q - y) % q).to_bytes(32, 'little')), seed) is False
-    pk.close(); ctx.close()
+    # (6) a B on the twist but outside G2 (the twist has a cofactor): refused by the membership test, as zkc_verify_bin refuses it
+    pt = ol.twist_point_outside_g2()
+    offg2 = b''.join(ol.le32(v) for v in (pt[0][0], pt[0][1], pt[1][0], pt[1][1]))
+    assert groth16.verify_batch(ctx, vk, pubs, with_patch(proofs, 256 * 4 + 64, offg2), seed) is False
+    # (7) a B at infinity contributes 1 to the product: the batch fails on that proof's equation, not on a crash
+    assert groth16.verify_batch(ctx, vk, pubs, with_patch(proofs, 256 * 6 + 64, bytes(128)), seed) is False

@@ -75,30 +75,8 @@ def test_verifier_strictness_and_return_codes():
     badvk = json.loads(json.dumps(vk)); badvk['vk_alpha_1'][0] = str(int(badvk['vk_alpha_1'][0]) + 1)
     assert lib.zkc_verify(t(badvk), t(sig), t(pr)) < 0                                        # alpha not on the curve
     assert lib.zkc_verify(b'{}', t(sig), t(pr)) < 0 and lib.zkc_verify(None, t(sig), t(pr)) < 0
-    # a twist point outside the order-r subgroup: x = 1 + u ... search a small x with a square right-hand side, in Python (Fq2 arithmetic)
-    q = ol.Q
-    def f2mul(a, b): return ((a[0] * b[0] - a[1] * b[1]) % q, (a[0] * b[1] + a[1] * b[0]) % q)
-    def f2pow(a, e):
-        r = (1, 0)
-        while e:
-            if e & 1: r = f2mul(r, a)
-            a = f2mul(a, a); e >>= 1
-        return r
-    def f2inv(a):
-        n = pow(a[0] * a[0] + a[1] * a[1], -1, q); return (a[0] * n % q, -a[1] * n % q)
-    def f2sqrt(a):                                         # q = 3 mod 4: complex method
-        if a == (0, 0): return a
-        a1 = f2pow(a, (q - 3) // 4); alpha = f2mul(f2mul(a1, a1), a); x0 = f2mul(a1, a)
-        if alpha == (q - 1, 0): return f2mul((0, 1), x0)
-        b = f2pow(((1 + alpha[0]) % q, alpha[1]), (q - 1) // 2); return f2mul(b, x0)
-    Btw = f2mul((3, 0), f2inv((9, 1)))
-    pt = None
-    for x0 in range(1, 50):
-        x = (x0, 1); rhs = f2mul(f2mul(x, x), x); rhs = ((rhs[0] + Btw[0]) % q, (rhs[1] + Btw[1]) % q)
-        y = f2sqrt(rhs)
-        if f2mul(y, y) == rhs:
-            pt = (x, y); break
-    assert pt is not None
+    # a twist point outside the order-r subgroup (oracle_lib.twist_point_outside_g2: a small x with a square right-hand side, Fq2 arithmetic in Python)
+    pt = ol.twist_point_outside_g2()
     prb = bytearray(ol.proof_bytes(pr))
     prb[64:192] = b''.join(ol.le32(v) for v in (pt[0][0], pt[0][1], pt[1][0], pt[1][1]))     # on the twist, (almost surely) not in the subgroup
     assert lib.zkc_verify_bin(ol.vk_bytes(vk), 8, b''.join(ol.le32(x) for x in sig), bytes(prb)) == 0

@@ -553,7 +553,7 @@ zkc_fold_gsum(const XYZZ<F>* __restrict__ in, const uint32_t* __restrict__ gstar
 }
 template <class F>
 static int fold_group_sums(zkc_ctx* ctx, const Affine<F>* tbl, const uint32_t* d_scalars, const uint32_t* d_wires, uint32_t nw, int32_t pt_shift,
-                           const uint32_t* d_gstart, uint32_t ngroups, XYZZ<F>* h_out) {
+                           const uint32_t* d_gstart, uint32_t ngroups, XYZZ<F>* h_out, XYZZ<F>** d_keep = nullptr) {
     XYZZ<F>*d_tmp = nullptr, *d_out = nullptr;
     ZKC_HIP_CHECK(ctx, hipMalloc(&d_tmp, (size_t)nw * sizeof(XYZZ<F>)));
     ZKC_HIP_CHECK(ctx, hipMalloc(&d_out, (size_t)ngroups * sizeof(XYZZ<F>)));
@@ -563,11 +563,16 @@ static int fold_group_sums(zkc_ctx* ctx, const Affine<F>* tbl, const uint32_t* d
     ZKC_HIP_CHECK(ctx, hipGetLastError());
     ZKC_HIP_CHECK(ctx, hipMemcpyAsync(h_out, d_out, (size_t)ngroups * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, ctx->stream));
     ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    ZKC_HIP_CHECK(ctx, hipFree(d_tmp)); ZKC_HIP_CHECK(ctx, hipFree(d_out));
+    ZKC_HIP_CHECK(ctx, hipFree(d_tmp));
+    if (d_keep) *d_keep = d_out; else ZKC_HIP_CHECK(ctx, hipFree(d_out));
     return ZKC_OK;
 }
 int fold_group_sums_g1(zkc_ctx* ctx, const G1Affine* tbl, const uint32_t* s, const uint32_t* w, uint32_t nw, int32_t sh, const uint32_t* gs, uint32_t ng, G1XYZZ* o) {
     return fold_group_sums<Fq>(ctx, tbl, s, w, nw, sh, gs, ng, o);
+}
+// the same, and the sums stay on the device as well (*d_keep, the caller's to hipFree): the batch verifier's Miller kernels read them there
+int fold_group_sums_g1_keep(zkc_ctx* ctx, const G1Affine* tbl, const uint32_t* s, const uint32_t* w, uint32_t nw, int32_t sh, const uint32_t* gs, uint32_t ng, G1XYZZ* o, G1XYZZ** d_keep) {
+    return fold_group_sums<Fq>(ctx, tbl, s, w, nw, sh, gs, ng, o, d_keep);
 }
 int fold_group_sums_g2(zkc_ctx* ctx, const G2Affine* tbl, const uint32_t* s, const uint32_t* w, uint32_t nw, int32_t sh, const uint32_t* gs, uint32_t ng, G2XYZZ* o) {
     return fold_group_sums<Fq2>(ctx, tbl, s, w, nw, sh, gs, ng, o);

@@ -1,0 +1,131 @@
+// zkc_pairing_dev.hip -- f4 on the GPU: the Miller loops of the batch verifier (zkc_verify_batch, csrc/zkc_verify.hip).
+//
+// A batch of N proofs needs prod_i f_{6x+2, B_i}(-rho_i A_i).  On one shared accumulator that product is
+//     F <- F^2 * prod_i line_{i, step}          for each of the 87 steps of the loop,
+// and the lines of a pair depend on its points only, never on F.  So the work splits into three data-parallel parts and a short tail:
+//   zkc_miller_lines   one lane per pair walks R <- 2R / R + Q on the twist and writes the 87 line coefficients, evaluated at the pair's G1 point (which stays in the
+//                      XYZZ form the fold kernels left it in: scaling a line by ZZ ZZZ in Fq costs nothing after the final exponentiation); N more lanes check the
+//                      B_i for membership in G2 (on the twist, psi(B) = [6x^2]B);
+//   zkc_line_pairs     the first level of a product tree per step: two sparse lines -> one dense Fq12 (9 products in Fq2);
+//   zkc_fq12_tree      the remaining levels, one Fq12 product per lane, 87 steps side by side;
+//   host               87 values come back; F = (..(L_0)^2 L_1..) is 63 squarings and 87 products, then the three pairs of the key and ONE final exponentiation.
+// Field elements are the 8 x 32-bit Montgomery residues of zkc_field.h on both sides, so the host continues where the device stopped.
+#include <algorithm>
+#include <vector>
+#include "zkc_prover.h"
+#include "zkc_pairing_host.h"
+
+namespace zkc {
+using namespace zkc::pairing;
+
+struct MillerConsts { Fq2 twist_b, psi_x, psi_y, psi2_x, psi2_y; Fq half; uint64_t pos, neg; uint64_t t_lo, t_hi; };
+
+__device__ __forceinline__ void store_line(Fq2* __restrict__ lines, uint32_t N, uint32_t step, uint32_t i, const Fq2 l[3]) {
+    Fq2* o = lines + ((size_t)step * N + i) * 3; o[0] = l[0]; o[1] = l[1]; o[2] = l[2];
+}
+// lanes [0, N): the lines of pair i at (-P_i) -- P in XYZZ (x = X / ZZ, y = Y / ZZZ): c y, d0 x, d1 become c Y ZZ, d0 X ZZZ, d1 ZZ ZZZ, the whole line scaled by ZZ ZZZ.
+// lanes [N, 2N): B_i on the twist and in G2; *bad is set when one is not.  A pair with P or Q at infinity contributes the line 1.
+__global__ void __launch_bounds__(64)
+zkc_miller_lines(const G1XYZZ* __restrict__ P, const G2Affine* __restrict__ Q, uint32_t N, MillerConsts C, Fq2* __restrict__ lines, int* __restrict__ bad) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= 2 * N) return;
+    const uint32_t i = gid < N ? gid : gid - N;
+    const G2Affine q = Q[i];
+    if (gid >= N) {
+        if (q.is_inf()) return;
+        bool ok = fp_sqr(q.y) == fp_sqr(q.x) * q.x + C.twist_b;
+        if (ok) {
+            G2XYZZ acc = G2XYZZ::from_affine(q);
+            for (int b = 125; b >= 0; b--) { acc = xyzz_dbl(acc); if (((b < 64 ? C.t_lo >> b : C.t_hi >> (b - 64)) & 1)) acc = xyzz_add_affine(acc, q); }
+            ok = !acc.is_inf() && acc.X == conj2(q.x) * C.psi_x * acc.ZZ && acc.Y == conj2(q.y) * C.psi_y * acc.ZZZ;
+        }
+        if (!ok) atomicOr(bad, 1);
+        return;
+    }
+    const G1XYZZ p = P[i];
+    const uint32_t nlines = 66 + (uint32_t)__popcll(C.pos | C.neg);
+    if (p.is_inf() || q.is_inf()) {
+        const Fq2 one[3] = {Fq2::one(), Fq2::zero(), Fq2::zero()};
+        for (uint32_t s = 0; s < nlines; s++) store_line(lines, N, s, i, one);
+        return;
+    }
+    const Fq yP = fp_neg(p.Y * p.ZZ), xP = p.X * p.ZZZ, sP = p.ZZ * p.ZZZ;
+    LinePoint R{q.x, q.y, Fq2::one()};
+    const Fq2 nqy = fp_neg(q.y);
+    uint32_t step = 0; Fq2 l[3];
+    auto put = [&]() { l[0] = scale2(l[0], yP); l[1] = scale2(l[1], xP); l[2] = scale2(l[2], sP); store_line(lines, N, step++, i, l); };
+    for (int b = 63; b >= 0; b--) {
+        line_dbl(R, C.twist_b, C.half, l); put();
+        if ((C.pos >> b) & 1) { line_add(R, q.x, q.y, l); put(); }
+        else if ((C.neg >> b) & 1) { line_add(R, q.x, nqy, l); put(); }
+    }
+    line_add(R, conj2(q.x) * C.psi_x, conj2(q.y) * C.psi_y, l); put();
+    line_add(R, q.x * C.psi2_x, fp_neg(q.y * C.psi2_y), l); put();
+}
+// out[s][t] = line[s][2t] * line[s][2t + 1] (the last one alone when N is odd), t < ceil(N / 2)
+__global__ void __launch_bounds__(64)
+zkc_line_pairs(const Fq2* __restrict__ lines, uint32_t N, uint32_t nlines, Fq12* __restrict__ out) {
+    const uint32_t half = (N + 1) / 2, gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= nlines * half) return;
+    const uint32_t s = gid / half, t = gid - s * half;
+    const Fq2* a = lines + ((size_t)s * N + 2 * t) * 3;
+    out[(size_t)s * half + t] = (2 * t + 1 < N) ? mul_034_by_034(a, a + 3) : dense_of_034(a);
+}
+// out[s][t] = in[s][2t] * in[s][2t + 1], t < ceil(n / 2)
+__global__ void __launch_bounds__(64)
+zkc_fq12_tree(const Fq12* __restrict__ in, uint32_t n, uint32_t nlines, Fq12* __restrict__ out) {
+    const uint32_t half = (n + 1) / 2, gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= nlines * half) return;
+    const uint32_t s = gid / half, t = gid - s * half;
+    const Fq12* a = in + (size_t)s * n + 2 * t;
+    out[(size_t)s * half + t] = (2 * t + 1 < n) ? a[0] * a[1] : a[0];
+}
+
+// prod_i f_{6x+2, Q_i}(-P_i) over N pairs, P on the device (XYZZ, as the fold kernels write them), Q on the host; *bad != 0: some Q_i is not in G2 (the product is
+// meaningless then).  Pairs are taken 16 384 at a time (300 MB of line coefficients).  The caller holds the context's lock.
+int miller_product_dev(zkc_ctx* ctx, const G1XYZZ* d_P, const G2Affine* h_Q, uint32_t N, Fq12* product, int* bad) {
+    const Consts& K = consts(); const AteLoop& L = ate_loop();
+    MillerConsts C; C.twist_b = K.twist_b; C.psi_x = K.psi_x; C.psi_y = K.psi_y; C.psi2_x = K.psi2_x; C.psi2_y = K.psi2_y; C.half = K.half; C.pos = C.neg = 0;
+    for (int b = 0; b < 64; b++) { if (L.digit[b] > 0) C.pos |= 1ull << b; else if (L.digit[b] < 0) C.neg |= 1ull << b; }
+    C.t_lo = 0xf83e9682e87cfd46ull; C.t_hi = 0x6f4d8248eeb859fbull;           // 6 x^2, bit 126 on top (zkc_pairing_host.h g2_in_subgroup)
+    const uint32_t nlines = 66 + (uint32_t)__builtin_popcountll(C.pos | C.neg);
+    constexpr uint32_t CHUNK = 16384;
+    const uint32_t cap = std::min(N, CHUNK), hcap = (cap + 1) / 2;
+    G2Affine* d_Q = nullptr; Fq2* d_lines = nullptr; Fq12 *d_a = nullptr, *d_b = nullptr; int* d_bad = nullptr;
+    auto cleanup = [&]() { for (void* q : {(void*)d_Q, (void*)d_lines, (void*)d_a, (void*)d_b, (void*)d_bad}) if (q) (void)hipFree(q); };
+    auto fail = [&](hipError_t e, const char* what) { cleanup(); ctx->err = std::string(what) + ": " + hipGetErrorString(e); (void)hipGetLastError(); return ZKC_ERR_HIP; };
+    hipError_t e;
+    if ((e = hipMalloc((void**)&d_Q, (size_t)cap * sizeof(G2Affine))) != hipSuccess || (e = hipMalloc((void**)&d_lines, (size_t)nlines * cap * 3 * sizeof(Fq2))) != hipSuccess ||
+        (e = hipMalloc((void**)&d_a, (size_t)nlines * hcap * sizeof(Fq12))) != hipSuccess || (e = hipMalloc((void**)&d_b, (size_t)nlines * ((hcap + 1) / 2) * sizeof(Fq12))) != hipSuccess ||
+        (e = hipMalloc((void**)&d_bad, sizeof(int))) != hipSuccess) return fail(e, "miller_product_dev: hipMalloc");
+    if ((e = hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream)) != hipSuccess) return fail(e, "miller_product_dev: hipMemset");
+    std::vector<Fq12> step(nlines), acc(nlines, one12());
+    for (uint32_t lo = 0; lo < N; lo += CHUNK) {
+        const uint32_t n = std::min(CHUNK, N - lo);
+        if ((e = hipMemcpyAsync(d_Q, h_Q + lo, (size_t)n * sizeof(G2Affine), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e, "miller_product_dev: upload");
+        hipLaunchKernelGGL(zkc_miller_lines, dim3((2 * n + 63) / 64), dim3(64), 0, ctx->stream, d_P + lo, d_Q, n, C, d_lines, d_bad);
+        uint32_t m = (n + 1) / 2;
+        hipLaunchKernelGGL(zkc_line_pairs, dim3((nlines * m + 63) / 64), dim3(64), 0, ctx->stream, d_lines, n, nlines, d_a);
+        Fq12 *src = d_a, *dst = d_b;
+        while (m > 1) {
+            const uint32_t h = (m + 1) / 2;
+            hipLaunchKernelGGL(zkc_fq12_tree, dim3((nlines * h + 63) / 64), dim3(64), 0, ctx->stream, src, m, nlines, dst);
+            std::swap(src, dst); m = h;
+        }
+        if ((e = hipGetLastError()) != hipSuccess) return fail(e, "miller_product_dev: launch");
+        if ((e = hipMemcpyAsync(step.data(), src, (size_t)nlines * sizeof(Fq12), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess ||
+            (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "miller_product_dev: download");
+        for (uint32_t s = 0; s < nlines; s++) acc[s] = lo ? acc[s] * step[s] : step[s];
+    }
+    int hb = 0;
+    if ((e = hipMemcpy(&hb, d_bad, sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "miller_product_dev: download");
+    cleanup();
+    *bad = hb;
+    // the accumulator, step by step (the same walk as pairing::multi_miller)
+    Fq12 f = one12(); uint32_t idx = 0;
+    for (int b = 63; b >= 0; b--) { if (b != 63) f = sqr12(f); f = f * acc[idx++]; if (L.digit[b]) f = f * acc[idx++]; }
+    f = f * acc[idx++]; f = f * acc[idx++];
+    *product = f;
+    return ZKC_OK;
+}
+}  // namespace zkc

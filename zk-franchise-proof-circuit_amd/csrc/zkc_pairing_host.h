@@ -15,42 +15,45 @@
 #include <vector>
 #include "zkc_curve.h"
 
+// host + device, inlined at the compiler's discretion (an Fq12 product is 54 field products: forcing it inline everywhere costs minutes of compile time and buys nothing)
+#define ZKC_HDI __host__ __device__ inline
+
 namespace zkc { namespace pairing {
 
-inline Fq2 mul_xi(const Fq2& a) {                                    // (9 + u) a
+ZKC_HDI Fq2 mul_xi(const Fq2& a) {                                    // (9 + u) a
     const Fq t0 = fp_dbl(fp_dbl(fp_dbl(a.c0))) + a.c0, t1 = fp_dbl(fp_dbl(fp_dbl(a.c1))) + a.c1;
     return {t0 - a.c1, t1 + a.c0};
 }
-inline Fq2 conj2(const Fq2& a) { return {a.c0, fp_neg(a.c1)}; }
-inline Fq2 scale2(const Fq2& a, const Fq& s) { return {a.c0 * s, a.c1 * s}; }
+ZKC_HDI Fq2 conj2(const Fq2& a) { return {a.c0, fp_neg(a.c1)}; }
+ZKC_HDI Fq2 scale2(const Fq2& a, const Fq& s) { return {a.c0 * s, a.c1 * s}; }
 inline Fq2 fq2_pow(const Fq2& a, const uint32_t* e, int nbits) { Fq2 r = Fq2::one(); for (int i = nbits - 1; i >= 0; i--) { r = fp_sqr(r); if ((e[i >> 5] >> (i & 31)) & 1) r = r * a; } return r; }
 
 struct Fq6 { Fq2 a0, a1, a2; };
 struct Fq12 { Fq6 a, b; };
-inline Fq6 operator+(const Fq6& x, const Fq6& y) { return {x.a0 + y.a0, x.a1 + y.a1, x.a2 + y.a2}; }
-inline Fq6 operator-(const Fq6& x, const Fq6& y) { return {x.a0 - y.a0, x.a1 - y.a1, x.a2 - y.a2}; }
-inline Fq6 neg6(const Fq6& x) { return {fp_neg(x.a0), fp_neg(x.a1), fp_neg(x.a2)}; }
-inline Fq6 mul_v(const Fq6& x) { return {mul_xi(x.a2), x.a0, x.a1}; }
-inline Fq6 operator*(const Fq6& x, const Fq6& y) {                   // Karatsuba: 6 products in Fq2
+ZKC_HDI Fq6 operator+(const Fq6& x, const Fq6& y) { return {x.a0 + y.a0, x.a1 + y.a1, x.a2 + y.a2}; }
+ZKC_HDI Fq6 operator-(const Fq6& x, const Fq6& y) { return {x.a0 - y.a0, x.a1 - y.a1, x.a2 - y.a2}; }
+ZKC_HDI Fq6 neg6(const Fq6& x) { return {fp_neg(x.a0), fp_neg(x.a1), fp_neg(x.a2)}; }
+ZKC_HDI Fq6 mul_v(const Fq6& x) { return {mul_xi(x.a2), x.a0, x.a1}; }
+ZKC_HDI Fq6 operator*(const Fq6& x, const Fq6& y) {                   // Karatsuba: 6 products in Fq2
     const Fq2 v0 = x.a0 * y.a0, v1 = x.a1 * y.a1, v2 = x.a2 * y.a2;
     return {v0 + mul_xi((x.a1 + x.a2) * (y.a1 + y.a2) - v1 - v2), (x.a0 + x.a1) * (y.a0 + y.a1) - v0 - v1 + mul_xi(v2), (x.a0 + x.a2) * (y.a0 + y.a2) - v0 - v2 + v1};
 }
-inline Fq6 mul_by_01(const Fq6& x, const Fq2& b0, const Fq2& b1) {  // x (b0 + b1 v): 5 products
+ZKC_HDI Fq6 mul_by_01(const Fq6& x, const Fq2& b0, const Fq2& b1) {  // x (b0 + b1 v): 5 products
     const Fq2 v0 = x.a0 * b0, v1 = x.a1 * b1;
     return {v0 + mul_xi((x.a1 + x.a2) * b1 - v1), (x.a0 + x.a1) * (b0 + b1) - v0 - v1, (x.a0 + x.a2) * b0 - v0 + v1};
 }
-inline Fq6 mul_by_fq2(const Fq6& x, const Fq2& b) { return {x.a0 * b, x.a1 * b, x.a2 * b}; }
+ZKC_HDI Fq6 mul_by_fq2(const Fq6& x, const Fq2& b) { return {x.a0 * b, x.a1 * b, x.a2 * b}; }
 inline Fq6 inv6(const Fq6& x) {
     const Fq2 c0 = fp_sqr(x.a0) - mul_xi(x.a1 * x.a2), c1 = mul_xi(fp_sqr(x.a2)) - x.a0 * x.a1, c2 = fp_sqr(x.a1) - x.a0 * x.a2;
     const Fq2 t = fp_inv_gcd(mul_xi(x.a2 * c1 + x.a1 * c2) + x.a0 * c0);
     return {c0 * t, c1 * t, c2 * t};
 }
-inline Fq12 one12() { Fq12 r{}; r.a.a0 = Fq2::one(); r.a.a1 = r.a.a2 = r.b.a0 = r.b.a1 = r.b.a2 = Fq2::zero(); return r; }
-inline Fq12 operator*(const Fq12& x, const Fq12& y) {                // Karatsuba: 3 products in Fq6
+ZKC_HDI Fq12 one12() { Fq12 r{}; r.a.a0 = Fq2::one(); r.a.a1 = r.a.a2 = r.b.a0 = r.b.a1 = r.b.a2 = Fq2::zero(); return r; }
+ZKC_HDI Fq12 operator*(const Fq12& x, const Fq12& y) {                // Karatsuba: 3 products in Fq6
     const Fq6 aa = x.a * y.a, bb = x.b * y.b;
     return {aa + mul_v(bb), (x.a + x.b) * (y.a + y.b) - aa - bb};
 }
-inline Fq12 sqr12(const Fq12& x) {                                   // complex squaring: 2 products in Fq6
+ZKC_HDI Fq12 sqr12(const Fq12& x) {                                   // complex squaring: 2 products in Fq6
     const Fq6 ab = x.a * x.b;
     return {(x.a + x.b) * (x.a + mul_v(x.b)) - ab - mul_v(ab), ab + ab};
 }
@@ -72,13 +75,38 @@ inline Fq12 cyclotomic_sqr(const Fq12& x) {
     o.a.a1 = three_minus_two(t2, r4); o.b.a2 = three_plus_two(t3, r5);
     return o;
 }
-inline Fq12 conj12(const Fq12& x) { return {x.a, neg6(x.b)}; }      // x^(q^6); the inverse inside the cyclotomic subgroup
+ZKC_HDI Fq12 conj12(const Fq12& x) { return {x.a, neg6(x.b)}; }      // x^(q^6); the inverse inside the cyclotomic subgroup
 inline Fq12 inv12(const Fq12& x) { const Fq6 t = inv6(x.a * x.a - mul_v(x.b * x.b)); return {x.a * t, neg6(x.b * t)}; }
 inline bool is_one12(const Fq12& x) { const Fq12 o = one12(); return memcmp(&x, &o, sizeof o) == 0; }
 // f (c0 + d0 w + d1 w^3): the product with a line, 13 products in Fq2 instead of 18
-inline Fq12 mul_by_034(const Fq12& f, const Fq2& c0, const Fq2& d0, const Fq2& d1) {
+ZKC_HDI Fq12 mul_by_034(const Fq12& f, const Fq2& c0, const Fq2& d0, const Fq2& d1) {
     const Fq6 a = mul_by_fq2(f.a, c0), b = mul_by_01(f.b, d0, d1), e = mul_by_01(f.a + f.b, c0 + d0, d1);
     return {a + mul_v(b), e - a - b};
+}
+
+// (c0 + d0 w + d1 w^3)(c0' + d0' w + d1' w^3): two lines into one dense element, 9 products in Fq2 (the first level of the batch verifier's product tree on the GPU)
+ZKC_HDI Fq12 mul_034_by_034(const Fq2* l, const Fq2* m) {
+    const Fq2 d1d1 = l[2] * m[2];
+    Fq12 r;
+    r.a.a0 = l[0] * m[0] + mul_xi(d1d1); r.a.a1 = l[1] * m[1]; r.a.a2 = l[1] * m[2] + l[2] * m[1];
+    r.b.a0 = l[0] * m[1] + l[1] * m[0]; r.b.a1 = l[0] * m[2] + l[2] * m[0]; r.b.a2 = Fq2::zero();
+    return r;
+}
+ZKC_HDI Fq12 dense_of_034(const Fq2* l) { Fq12 r; r.a.a0 = l[0]; r.a.a1 = r.a.a2 = r.b.a2 = Fq2::zero(); r.b.a0 = l[1]; r.b.a1 = l[2]; return r; }
+// ---- the point side of the Miller loop: R <- 2R or R + Q on the twist in homogeneous projective coordinates, and the coefficients (c, d0, d1) of the line through
+// the points involved (Costello-Lange-Naehrig formulas, as arkworks' bn / gnark lay them out): the line at P is c yP + d0 xP w + d1 w^3, up to factors in Fq2 ----
+struct LinePoint { Fq2 X, Y, Z; };
+ZKC_HDI void line_dbl(LinePoint& R, const Fq2& twist_b, const Fq& half, Fq2 out[3]) {
+    const Fq2 a = scale2(R.X * R.Y, half), b = fp_sqr(R.Y), c = fp_sqr(R.Z), c3 = fp_dbl(c) + c, e = twist_b * c3, f = fp_dbl(e) + e, g = scale2(b + f, half),
+              h = fp_sqr(R.Y + R.Z) - (b + c), i = e - b, j = fp_sqr(R.X), e2 = fp_sqr(e);
+    R.X = a * (b - f); R.Y = fp_sqr(g) - (fp_dbl(e2) + e2); R.Z = b * h;
+    out[0] = fp_neg(h); out[1] = fp_dbl(j) + j; out[2] = i;
+}
+ZKC_HDI void line_add(LinePoint& R, const Fq2& xq, const Fq2& yq, Fq2 out[3]) {
+    const Fq2 theta = R.Y - yq * R.Z, lambda = R.X - xq * R.Z, c = fp_sqr(theta), d = fp_sqr(lambda), e = lambda * d, f = R.Z * c, g = R.X * d, h = e + f - fp_dbl(g);
+    const Fq2 j = theta * xq - lambda * yq;
+    R.X = lambda * h; R.Y = theta * (g - h) - e * R.Y; R.Z = R.Z * e;
+    out[0] = lambda; out[1] = fp_neg(theta); out[2] = j;
 }
 
 // ---- constants derived once: xi^((q-1)/6) and its powers (Frobenius on Fq12 and on the twist), the twist's b, 1/2 ----
@@ -148,7 +176,7 @@ inline bool g2_in_subgroup(const G2Affine& a) {
 typedef std::array<Fq2, 3> LineCoeffs;                               // (c, d0, d1): the line is c yP + d0 xP w + d1 w^3
 struct G2Prepared { std::vector<LineCoeffs> lines; bool inf = true; };
 // 6x + 2 = 29793968203157093288 (x = 4965661367192848881, 65 bits) in signed digits: the non-adjacent form, its top "1 0 -1" folded back to "1 1" so that the loop
-// keeps 64 doublings -- 24 additions instead of the 36 set bits.  digit[64] = 1 is the starting point R = Q.
+// keeps 64 doublings -- 21 additions instead of the 36 set bits.  digit[64] = 1 is the starting point R = Q.
 struct AteLoop { int8_t digit[65]; };
 inline const AteLoop& ate_loop() {
     static const AteLoop L = [] {
@@ -164,24 +192,14 @@ inline const AteLoop& ate_loop() {
     }();
     return L;
 }
-// Q -> the coefficients of every line of its Miller loop, in loop order (Costello-Lange-Naehrig homogeneous formulas, as arkworks' bn / gnark lay them out)
+// Q -> the coefficients of every line of its Miller loop, in loop order
 inline G2Prepared prepare_g2(const G2Affine& Q) {
     G2Prepared out; if (Q.is_inf()) return out;
     out.inf = false; out.lines.reserve(96);
     const Consts& C = consts(); const AteLoop& L = ate_loop();
-    Fq2 X = Q.x, Y = Q.y, Z = Fq2::one();
-    auto dbl = [&] {
-        const Fq2 a = scale2(X * Y, C.half), b = fp_sqr(Y), c = fp_sqr(Z), c3 = fp_dbl(c) + c, e = C.twist_b * c3, f = fp_dbl(e) + e, g = scale2(b + f, C.half),
-                  h = fp_sqr(Y + Z) - (b + c), i = e - b, j = fp_sqr(X), e2 = fp_sqr(e);
-        X = a * (b - f); Y = fp_sqr(g) - (fp_dbl(e2) + e2); Z = b * h;
-        out.lines.push_back({fp_neg(h), fp_dbl(j) + j, i});
-    };
-    auto add = [&](const Fq2& xq, const Fq2& yq) {
-        const Fq2 theta = Y - yq * Z, lambda = X - xq * Z, c = fp_sqr(theta), d = fp_sqr(lambda), e = lambda * d, f = Z * c, g = X * d, h = e + f - fp_dbl(g);
-        const Fq2 j = theta * xq - lambda * yq;
-        X = lambda * h; Y = theta * (g - h) - e * Y; Z = Z * e;
-        out.lines.push_back({lambda, fp_neg(theta), j});
-    };
+    LinePoint R{Q.x, Q.y, Fq2::one()};
+    auto dbl = [&] { LineCoeffs l; line_dbl(R, C.twist_b, C.half, l.data()); out.lines.push_back(l); };
+    auto add = [&](const Fq2& xq, const Fq2& yq) { LineCoeffs l; line_add(R, xq, yq, l.data()); out.lines.push_back(l); };
     const Fq2 nQy = fp_neg(Q.y);
     for (int i = 63; i >= 0; i--) { dbl(); if (L.digit[i] > 0) add(Q.x, Q.y); else if (L.digit[i] < 0) add(Q.x, nQy); }
     add(conj2(Q.x) * C.psi_x, conj2(Q.y) * C.psi_y);                               // + pi(Q)

@@ -22,6 +22,7 @@
 
 using namespace zkc;
 using namespace zkc::pairing;
+namespace zkc { int miller_product_dev(zkc_ctx* ctx, const G1XYZZ* d_P, const G2Affine* h_Q, uint32_t N, pairing::Fq12* product, int* bad); }      // zkc_pairing_dev.hip
 
 namespace {
 
@@ -309,24 +310,37 @@ extern "C" int zkc_verify_batch(zkc_ctx* ctx, const uint8_t* vk, int nPublic, co
             xsum[j] = xsum[j] + rm * fp_from_std<FrParams>(k);
         }
     }
-    // ---- G1 side on the GPU: rho_i A_i (N single-element groups) and sum rho_i C_i (one group) ----
-    std::vector<G1XYZZ> gout(N + 1);
+    // ---- G1 side on the GPU: rho_i A_i (N single-element groups) and sum rho_i C_i (one group); from 128 proofs on, the Miller loops too (zkc_pairing_dev.hip;
+    // ZKC_VERIFY_BATCH_GPU=0 / 1 forces the host threads / the GPU) ----
+    const char* gpu_e = getenv("ZKC_VERIFY_BATCH_GPU"); const int gpu_env = gpu_e ? atoi(gpu_e) : -1;
+    const bool on_gpu = gpu_env < 0 ? N >= 128 : gpu_env != 0;
+    Fq12 gpu_product = one12(); int gpu_bad = 0;
+    // groups: N singletons (rho_i A_i), then the rho_i C_i in runs of 64 -- a group is summed by ONE lane, and one lane adding all N of them was 100 ms at N = 8192
+    const uint32_t ncg = ((uint32_t)N + 63) / 64, ngroups = (uint32_t)N + ncg;
+    std::vector<G1XYZZ> gout(ngroups);
     {
         ZKC_LOCK(ctx);
         if (hipSetDevice(ctx->device) != hipSuccess) return vfail(-ZKC_ERR_HIP, "zkc_verify_batch: hipSetDevice failed");     // never a positive code: 1 means "all valid"
         G1Affine* d_pts = nullptr; uint32_t *d_rho = nullptr, *d_idx = nullptr, *d_gs = nullptr;
-        std::vector<uint32_t> idx(2 * (size_t)N), gs(N + 2);
+        std::vector<uint32_t> idx(2 * (size_t)N), gs((size_t)ngroups + 1);
         for (size_t i = 0; i < idx.size(); i++) idx[i] = (uint32_t)i;
-        for (int i = 0; i <= N; i++) gs[i] = (uint32_t)i; gs[N + 1] = 2 * (uint32_t)N;
+        for (int i = 0; i < N; i++) gs[i] = (uint32_t)i;
+        for (uint32_t g = 0; g <= ncg; g++) gs[(size_t)N + g] = (uint32_t)N + std::min(64 * g, (uint32_t)N);
         int rc = ZKC_OK;
         auto cleanup = [&]() { for (void* q : {(void*)d_pts, (void*)d_rho, (void*)d_idx, (void*)d_gs}) if (q) (void)hipFree(q); };
         if (hipMalloc((void**)&d_pts, pts.size() * sizeof(G1Affine)) != hipSuccess || hipMalloc((void**)&d_rho, rho.size() * 4) != hipSuccess ||
             hipMalloc((void**)&d_idx, idx.size() * 4) != hipSuccess || hipMalloc((void**)&d_gs, gs.size() * 4) != hipSuccess) { cleanup(); return vfail(-ZKC_ERR_HIP, "zkc_verify_batch: hipMalloc failed"); }
         if (hipMemcpy(d_pts, pts.data(), pts.size() * sizeof(G1Affine), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_rho, rho.data(), rho.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(d_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_gs, gs.data(), gs.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return vfail(-ZKC_ERR_HIP, "zkc_verify_batch: hipMemcpy failed"); }
-        rc = fold_group_sums_g1(ctx, d_pts, d_rho, d_idx, 2 * (uint32_t)N, 0, d_gs, (uint32_t)N + 1, gout.data());
+        G1XYZZ* d_gout = nullptr;
+        rc = fold_group_sums_g1_keep(ctx, d_pts, d_rho, d_idx, 2 * (uint32_t)N, 0, d_gs, ngroups, gout.data(), on_gpu ? &d_gout : nullptr);
         cleanup();
         if (rc) return vfail(rc > 0 ? -rc : -ZKC_ERR_GENERIC, std::string("zkc_verify_batch: ") + zkc_last_error(ctx));
+        if (on_gpu) {
+            rc = miller_product_dev(ctx, d_gout, Bs.data(), (uint32_t)N, &gpu_product, &gpu_bad);
+            (void)hipFree(d_gout);
+            if (rc) return vfail(-rc, std::string("zkc_verify_batch: ") + zkc_last_error(ctx));
+        }
     }
     // ---- vk_x side: (sum rho) IC0 + sum_j (sum_i rho_i x_ij) IC_j ----
     std::vector<std::array<uint32_t, 8>> ks((size_t)nPublic + 1);
@@ -353,12 +367,16 @@ extern "C" int zkc_verify_batch(zkc_ctx* ctx, const uint8_t* vk, int nPublic, co
         }
         part[t] = f;
     };
-    std::vector<std::thread> th; for (unsigned t = 1; t < nthr; t++) th.emplace_back(work, t);
-    work(0); for (auto& x : th) x.join();
-    for (unsigned t = 0; t < nthr; t++) if (bad[t]) return 0;
-    const Pair tail[3] = {{ralpha, &V->pbeta}, {xyzz_to_affine_gcd(vx), &V->pgamma}, {xyzz_to_affine_gcd(gout[N]), &V->pdelta}};
+    if (on_gpu) { if (gpu_bad) return 0; part.assign(1, gpu_product); }
+    else {
+        std::vector<std::thread> th; for (unsigned t = 1; t < nthr; t++) th.emplace_back(work, t);
+        work(0); for (auto& x : th) x.join();
+        for (unsigned t = 0; t < nthr; t++) if (bad[t]) return 0;
+    }
+    G1XYZZ csum = G1XYZZ::inf(); for (uint32_t g = 0; g < ncg; g++) csum = xyzz_add(csum, gout[(size_t)N + g]);
+    const Pair tail[3] = {{ralpha, &V->pbeta}, {xyzz_to_affine_gcd(vx), &V->pgamma}, {xyzz_to_affine_gcd(csum), &V->pdelta}};
     Fq12 f = multi_miller(tail, 3);
-    for (unsigned t = 0; t < nthr; t++) f = f * part[t];
+    for (const Fq12& x : part) f = f * x;
     return is_one12(final_exp(f)) ? 1 : 0;
 }
 
