@@ -274,7 +274,9 @@ extern "C" int zkc_verify_bin(const uint8_t* vk, int nPublic, const uint8_t* pub
 // N proofs under one key are folded into one pairing-product check with random 128-bit weights rho_i:
 //     prod_i e(-rho_i A_i, B_i) * e((sum rho_i) alpha, beta) * e(sum_i rho_i vk_x_i, gamma) * e(sum_i rho_i C_i, delta) == 1
 // i.e. N + 3 Miller loops and ONE final exponentiation instead of 4 N and N.  The G1 work (rho_i A_i for every proof and the MSM
-// sum rho_i C_i) runs on the GPU with the prover's double-and-add / group-sum kernels; Miller loops run on host threads.
+// sum rho_i C_i) runs on the GPU with the prover's double-and-add / group-sum kernels; so do the N Miller loops and the membership tests of the B_i from 128
+// proofs on (zkc_pairing_dev.hip: one lane per pair writes its lines, a product tree per loop step, the host finishes the accumulator); smaller batches keep them on
+// host threads, sixteen pairs per shared accumulator.
 // A cheating prover passes with probability about 2^-128 provided the weights are unpredictable to it: `seed32` must be fresh
 // randomness (NULL: std::random_device).  Each B_i is checked to lie in the order-r subgroup of the twist (G2 has a cofactor), as
 // zkc_verify_bin does.  Returns 1 all valid / 0 at least one invalid / <0 = -ZKC_ERR_*.
