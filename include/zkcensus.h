@@ -225,7 +225,7 @@ int groth16_fullprove(const void* zkey_buffer, unsigned long zkey_size, const vo
  * Never a positive value other than 1.  Proof points must be on their curves and B in the order-r subgroup of the twist (both
  * entry points, single and batch, apply the same membership checks); JSON points must have z = 1 (or 0 = infinity).
  * zkc_verify_bin takes vk = alpha1(64) beta2(128) gamma2(128) delta2(128) IC[nPublic+1](64 each), standard form.
- * [r5] About 1.4 ms per proof on the GPU boxes' hosts (csrc/zkc_pairing_host.h); the latest eight verification keys are kept ready by their bytes (their checks and
+ * [r5] About 1.4 ms per proof on the GPU boxes' hosts (csrc/zkc_pairing.h); the latest eight verification keys are kept ready by their bytes (their checks and
  * line coefficients are computed on first use, ~6 ms), any thread may call. */
 int zkc_verify(const char* vkey_json, const char* public_json, const char* proof_json);
 int zkc_verify_bin(const uint8_t* vk, int nPublic, const uint8_t* pub, const uint8_t* proof);

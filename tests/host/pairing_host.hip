@@ -1,11 +1,11 @@
-// Host checks of the verifier's pairing (csrc/zkc_pairing_host.h), beyond the pin of its value against the reference key's vk_alphabeta_12 (tests/test_oracle_pinning.py):
+// Host checks of the verifier's pairing (csrc/zkc_pairing.h), beyond the pin of its value against the reference key's vk_alphabeta_12 (tests/test_oracle_pinning.py):
 //   * bilinearity: e([a]P, [b]Q) = e(P, Q)^(ab), and the shared-accumulator loop over several pairs = the product of the single loops;
 //   * cyclotomic squaring = plain squaring on elements past the easy part of the final exponentiation;
 //   * membership in G2 by the endomorphism (psi(Q) = [6x^2]Q) = membership by definition ([r]Q = infinity), on multiples of the generator AND on twist points
 //     outside the subgroup (found by taking square roots in Fq2);
 //   * the signed-digit loop constant recomposes to 6x + 2.
 //   hipcc --offload-arch=gfx950 -std=c++17 -O2 -I zk-franchise-proof-circuit_amd/csrc -I include tests/host/pairing_host.hip -o pairing_host && ./pairing_host
-#include "zkc_pairing_host.h"
+#include "zkc_pairing.h"
 #include <cstdio>
 #include <random>
 using namespace zkc; using namespace zkc::pairing;

@@ -19,7 +19,7 @@ def test_gcd_inversion_equals_fermat_inversion(tmp_path):
 
 
 def test_pairing_of_the_cpu_verifier(tmp_path):
-    """[r5] csrc/zkc_pairing_host.h (optimal ate, projective sparse lines, shared accumulator, signed-digit loop, cyclotomic final exponentiation, endomorphism subgroup test):
+    """[r5] csrc/zkc_pairing.h (optimal ate, projective sparse lines, shared accumulator, signed-digit loop, cyclotomic final exponentiation, endomorphism subgroup test):
     bilinearity, several pairs on one accumulator = separate loops, cyclotomic = plain squaring, Frobenius maps, and membership in G2 by psi(Q) = [6x^2]Q against [r]Q = infinity
     on subgroup points and on 40 twist points outside the subgroup (tests/host/pairing_host.hip).  Its VALUE is pinned by test_oracle_pinning.py (vk_alphabeta_12)."""
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'

@@ -1,4 +1,5 @@
-// zkc_pairing_host.h -- the BN254 pairing of the CPU verifier (a9 / f4; host only, included by zkc_verify.hip).
+// zkc_pairing.h -- the BN254 pairing of the verifiers (a9 / f4).  The tower arithmetic and the line steps are host + device code (the batch verifier's kernels,
+// zkc_pairing_dev.hip, run them on the GPU); the loop drivers, the prepared points, the final exponentiation and the membership tests are host code (zkc_verify.hip).
 //
 // What go-rapidsnark's verifier does behind (*Proof).Verify (zk_census_test.go:122) and snarkjs behind groth16.verify, restated: optimal ate Miller loop over 6x + 2
 // with the two Frobenius steps, homogeneous projective line functions (no inversions), lines multiplied in sparsely, several pairs sharing ONE accumulator (one squaring

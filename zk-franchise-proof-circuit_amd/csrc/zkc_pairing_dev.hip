@@ -13,7 +13,7 @@
 #include <algorithm>
 #include <vector>
 #include "zkc_prover.h"
-#include "zkc_pairing_host.h"
+#include "zkc_pairing.h"
 
 namespace zkc {
 using namespace zkc::pairing;
@@ -87,7 +87,7 @@ int miller_product_dev(zkc_ctx* ctx, const G1XYZZ* d_P, const G2Affine* h_Q, uin
     const Consts& K = consts(); const AteLoop& L = ate_loop();
     MillerConsts C; C.twist_b = K.twist_b; C.psi_x = K.psi_x; C.psi_y = K.psi_y; C.psi2_x = K.psi2_x; C.psi2_y = K.psi2_y; C.half = K.half; C.pos = C.neg = 0;
     for (int b = 0; b < 64; b++) { if (L.digit[b] > 0) C.pos |= 1ull << b; else if (L.digit[b] < 0) C.neg |= 1ull << b; }
-    C.t_lo = 0xf83e9682e87cfd46ull; C.t_hi = 0x6f4d8248eeb859fbull;           // 6 x^2, bit 126 on top (zkc_pairing_host.h g2_in_subgroup)
+    C.t_lo = 0xf83e9682e87cfd46ull; C.t_hi = 0x6f4d8248eeb859fbull;           // 6 x^2, bit 126 on top (zkc_pairing.h g2_in_subgroup)
     const uint32_t nlines = 66 + (uint32_t)__builtin_popcountll(C.pos | C.neg);
     constexpr uint32_t CHUNK = 16384;
     const uint32_t cap = std::min(N, CHUNK), hcap = (cap + 1) / 2;

@@ -3,7 +3,7 @@
 //
 // Mirrors go-rapidsnark/verifier VerifyGroth16 behind dvote's proof.Verify (zk_census_test.go:122) and snarkjs
 // groth16.verify: vk_x = IC0 + sum s_i IC_{i+1};  e(-A, B) e(alpha, beta) e(vk_x, gamma) e(C, delta) == 1.
-// The pairing lives in zkc_pairing_host.h (optimal ate, projective sparse lines, shared accumulator, prepared G2 points, cyclotomic final exponentiation).
+// The pairing lives in zkc_pairing.h (optimal ate, projective sparse lines, shared accumulator, prepared G2 points, cyclotomic final exponentiation).
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -13,7 +13,7 @@
 #include <algorithm>
 #include "zkc_prover.h"
 #include "zkc_hostparse.h"
-#include "zkc_pairing_host.h"
+#include "zkc_pairing.h"
 #include <sys/random.h>
 #include <cerrno>
 #include <mutex>
