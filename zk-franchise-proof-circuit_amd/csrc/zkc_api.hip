@@ -250,16 +250,21 @@ static int get_template(zkc_ctx* ctx, const WitnessLayout& L, uint32_t** out) {
     auto it = ctx->tmpl.find(L.nL);
     if (it != ctx->tmpl.end()) { *out = it->second; return ZKC_OK; }
     uint32_t *d_t = nullptr, *d_in = nullptr; int32_t* d_st = nullptr;
-    ZKC_HIP_CHECK(ctx, hipMalloc(&d_t, (size_t)L.nWires * 32));
-    ZKC_HIP_CHECK(ctx, hipMalloc(&d_in, (size_t)L.nInputs * 32));
-    ZKC_HIP_CHECK(ctx, hipMalloc(&d_st, 3 * sizeof(int32_t)));
-    ZKC_HIP_CHECK(ctx, hipMemsetAsync(d_t, 0, (size_t)L.nWires * 32, ctx->stream));
-    ZKC_HIP_CHECK(ctx, hipMemsetAsync(d_in, 0, (size_t)L.nInputs * 32, ctx->stream));
-    hipLaunchKernelGGL(zkc_witness_chains_wave, dim3(3), dim3(64), 0, ctx->stream, L, ctx->ptab, d_in, d_t, d_st, 1, 1);
-    hipLaunchKernelGGL(zkc_witness_tostd, dim3((L.nWires + 255) / 256), dim3(256), 0, ctx->stream, d_t, (size_t)L.nWires);
-    ZKC_HIP_CHECK(ctx, hipGetLastError());
-    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    ZKC_HIP_CHECK(ctx, hipFree(d_in)); ZKC_HIP_CHECK(ctx, hipFree(d_st));
+    const int rc = [&]() -> int {
+        ZKC_HIP_CHECK(ctx, hipMalloc(&d_t, (size_t)L.nWires * 32));
+        ZKC_HIP_CHECK(ctx, hipMalloc(&d_in, (size_t)L.nInputs * 32));
+        ZKC_HIP_CHECK(ctx, hipMalloc(&d_st, 3 * sizeof(int32_t)));
+        ZKC_HIP_CHECK(ctx, hipMemsetAsync(d_t, 0, (size_t)L.nWires * 32, ctx->stream));
+        ZKC_HIP_CHECK(ctx, hipMemsetAsync(d_in, 0, (size_t)L.nInputs * 32, ctx->stream));
+        hipLaunchKernelGGL(zkc_witness_chains_wave, dim3(3), dim3(64), 0, ctx->stream, L, ctx->ptab, d_in, d_t, d_st, 1, 1);
+        hipLaunchKernelGGL(zkc_witness_tostd, dim3((L.nWires + 255) / 256), dim3(256), 0, ctx->stream, d_t, (size_t)L.nWires);
+        ZKC_HIP_CHECK(ctx, hipGetLastError());
+        ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        return ZKC_OK;
+    }();
+    if (d_in) (void)hipFree(d_in);
+    if (d_st) (void)hipFree(d_st);
+    if (rc) { if (d_t) (void)hipFree(d_t); return rc; }                  // a failed build leaves nothing behind
     ctx->tmpl[L.nL] = d_t; *out = d_t;
     return ZKC_OK;
 }

@@ -536,7 +536,10 @@ zkc_fold_mul(const Affine<F>* __restrict__ tbl, const uint32_t* __restrict__ sca
     const uint32_t k[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     Affine<F> p = PointIO<F>::load(tbl + (uint32_t)((int32_t)wire - pt_shift));
     XYZZ<F> r = XYZZ<F>::inf();
-    for (int bit = 255; bit >= 0; bit--) {
+    int top = -1;                                                    // the batch verifier's weights are 128 bits wide: start at the scalar's own top bit
+#pragma unroll
+    for (int q = 7; q >= 0; q--) if (top < 0 && k[q]) top = 32 * q + 31 - __clz(k[q]);
+    for (int bit = top; bit >= 0; bit--) {
         r = xyzz_dbl(r);
         if ((limb_of(k, bit >> 5) >> (bit & 31)) & 1) r = xyzz_add_affine(r, p);
     }
@@ -555,17 +558,21 @@ template <class F>
 static int fold_group_sums(zkc_ctx* ctx, const Affine<F>* tbl, const uint32_t* d_scalars, const uint32_t* d_wires, uint32_t nw, int32_t pt_shift,
                            const uint32_t* d_gstart, uint32_t ngroups, XYZZ<F>* h_out, XYZZ<F>** d_keep = nullptr) {
     XYZZ<F>*d_tmp = nullptr, *d_out = nullptr;
-    ZKC_HIP_CHECK(ctx, hipMalloc(&d_tmp, (size_t)nw * sizeof(XYZZ<F>)));
-    ZKC_HIP_CHECK(ctx, hipMalloc(&d_out, (size_t)ngroups * sizeof(XYZZ<F>)));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_fold_mul<F>), dim3((nw + 63) / 64), dim3(64), 0, ctx->stream, tbl, d_scalars, d_wires, nw, pt_shift, d_tmp);
-    ZKC_HIP_CHECK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_fold_gsum<F>), dim3((ngroups + 63) / 64), dim3(64), 0, ctx->stream, d_tmp, d_gstart, ngroups, d_out);
-    ZKC_HIP_CHECK(ctx, hipGetLastError());
-    ZKC_HIP_CHECK(ctx, hipMemcpyAsync(h_out, d_out, (size_t)ngroups * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, ctx->stream));
-    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    ZKC_HIP_CHECK(ctx, hipFree(d_tmp));
-    if (d_keep) *d_keep = d_out; else ZKC_HIP_CHECK(ctx, hipFree(d_out));
-    return ZKC_OK;
+    const int rc = [&]() -> int {
+        ZKC_HIP_CHECK(ctx, hipMalloc(&d_tmp, (size_t)nw * sizeof(XYZZ<F>)));
+        ZKC_HIP_CHECK(ctx, hipMalloc(&d_out, (size_t)ngroups * sizeof(XYZZ<F>)));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_fold_mul<F>), dim3((nw + 63) / 64), dim3(64), 0, ctx->stream, tbl, d_scalars, d_wires, nw, pt_shift, d_tmp);
+        ZKC_HIP_CHECK(ctx, hipGetLastError());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_fold_gsum<F>), dim3((ngroups + 63) / 64), dim3(64), 0, ctx->stream, d_tmp, d_gstart, ngroups, d_out);
+        ZKC_HIP_CHECK(ctx, hipGetLastError());
+        ZKC_HIP_CHECK(ctx, hipMemcpyAsync(h_out, d_out, (size_t)ngroups * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, ctx->stream));
+        ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        return ZKC_OK;
+    }();
+    if (d_tmp) (void)hipFree(d_tmp);
+    if (rc || !d_keep) { if (d_out) (void)hipFree(d_out); }
+    else *d_keep = d_out;
+    return rc;
 }
 int fold_group_sums_g1(zkc_ctx* ctx, const G1Affine* tbl, const uint32_t* s, const uint32_t* w, uint32_t nw, int32_t sh, const uint32_t* gs, uint32_t ng, G1XYZZ* o) {
     return fold_group_sums<Fq>(ctx, tbl, s, w, nw, sh, gs, ng, o);
