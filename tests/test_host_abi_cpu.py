@@ -139,3 +139,27 @@ def test_zkey_fingerprint_identifies_keys(tmp_path):
     t0 = time.perf_counter()
     for _ in range(20): fp(a)
     assert (time.perf_counter() - t0) / 20 < 0.02
+
+
+def test_verifier_from_many_threads_with_the_key_cache():
+    """[r5] zkc_verify keeps the latest verification keys ready by their bytes (csrc/zkc_verify.hip vk_ready): eight threads verify the reference's triple, a triple with a
+    changed signal and triples under nine OTHER keys (the reference's with IC points permuted: well-formed keys under which the proof is invalid -- more keys than the cache
+    holds, so entries are evicted while others use them) and every verdict is the sequential one."""
+    from concurrent.futures import ThreadPoolExecutor
+    lib = _native.load()
+    vk = ol.load_json('ref/verification_key.json'); pr = ol.load_json('ref/proof.json'); sig = ol.load_json('ref/signals.json')
+    t = lambda x: json.dumps(x).encode()
+    keys = [vk]
+    for i in range(9):
+        k = json.loads(json.dumps(vk)); ic = k['IC']; a, b = 1 + i % 8, 1 + (i + 3) % 8
+        if a == b: b = 1 + (b % 8)
+        ic[a], ic[b] = ic[b], ic[a]; keys.append(k)
+    bad_sig = list(sig); bad_sig[0] = str(int(sig[0]) + 1)
+    jobs = []
+    for rep in range(6):
+        for ki, k in enumerate(keys):
+            jobs.append((t(k), t(sig), t(pr), 1 if ki == 0 else 0))
+            jobs.append((t(k), t(bad_sig), t(pr), 0))
+    with ThreadPoolExecutor(8) as ex:
+        got = list(ex.map(lambda j: lib.zkc_verify(j[0], j[1], j[2]), jobs))
+    assert got == [j[3] for j in jobs]
