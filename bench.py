@@ -651,14 +651,24 @@ def main():
     npass = -(-B // inflight); per = -(-B // npass)                       # the library cuts a batch into equal passes of at most `inflight` proofs (zkc_zkey_pass_info)
     sample = sorted({i for i in (0, 1, per - 1, per, 2 * per - 1, 2 * per, B // 2, (npass - 1) * per - 1, (npass - 1) * per, B - 2, B - 1) if 0 <= i < B})
     if not args.no_verify:
-        ok_batch = groth16.verify_batch(ctx, vk, out['pubs'], out['proofs'])                  # all B proofs of the step, product batch verifier
+        groth16.verify_batch(ctx, vk, out['pubs'][:256 * 8], out['proofs'][:256 * 8])        # the key is made ready once (its checks, prepared gamma / delta); kernels load
+        t_v = time.perf_counter()
+        ok_batch = groth16.verify_batch(ctx, vk, out['pubs'], out['proofs'])                  # all B proofs of the step, product batch verifier (Miller loops on the GPU)
+        batch_verify_ms = 1e3 * (time.perf_counter() - t_v)
+        from zkcensus_amd import _native as _nat
+        vkb = groth16.vk_to_bytes(vk); _vlib = _nat.load(); t_v = time.perf_counter()
+        ok_single = [_vlib.zkc_verify_bin(vkb, 8, out['pubs'][256 * i:256 * i + 256], out['proofs'][256 * i:256 * i + 256]) == 1 for i in range(min(B, 16))]   # proof.Verify per vote (zk_census_test.go:122), CPU
+        single_verify_ms = 1e3 * (time.perf_counter() - t_v) / len(ok_single)
+        ok_batch = ok_batch and all(ok_single)
         ok_gather = bool((out['records'][lo:hi].cpu() == out['rec']).all())                  # gathered records carry this rank's proofs
         flags = torch.tensor([1 if ok_batch else 0, 1 if ok_gather else 0])
         if world > 1:
             f = flags if share else flags.cuda(dev)
             dist.all_reduce(f, op=dist.ReduceOp.MIN); flags = f.cpu()
         verified = {'step': 'last timed step', 'proofs': B * world, 'batch_verifier_all_valid': bool(flags[0].item()),
-                    'gathered_records_equal_per_rank_records': bool(flags[1].item())}
+                    'gathered_records_equal_per_rank_records': bool(flags[1].item()),
+                    'batch_verifier_ms_per_rank': round(batch_verify_ms, 2), 'batch_verifier_proofs_per_s_per_rank': round(B / (batch_verify_ms / 1e3), 0),
+                    'single_verify_cpu_ms': round(single_verify_ms, 2)}
 
     cpu = None
     if rank == 0 and not args.no_verify:
