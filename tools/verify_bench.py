@@ -20,7 +20,7 @@ def main():
     proofs, pubs = pk.fullprove_batch_dev(d_in.data_ptr(), N, d_w.data_ptr(), d_s.data_ptr(), rs.tobytes())
     assert int(d_s.abs().sum().item()) == 0
     vkb = groth16.vk_to_bytes(vk)
-    groth16.verify_batch(ctx, vkb, pubs[:256 * 8], proofs[:256 * 8], os.urandom(32))          # the key is made ready once (subgroup checks, prepared gamma / delta) and the fold kernels load
+    t0 = time.perf_counter(); groth16.verify_batch(ctx, vkb, pubs, proofs, os.urandom(32)); first = time.perf_counter() - t0      # the key is made ready, the kernels load, the work space is allocated
     cpu0 = time.process_time(); t0 = time.perf_counter(); ok = groth16.verify_batch(ctx, vkb, pubs, proofs, os.urandom(32)); t1 = time.perf_counter(); cpu1 = time.process_time()
     lib = _native.load(); k = min(N, 64)
     t2 = time.perf_counter()
@@ -29,7 +29,7 @@ def main():
     t3 = time.perf_counter()
     bad = bytearray(proofs); bad[256 * (N // 2) + 192:256 * (N // 2) + 256] = proofs[192:256]       # one proof gets another proof's C
     rej = groth16.verify_batch(ctx, vkb, pubs, bytes(bad), os.urandom(32))
-    print(json.dumps({'N': N, 'batch_valid': ok, 'tampered_batch_rejected': not rej, 'batch_verify_s': round(t1 - t0, 3), 'proofs_per_s_batch': round(N / (t1 - t0), 1),
+    print(json.dumps({'N': N, 'batch_valid': ok, 'tampered_batch_rejected': not rej, 'batch_verify_s': round(t1 - t0, 4), 'first_call_s': round(first, 3), 'proofs_per_s_batch': round(N / (t1 - t0), 1),
                       'single_verify_ms': round(1e3 * (t3 - t2) / k, 2), 'speedup_vs_single': round((t3 - t2) / k * N / (t1 - t0), 1), 'host_threads': min(32, os.cpu_count()), 'host_cpu_s_batch': round(cpu1 - cpu0, 3)}))
 
 if __name__ == '__main__':

@@ -51,6 +51,12 @@ int zkc_ensure(zkc_ctx* ctx, void** p, size_t* cur, size_t need) {
     return ZKC_OK;
 }
 
+void zkc_verify_ws_trim(zkc_ctx* ctx, size_t keep_bytes) {
+    size_t total = 0; for (size_t b : ctx->vws_sz) total += b;
+    if (total <= keep_bytes && keep_bytes) return;
+    for (int i = 0; i < zkc_ctx::VWS_N; i++) { if (ctx->vws[i]) (void)hipFree(ctx->vws[i]); ctx->vws[i] = nullptr; ctx->vws_sz[i] = 0; }
+}
+
 extern "C" __global__ void zkc_poseidon_batch_kernel(PoseidonTable tab, const uint32_t* in, uint32_t* out, int nin, size_t B);
 
 static hipEvent_t prof_event(zkc_ctx* ctx) {
@@ -216,6 +222,7 @@ extern "C" void zkc_ctx_destroy(zkc_ctx* ctx) {
     if (ctx->d_status3) (void)hipFree(ctx->d_status3);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_prof_entries) (void)hipFree(ctx->d_prof_entries);
+    zkc_verify_ws_trim(ctx, 0);
     for (auto& ls : ctx->lane_streams) for (hipStream_t q : {ls.st, ls.st2, ls.fin, ls.red}) if (q) (void)hipStreamSynchronize(q);      // (the streams are the DEVICE's and stay: zkc_lane_streams)
     zkc_ctx_lanes_destroy(ctx);
     if (ctx->ev_acc_chain) (void)hipEventDestroy(ctx->ev_acc_chain);

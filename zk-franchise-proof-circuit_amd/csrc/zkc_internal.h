@@ -58,6 +58,11 @@ struct zkc_ctx {
     void* d_scratch_out = nullptr; size_t scratch_out_sz = 0;
     int32_t* d_status3 = nullptr; size_t status3_n = 0;
     int32_t* d_status = nullptr; size_t status_n = 0;
+    // [r5] the batch verifier's device buffers (zkc_verify_batch, zkc_pairing_dev.hip): points, weights, group table, fold sums, line coefficients, product-tree levels.
+    // Kept between calls (a node verifies batch after batch; hipFree waits for the whole device, including any proving lanes) while they add up to at most 256 MB, released
+    // at the end of a call that needed more (zkc_verify_ws_trim).
+    enum { VWS_PTS = 0, VWS_RHO, VWS_IDX, VWS_GS, VWS_FOLD_TMP, VWS_FOLD_OUT, VWS_Q, VWS_LINES, VWS_TREE_A, VWS_TREE_B, VWS_BAD, VWS_N };
+    void* vws[VWS_N] = {nullptr}; size_t vws_sz[VWS_N] = {0};
     zkc_prof prof;
     unsigned long long* d_prof_entries = nullptr;      // device counter: (digit, point) entries = group additions of the G1 passes while profiling is on
 };
@@ -71,6 +76,8 @@ int zkc_fail(zkc_ctx* ctx, int code, const std::string& msg);
 hipError_t zkc_wait_event(hipEvent_t ev, unsigned spin_us = 0);        // spin_us: keep polling back to back for that long before the naps start (a lone caller's 3 ms proof: the nap would add 2 % to its latency)
 hipError_t zkc_wait_stream(hipStream_t st, hipEvent_t scratch_ev);      // record scratch_ev on st, then zkc_wait_event (scratch_ev: any event of the caller's that is not otherwise in flight)
 int zkc_ensure(zkc_ctx* ctx, void** p, size_t* cur, size_t need);
+inline int zkc_vws(zkc_ctx* ctx, int which, size_t need, void** out) { const int rc = zkc_ensure(ctx, &ctx->vws[which], &ctx->vws_sz[which], need); *out = ctx->vws[which]; return rc; }
+void zkc_verify_ws_trim(zkc_ctx* ctx, size_t keep_bytes);      // free the verifier's buffers when they hold more than keep_bytes (0: always)
 // RAII bracket: records two events around the launches made while it is alive when category `cat` is enabled
 struct zkc_prof_scope {
     zkc_ctx* ctx; int cat; hipEvent_t a = nullptr, b = nullptr; bool on; hipStream_t st;

@@ -556,7 +556,7 @@ zkc_fold_gsum(const XYZZ<F>* __restrict__ in, const uint32_t* __restrict__ gstar
 }
 template <class F>
 static int fold_group_sums(zkc_ctx* ctx, const Affine<F>* tbl, const uint32_t* d_scalars, const uint32_t* d_wires, uint32_t nw, int32_t pt_shift,
-                           const uint32_t* d_gstart, uint32_t ngroups, XYZZ<F>* h_out, XYZZ<F>** d_keep = nullptr) {
+                           const uint32_t* d_gstart, uint32_t ngroups, XYZZ<F>* h_out) {
     XYZZ<F>*d_tmp = nullptr, *d_out = nullptr;
     const int rc = [&]() -> int {
         ZKC_HIP_CHECK(ctx, hipMalloc(&d_tmp, (size_t)nw * sizeof(XYZZ<F>)));
@@ -570,16 +570,21 @@ static int fold_group_sums(zkc_ctx* ctx, const Affine<F>* tbl, const uint32_t* d
         return ZKC_OK;
     }();
     if (d_tmp) (void)hipFree(d_tmp);
-    if (rc || !d_keep) { if (d_out) (void)hipFree(d_out); }
-    else *d_keep = d_out;
+    if (d_out) (void)hipFree(d_out);
     return rc;
 }
 int fold_group_sums_g1(zkc_ctx* ctx, const G1Affine* tbl, const uint32_t* s, const uint32_t* w, uint32_t nw, int32_t sh, const uint32_t* gs, uint32_t ng, G1XYZZ* o) {
     return fold_group_sums<Fq>(ctx, tbl, s, w, nw, sh, gs, ng, o);
 }
-// the same, and the sums stay on the device as well (*d_keep, the caller's to hipFree): the batch verifier's Miller kernels read them there
-int fold_group_sums_g1_keep(zkc_ctx* ctx, const G1Affine* tbl, const uint32_t* s, const uint32_t* w, uint32_t nw, int32_t sh, const uint32_t* gs, uint32_t ng, G1XYZZ* o, G1XYZZ** d_keep) {
-    return fold_group_sums<Fq>(ctx, tbl, s, w, nw, sh, gs, ng, o, d_keep);
+// the batch verifier's form: scratch and sums in buffers of the caller's (the context's verifier work space), the sums left on the device for the Miller kernels and copied to h_out
+int fold_group_sums_g1_ws(zkc_ctx* ctx, const G1Affine* tbl, const uint32_t* s, const uint32_t* w, uint32_t nw, const uint32_t* gs, uint32_t ng, G1XYZZ* d_tmp, G1XYZZ* d_out, G1XYZZ* h_out) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_fold_mul<Fq>), dim3((nw + 63) / 64), dim3(64), 0, ctx->stream, tbl, s, w, nw, 0, d_tmp);
+    ZKC_HIP_CHECK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(zkc_fold_gsum<Fq>), dim3((ng + 63) / 64), dim3(64), 0, ctx->stream, d_tmp, gs, ng, d_out);
+    ZKC_HIP_CHECK(ctx, hipGetLastError());
+    ZKC_HIP_CHECK(ctx, hipMemcpyAsync(h_out, d_out, (size_t)ng * sizeof(G1XYZZ), hipMemcpyDeviceToHost, ctx->stream));
+    ZKC_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKC_OK;
 }
 int fold_group_sums_g2(zkc_ctx* ctx, const G2Affine* tbl, const uint32_t* s, const uint32_t* w, uint32_t nw, int32_t sh, const uint32_t* gs, uint32_t ng, G2XYZZ* o) {
     return fold_group_sums<Fq2>(ctx, tbl, s, w, nw, sh, gs, ng, o);

@@ -11,6 +11,9 @@
 //   host               87 values come back; F = (..(L_0)^2 L_1..) is 63 squarings and 87 products, then the three pairs of the key and ONE final exponentiation.
 // Field elements are the 8 x 32-bit Montgomery residues of zkc_field.h on both sides, so the host continues where the device stopped.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <ctime>
 #include <vector>
 #include "zkc_prover.h"
 #include "zkc_pairing.h"
@@ -82,7 +85,7 @@ zkc_fq12_tree(const Fq12* __restrict__ in, uint32_t n, uint32_t nlines, Fq12* __
 }
 
 // prod_i f_{6x+2, Q_i}(-P_i) over N pairs, P on the device (XYZZ, as the fold kernels write them), Q on the host; *bad != 0: some Q_i is not in G2 (the product is
-// meaningless then).  Pairs are taken 16 384 at a time (300 MB of line coefficients).  The caller holds the context's lock.
+// meaningless then).  Pairs are taken 16 384 at a time (300 MB of line coefficients).  Buffers come from the context's verifier work space; the caller holds the context's lock.
 int miller_product_dev(zkc_ctx* ctx, const G1XYZZ* d_P, const G2Affine* h_Q, uint32_t N, Fq12* product, int* bad) {
     const Consts& K = consts(); const AteLoop& L = ate_loop();
     MillerConsts C; C.twist_b = K.twist_b; C.psi_x = K.psi_x; C.psi_y = K.psi_y; C.psi2_x = K.psi2_x; C.psi2_y = K.psi2_y; C.half = K.half; C.pos = C.neg = 0;
@@ -91,14 +94,18 @@ int miller_product_dev(zkc_ctx* ctx, const G1XYZZ* d_P, const G2Affine* h_Q, uin
     const uint32_t nlines = 66 + (uint32_t)__builtin_popcountll(C.pos | C.neg);
     constexpr uint32_t CHUNK = 16384;
     const uint32_t cap = std::min(N, CHUNK), hcap = (cap + 1) / 2;
-    G2Affine* d_Q = nullptr; Fq2* d_lines = nullptr; Fq12 *d_a = nullptr, *d_b = nullptr; int* d_bad = nullptr;
-    auto cleanup = [&]() { for (void* q : {(void*)d_Q, (void*)d_lines, (void*)d_a, (void*)d_b, (void*)d_bad}) if (q) (void)hipFree(q); };
-    auto fail = [&](hipError_t e, const char* what) { cleanup(); ctx->err = std::string(what) + ": " + hipGetErrorString(e); (void)hipGetLastError(); return ZKC_ERR_HIP; };
+    G2Affine* d_Q; Fq2* d_lines; Fq12 *d_a, *d_b; int* d_bad; int rc; void* q;
+    if ((rc = zkc_vws(ctx, zkc_ctx::VWS_Q, (size_t)cap * sizeof(G2Affine), &q))) return rc; d_Q = (G2Affine*)q;
+    if ((rc = zkc_vws(ctx, zkc_ctx::VWS_LINES, (size_t)nlines * cap * 3 * sizeof(Fq2), &q))) return rc; d_lines = (Fq2*)q;
+    if ((rc = zkc_vws(ctx, zkc_ctx::VWS_TREE_A, (size_t)nlines * hcap * sizeof(Fq12), &q))) return rc; d_a = (Fq12*)q;
+    if ((rc = zkc_vws(ctx, zkc_ctx::VWS_TREE_B, (size_t)nlines * ((hcap + 1) / 2) * sizeof(Fq12), &q))) return rc; d_b = (Fq12*)q;
+    if ((rc = zkc_vws(ctx, zkc_ctx::VWS_BAD, sizeof(int), &q))) return rc; d_bad = (int*)q;
+    auto fail = [&](hipError_t e, const char* what) { ctx->err = std::string(what) + ": " + hipGetErrorString(e); (void)hipGetLastError(); return ZKC_ERR_HIP; };
     hipError_t e;
-    if ((e = hipMalloc((void**)&d_Q, (size_t)cap * sizeof(G2Affine))) != hipSuccess || (e = hipMalloc((void**)&d_lines, (size_t)nlines * cap * 3 * sizeof(Fq2))) != hipSuccess ||
-        (e = hipMalloc((void**)&d_a, (size_t)nlines * hcap * sizeof(Fq12))) != hipSuccess || (e = hipMalloc((void**)&d_b, (size_t)nlines * ((hcap + 1) / 2) * sizeof(Fq12))) != hipSuccess ||
-        (e = hipMalloc((void**)&d_bad, sizeof(int))) != hipSuccess) return fail(e, "miller_product_dev: hipMalloc");
     if ((e = hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream)) != hipSuccess) return fail(e, "miller_product_dev: hipMemset");
+    const bool vtrace = getenv("ZKC_VERIFY_TRACE") != nullptr;
+    auto vnow = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double mt0 = vnow(); double mt_chunks = 0;
     std::vector<Fq12> step(nlines), acc(nlines, one12());
     for (uint32_t lo = 0; lo < N; lo += CHUNK) {
         const uint32_t n = std::min(CHUNK, N - lo);
@@ -117,15 +124,16 @@ int miller_product_dev(zkc_ctx* ctx, const G1XYZZ* d_P, const G2Affine* h_Q, uin
             (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "miller_product_dev: download");
         for (uint32_t s = 0; s < nlines; s++) acc[s] = lo ? acc[s] * step[s] : step[s];
     }
+    mt_chunks = vnow();
     int hb = 0;
     if ((e = hipMemcpy(&hb, d_bad, sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "miller_product_dev: download");
-    cleanup();
     *bad = hb;
     // the accumulator, step by step (the same walk as pairing::multi_miller)
     Fq12 f = one12(); uint32_t idx = 0;
     for (int b = 63; b >= 0; b--) { if (b != 63) f = sqr12(f); f = f * acc[idx++]; if (L.digit[b]) f = f * acc[idx++]; }
     f = f * acc[idx++]; f = f * acc[idx++];
     *product = f;
+    if (vtrace) fprintf(stderr, "miller_product_dev N=%u: kernels + transfers %.2f ms, accumulator on the host %.2f ms\n", N, mt_chunks - mt0, vnow() - mt_chunks);
     return ZKC_OK;
 }
 }  // namespace zkc

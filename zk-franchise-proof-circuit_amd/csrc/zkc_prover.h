@@ -275,8 +275,8 @@ int msm_g2_table29(zkc_ctx* ctx, const G2Affine* d_table, uint32_t* d_out, size_
 // out[i] = scalar[wires[i]] * P[wires[i] - pt_shift] (window-0 table), then per-group sums: gsum[g] = sum out[gstart[g]..gstart[g+1])
 int fold_group_sums_g1(zkc_ctx* ctx, const G1Affine* tbl, const uint32_t* d_scalars, const uint32_t* d_wires, uint32_t nw, int32_t pt_shift,
                        const uint32_t* d_gstart, uint32_t ngroups, G1XYZZ* h_out);
-int fold_group_sums_g1_keep(zkc_ctx* ctx, const G1Affine* tbl, const uint32_t* d_scalars, const uint32_t* d_wires, uint32_t nw, int32_t pt_shift,
-                            const uint32_t* d_gstart, uint32_t ngroups, G1XYZZ* h_out, G1XYZZ** d_keep);
+int fold_group_sums_g1_ws(zkc_ctx* ctx, const G1Affine* tbl, const uint32_t* d_scalars, const uint32_t* d_wires, uint32_t nw, const uint32_t* d_gstart, uint32_t ngroups,
+                          G1XYZZ* d_tmp /* nw */, G1XYZZ* d_out /* ngroups */, G1XYZZ* h_out);
 int fold_group_sums_g2(zkc_ctx* ctx, const G2Affine* tbl, const uint32_t* d_scalars, const uint32_t* d_wires, uint32_t nw, int32_t pt_shift,
                        const uint32_t* d_gstart, uint32_t ngroups, G2XYZZ* h_out);
 }

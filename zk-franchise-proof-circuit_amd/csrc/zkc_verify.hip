@@ -5,6 +5,7 @@
 // groth16.verify: vk_x = IC0 + sum s_i IC_{i+1};  e(-A, B) e(alpha, beta) e(vk_x, gamma) e(C, delta) == 1.
 // The pairing lives in zkc_pairing.h (optimal ate, projective sparse lines, shared accumulator, prepared G2 points, cyclotomic final exponentiation).
 #include <cstdio>
+#include <ctime>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -292,28 +293,44 @@ extern "C" int zkc_verify_batch(zkc_ctx* ctx, const uint8_t* vk, int nPublic, co
     const std::shared_ptr<const VkReady> V = vk_ready(vk, nPublic, &code);
     if (!V) return code;
     const std::vector<G1Affine>& ic = V->ic;
+    const bool vtrace = getenv("ZKC_VERIFY_TRACE") != nullptr; double vt0 = 0, vt1 = 0, vt2 = 0, vt3 = 0;
+    auto vnow = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    vt0 = vnow();
     Xoshiro rng;
     if (seed32) memcpy(rng.s, seed32, 32); else { std::random_device rd; for (auto& x : rng.s) x = ((uint64_t)rd() << 32) | rd(); }
     if (!(rng.s[0] | rng.s[1] | rng.s[2] | rng.s[3])) rng.s[0] = 1;
     // ---- parse, per-proof membership checks, weights ----
     std::vector<G1Affine> pts(2 * (size_t)N); std::vector<G2Affine> Bs(N); std::vector<uint32_t> rho(8 * 2 * (size_t)N, 0);
     std::vector<Fr> xsum(nPublic, Fr::zero()); Fr rsum = Fr::zero();
-    for (int i = 0; i < N; i++) {
-        const uint8_t* pr = proofs + 256 * (size_t)i;
-        if (!rd_g1_std(pts[i], pr) || !rd_g2_std(Bs[i], pr + 64) || !rd_g1_std(pts[N + i], pr + 192)) return 0;
-        if (!g1_on_curve(pts[i]) || !g1_on_curve(pts[N + i]) || !g2_on_curve(Bs[i])) return 0;
+    for (int i = 0; i < N; i++) {                                        // the weights first, from the one generator: the same whatever the number of parsing threads
         uint32_t* r = rho.data() + 8 * (size_t)i;
         const uint64_t lo = rng.next(), hi = rng.next(); r[0] = (uint32_t)lo; r[1] = (uint32_t)(lo >> 32); r[2] = (uint32_t)hi; r[3] = (uint32_t)(hi >> 32);
         memcpy(rho.data() + 8 * ((size_t)N + i), r, 32);
-        const Fr rm = fp_from_std<FrParams>(r); rsum = rsum + rm;
-        for (int j = 0; j < nPublic; j++) {
-            uint32_t k[8]; memcpy(k, pubs + 32 * ((size_t)i * nPublic + j), 32);
-            if (!fp_std_lt_p<FrParams>(k)) return 0;
-            xsum[j] = xsum[j] + rm * fp_from_std<FrParams>(k);
-        }
     }
-    // ---- G1 side on the GPU: rho_i A_i (N single-element groups) and sum rho_i C_i (one group); from 128 proofs on, the Miller loops too (zkc_pairing_dev.hip;
-    // ZKC_VERIFY_BATCH_GPU=0 / 1 forces the host threads / the GPU) ----
+    auto parse_range = [&](int lo, int hi, std::vector<Fr>& xs, Fr& rs) -> bool {
+        for (int i = lo; i < hi; i++) {
+            const uint8_t* pr = proofs + 256 * (size_t)i;
+            if (!rd_g1_std(pts[i], pr) || !rd_g2_std(Bs[i], pr + 64) || !rd_g1_std(pts[N + i], pr + 192)) return false;
+            if (!g1_on_curve(pts[i]) || !g1_on_curve(pts[N + i]) || !g2_on_curve(Bs[i])) return false;
+            const Fr rm = fp_from_std<FrParams>(rho.data() + 8 * (size_t)i); rs = rs + rm;
+            for (int j = 0; j < nPublic; j++) {
+                uint32_t k[8]; memcpy(k, pubs + 32 * ((size_t)i * nPublic + j), 32);
+                if (!fp_std_lt_p<FrParams>(k)) return false;
+                xs[j] = xs[j] + rm * fp_from_std<FrParams>(k);
+            }
+        }
+        return true;
+    };
+    {
+        const unsigned np = N >= 4096 ? std::max(1u, std::min({std::thread::hardware_concurrency(), 8u})) : 1u;      // a microsecond per proof: worth threads from a few thousand on
+        std::vector<std::vector<Fr>> xs(np, std::vector<Fr>(nPublic, Fr::zero())); std::vector<Fr> rs(np, Fr::zero()); std::vector<char> okp(np, 1);
+        std::vector<std::thread> th;
+        auto run = [&](unsigned t) { okp[t] = parse_range((int)((size_t)N * t / np), (int)((size_t)N * (t + 1) / np), xs[t], rs[t]) ? 1 : 0; };
+        for (unsigned t = 1; t < np; t++) th.emplace_back(run, t);
+        run(0); for (auto& x : th) x.join();
+        for (unsigned t = 0; t < np; t++) { if (!okp[t]) return 0; rsum = rsum + rs[t]; for (int j = 0; j < nPublic; j++) xsum[j] = xsum[j] + xs[t][j]; }
+    }
+    vt1 = vnow();
     const char* gpu_e = getenv("ZKC_VERIFY_BATCH_GPU"); const int gpu_env = gpu_e ? atoi(gpu_e) : -1;
     const bool on_gpu = gpu_env < 0 ? N >= 128 : gpu_env != 0;
     Fq12 gpu_product = one12(); int gpu_bad = 0;
@@ -323,27 +340,29 @@ extern "C" int zkc_verify_batch(zkc_ctx* ctx, const uint8_t* vk, int nPublic, co
     {
         ZKC_LOCK(ctx);
         if (hipSetDevice(ctx->device) != hipSuccess) return vfail(-ZKC_ERR_HIP, "zkc_verify_batch: hipSetDevice failed");     // never a positive code: 1 means "all valid"
-        G1Affine* d_pts = nullptr; uint32_t *d_rho = nullptr, *d_idx = nullptr, *d_gs = nullptr;
         std::vector<uint32_t> idx(2 * (size_t)N), gs((size_t)ngroups + 1);
         for (size_t i = 0; i < idx.size(); i++) idx[i] = (uint32_t)i;
         for (int i = 0; i < N; i++) gs[i] = (uint32_t)i;
         for (uint32_t g = 0; g <= ncg; g++) gs[(size_t)N + g] = (uint32_t)N + std::min(64 * g, (uint32_t)N);
-        int rc = ZKC_OK;
-        auto cleanup = [&]() { for (void* q : {(void*)d_pts, (void*)d_rho, (void*)d_idx, (void*)d_gs}) if (q) (void)hipFree(q); };
-        if (hipMalloc((void**)&d_pts, pts.size() * sizeof(G1Affine)) != hipSuccess || hipMalloc((void**)&d_rho, rho.size() * 4) != hipSuccess ||
-            hipMalloc((void**)&d_idx, idx.size() * 4) != hipSuccess || hipMalloc((void**)&d_gs, gs.size() * 4) != hipSuccess) { cleanup(); return vfail(-ZKC_ERR_HIP, "zkc_verify_batch: hipMalloc failed"); }
-        if (hipMemcpy(d_pts, pts.data(), pts.size() * sizeof(G1Affine), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_rho, rho.data(), rho.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(d_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_gs, gs.data(), gs.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return vfail(-ZKC_ERR_HIP, "zkc_verify_batch: hipMemcpy failed"); }
-        G1XYZZ* d_gout = nullptr;
-        rc = fold_group_sums_g1_keep(ctx, d_pts, d_rho, d_idx, 2 * (uint32_t)N, 0, d_gs, ngroups, gout.data(), on_gpu ? &d_gout : nullptr);
-        cleanup();
-        if (rc) return vfail(rc > 0 ? -rc : -ZKC_ERR_GENERIC, std::string("zkc_verify_batch: ") + zkc_last_error(ctx));
-        if (on_gpu) {
-            rc = miller_product_dev(ctx, d_gout, Bs.data(), (uint32_t)N, &gpu_product, &gpu_bad);
-            (void)hipFree(d_gout);
-            if (rc) return vfail(-rc, std::string("zkc_verify_batch: ") + zkc_last_error(ctx));
-        }
+        // device buffers from the context's verifier work space (kept between calls while small: zkc_internal.h)
+        const int rc = [&]() -> int {
+            void *d_pts, *d_rho, *d_idx, *d_gs, *d_tmp, *d_gout; int e;
+            if ((e = zkc_vws(ctx, zkc_ctx::VWS_PTS, pts.size() * sizeof(G1Affine), &d_pts)) || (e = zkc_vws(ctx, zkc_ctx::VWS_RHO, rho.size() * 4, &d_rho)) ||
+                (e = zkc_vws(ctx, zkc_ctx::VWS_IDX, idx.size() * 4, &d_idx)) || (e = zkc_vws(ctx, zkc_ctx::VWS_GS, gs.size() * 4, &d_gs)) ||
+                (e = zkc_vws(ctx, zkc_ctx::VWS_FOLD_TMP, 2 * (size_t)N * sizeof(G1XYZZ), &d_tmp)) || (e = zkc_vws(ctx, zkc_ctx::VWS_FOLD_OUT, (size_t)ngroups * sizeof(G1XYZZ), &d_gout))) return e;
+            ZKC_HIP_CHECK(ctx, hipMemcpyAsync(d_pts, pts.data(), pts.size() * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->stream));
+            ZKC_HIP_CHECK(ctx, hipMemcpyAsync(d_rho, rho.data(), rho.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            ZKC_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            ZKC_HIP_CHECK(ctx, hipMemcpyAsync(d_gs, gs.data(), gs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            if ((e = fold_group_sums_g1_ws(ctx, (const G1Affine*)d_pts, (const uint32_t*)d_rho, (const uint32_t*)d_idx, 2 * (uint32_t)N, (const uint32_t*)d_gs, ngroups,
+                                           (G1XYZZ*)d_tmp, (G1XYZZ*)d_gout, gout.data()))) return e;
+            if (on_gpu && (e = miller_product_dev(ctx, (const G1XYZZ*)d_gout, Bs.data(), (uint32_t)N, &gpu_product, &gpu_bad))) return e;
+            return ZKC_OK;
+        }();
+        zkc_verify_ws_trim(ctx, (size_t)256 << 20);
+        if (rc) return vfail(-rc, std::string("zkc_verify_batch: ") + zkc_last_error(ctx));
     }
+    vt2 = vnow();
     // ---- vk_x side: (sum rho) IC0 + sum_j (sum_i rho_i x_ij) IC_j ----
     std::vector<std::array<uint32_t, 8>> ks((size_t)nPublic + 1);
     fp_to_std<FrParams>(ks[0].data(), rsum);
@@ -379,7 +398,10 @@ extern "C" int zkc_verify_batch(zkc_ctx* ctx, const uint8_t* vk, int nPublic, co
     const Pair tail[3] = {{ralpha, &V->pbeta}, {xyzz_to_affine_gcd(vx), &V->pgamma}, {xyzz_to_affine_gcd(csum), &V->pdelta}};
     Fq12 f = multi_miller(tail, 3);
     for (const Fq12& x : part) f = f * x;
-    return is_one12(final_exp(f)) ? 1 : 0;
+    const int verdict = is_one12(final_exp(f)) ? 1 : 0;
+    vt3 = vnow();
+    if (vtrace) fprintf(stderr, "zkc_verify_batch N=%d: parse %.2f ms, device %.2f ms, host tail %.2f ms\n", N, vt1 - vt0, vt2 - vt1, vt3 - vt2);
+    return verdict;
 }
 
 // JSON surface: the three artifact files of the reference (verification_key.json, signals.json, proof.json). 1 valid / 0 invalid / <0 error
