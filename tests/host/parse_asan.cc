@@ -116,6 +116,11 @@ int main() {
         v2[rnd() % v2.size()] = (char)rnd(); p2[rnd() % p2.size()] = (char)rnd(); if (it & 1) s2[rnd() % s2.size()] = (char)rnd();
         (void)verify_inputs_from_json(v2, s2, p2, a, b, c, np, err);
     }
+    // the two halves on their own (zkc_proof_from_json / zkc_vkey_from_json at the C ABI): codes, and the same truncation sweep
+    { int n2 = 0, nic = 0; CHECK(proof_from_json(pub, pr, b, c, n2, err) == 1 && n2 == 1 && c.size() == 256); CHECK(vkey_from_json(vk, a, nic, err) == 1 && nic == 2 && a.size() == 448 + 128);
+      CHECK(proof_from_json("[5]", pr, b, c, n2, err) == -1); CHECK(proof_from_json(pub, "[]", b, c, n2, err) == -1); CHECK(vkey_from_json("[]", a, nic, err) == -1);
+      for (size_t n = 0; n < pr.size(); n++) CHECK(proof_from_json(pub, pr.substr(0, n), b, c, n2, err) == -1);
+      for (size_t n = 0; n < vk.size(); n++) CHECK(vkey_from_json(vk.substr(0, n), a, nic, err) == -1); }
     // ---- [r5] the strict JSON reader and the circuit-inputs reader (zkc_json.h, circuit_inputs_from_json): truncations, mutations, deep nesting, long numbers ----
     {
         std::string in = "{\"electionId\":[\"1\",\"2\"],\"nullifier\":\"3\",\"availableWeight\":\"4\",\"voteHash\":[\"5\",\"6\"],\"sikRoot\":\"7\",\"censusRoot\":\"8\",\"address\":\"0x9\",\"password\":-10,"
