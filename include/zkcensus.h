@@ -240,7 +240,8 @@ int zkc_pairing_bin(const uint8_t g1[64], const uint8_t g2[128], uint8_t out[384
  * the GPU of `ctx`, and from 128 proofs on so do the Miller loops and the G2 membership tests (csrc/zkc_pairing_dev.hip: 8 192 proofs in 15 ms; below that, host
  * threads, sixteen pairs per shared accumulator).  vk as for zkc_verify_bin; pubs: N x nPublic x 32 B; proofs: N x 256 B (standard
  * form).  seed32: 32 bytes of FRESH randomness for the weights (NULL: taken from the OS); soundness error about 2^-128.
- * Returns 1 when every proof is valid, 0 when at least one is not (verify singly to find it), <0 = -ZKC_ERR_*. */
+ * Returns 1 when every proof is valid, 0 when at least one is not (verify singly to find it), <0 = -ZKC_ERR_*.
+ * Environment: ZKC_VERIFY_BATCH_GPU=0 / 1 keeps the Miller loops on host threads / sends them to the GPU whatever N; ZKC_VERIFY_TRACE=1 prints the time of each phase. */
 int zkc_verify_batch(zkc_ctx* ctx, const uint8_t* vk, int nPublic, const uint8_t* pubs, const uint8_t* proofs, int N, const uint8_t* seed32);
 const char* zkc_verify_last_error(void);
 
