@@ -72,3 +72,44 @@ def _verdicts(ctx, groth16, vk, pubs, proofs, seed, npub):
     assert groth16.verify_batch(ctx, vk, pubs, with_patch(proofs, 256 * 4 + 64, offg2), seed) is False
     # (7) a B at infinity contributes 1 to the product: the batch fails on that proof's equation, not on a crash
     assert groth16.verify_batch(ctx, vk, pubs, with_patch(proofs, 256 * 6 + 64, bytes(128)), seed) is False
+
+
+def test_batch_verify_gpu_path_odd_sizes_and_several_rounds():
+    """[r5] The default path from 128 proofs on (Miller loops on the GPU, csrc/zkc_pairing_dev.hip) at sizes that are not powers of two -- odd levels in the product tree --
+    and with the pairs taken in several rounds of kernels (ZKC_VERIFY_CHUNK shrinks the 16 384 of a round): the verdicts of the host-thread path, which the test above pins to the
+    oracle's, on an honest batch and on batches with one bad member at the start, in the middle (across a round boundary) and at the end."""
+    import torch, numpy as np  # noqa: F401
+    import zkcensus_amd
+    from zkcensus_amd import groth16, setup
+    from census_gen import random_voter
+    nl, base = 10, 12
+    ctx = zkcensus_amd.Context(0)
+    _, zp, vp = setup.ensure_test_artifacts(nl)
+    pk = zkcensus_amd.ProvingKey(ctx, open(zp, 'rb').read()); vk = json.load(open(vp))
+    rng = random.Random(7)
+    voters = [random_voter(rng, ol.poseidon, nLevels=nl, depth_c=rng.randint(1, nl), depth_s=rng.randint(1, nl)) for _ in range(base)]
+    ws, st = ctx.witness(voters, nLevels=nl); assert st == [0] * base
+    d = torch.from_numpy(np.frombuffer(b''.join(ws), dtype=np.uint8).copy()).cuda()
+    rs = b''.join(rng.randrange(1 << 248).to_bytes(32, 'little') for _ in range(2 * base))
+    proofs, pubs = pk.prove_batch_dev(d.data_ptr(), base, rs)
+    assert all(ol.verify(vk, pubs[256 * i:256 * (i + 1)], proofs[256 * i:256 * (i + 1)]) for i in range(base))
+    for N, chunk in ((129, None), (301, '100'), (257, '2')):
+        P = b''.join(proofs[256 * (i % base):256 * (i % base + 1)] for i in range(N)); U = b''.join(pubs[256 * (i % base):256 * (i % base + 1)] for i in range(N))
+        if chunk:
+            os.environ['ZKC_VERIFY_CHUNK'] = chunk
+        try:
+            assert groth16.verify_batch(ctx, vk, U, P) is True
+            for bad_at in (0, 100, N - 1):
+                other = (bad_at + 1) % base
+                Pb = bytearray(P); Pb[256 * bad_at + 192:256 * bad_at + 256] = proofs[256 * other + 192:256 * other + 256]        # another proof's C
+                if bad_at % base == other:
+                    continue
+                assert groth16.verify_batch(ctx, vk, U, bytes(Pb)) is False, (N, chunk, bad_at)
+                os.environ['ZKC_VERIFY_BATCH_GPU'] = '0'
+                try:
+                    assert groth16.verify_batch(ctx, vk, U, bytes(Pb)) is False                      # the host-thread path agrees
+                finally:
+                    del os.environ['ZKC_VERIFY_BATCH_GPU']
+        finally:
+            os.environ.pop('ZKC_VERIFY_CHUNK', None)
+    pk.close(); ctx.close()

@@ -92,7 +92,8 @@ int miller_product_dev(zkc_ctx* ctx, const G1XYZZ* d_P, const G2Affine* h_Q, uin
     for (int b = 0; b < 64; b++) { if (L.digit[b] > 0) C.pos |= 1ull << b; else if (L.digit[b] < 0) C.neg |= 1ull << b; }
     C.t_lo = 0xf83e9682e87cfd46ull; C.t_hi = 0x6f4d8248eeb859fbull;           // 6 x^2, bit 126 on top (zkc_pairing.h g2_in_subgroup)
     const uint32_t nlines = 66 + (uint32_t)__builtin_popcountll(C.pos | C.neg);
-    constexpr uint32_t CHUNK = 16384;
+    const char* ce = getenv("ZKC_VERIFY_CHUNK");                               // pairs per round of kernels (tests shrink it to walk several rounds with a few hundred proofs)
+    const uint32_t CHUNK = ce ? (uint32_t)std::min(16384, std::max(2, atoi(ce))) : 16384u;
     const uint32_t cap = std::min(N, CHUNK), hcap = (cap + 1) / 2;
     G2Affine* d_Q; Fq2* d_lines; Fq12 *d_a, *d_b; int* d_bad; int rc; void* q;
     if ((rc = zkc_vws(ctx, zkc_ctx::VWS_Q, (size_t)cap * sizeof(G2Affine), &q))) return rc; d_Q = (G2Affine*)q;
