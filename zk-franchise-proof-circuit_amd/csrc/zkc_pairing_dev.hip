@@ -4,8 +4,8 @@
 //     F <- F^2 * prod_i line_{i, step}          for each of the 87 steps of the loop,
 // and the lines of a pair depend on its points only, never on F.  So the work splits into three data-parallel parts and a short tail:
 //   zkc_miller_lines   one lane per pair walks R <- 2R / R + Q on the twist and writes the 87 line coefficients, evaluated at the pair's G1 point (which stays in the
-//                      XYZZ form the fold kernels left it in: scaling a line by ZZ ZZZ in Fq costs nothing after the final exponentiation); N more lanes check the
-//                      B_i for membership in G2 (on the twist, psi(B) = [6x^2]B);
+//                      XYZZ form the fold kernels left it in: scaling a line by ZZ ZZZ in Fq costs nothing after the final exponentiation);
+//   zkc_g2_membership  one lane per B_i: on the twist and psi(B) = [6x^2]B, on the context's second stream, beside the lines and the tree;
 //   zkc_line_pairs     the first level of a product tree per step: two sparse lines -> one dense Fq12 (9 products in Fq2);
 //   zkc_fq12_tree      the remaining levels, one Fq12 product per lane, 87 steps side by side;
 //   host               87 values come back; F = (..(L_0)^2 L_1..) is 63 squarings and 87 products, then the three pairs of the key and ONE final exponentiation.
@@ -26,25 +26,29 @@ struct MillerConsts { Fq2 twist_b, psi_x, psi_y, psi2_x, psi2_y; Fq half; uint64
 __device__ __forceinline__ void store_line(Fq2* __restrict__ lines, uint32_t N, uint32_t step, uint32_t i, const Fq2 l[3]) {
     Fq2* o = lines + ((size_t)step * N + i) * 3; o[0] = l[0]; o[1] = l[1]; o[2] = l[2];
 }
-// lanes [0, N): the lines of pair i at (-P_i) -- P in XYZZ (x = X / ZZ, y = Y / ZZZ): c y, d0 x, d1 become c Y ZZ, d0 X ZZZ, d1 ZZ ZZZ, the whole line scaled by ZZ ZZZ.
-// lanes [N, 2N): B_i on the twist and in G2; *bad is set when one is not.  A pair with P or Q at infinity contributes the line 1.
+// B_i on the twist and in G2 (psi(B) = [6x^2]B, zkc_pairing.h); *bad is set when one is not.  Its own launch on the context's second stream: a 126-step double-and-add
+// per lane, longer than the walk of the lines, and nothing but the verdict waits for it -- the product tree starts as soon as the lines are written.
 __global__ void __launch_bounds__(64)
-zkc_miller_lines(const G1XYZZ* __restrict__ P, const G2Affine* __restrict__ Q, uint32_t N, MillerConsts C, Fq2* __restrict__ lines, int* __restrict__ bad) {
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= 2 * N) return;
-    const uint32_t i = gid < N ? gid : gid - N;
+zkc_g2_membership(const G2Affine* __restrict__ Q, uint32_t N, MillerConsts C, int* __restrict__ bad) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
     const G2Affine q = Q[i];
-    if (gid >= N) {
-        if (q.is_inf()) return;
-        bool ok = fp_sqr(q.y) == fp_sqr(q.x) * q.x + C.twist_b;
-        if (ok) {
-            G2XYZZ acc = G2XYZZ::from_affine(q);
-            for (int b = 125; b >= 0; b--) { acc = xyzz_dbl(acc); if (((b < 64 ? C.t_lo >> b : C.t_hi >> (b - 64)) & 1)) acc = xyzz_add_affine(acc, q); }
-            ok = !acc.is_inf() && acc.X == conj2(q.x) * C.psi_x * acc.ZZ && acc.Y == conj2(q.y) * C.psi_y * acc.ZZZ;
-        }
-        if (!ok) atomicOr(bad, 1);
-        return;
+    if (q.is_inf()) return;
+    bool ok = fp_sqr(q.y) == fp_sqr(q.x) * q.x + C.twist_b;
+    if (ok) {
+        G2XYZZ acc = G2XYZZ::from_affine(q);
+        for (int b = 125; b >= 0; b--) { acc = xyzz_dbl(acc); if (((b < 64 ? C.t_lo >> b : C.t_hi >> (b - 64)) & 1)) acc = xyzz_add_affine(acc, q); }
+        ok = !acc.is_inf() && acc.X == conj2(q.x) * C.psi_x * acc.ZZ && acc.Y == conj2(q.y) * C.psi_y * acc.ZZZ;
     }
+    if (!ok) atomicOr(bad, 1);
+}
+// the lines of pair i at (-P_i) -- P in XYZZ (x = X / ZZ, y = Y / ZZZ): c y, d0 x, d1 become c Y ZZ, d0 X ZZZ, d1 ZZ ZZZ, the whole line scaled by ZZ ZZZ.
+// A pair with P or Q at infinity contributes the line 1.
+__global__ void __launch_bounds__(64)
+zkc_miller_lines(const G1XYZZ* __restrict__ P, const G2Affine* __restrict__ Q, uint32_t N, MillerConsts C, Fq2* __restrict__ lines) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const G2Affine q = Q[i];
     const G1XYZZ p = P[i];
     const uint32_t nlines = 66 + (uint32_t)__popcll(C.pos | C.neg);
     if (p.is_inf() || q.is_inf()) {
@@ -108,10 +112,20 @@ int miller_product_dev(zkc_ctx* ctx, const G1XYZZ* d_P, const G2Affine* h_Q, uin
     auto vnow = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const double mt0 = vnow(); double mt_chunks = 0;
     std::vector<Fq12> step(nlines), acc(nlines, one12());
+    hipEvent_t ev_up = nullptr, ev_mem = nullptr;
+    if ((e = hipEventCreateWithFlags(&ev_up, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&ev_mem, hipEventDisableTiming)) != hipSuccess) {
+        if (ev_up) (void)hipEventDestroy(ev_up);
+        return fail(e, "miller_product_dev: hipEventCreate");
+    }
+    auto fail_ev = [&](hipError_t err, const char* what) { (void)hipStreamSynchronize(ctx->stream2); (void)hipEventDestroy(ev_up); (void)hipEventDestroy(ev_mem); return fail(err, what); };
     for (uint32_t lo = 0; lo < N; lo += CHUNK) {
         const uint32_t n = std::min(CHUNK, N - lo);
-        if ((e = hipMemcpyAsync(d_Q, h_Q + lo, (size_t)n * sizeof(G2Affine), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e, "miller_product_dev: upload");
-        hipLaunchKernelGGL(zkc_miller_lines, dim3((2 * n + 63) / 64), dim3(64), 0, ctx->stream, d_P + lo, d_Q, n, C, d_lines, d_bad);
+        if ((e = hipMemcpyAsync(d_Q, h_Q + lo, (size_t)n * sizeof(G2Affine), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail_ev(e, "miller_product_dev: upload");
+        // membership of this round's B_i beside everything else (second stream; it reads d_Q, which the next round overwrites only after ev_mem)
+        if ((e = hipEventRecord(ev_up, ctx->stream)) != hipSuccess || (e = hipStreamWaitEvent(ctx->stream2, ev_up, 0)) != hipSuccess) return fail_ev(e, "miller_product_dev: event");
+        hipLaunchKernelGGL(zkc_g2_membership, dim3((n + 63) / 64), dim3(64), 0, ctx->stream2, d_Q, n, C, d_bad);
+        if ((e = hipEventRecord(ev_mem, ctx->stream2)) != hipSuccess) return fail_ev(e, "miller_product_dev: event");
+        hipLaunchKernelGGL(zkc_miller_lines, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_P + lo, d_Q, n, C, d_lines);
         uint32_t m = (n + 1) / 2;
         hipLaunchKernelGGL(zkc_line_pairs, dim3((nlines * m + 63) / 64), dim3(64), 0, ctx->stream, d_lines, n, nlines, d_a);
         Fq12 *src = d_a, *dst = d_b;
@@ -120,11 +134,13 @@ int miller_product_dev(zkc_ctx* ctx, const G1XYZZ* d_P, const G2Affine* h_Q, uin
             hipLaunchKernelGGL(zkc_fq12_tree, dim3((nlines * h + 63) / 64), dim3(64), 0, ctx->stream, src, m, nlines, dst);
             std::swap(src, dst); m = h;
         }
-        if ((e = hipGetLastError()) != hipSuccess) return fail(e, "miller_product_dev: launch");
+        if ((e = hipGetLastError()) != hipSuccess) return fail_ev(e, "miller_product_dev: launch");
+        if ((e = hipStreamWaitEvent(ctx->stream, ev_mem, 0)) != hipSuccess) return fail_ev(e, "miller_product_dev: event");           // the round ends when both streams are through
         if ((e = hipMemcpyAsync(step.data(), src, (size_t)nlines * sizeof(Fq12), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess ||
-            (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "miller_product_dev: download");
+            (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail_ev(e, "miller_product_dev: download");
         for (uint32_t s = 0; s < nlines; s++) acc[s] = lo ? acc[s] * step[s] : step[s];
     }
+    (void)hipEventDestroy(ev_up); (void)hipEventDestroy(ev_mem);
     mt_chunks = vnow();
     int hb = 0;
     if ((e = hipMemcpy(&hb, d_bad, sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "miller_product_dev: download");
