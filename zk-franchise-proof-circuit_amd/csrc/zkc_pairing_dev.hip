@@ -88,62 +88,77 @@ zkc_fq12_tree(const Fq12* __restrict__ in, uint32_t n, uint32_t nlines, Fq12* __
     out[(size_t)s * half + t] = (2 * t + 1 < n) ? a[0] * a[1] : a[0];
 }
 
-// prod_i f_{6x+2, Q_i}(-P_i) over N pairs, P on the device (XYZZ, as the fold kernels write them), Q on the host; *bad != 0: some Q_i is not in G2 (the product is
-// meaningless then).  Pairs are taken 16 384 at a time (300 MB of line coefficients).  Buffers come from the context's verifier work space; the caller holds the context's lock.
-int miller_product_dev(zkc_ctx* ctx, const G1XYZZ* d_P, const G2Affine* h_Q, uint32_t N, Fq12* product, int* bad) {
+static MillerConsts miller_consts() {
     const Consts& K = consts(); const AteLoop& L = ate_loop();
     MillerConsts C; C.twist_b = K.twist_b; C.psi_x = K.psi_x; C.psi_y = K.psi_y; C.psi2_x = K.psi2_x; C.psi2_y = K.psi2_y; C.half = K.half; C.pos = C.neg = 0;
     for (int b = 0; b < 64; b++) { if (L.digit[b] > 0) C.pos |= 1ull << b; else if (L.digit[b] < 0) C.neg |= 1ull << b; }
     C.t_lo = 0xf83e9682e87cfd46ull; C.t_hi = 0x6f4d8248eeb859fbull;           // 6 x^2, bit 126 on top (zkc_pairing.h g2_in_subgroup)
+    return C;
+}
+static int dev_fail(zkc_ctx* ctx, hipError_t e, const char* what) { ctx->err = std::string(what) + ": " + hipGetErrorString(e); (void)hipGetLastError(); return ZKC_ERR_HIP; }
+
+// First half, before anything else of the batch touches the GPU: all N points B_i go up (they stay in the verifier work space for the lines) and their membership tests start
+// on the context's SECOND stream -- the longest kernel of a batch, needed only for the verdict, so it runs beside the fold kernels, the lines and the product tree.
+// miller_product_dev joins it.  The caller holds the context's lock.
+int miller_membership_begin(zkc_ctx* ctx, const G2Affine* h_Q, uint32_t N) {
+    void* q; int rc;
+    if ((rc = zkc_vws(ctx, zkc_ctx::VWS_Q, (size_t)N * sizeof(G2Affine), &q))) return rc;
+    G2Affine* d_Q = (G2Affine*)q;
+    if ((rc = zkc_vws(ctx, zkc_ctx::VWS_BAD, sizeof(int), &q))) return rc;
+    int* d_bad = (int*)q;
+    hipError_t e;
+    if (!ctx->ev_vws_up && (e = hipEventCreateWithFlags(&ctx->ev_vws_up, hipEventDisableTiming)) != hipSuccess) return dev_fail(ctx, e, "miller_membership_begin: hipEventCreate");
+    if ((e = hipMemcpyAsync(d_Q, h_Q, (size_t)N * sizeof(G2Affine), hipMemcpyHostToDevice, ctx->stream2)) != hipSuccess ||
+        (e = hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream2)) != hipSuccess ||
+        (e = hipEventRecord(ctx->ev_vws_up, ctx->stream2)) != hipSuccess ||                   // the lines kernels (first stream) read these points: they wait for the copy, not for the membership kernel
+        (e = hipStreamWaitEvent(ctx->stream, ctx->ev_vws_up, 0)) != hipSuccess) { (void)hipStreamSynchronize(ctx->stream2); return dev_fail(ctx, e, "miller_membership_begin: upload"); }
+    hipLaunchKernelGGL(zkc_g2_membership, dim3((N + 63) / 64), dim3(64), 0, ctx->stream2, d_Q, N, miller_consts(), d_bad);
+    if ((e = hipGetLastError()) != hipSuccess) { (void)hipStreamSynchronize(ctx->stream2); return dev_fail(ctx, e, "miller_membership_begin: launch"); }
+    return ZKC_OK;
+}
+// Second half: prod_i f_{6x+2, Q_i}(-P_i) over the N pairs, P on the device (XYZZ, as the fold kernels write them), Q where miller_membership_begin put them; *bad != 0: some
+// Q_i is not in G2 (the product is meaningless then).  Pairs are taken 16 384 at a time (300 MB of line coefficients).  Always waits for the second stream, error or not.
+int miller_product_dev(zkc_ctx* ctx, const G1XYZZ* d_P, uint32_t N, Fq12* product, int* bad) {
+    const AteLoop& L = ate_loop(); const MillerConsts C = miller_consts();
     const uint32_t nlines = 66 + (uint32_t)__builtin_popcountll(C.pos | C.neg);
     const char* ce = getenv("ZKC_VERIFY_CHUNK");                               // pairs per round of kernels (tests shrink it to walk several rounds with a few hundred proofs)
     const uint32_t CHUNK = ce ? (uint32_t)std::min(16384, std::max(2, atoi(ce))) : 16384u;
     const uint32_t cap = std::min(N, CHUNK), hcap = (cap + 1) / 2;
-    G2Affine* d_Q; Fq2* d_lines; Fq12 *d_a, *d_b; int* d_bad; int rc; void* q;
-    if ((rc = zkc_vws(ctx, zkc_ctx::VWS_Q, (size_t)cap * sizeof(G2Affine), &q))) return rc; d_Q = (G2Affine*)q;
-    if ((rc = zkc_vws(ctx, zkc_ctx::VWS_LINES, (size_t)nlines * cap * 3 * sizeof(Fq2), &q))) return rc; d_lines = (Fq2*)q;
-    if ((rc = zkc_vws(ctx, zkc_ctx::VWS_TREE_A, (size_t)nlines * hcap * sizeof(Fq12), &q))) return rc; d_a = (Fq12*)q;
-    if ((rc = zkc_vws(ctx, zkc_ctx::VWS_TREE_B, (size_t)nlines * ((hcap + 1) / 2) * sizeof(Fq12), &q))) return rc; d_b = (Fq12*)q;
-    if ((rc = zkc_vws(ctx, zkc_ctx::VWS_BAD, sizeof(int), &q))) return rc; d_bad = (int*)q;
-    auto fail = [&](hipError_t e, const char* what) { ctx->err = std::string(what) + ": " + hipGetErrorString(e); (void)hipGetLastError(); return ZKC_ERR_HIP; };
-    hipError_t e;
-    if ((e = hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream)) != hipSuccess) return fail(e, "miller_product_dev: hipMemset");
     const bool vtrace = getenv("ZKC_VERIFY_TRACE") != nullptr;
     auto vnow = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const double mt0 = vnow(); double mt_chunks = 0;
     std::vector<Fq12> step(nlines), acc(nlines, one12());
-    hipEvent_t ev_up = nullptr, ev_mem = nullptr;
-    if ((e = hipEventCreateWithFlags(&ev_up, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&ev_mem, hipEventDisableTiming)) != hipSuccess) {
-        if (ev_up) (void)hipEventDestroy(ev_up);
-        return fail(e, "miller_product_dev: hipEventCreate");
-    }
-    auto fail_ev = [&](hipError_t err, const char* what) { (void)hipStreamSynchronize(ctx->stream2); (void)hipEventDestroy(ev_up); (void)hipEventDestroy(ev_mem); return fail(err, what); };
-    for (uint32_t lo = 0; lo < N; lo += CHUNK) {
-        const uint32_t n = std::min(CHUNK, N - lo);
-        if ((e = hipMemcpyAsync(d_Q, h_Q + lo, (size_t)n * sizeof(G2Affine), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail_ev(e, "miller_product_dev: upload");
-        // membership of this round's B_i beside everything else (second stream; it reads d_Q, which the next round overwrites only after ev_mem)
-        if ((e = hipEventRecord(ev_up, ctx->stream)) != hipSuccess || (e = hipStreamWaitEvent(ctx->stream2, ev_up, 0)) != hipSuccess) return fail_ev(e, "miller_product_dev: event");
-        hipLaunchKernelGGL(zkc_g2_membership, dim3((n + 63) / 64), dim3(64), 0, ctx->stream2, d_Q, n, C, d_bad);
-        if ((e = hipEventRecord(ev_mem, ctx->stream2)) != hipSuccess) return fail_ev(e, "miller_product_dev: event");
-        hipLaunchKernelGGL(zkc_miller_lines, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_P + lo, d_Q, n, C, d_lines);
-        uint32_t m = (n + 1) / 2;
-        hipLaunchKernelGGL(zkc_line_pairs, dim3((nlines * m + 63) / 64), dim3(64), 0, ctx->stream, d_lines, n, nlines, d_a);
-        Fq12 *src = d_a, *dst = d_b;
-        while (m > 1) {
-            const uint32_t h = (m + 1) / 2;
-            hipLaunchKernelGGL(zkc_fq12_tree, dim3((nlines * h + 63) / 64), dim3(64), 0, ctx->stream, src, m, nlines, dst);
-            std::swap(src, dst); m = h;
+    const int rc = [&]() -> int {
+        const G2Affine* d_Q = (const G2Affine*)ctx->vws[zkc_ctx::VWS_Q];
+        Fq2* d_lines; Fq12 *d_a, *d_b; void* q; int r;
+        if ((r = zkc_vws(ctx, zkc_ctx::VWS_LINES, (size_t)nlines * cap * 3 * sizeof(Fq2), &q))) return r; d_lines = (Fq2*)q;
+        if ((r = zkc_vws(ctx, zkc_ctx::VWS_TREE_A, (size_t)nlines * hcap * sizeof(Fq12), &q))) return r; d_a = (Fq12*)q;
+        if ((r = zkc_vws(ctx, zkc_ctx::VWS_TREE_B, (size_t)nlines * ((hcap + 1) / 2) * sizeof(Fq12), &q))) return r; d_b = (Fq12*)q;
+        hipError_t e;
+        for (uint32_t lo = 0; lo < N; lo += CHUNK) {
+            const uint32_t n = std::min(CHUNK, N - lo);
+            hipLaunchKernelGGL(zkc_miller_lines, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_P + lo, d_Q + lo, n, C, d_lines);
+            uint32_t m = (n + 1) / 2;
+            hipLaunchKernelGGL(zkc_line_pairs, dim3((nlines * m + 63) / 64), dim3(64), 0, ctx->stream, d_lines, n, nlines, d_a);
+            Fq12 *src = d_a, *dst = d_b;
+            while (m > 1) {
+                const uint32_t h = (m + 1) / 2;
+                hipLaunchKernelGGL(zkc_fq12_tree, dim3((nlines * h + 63) / 64), dim3(64), 0, ctx->stream, src, m, nlines, dst);
+                std::swap(src, dst); m = h;
+            }
+            if ((e = hipGetLastError()) != hipSuccess) return dev_fail(ctx, e, "miller_product_dev: launch");
+            if ((e = hipMemcpyAsync(step.data(), src, (size_t)nlines * sizeof(Fq12), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess ||
+                (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return dev_fail(ctx, e, "miller_product_dev: download");
+            for (uint32_t s = 0; s < nlines; s++) acc[s] = lo ? acc[s] * step[s] : step[s];
         }
-        if ((e = hipGetLastError()) != hipSuccess) return fail_ev(e, "miller_product_dev: launch");
-        if ((e = hipStreamWaitEvent(ctx->stream, ev_mem, 0)) != hipSuccess) return fail_ev(e, "miller_product_dev: event");           // the round ends when both streams are through
-        if ((e = hipMemcpyAsync(step.data(), src, (size_t)nlines * sizeof(Fq12), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess ||
-            (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail_ev(e, "miller_product_dev: download");
-        for (uint32_t s = 0; s < nlines; s++) acc[s] = lo ? acc[s] * step[s] : step[s];
-    }
-    (void)hipEventDestroy(ev_up); (void)hipEventDestroy(ev_mem);
+        return ZKC_OK;
+    }();
+    const hipError_t ej = hipStreamSynchronize(ctx->stream2);                  // the membership tests
+    if (rc) return rc;
+    if (ej != hipSuccess) return dev_fail(ctx, ej, "miller_product_dev: membership kernel");
     mt_chunks = vnow();
-    int hb = 0;
-    if ((e = hipMemcpy(&hb, d_bad, sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "miller_product_dev: download");
+    int hb = 0; hipError_t e;
+    if ((e = hipMemcpy(&hb, ctx->vws[zkc_ctx::VWS_BAD], sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) return dev_fail(ctx, e, "miller_product_dev: download");
     *bad = hb;
     // the accumulator, step by step (the same walk as pairing::multi_miller)
     Fq12 f = one12(); uint32_t idx = 0;

@@ -23,7 +23,10 @@
 
 using namespace zkc;
 using namespace zkc::pairing;
-namespace zkc { int miller_product_dev(zkc_ctx* ctx, const G1XYZZ* d_P, const G2Affine* h_Q, uint32_t N, pairing::Fq12* product, int* bad); }      // zkc_pairing_dev.hip
+namespace zkc {      // zkc_pairing_dev.hip
+int miller_membership_begin(zkc_ctx* ctx, const G2Affine* h_Q, uint32_t N);
+int miller_product_dev(zkc_ctx* ctx, const G1XYZZ* d_P, uint32_t N, pairing::Fq12* product, int* bad);
+}
 
 namespace {
 
@@ -350,13 +353,15 @@ extern "C" int zkc_verify_batch(zkc_ctx* ctx, const uint8_t* vk, int nPublic, co
             if ((e = zkc_vws(ctx, zkc_ctx::VWS_PTS, pts.size() * sizeof(G1Affine), &d_pts)) || (e = zkc_vws(ctx, zkc_ctx::VWS_RHO, rho.size() * 4, &d_rho)) ||
                 (e = zkc_vws(ctx, zkc_ctx::VWS_IDX, idx.size() * 4, &d_idx)) || (e = zkc_vws(ctx, zkc_ctx::VWS_GS, gs.size() * 4, &d_gs)) ||
                 (e = zkc_vws(ctx, zkc_ctx::VWS_FOLD_TMP, 2 * (size_t)N * sizeof(G1XYZZ), &d_tmp)) || (e = zkc_vws(ctx, zkc_ctx::VWS_FOLD_OUT, (size_t)ngroups * sizeof(G1XYZZ), &d_gout))) return e;
+            if (on_gpu && (e = miller_membership_begin(ctx, Bs.data(), (uint32_t)N))) return e;       // the B_i go up and their membership tests start on the second stream, beside all that follows
+            struct Join { zkc_ctx* c; bool armed; ~Join() { if (armed) (void)hipStreamSynchronize(c->stream2); } } join{ctx, on_gpu};      // whatever happens below, that kernel is through before the buffers can be trimmed
             ZKC_HIP_CHECK(ctx, hipMemcpyAsync(d_pts, pts.data(), pts.size() * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->stream));
             ZKC_HIP_CHECK(ctx, hipMemcpyAsync(d_rho, rho.data(), rho.size() * 4, hipMemcpyHostToDevice, ctx->stream));
             ZKC_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, ctx->stream));
             ZKC_HIP_CHECK(ctx, hipMemcpyAsync(d_gs, gs.data(), gs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
             if ((e = fold_group_sums_g1_ws(ctx, (const G1Affine*)d_pts, (const uint32_t*)d_rho, (const uint32_t*)d_idx, 2 * (uint32_t)N, (const uint32_t*)d_gs, ngroups,
                                            (G1XYZZ*)d_tmp, (G1XYZZ*)d_gout, gout.data()))) return e;
-            if (on_gpu && (e = miller_product_dev(ctx, (const G1XYZZ*)d_gout, Bs.data(), (uint32_t)N, &gpu_product, &gpu_bad))) return e;
+            if (on_gpu && (e = miller_product_dev(ctx, (const G1XYZZ*)d_gout, (uint32_t)N, &gpu_product, &gpu_bad))) return e;
             return ZKC_OK;
         }();
         zkc_verify_ws_trim(ctx, (size_t)256 << 20);
