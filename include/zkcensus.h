@@ -237,7 +237,7 @@ int zkc_pairing_bin(const uint8_t g1[64], const uint8_t g2[128], uint8_t out[384
 
 /* ---- f4: batch verification of N proofs under one key (what a vote-counting node does after zk_census_test.go:103-124 per vote).
  * One random-linear-combination pairing check: N + 3 Miller loops and one final exponentiation; the G1 scalar multiplications run on
- * the GPU of `ctx`, and from 128 proofs on so do the Miller loops and the G2 membership tests (csrc/zkc_pairing_dev.hip: 8 192 proofs in 14 ms; below that, host
+ * the GPU of `ctx`, and from 128 proofs on so do the Miller loops and the G2 membership tests (csrc/zkc_pairing_dev.hip: 8 192 proofs in 10 ms; below that, host
  * threads, sixteen pairs per shared accumulator).  vk as for zkc_verify_bin; pubs: N x nPublic x 32 B; proofs: N x 256 B (standard
  * form).  seed32: 32 bytes of FRESH randomness for the weights (NULL: taken from the OS); soundness error about 2^-128.
  * Returns 1 when every proof is valid, 0 when at least one is not (verify singly to find it), <0 = -ZKC_ERR_*.

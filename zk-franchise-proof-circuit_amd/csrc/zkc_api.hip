@@ -224,6 +224,7 @@ extern "C" void zkc_ctx_destroy(zkc_ctx* ctx) {
     if (ctx->d_prof_entries) (void)hipFree(ctx->d_prof_entries);
     zkc_verify_ws_trim(ctx, 0);
     if (ctx->ev_vws_up) (void)hipEventDestroy(ctx->ev_vws_up);
+    if (ctx->ev_vws_lines) (void)hipEventDestroy(ctx->ev_vws_lines);
     for (auto& ls : ctx->lane_streams) for (hipStream_t q : {ls.st, ls.st2, ls.fin, ls.red}) if (q) (void)hipStreamSynchronize(q);      // (the streams are the DEVICE's and stay: zkc_lane_streams)
     zkc_ctx_lanes_destroy(ctx);
     if (ctx->ev_acc_chain) (void)hipEventDestroy(ctx->ev_acc_chain);

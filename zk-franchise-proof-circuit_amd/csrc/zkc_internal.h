@@ -63,7 +63,7 @@ struct zkc_ctx {
     // at the end of a call that needed more (zkc_verify_ws_trim).
     enum { VWS_PTS = 0, VWS_RHO, VWS_IDX, VWS_GS, VWS_FOLD_TMP, VWS_FOLD_OUT, VWS_Q, VWS_LINES, VWS_TREE_A, VWS_TREE_B, VWS_BAD, VWS_N };
     void* vws[VWS_N] = {nullptr}; size_t vws_sz[VWS_N] = {0};
-    hipEvent_t ev_vws_up = nullptr;       // the batch verifier's upload on the second stream -> its kernels on the first (zkc_pairing_dev.hip)
+    hipEvent_t ev_vws_up = nullptr, ev_vws_lines = nullptr;       // the batch verifier's upload (second stream) -> its line kernel (third stream) -> the product tree (first): zkc_pairing_dev.hip
     zkc_prof prof;
     unsigned long long* d_prof_entries = nullptr;      // device counter: (digit, point) entries = group additions of the G1 passes while profiling is on
 };

@@ -25,6 +25,7 @@ using namespace zkc;
 using namespace zkc::pairing;
 namespace zkc {      // zkc_pairing_dev.hip
 int miller_membership_begin(zkc_ctx* ctx, const G2Affine* h_Q, uint32_t N);
+void miller_join(zkc_ctx* ctx);
 int miller_product_dev(zkc_ctx* ctx, const G1XYZZ* d_P, uint32_t N, pairing::Fq12* product, int* bad);
 }
 
@@ -353,8 +354,8 @@ extern "C" int zkc_verify_batch(zkc_ctx* ctx, const uint8_t* vk, int nPublic, co
             if ((e = zkc_vws(ctx, zkc_ctx::VWS_PTS, pts.size() * sizeof(G1Affine), &d_pts)) || (e = zkc_vws(ctx, zkc_ctx::VWS_RHO, rho.size() * 4, &d_rho)) ||
                 (e = zkc_vws(ctx, zkc_ctx::VWS_IDX, idx.size() * 4, &d_idx)) || (e = zkc_vws(ctx, zkc_ctx::VWS_GS, gs.size() * 4, &d_gs)) ||
                 (e = zkc_vws(ctx, zkc_ctx::VWS_FOLD_TMP, 2 * (size_t)N * sizeof(G1XYZZ), &d_tmp)) || (e = zkc_vws(ctx, zkc_ctx::VWS_FOLD_OUT, (size_t)ngroups * sizeof(G1XYZZ), &d_gout))) return e;
-            if (on_gpu && (e = miller_membership_begin(ctx, Bs.data(), (uint32_t)N))) return e;       // the B_i go up and their membership tests start on the second stream, beside all that follows
-            struct Join { zkc_ctx* c; bool armed; ~Join() { if (armed) (void)hipStreamSynchronize(c->stream2); } } join{ctx, on_gpu};      // whatever happens below, that kernel is through before the buffers can be trimmed
+            if (on_gpu && (e = miller_membership_begin(ctx, Bs.data(), (uint32_t)N))) return e;       // the B_i go up; their membership tests (second stream) and the lines of their Miller loops (third) start beside all that follows
+            struct Join { zkc_ctx* c; bool armed; ~Join() { if (armed) miller_join(c); } } join{ctx, on_gpu};      // whatever happens below, that kernel is through before the buffers can be trimmed
             ZKC_HIP_CHECK(ctx, hipMemcpyAsync(d_pts, pts.data(), pts.size() * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->stream));
             ZKC_HIP_CHECK(ctx, hipMemcpyAsync(d_rho, rho.data(), rho.size() * 4, hipMemcpyHostToDevice, ctx->stream));
             ZKC_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, ctx->stream));
