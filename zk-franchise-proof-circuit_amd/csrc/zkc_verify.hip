@@ -326,7 +326,7 @@ extern "C" int zkc_verify_batch(zkc_ctx* ctx, const uint8_t* vk, int nPublic, co
         return true;
     };
     {
-        const unsigned np = N >= 4096 ? std::max(1u, std::min({std::thread::hardware_concurrency(), 8u})) : 1u;      // a microsecond per proof: worth threads from a few thousand on
+        const unsigned np = N >= 4096 ? std::max(1u, std::min({std::thread::hardware_concurrency(), N >= 32768 ? 16u : 8u})) : 1u;      // a microsecond per proof: worth threads from a few thousand on
         std::vector<std::vector<Fr>> xs(np, std::vector<Fr>(nPublic, Fr::zero())); std::vector<Fr> rs(np, Fr::zero()); std::vector<char> okp(np, 1);
         std::vector<std::thread> th;
         auto run = [&](unsigned t) { okp[t] = parse_range((int)((size_t)N * t / np), (int)((size_t)N * (t + 1) / np), xs[t], rs[t]) ? 1 : 0; };
