@@ -157,10 +157,16 @@ int miller_product_dev(zkc_ctx* ctx, const G1XYZZ* d_P, uint32_t N, Fq12* produc
         hipError_t e;
         for (uint32_t lo = 0; lo < N; lo += CHUNK) {
             const uint32_t n = std::min(CHUNK, N - lo);
-            if (lo == 0) { if ((e = hipStreamWaitEvent(ctx->stream, ctx->ev_vws_lines, 0)) != hipSuccess) return dev_fail(ctx, e, "miller_product_dev: event"); }
-            else hipLaunchKernelGGL(zkc_miller_lines, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_Q + lo, n, C, d_lines);
+            // this round's lines were started on the third stream: by miller_membership_begin (round 0) or by the round before, as soon as ITS pairs kernel had read the buffer
+            if ((e = hipStreamWaitEvent(ctx->stream, ctx->ev_vws_lines, 0)) != hipSuccess) return dev_fail(ctx, e, "miller_product_dev: event");
             uint32_t m = (n + 1) / 2;
             hipLaunchKernelGGL(zkc_line_pairs, dim3((nlines * m + 63) / 64), dim3(64), 0, ctx->stream, d_lines, d_P + lo, n, nlines, d_a);
+            if (lo + CHUNK < N) {                                   // the next round's lines run beside this round's product tree (the pairs kernel is the only reader of d_lines)
+                const uint32_t lo2 = lo + CHUNK, n2 = std::min(CHUNK, N - lo2);
+                if ((e = hipEventRecord(ctx->ev_vws_up, ctx->stream)) != hipSuccess || (e = hipStreamWaitEvent(ctx->fin_stream, ctx->ev_vws_up, 0)) != hipSuccess) return dev_fail(ctx, e, "miller_product_dev: event");
+                hipLaunchKernelGGL(zkc_miller_lines, dim3((n2 + 63) / 64), dim3(64), 0, ctx->fin_stream, d_Q + lo2, n2, C, d_lines);
+                if ((e = hipEventRecord(ctx->ev_vws_lines, ctx->fin_stream)) != hipSuccess) return dev_fail(ctx, e, "miller_product_dev: event");
+            }
             Fq12 *src = d_a, *dst = d_b;
             while (m > 1) {
                 const uint32_t h = (m + 1) / 2;
